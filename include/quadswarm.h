@@ -1,0 +1,225 @@
+/*
+ * quadswarm.h - C ABI of the MI355X-native vectorised QuadSwarm environment stepper.
+ *
+ * The reference (Zhehui-Huang/quad-swarm-rl) has NO FFI boundary: its hot path is the Python
+ * object protocol `QuadrotorEnvMulti.reset()/step(actions)` registered with Sample Factory
+ *   - gym_art/quadrotor_multi/quadrotor_multi.py:339-411  (reset)
+ *   - gym_art/quadrotor_multi/quadrotor_multi.py:413-724  (step, auto-reset inside step)
+ *   - swarm_rl/env_wrappers/quad_utils.py:20-117          (make_quadrotor_env[_multi], env factory)
+ * This header is the boundary a maintainer would bind underneath that protocol (ctypes stub in
+ * INTEGRATION.md).  Plain pointers and sizes only; every device pointer is a hipMalloc'd address
+ * owned by the library and valid until qs_destroy().
+ *
+ * E environments x N drones are stepped at once.  Drone d of environment e has flat index e*N+d.
+ * All per-drone arrays are struct-of-arrays: component c of a field with C components lives at
+ * field[c*E*N + e*N + d] (coalesced across lanes).  Observations are the exception: they are what
+ * the policy consumes and are stored row-major [E*N, obs_dim] like the reference returns them.
+ *
+ * The same `qs_config` / entry-point shapes are mirrored by the CPU oracle (oracle/quadswarm_oracle.h,
+ * test infrastructure only) so parity tests drive both through identical calls.
+ */
+#ifndef QUADSWARM_H
+#define QUADSWARM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_VERSION 100            /* 0.1.0 */
+#define QS_MAX_AGENTS 64          /* per environment (pair/id sets are 64-bit masks) */
+#define QS_MAX_OBSTACLES 64
+
+/* obs_repr (quad_utils.py:30-34 QUADS_OBS_REPR) */
+enum { QS_OBS_XYZ_VXYZ_R_OMEGA = 0, QS_OBS_XYZ_VXYZ_R_OMEGA_FLOOR = 1, QS_OBS_XYZ_VXYZ_R_OMEGA_WALL = 2 };
+/* scenario (scenarios/mix.py:31 create_scenario) */
+enum { QS_SCENARIO_STATIC_SAME_GOAL = 0, QS_SCENARIO_O_STATIC_SAME_GOAL = 1, QS_SCENARIO_SWARM_VS_SWARM = 2 };
+/* floor_mode: which of the two reference semantics */
+enum { QS_FLOOR_NUMBA = 0, QS_FLOOR_NUMPY = 1 };
+/* precision of the device state / arithmetic */
+enum { QS_PRECISION_F32 = 0, QS_PRECISION_F64 = 1 };
+/* status codes */
+enum { QS_OK = 0, QS_ERR_INVALID = -1, QS_ERR_HIP = -2, QS_ERR_NAN_REWARD = -3, QS_ERR_UNSUPPORTED = -4 };
+
+/* indices into qs_config.rew_coeff (quadrotor_multi.py:91-94) */
+enum { QS_REW_POS = 0, QS_REW_EFFORT, QS_REW_CRASH, QS_REW_ORIENT, QS_REW_SPIN,
+       QS_REW_QUADCOL_BIN, QS_REW_QUADCOL_SMOOTH_MAX, QS_REW_QUADCOL_OBST, QS_REW_COUNT };
+
+/* columns of the per-drone reward-info matrix (quadrotor_single.py:68-85, quadrotor_multi.py:533-540) */
+enum { QS_RI_REW_MAIN = 0, QS_RI_REW_POS, QS_RI_REW_ACTION, QS_RI_REW_CRASH, QS_RI_REW_ORIENT, QS_RI_REW_SPIN,
+       QS_RI_RAW_MAIN, QS_RI_RAW_POS, QS_RI_RAW_ACTION, QS_RI_RAW_CRASH, QS_RI_RAW_ORIENT, QS_RI_RAW_SPIN,
+       QS_RI_REW_QUADCOL, QS_RI_REW_PROXIMITY, QS_RI_RAW_QUADCOL, QS_RI_REW_QUADCOL_OBST, QS_RI_RAW_QUADCOL_OBST,
+       QS_RI_COUNT };
+
+/* per-environment integer counters (quadrotor_multi.py:143-161, :626-718) */
+enum { QS_CNT_COLLISIONS = 0, QS_CNT_COLLISIONS_AFTER_SETTLE, QS_CNT_COLLISIONS_FINAL_5S,
+       QS_CNT_ROOM, QS_CNT_FLOOR, QS_CNT_WALL, QS_CNT_CEILING,
+       QS_CNT_OBST, QS_CNT_OBST_AFTER_SETTLE, QS_CNT_OBST_DIST_3_5, QS_CNT_OBST_DIST_5, QS_CNT_COUNT };
+
+/* per-drone episode statistics written when an episode ends (quadrotor_multi.py:626-718) */
+enum { QS_EPS_DIST_1S = 0, QS_EPS_DIST_3S, QS_EPS_DIST_5S, QS_EPS_REACHED_GOAL, QS_EPS_COL_AGENT_OK,
+       QS_EPS_COL_OBST_OK, QS_EPS_COUNT };
+
+typedef struct qs_config {
+    /* ---- batch ---- */
+    int32_t num_envs;          /* E (this shard) */
+    int32_t num_agents;        /* N, cfg.quads_num_agents */
+    int32_t env_id_offset;     /* global id of local env 0 (multi-GPU sharding; RNG is keyed by global id) */
+    int32_t precision;         /* QS_PRECISION_* */
+    uint64_t seed;
+
+    /* ---- airframe constants (quad_models.py:1-42 -> inertia.py:182-309 -> quadrotor_dynamics.py:104-166) ---- */
+    double mass, inertia[3], arm;
+    double prop_cross[4][3];   /* prop_pos x z_hat */
+    double prop_ccw[4];
+    double thrust_max[4], torque_max[4];
+    double motor_tau_up, motor_tau_down;   /* 4*dt/(damp_time+1e-6), quadrotor_dynamics.py:63-64 */
+    double motor_linearity, vel_damp, damp_omega_quadratic, omega_max, gravity;
+    double thrust_noise_sigma; /* 0.2*thrust_noise_ratio, OU sigma (quadrotor_dynamics.py:168-173) */
+    double ou_theta;           /* 0.15 */
+
+    /* ---- simulation ---- */
+    double dt;                 /* 1/sim_freq = 0.005 */
+    int32_t sim_steps;         /* 2 */
+    int32_t ep_len;            /* int(ep_time/(dt*sim_steps)) */
+    double room_lo[3], room_hi[3];
+    int32_t floor_mode;        /* QS_FLOOR_* */
+    int32_t svd_period;        /* sub-steps between re-orthogonalisations = first n with fl(sum_n dt) > 0.5 */
+
+    /* ---- sensor noise (sensor_noise.py:69-110); sense_noise=0 bypasses ---- */
+    int32_t sense_noise;
+    int32_t obs_repr;          /* QS_OBS_* */
+    double pos_norm_std, pos_unif_range, vel_norm_std, vel_unif_range;
+    double quat_norm_std, quat_unif_range, gyro_noise_density;
+
+    /* ---- multi-drone env (quadrotor_multi.py:24-207) ---- */
+    int32_t num_neighbors;     /* K = resolved neighbor_visible_num (N-1 if -1; 0 if obs type 'none') */
+    int32_t use_downwash;
+    int32_t use_obstacles;
+    int32_t scenario;          /* QS_SCENARIO_* */
+    double collision_threshold;          /* hitbox_radius * arm */
+    double collision_falloff_threshold;  /* falloff_radius * arm */
+    double rew_coeff[QS_REW_COUNT];
+    double spawn_box;          /* 2.0, or 0.1 with obstacles (quadrotor_single.py:215-218) */
+    double approach_goal_metric; /* 0.5, 1.0 for obstacle scenarios */
+    double nbr_clip_pos[3], nbr_clip_vel[3]; /* quadrotor_single.py:294-295 */
+
+    /* ---- obstacles (quadrotor_multi.py:117-131, :304-325) ---- */
+    double obst_size, obst_density;
+    int32_t obst_area[2];      /* int(obst_spawn_area) */
+    int32_t num_obstacles;     /* int(density*area0*area1) */
+} qs_config;
+
+/* Device pointers (element type = float for QS_PRECISION_F32, double for QS_PRECISION_F64 where
+ * marked `real`).  Valid until qs_destroy(). */
+typedef struct qs_buffers {
+    void *obs;            /* real  [E*N, obs_dim] row-major */
+    void *reward;         /* real  [E*N] */
+    void *done;           /* uint8 [E*N] */
+    void *rew_info;       /* real  [QS_RI_COUNT, E*N] */
+    void *actions;        /* real  [E*N, 4] staging buffer callers may fill instead of passing their own */
+    /* state (SoA, component-major) */
+    void *pos, *vel, *omega;  /* real [3, E*N] */
+    void *rot;                /* real [9, E*N] row-major R */
+    void *thrust_rot_damp, *thrust_cmds_damp, *ou_state; /* real [4, E*N] */
+    void *goal;               /* real [3, E*N] */
+    void *flags;              /* uint32 [E*N] bit0 on_floor, bit1 crashed_floor, bit2 crashed_wall,
+                                 bit3 crashed_ceiling, bit4 prev_new_wall, bit5 prev_new_ceiling,
+                                 bit6 prev_new_room, bit7 obst_hit_prev */
+    void *obst_hit_idx;       /* int32 [E*N]: first obstacle hit this step, -1 none (obstacles/utils.py:31-43) */
+    void *col_pair_mask;      /* uint64 [E*N]: bit j set <=> pair (d,j), j>d, within collision_threshold */
+    void *new_pair_mask;      /* uint64 [E*N]: pairs new this step (quadrotor_multi.py:437-438) */
+    void *unique_col_mask;    /* uint64 [E]: ids of last_step_unique_collisions (quadrotor_multi.py:440) */
+    void *obst_new_mask;      /* uint64 [E]: curr_quad_col (quadrotor_multi.py:467) */
+    void *room_new_mask;      /* uint64 [E]: room_crash_list (quadrotor_multi.py:492-493) */
+    void *counters;           /* int32 [QS_CNT_COUNT, E] */
+    void *tick;               /* int32 [E] */
+    void *obst_pos;           /* real  [2, E*num_obstacles] */
+    void *ep_stats;           /* real  [QS_EPS_COUNT, E*N], ep_counters int32 [QS_CNT_COUNT, E]: snapshot at last done */
+    void *ep_counters;
+    void *error_flag;         /* uint32 [1]: nonzero if a reward was NaN/Inf (quadrotor_single.py:87-90) */
+    int32_t obs_dim;
+    int32_t real_size;        /* 4 or 8 */
+} qs_buffers;
+
+typedef struct qs_handle qs_handle;
+
+/* Library version (QS_VERSION). */
+int qs_version(void);
+
+/* sizeof(qs_config) as compiled into the library (binding sanity check). */
+size_t qs_sizeof_config(void);
+
+/* Last error message of the calling thread's most recent failing call. */
+const char *qs_last_error(void);
+
+/* Fill *cfg with the reference defaults for the Crazyflie airframe and the given batch/env sizes
+ * (swarm_rl/env_wrappers/quad_utils.py:20-65 + quadrotor_params.py:15-120).  Replaces the
+ * QuadrotorEnvMulti.__init__ constant derivation (quadrotor_multi.py:24-207). */
+int qs_default_config(qs_config *cfg, int32_t num_envs, int32_t num_agents);
+
+/* obs_dim implied by a config (quad_utils.py:30-44 + quadrotor_single.py:311-316). */
+int qs_obs_dim(const qs_config *cfg);
+
+/* Create a stepper on HIP device `device`.  Replaces QuadrotorEnvMulti.__init__. */
+int qs_create(const qs_config *cfg, int device, qs_handle **out);
+int qs_destroy(qs_handle *h);
+
+/* Episode reset (QuadrotorEnvMulti.reset, quadrotor_multi.py:339-411) of the envs whose byte in
+ * env_mask_host is nonzero (NULL = all).  Asynchronous on `stream` (a hipStream_t, NULL = default). */
+int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream);
+
+/* One control step for all envs (QuadrotorEnvMulti.step, quadrotor_multi.py:413-724), including the
+ * in-step auto-reset.  actions_dev: device pointer real[E*N,4] (NULL = use qs_buffers.actions).
+ * Asynchronous on `stream`; results are in qs_buffers after the stream is synchronised. */
+int qs_step(qs_handle *h, const void *actions_dev, void *stream);
+
+/* K back-to-back control steps with actions_dev = real[K][E*N,4] (rollout with pre-generated actions;
+ * one launch sequence, optionally replayed from a captured hipGraph). */
+int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream);
+
+int qs_sync(qs_handle *h, void *stream);
+int qs_get_buffers(qs_handle *h, qs_buffers *out);
+
+/* Push new reward coefficients (the SF reward-shaping wrapper mutates env.rew_coeff,
+ * swarm_rl/env_wrappers/reward_shaping.py:57-59,111-118). */
+int qs_set_reward_coeffs(qs_handle *h, const double *coeffs /* [QS_REW_COUNT] */);
+
+/* Copy the dynamic state of env `env` to / from host doubles (replaces the deepcopy snapshots of
+ * quad_experience_replay.py:99-104; also the teacher-forcing hook of the parity tests).
+ * Layout per drone d (stride QS_STATE_STRIDE doubles): pos3 vel3 rot9 omega3 rot_damp4 cmds_damp4 ou4
+ * on_floor1 svd_count1 goal3.  */
+#define QS_STATE_STRIDE 35
+int qs_get_state(qs_handle *h, int32_t env, double *state_host /* [N*QS_STATE_STRIDE] */, int32_t *tick);
+int qs_set_state(qs_handle *h, int32_t env, const double *state_host, int32_t tick);
+
+/* Check the device NaN flag; returns QS_ERR_NAN_REWARD if set (maps to ValueError('QuadEnv: reward is Nan')). */
+int qs_check_errors(qs_handle *h);
+
+/* Time of the dominant kernel: average duration (ms) of the step kernel over the launches issued since
+ * the last call, measured with HIP events recorded on the launch stream around each launch when
+ * profiling is enabled with qs_set_profiling(h, 1). */
+int qs_set_profiling(qs_handle *h, int32_t enable);
+int qs_get_kernel_time(qs_handle *h, double *avg_ms, int64_t *launches);
+
+/*
+ * Random numbers.  Every stochastic term of the reference is drawn from a
+ * counter-based Philox4x32-10 generator:   bits = philox(counter={env_global, step_ctr, site|slot<<8,
+ * i|j<<16}, key={seed_lo, seed_hi});  u = ((bits>>9)+0.5)*2^-23 (exact in fp32 and fp64);
+ * normals by Box-Muller on word pairs (0,1) and (2,3).  Results therefore do not depend on how
+ * environments are sharded over GPUs, and the CPU oracle generates bit-identical uniforms.
+ */
+enum { QS_SITE_OU = 0, QS_SITE_SENS_POS_N, QS_SITE_SENS_POS_U, QS_SITE_SENS_VEL_N, QS_SITE_SENS_VEL_U,
+       QS_SITE_SENS_OMEGA_N, QS_SITE_SENS_THETA_N, QS_SITE_SENS_THETA_U, QS_SITE_FLOOR_YAW,
+       QS_SITE_DW_I, QS_SITE_DW_IJ_V, QS_SITE_DW_IJ_W,
+       QS_SITE_DD_N, QS_SITE_DD_U, QS_SITE_DD_W,
+       QS_SITE_OBST_N, QS_SITE_OBST_U, QS_SITE_OBST_W,
+       QS_SITE_WALL, QS_SITE_CEIL,
+       QS_SITE_SPAWN, QS_SITE_SPAWN_YAW, QS_SITE_OBST_MAP, QS_SITE_SCEN, QS_SITE_SCEN_SHUFFLE };
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUADSWARM_H */

@@ -1,0 +1,110 @@
+"""Pins the CPU oracle (oracle/quadswarm_oracle.c) against the REFERENCE itself.
+
+Every fixture in tests/golden/ was produced by running the reference's QuadrotorEnvMulti in the build
+container (oracle/ref_harness/capture.py) with all random draws recorded on a sequential tape.  Here
+the tape is replayed through the oracle: float outputs must agree to 1e-9 (they typically agree to
+1e-13), every flag / index / mask / counter exactly, and the tape must be consumed draw-for-draw.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests import golden_util as gu
+
+CASES = ["c1_single_numpy", "c1_single_numba", "c2_n8_random", "c2_n8_hover_svd", "c2_n8_events", "c2_n8_episode",
+         "c2_n8_k2_numpy", "c2_n8_kall", "c3_n8_obst", "c3_n8_obst_episode", "c4_n32_svs", "c4_n6_svs_switch",
+         "c4_svs_resets"]
+TOL = 1e-9
+
+
+def mask_of(flags, bit):
+    m = 0
+    for i, f in enumerate(flags):
+        if f & bit:
+            m |= 1 << i
+    return m
+
+
+def check_episode_stats(st, info, n, use_obstacles):
+    cnt = np.array(info.ep_counters)
+    assert cnt[0] == st["num_collisions"] and cnt[3] == st["num_collisions_with_room"]
+    assert cnt[4] == st["num_collisions_with_floor"] and cnt[5] == st["num_collisions_with_wall"]
+    assert cnt[6] == st["num_collisions_with_ceiling"] and cnt[1] == st["num_collisions_after_settle"]
+    assert cnt[2] == st["num_collisions_final_5_s"]
+    eps = np.array(info.ep_stats)[:n]
+    # the fixture stores infos[0]['episode_extra_stats'], i.e. drone 0's distance statistics
+    np.testing.assert_allclose(eps[0, 0:3], [st["distance_to_goal_1s"], st["distance_to_goal_3s"],
+                                             st["distance_to_goal_5s"]], rtol=1e-9)
+    ok = np.logical_and(eps[:, 4], eps[:, 5])
+    np.testing.assert_allclose(np.sum(np.logical_and(ok, eps[:, 3])) / n, st["metric/agent_success_rate"])
+    np.testing.assert_allclose(np.sum(np.logical_and(ok, 1 - eps[:, 3])) / n, st["metric/agent_deadlock_rate"])
+    np.testing.assert_allclose(1.0 - np.sum(ok) / n, st["metric/agent_col_rate"])
+    np.testing.assert_allclose(1.0 - np.sum(eps[:, 4]) / n, st["metric/agent_neighbor_col_rate"])
+    np.testing.assert_allclose(1.0 - np.sum(eps[:, 5]) / n, st["metric/agent_obst_col_rate"])
+    if use_obstacles:
+        assert cnt[7] == st["num_collisions_obst_quad"] and cnt[8] == st["num_collisions_obst_quad_after_settle"]
+        assert cnt[9] == st["num_collisions_obst_quad_3_5"] and cnt[10] == st["num_collisions_obst_quad_5"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_replay(name):
+    g, cfgd = gu.load(name)
+    cfg = gu.config_from_golden(cfgd)
+    n = cfgd["num_agents"]
+    env = orc.OracleEnv(cfg, tape=g["tape"])
+    obs0 = env.reset()
+    assert env.tape_pos == g["tape_pos"][0], "reset consumed a different number of draws than the reference"
+    np.testing.assert_allclose(obs0, g["obs0"], rtol=0, atol=TOL)
+    s, tick = env.get_state()
+    np.testing.assert_allclose(s[:, :18], gu.state_from_golden(g, "s0_")[:, :18], rtol=0, atol=TOL)
+
+    force = {int(t): k for k, t in enumerate(g["force_steps"])}
+    ep_stats = {d["step"]: d["stats"] for d in json.loads(str(g["ep_stats"]))}
+    checked_eps = 0
+    steps = g["actions"].shape[0]
+    worst = 0.0
+    for t in range(steps):
+        if t in force:
+            k = force[t]
+            s, tick = env.get_state()
+            s[:, 0:3] = g["force_pos"][k]; s[:, 3:6] = g["force_vel"][k]
+            s[:, 6:15] = g["force_rot"][k].reshape(n, 9); s[:, 15:18] = g["force_omega"][k]
+            env.set_state(s, tick)
+        obs, rew, done, ri = env.step(g["actions"][t])
+        info = env.info()
+        assert not info.tape_underrun
+        assert env.tape_pos == g["tape_pos"][t + 1], f"step {t}: tape position {env.tape_pos} != {g['tape_pos'][t + 1]}"
+        np.testing.assert_array_equal(done, g["done"][t], err_msg=f"done step {t}")
+        for nm, a, b in (("obs", obs, g["obs"][t]), ("rew", rew, g["rew"][t]), ("rew_info", ri, g["rew_info"][t])):
+            err = np.abs(a - b).max()
+            worst = max(worst, err)
+            assert err <= TOL, f"{nm} step {t}: max abs err {err}"
+        s, tick = env.get_state()
+        ref = gu.state_from_golden(g, "s_", t)
+        err = np.abs(s[:, :30] - ref[:, :30]).max()
+        assert err <= TOL, f"state step {t}: {err}"
+        np.testing.assert_array_equal(s[:, 30], ref[:, 30], err_msg=f"on_floor step {t}")
+        np.testing.assert_allclose(s[:, 32:35], ref[:, 32:35], atol=TOL, err_msg=f"goal step {t}")
+        assert tick == g["s_tick"][t][0]
+        flags = list(info.flags)[:n]
+        if not done.any():
+            assert mask_of(flags, 2) == mask_of(g["s_crashed_floor"][t], 1)
+            assert mask_of(flags, 4) == mask_of(g["s_crashed_wall"][t], 1)
+            assert mask_of(flags, 8) == mask_of(g["s_crashed_ceiling"][t], 1)
+            assert info.unique_col_mask == int(g["unique_col"][t]), f"unique collisions step {t}"
+            np.testing.assert_array_equal(np.array(info.col_pair_mask[:n], dtype=np.uint64), g["curr_pairs"][t])
+            np.testing.assert_array_equal(np.array(info.new_pair_mask[:n], dtype=np.uint64), g["new_pairs"][t])
+            assert info.obst_new_mask == int(g["obst_new"][t]), f"obstacle collisions step {t}"
+            assert info.obst_hit_mask == int(g["obst_hit"][t])
+            assert info.room_new_mask == int(g["room_new"][t]), f"room collisions step {t}"
+            np.testing.assert_allclose(np.array(info.acc)[:n], g["s_acc"][t], atol=1e-7)
+        np.testing.assert_array_equal(np.array(info.counters), g["counters"][t], err_msg=f"counters step {t}")
+        if done.any():  # episode stats (quadrotor_multi.py:626-718)
+            check_episode_stats(ep_stats[t], info, n, cfgd["use_obstacles"])
+            checked_eps += 1
+    assert env.tape_pos == len(g["tape"])
+    assert checked_eps == len(ep_stats)
+
+    print(f"{name}: worst abs err {worst:.3e}")
