@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py - env-steps/s of the HIP QuadSwarm stepper on BASELINE.json's metric.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one control step (= 2 physics sub-steps) of all environments of the workload on synthetic
+U(-1,1)^4 actions that are already resident in HBM.  Workload at N=1 (BASELINE.json configs[1], "C2"):
+8 drones x 1024 envs, static_same_goal, 6 visible neighbours (obs 54), downwash on, Numba-path semantics,
+sensor + thrust noise on, auto-resets included.  Each extra GPU gets its own 1024-env shard (weak scaling)
+and every rollout step ends with ONE RCCL all-gather of the observations.
+
+metric:  env-steps/s = drones x envs x sim_steps(2) x control-steps/s   (BASELINE.md "Metric")
+roofline: HBM-bound; algorithmic bytes per drone-control-step = 500 B (read state 120 + flags 4 +
+          goal 12 + action 16, write state 120 + flags 4 + obs 216 + reward 4 + done 4); achieved = 500 B x drones
+          per launch / average step-kernel duration, measured here with HIP events on the launch stream.
+cpu_baseline: the validated C oracle (oracle/, OpenMP over envs) on this box's host cores, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+ALGO_BYTES_PER_DRONE_STEP = {"c2": 500, "c3": 456, "c4": 500, "c1": 356}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+WORKLOADS = {
+    "c2": dict(num_envs=1024, kw=dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True,
+                                      use_numba=True, collision_hitbox_radius=2.0, collision_falloff_radius=4.0,
+                                      quads_mode="static_same_goal",
+                                      rew_coeff=dict(quadcol_bin=5.0, quadcol_bin_smooth_max=10.0))),
+    "c3": dict(num_envs=1024, kw=dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_downwash=True,
+                                      use_numba=True, collision_falloff_radius=4.0, use_obstacles=True, obst_density=0.2,
+                                      obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_static_same_goal",
+                                      obs_repr="xyz_vxyz_R_omega_floor",
+                                      rew_coeff=dict(quadcol_bin=5.0, quadcol_bin_smooth_max=4.0, quadcol_bin_obst=5.0))),
+    "c4": dict(num_envs=512, kw=dict(num_agents=32, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True,
+                                     use_numba=True, collision_falloff_radius=4.0, quads_mode="swarm_vs_swarm",
+                                     rew_coeff=dict(quadcol_bin=5.0, quadcol_bin_smooth_max=10.0))),
+    "c1": dict(num_envs=1, kw=dict(num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none", use_numba=False)),
+}
+
+
+def cpu_baseline(workload, seconds):
+    """Times the oracle (kind 'port': validated C restatement of the reference) on the host cores."""
+    from oracle import oracle as orc
+    from quad_swarm_rl_amd import config as qcfg
+    w = WORKLOADS[workload]
+    threads = os.cpu_count() or 1
+    num_envs = min(w["num_envs"], max(64, 4 * threads))
+    cfg = qcfg.make_config(num_envs=num_envs, seed=0, **w["kw"])
+    batch = orc.OracleBatch(cfg, num_envs)
+    batch.reset()
+    n = cfg.num_agents
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-1, 1, size=(8, num_envs, n, 4))
+    for t in range(3):
+        batch.step(acts[t % 8])
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for t in range(10):
+            batch.step(acts[(steps + t) % 8])
+        steps += 10
+    dt = time.perf_counter() - t0
+    return dict(value=num_envs * n * 2 * steps / dt, unit="env-steps/s", cores=threads, kind="port",
+                sample=f"{num_envs} envs x {n} drones x {steps} control steps ({dt:.1f} s), C oracle, OpenMP over envs, float64")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's env count per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=400, help="steps of the HIP-event kernel-duration pass")
+    ap.add_argument("--no-gather", action="store_true", help="skip the per-step obs all-gather at N>1")
+    args = ap.parse_args()
+
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP stepper has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    w = WORKLOADS[args.workload]
+    E = args.envs_per_gpu or w["num_envs"]
+    cfg = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f32", **w["kw"])
+    st = native.Stepper(cfg, device=local_rank)
+    N, T, D = cfg.num_agents, E * cfg.num_agents, st.obs_dim
+    stream = torch.cuda.current_stream(local_rank)
+
+    # synthetic actions, resident in HBM before the timed region: a ring of pre-drawn U(-1,1)^4 batches
+    gen = torch.Generator(device=f"cuda:{local_rank}")
+    gen.manual_seed(1234 + rank)
+    ring = 64
+    actions = (torch.rand((ring, T, 4), device=f"cuda:{local_rank}", generator=gen, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+    aptr, astride = actions.data_ptr(), T * 4 * 4
+    obs = st.tensor("obs")
+    gathered = torch.empty((world * T, D), device=f"cuda:{local_rank}", dtype=torch.float32) if world > 1 else None
+
+    def run(k, offset=0):
+        for t in range(k):
+            st.step(aptr + ((offset + t) % ring) * astride, stream=stream)
+            if gathered is not None and not args.no_gather:
+                dist.all_gather_into_tensor(gathered, obs)
+
+    st.reset(stream=stream)
+    run(args.warmup)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, args.warmup)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    st.check_errors()
+
+    # dominant-kernel duration: HIP events recorded on the launch stream around every step-kernel launch
+    st.set_profiling(True)
+    for t in range(args.profile_steps):
+        st.step(aptr + (t % ring) * astride, stream=stream)
+    kernel_ms, launches = st.kernel_time()
+    st.set_profiling(False)
+
+    if rank == 0:
+        value = world * T * 2 * args.steps / elapsed
+        algo = ALGO_BYTES_PER_DRONE_STEP[args.workload]
+        achieved = algo * T / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "env-steps/s (drones x envs x sim_steps)", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {N} drones x {E} envs per GPU, {WORKLOADS[args.workload]['kw'].get('quads_mode', 'static_same_goal')}, "
+                                   f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
+                       "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N,
+                       "obs_gather": "rccl all_gather_into_tensor per step" if (world > 1 and not args.no_gather) else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "qs_step_kernel<float>", "kernel_avg_us": kernel_ms * 1e3, "kernel_launches": launches,
+                         "algorithmic_bytes_per_launch": algo * T},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    st.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,6 +195,11 @@ int qs_set_reward_coeffs(qs_handle *h, const double *coeffs /* [QS_REW_COUNT] */
 int qs_get_state(qs_handle *h, int32_t env, double *state_host /* [N*QS_STATE_STRIDE] */, int32_t *tick);
 int qs_set_state(qs_handle *h, int32_t env, const double *state_host, int32_t tick);
 
+/* Plain copies between host memory and any device pointer of qs_buffers (for callers without a HIP
+ * runtime binding of their own, e.g. the ctypes stub of INTEGRATION.md).  Synchronous. */
+int qs_memcpy_d2h(qs_handle *h, void *host_dst, const void *dev_src, size_t bytes);
+int qs_memcpy_h2d(qs_handle *h, void *dev_dst, const void *host_src, size_t bytes);
+
 /* Check the device NaN flag; returns QS_ERR_NAN_REWARD if set (maps to ValueError('QuadEnv: reward is Nan')). */
 int qs_check_errors(qs_handle *h);
 

@@ -1,0 +1,585 @@
+// qs_device.h - device-side building blocks of the QuadSwarm stepper (gfx950 / CDNA4, wave64).
+//
+// Everything here is per-lane code: one lane owns one drone.  Cross-drone data of one environment is
+// exchanged through LDS by the kernels in quadswarm_hip.hip.  Templated on `real` (float = production,
+// double = parity instantiation).  Reference citations are relative to gym_art/quadrotor_multi/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/quadswarm.h"
+
+namespace qs {
+
+enum : uint32_t {
+    F_ON_FLOOR = 1u << 0, F_CRASH_FLOOR = 1u << 1, F_CRASH_WALL = 1u << 2, F_CRASH_CEIL = 1u << 3,
+    F_PREV_WALL = 1u << 4, F_PREV_CEIL = 1u << 5, F_PREV_ROOM = 1u << 6, F_PREV_OBST = 1u << 7,
+    F_REACHED = 1u << 8, F_COL_AGENT_OK = 1u << 9, F_COL_OBST_OK = 1u << 10,
+    F_SVD_SHIFT = 16, F_SVD_MASK = 0xffu << 16
+};
+
+// per-lane event bits exchanged through LDS inside the step kernel
+enum : uint32_t { B_OBST_HIT = 1, B_OBST_NEW = 2, B_FLOOR = 4, B_WALL_NEW = 8, B_CEIL_NEW = 16, B_ROOM_NEW = 32, B_DOWNWASH = 64 };
+
+#define QS_PI_D 3.141592653589793
+
+// ------------------------------------------------------------------------------------------------
+// math dispatch
+// ------------------------------------------------------------------------------------------------
+template <typename real> struct M;
+template <> struct M<float> {
+    static __device__ __forceinline__ float sqrt(float x) { return __fsqrt_rn(x); }
+    static __device__ __forceinline__ float sin(float x) { return sinf(x); }
+    static __device__ __forceinline__ float cos(float x) { return cosf(x); }
+    static __device__ __forceinline__ void sincos(float x, float *s, float *c) { sincosf(x, s, c); }
+    static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
+    static __device__ __forceinline__ float log(float x) { return logf(x); }
+    static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
+    static __device__ __forceinline__ float fabs(float x) { return fabsf(x); }
+    static __device__ __forceinline__ float fmax(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float fmin(float a, float b) { return fminf(a, b); }
+    static __device__ __forceinline__ float floor(float x) { return floorf(x); }
+    // sin/cos of 2*pi*u for u in (0,1): v_sin_f32 / v_cos_f32 take their argument in revolutions
+    static __device__ __forceinline__ void sincos2pi(float u, float *s, float *c) {
+        *s = __builtin_amdgcn_sinf(u); *c = __builtin_amdgcn_cosf(u);
+    }
+};
+template <> struct M<double> {
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+    static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
+    static __device__ __forceinline__ void sincos(double x, double *s, double *c) { *s = ::sin(x); *c = ::cos(x); }
+    static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
+    static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
+    static __device__ __forceinline__ double fmax(double a, double b) { return ::fmax(a, b); }
+    static __device__ __forceinline__ double fmin(double a, double b) { return ::fmin(a, b); }
+    static __device__ __forceinline__ double floor(double x) { return ::floor(x); }
+    static __device__ __forceinline__ void sincos2pi(double u, double *s, double *c) {
+        double th = 2.0 * QS_PI_D * u; *s = ::sin(th); *c = ::cos(th);
+    }
+};
+
+template <typename real> __device__ __forceinline__ real clipr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+template <typename real> __device__ __forceinline__ real norm3(const real v[3]) { return M<real>::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+template <typename real> __device__ __forceinline__ real dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10, the stream specified in include/quadswarm.h
+// ------------------------------------------------------------------------------------------------
+struct RngKey { uint32_t k0, k1, env, step; };
+
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t w[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
+}
+__device__ __forceinline__ void rng_words(const RngKey &k, int site, int slot, int i, int j, uint32_t w[4]) {
+    philox4x32(k.env, k.step, (uint32_t)site | ((uint32_t)slot << 8), (uint32_t)i | ((uint32_t)j << 16), k.k0, k.k1, w);
+}
+template <typename real> __device__ __forceinline__ real u01(uint32_t x) { return ((real)(x >> 9) + (real)0.5) * (real)(1.0 / 8388608.0); }
+
+// n <= 4 standard normals (Box-Muller on word pairs (0,1),(2,3))
+template <typename real, int NN> __device__ __forceinline__ void rng_normal(const RngKey &k, int site, int slot, int i, int j, real z[NN]) {
+    uint32_t w[4];
+    rng_words(k, site, slot, i, j, w);
+    real r0 = M<real>::sqrt((real)-2.0 * M<real>::log(u01<real>(w[0]))), s0, c0;
+    M<real>::sincos2pi(u01<real>(w[1]), &s0, &c0);
+    z[0] = r0 * c0;
+    if (NN > 1) z[1] = r0 * s0;
+    if (NN > 2) {
+        real r1 = M<real>::sqrt((real)-2.0 * M<real>::log(u01<real>(w[2]))), s1, c1;
+        M<real>::sincos2pi(u01<real>(w[3]), &s1, &c1);
+        z[2] = r1 * c1;
+        if (NN > 3) z[3] = r1 * s1;
+    }
+}
+template <typename real, int NN> __device__ __forceinline__ void rng_uniform(const RngKey &k, int site, int slot, int i, int j, real lo, real hi, real u[NN]) {
+    uint32_t w[4];
+    rng_words(k, site, slot, i, j, w);
+#pragma unroll
+    for (int q = 0; q < NN; ++q) u[q] = lo + (hi - lo) * u01<real>(w[q]);
+}
+template <typename real> __device__ __forceinline__ real rng_uniform1(const RngKey &k, int site, int slot, int i, int j, real lo, real hi) {
+    real u[1]; rng_uniform<real, 1>(k, site, slot, i, j, lo, hi, u); return u[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernel constants (converted once on the host from qs_config)
+// ------------------------------------------------------------------------------------------------
+template <typename real> struct Consts {
+    real inertia[3], inv_inertia[3], arm, mass, inv_mass;
+    real prop_cross[4][3], prop_ccw[4], thrust_max[4], torque_max[4];
+    real motor_tau_up, motor_tau_down, motor_linearity, vel_damp, damp_omega_quadratic, omega_max;
+    real thrust_noise_sigma, ou_theta;
+    real dt, control_dt;
+    real room_lo[3], room_hi[3];
+    real floor_threshold;
+    real pos_norm_std, pos_unif_range, vel_norm_std, vel_unif_range, quat_norm_std, quat_unif_range, gyro_noise_density;
+    real collision_threshold, collision_falloff_threshold;
+    real rew_coeff[QS_REW_COUNT];
+    real spawn_box, approach_goal_metric;
+    real nbr_clip_pos[3], nbr_clip_vel[3];
+    real obst_radius, obst_hit_threshold, obst_size, room_mid_z;
+    int32_t sim_steps, ep_len, floor_mode, svd_period, sense_noise, obs_repr, self_dim, obs_dim;
+    int32_t num_neighbors, use_downwash, use_obstacles, scenario, num_obstacles, obst_area[2];
+    int32_t grace_steps, final_steps, control_freq;
+    int32_t cube_fd[2];   // int(n ** (1/3)) for the two half-swarms, evaluated on the host with libm's pow (scenarios/base.py:98-99)
+    uint32_t seed_lo, seed_hi;
+    int32_t env_id_offset, num_envs, num_agents;
+};
+
+// per-drone dynamic state held in registers
+template <typename real> struct Drone {
+    real pos[3], vel[3], rot[9], omega[3];
+    real rot_damp[4], cmds_damp[4], ou[4];
+    uint32_t flags;
+};
+
+template <typename real> __device__ __forceinline__ void matmul3(const real a[9], const real b[9], real o[9]) {
+    real t[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[r * 3 + c] = a[r * 3] * b[c] + a[r * 3 + 1] * b[3 + c] + a[r * 3 + 2] * b[6 + c];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) o[q] = t[q];
+}
+template <typename real> __device__ __forceinline__ void yaw_rot(real theta, real r[9]) {
+    real s, c; M<real>::sincos(theta, &s, &c);
+    r[0] = c; r[1] = -s; r[2] = 0; r[3] = s; r[4] = c; r[5] = 0; r[6] = 0; r[7] = 0; r[8] = 1;
+}
+
+// nearest rotation (orthogonal polar factor) == U V^T of the SVD, quadrotor_dynamics.py:546-551.
+// Newton iteration X <- (X + X^-T)/2; from a nearly orthogonal start 4 iterations reach round-off.
+template <typename real> __device__ __forceinline__ void polar_rotation(real x[9]) {
+#pragma unroll 1
+    for (int it = 0; it < 5; ++it) {
+        real c00 = x[4] * x[8] - x[5] * x[7], c01 = x[5] * x[6] - x[3] * x[8], c02 = x[3] * x[7] - x[4] * x[6];
+        real c10 = x[2] * x[7] - x[1] * x[8], c11 = x[0] * x[8] - x[2] * x[6], c12 = x[1] * x[6] - x[0] * x[7];
+        real c20 = x[1] * x[5] - x[2] * x[4], c21 = x[2] * x[3] - x[0] * x[5], c22 = x[0] * x[4] - x[1] * x[3];
+        real inv = (real)1.0 / (x[0] * c00 + x[1] * c01 + x[2] * c02), h = (real)0.5;
+        x[0] = h * (x[0] + c00 * inv); x[1] = h * (x[1] + c01 * inv); x[2] = h * (x[2] + c02 * inv);
+        x[3] = h * (x[3] + c10 * inv); x[4] = h * (x[4] + c11 * inv); x[5] = h * (x[5] + c12 * inv);
+        x[6] = h * (x[6] + c20 * inv); x[7] = h * (x[7] + c21 * inv); x[8] = h * (x[8] + c22 * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one physics sub-step: step1_numba quadrotor_dynamics.py:348-383 =
+//   calculate_torque_integrate_rotations_and_update_omega :498-566 + room clip :360-367 +
+//   floor_interaction_numba :570-639 (numpy semantics :389-457 behind floor_mode) +
+//   compute_velocity_and_acceleration :643-649
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+__device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key, int drone, int sub, Drone<real> &d,
+                                        const real cmds[4], real acc[3]) {
+    const real dt = c.dt;
+    real thrust_z = 0, torque[3] = {0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        real cmd = cmds[m];  // already clipped to [0,1] by RawControl
+        real tau = (cmd < d.cmds_damp[m]) ? c.motor_tau_down : c.motor_tau_up;
+        tau = tau > (real)1 ? (real)1 : tau;
+        real trot = M<real>::sqrt(cmd);
+        d.rot_damp[m] = tau * (trot - d.rot_damp[m]) + d.rot_damp[m];
+        real cd = d.rot_damp[m] * d.rot_damp[m];
+        cd = clipr<real>(cd + cmd * d.ou[m], (real)0, (real)1);
+        d.cmds_damp[m] = cd;
+        real th = c.thrust_max[m] * (((real)1 - c.motor_linearity) * (cd * cd) + c.motor_linearity * cd);
+        torque[0] += c.prop_cross[m][0] * th;
+        torque[1] += c.prop_cross[m][1] * th;
+        torque[2] += c.prop_cross[m][2] * th + c.torque_max[m] * c.prop_ccw[m] * cd;
+        thrust_z += th;
+    }
+    // Rodrigues rotation update (:535-544)
+    real *R = d.rot, *om = d.omega;
+    real wv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) wv[r] = R[r * 3] * om[0] + R[r * 3 + 1] * om[1] + R[r * 3 + 2] * om[2];
+    real wn = norm3<real>(wv);
+    if (wn != (real)0) {
+        real iw = (real)1 / wn;
+        real kx = wv[0] * iw, ky = wv[1] * iw, kz = wv[2] * iw;
+        real K[9] = {0, -kz, ky, kz, 0, -kx, -ky, kx, 0};
+        real s, cc; M<real>::sincos(wn * dt, &s, &cc);
+        cc = (real)1 - cc;
+        real KK[9], dR[9];
+        matmul3<real>(K, K, KK);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dR[q] = ((q % 4 == 0) ? (real)1 : (real)0) + s * K[q] + cc * KK[q];
+        matmul3<real>(dR, R, R);
+    }
+    // rare re-orthogonalisation (:546-551); counter in flags bits 16..23
+    uint32_t svd = ((d.flags & F_SVD_MASK) >> F_SVD_SHIFT) + 1;
+    if ((int)svd >= c.svd_period) { polar_rotation<real>(R); svd = 0; }
+    d.flags = (d.flags & ~F_SVD_MASK) | (svd << F_SVD_SHIFT);
+    // omega update (:555-560)
+    real Iw[3] = {c.inertia[0] * om[0], c.inertia[1] * om[1], c.inertia[2] * om[2]};
+    real a0 = -om[0], a1 = -om[1], a2 = -om[2];
+    real cr[3] = {a1 * Iw[2] - a2 * Iw[1], a2 * Iw[0] - a0 * Iw[2], a0 * Iw[1] - a1 * Iw[0]};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        real od = c.inv_inertia[q] * (cr[q] + torque[q]);
+        real damp = clipr<real>(c.damp_omega_quadratic * (om[q] * om[q]), (real)0, (real)1);
+        om[q] = clipr<real>(om[q] + ((real)1 - damp) * dt * od, -c.omega_max, c.omega_max);
+    }
+    // position, room clip and wall / ceiling flags (:360-367, :563)
+    real before[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { before[q] = d.pos[q] + dt * d.vel[q]; d.pos[q] = clipr<real>(before[q], c.room_lo[q], c.room_hi[q]); }
+    uint32_t f = d.flags & ~(F_CRASH_WALL | F_CRASH_CEIL | F_CRASH_FLOOR);
+    if (before[0] != d.pos[0] || before[1] != d.pos[1]) f |= F_CRASH_WALL;
+    if (before[2] > d.pos[2]) f |= F_CRASH_CEIL;
+    // floor interaction
+    real force[3] = {R[2] * thrust_z, R[5] * thrust_z, R[8] * thrust_z};
+    if (d.pos[2] <= c.floor_threshold) {
+        d.pos[2] = c.floor_threshold;
+        if (f & F_ON_FLOOR) {
+            real theta = M<real>::atan2(R[3], R[0] + (real)1e-6);
+            yaw_rot<real>(theta, R);
+            real fr = (real)0.6 * (c.mass * (real)9.81 - force[2]);
+            real vn = norm3<real>(d.vel);
+            bool is_static = (c.floor_mode == QS_FLOOR_NUMPY) ? (vn == (real)0) : (vn < (real)1e-6);
+            if (is_static) {
+                real fxy = M<real>::sqrt(force[0] * force[0] + force[1] * force[1]);
+                fxy = M<real>::fmax(fxy - fr, (real)0);
+                if (fxy == (real)0) { force[0] = 0; force[1] = 0; }
+                else {
+                    real ang = M<real>::atan2(force[1], force[0]), s, cs; M<real>::sincos(ang, &s, &cs);
+                    force[0] = fxy * cs; force[1] = fxy * s;
+                }
+            } else {
+                real ang = (c.floor_mode == QS_FLOOR_NUMPY) ? M<real>::atan2((real)-1 * d.vel[1], (real)-1 * d.vel[0])
+                                                            : M<real>::atan2(d.vel[1], d.vel[0]);
+                real s, cs; M<real>::sincos(ang, &s, &cs);
+                force[0] = force[0] - cs * fr; force[1] = force[1] - s * fr;
+            }
+        } else {
+            f |= F_ON_FLOOR | F_CRASH_FLOOR;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { d.vel[q] = 0; om[q] = 0; }
+            real theta = M<real>::atan2(R[3], R[0] + (real)1e-6);
+            if (R[8] < (real)0) {
+                if (c.floor_mode != QS_FLOOR_NUMPY) {
+                    theta = rng_uniform1<real>(key, QS_SITE_FLOOR_YAW, sub * 64, drone, 0, (real)-QS_PI_D, (real)QS_PI_D);
+                    yaw_rot<real>(theta, R);
+                } else {
+                    real xy[3] = {-d.pos[0], -d.pos[1], 0}, n = norm3<real>(xy);
+                    if (n >= (real)0.00001) { xy[0] /= n; xy[1] /= n; }
+                    for (int t = 0; t < 64; ++t) {
+                        theta = rng_uniform1<real>(key, QS_SITE_FLOOR_YAW, sub * 64 + t, drone, 0, (real)-QS_PI_D, (real)QS_PI_D);
+                        yaw_rot<real>(theta, R);
+                        if (!(R[0] * xy[0] + R[3] * xy[1] < (real)0.5)) break;
+                    }
+                }
+            } else {
+                yaw_rot<real>(theta, R);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { d.cmds_damp[m] = 0; d.rot_damp[m] = 0; }
+        }
+        acc[0] = c.inv_mass * force[0];
+        acc[1] = c.inv_mass * force[1];
+        acc[2] = M<real>::fmax((real)0, (real)-9.81 + c.inv_mass * force[2]);
+    } else {
+        f &= ~F_ON_FLOOR;
+        acc[0] = c.inv_mass * force[0];
+        acc[1] = c.inv_mass * force[1];
+        acc[2] = (real)-9.81 + c.inv_mass * force[2];
+    }
+    d.flags = f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) d.vel[q] = ((real)1 - c.vel_damp) * d.vel[q] + dt * acc[q];
+}
+
+// rot2quat sensor_noise.py:34-63
+template <typename real> __device__ __forceinline__ void rot2quat(const real r[9], real q[4]) {
+    real trace = r[0] + r[4] + r[8];
+    if (trace > (real)0) {
+        real S = M<real>::sqrt(trace + (real)1) * (real)2, iS = (real)1 / S;
+        q[0] = (real)0.25 * S; q[1] = (r[7] - r[5]) * iS; q[2] = (r[2] - r[6]) * iS; q[3] = (r[3] - r[1]) * iS;
+    } else if (r[0] > r[4] && r[0] > r[8]) {
+        real S = M<real>::sqrt((real)1 + r[0] - r[4] - r[8]) * (real)2, iS = (real)1 / S;
+        q[0] = (r[7] - r[5]) * iS; q[1] = (real)0.25 * S; q[2] = (r[1] + r[3]) * iS; q[3] = (r[2] + r[6]) * iS;
+    } else if (r[4] > r[8]) {
+        real S = M<real>::sqrt((real)1 + r[4] - r[0] - r[8]) * (real)2, iS = (real)1 / S;
+        q[0] = (r[2] - r[6]) * iS; q[1] = (r[1] + r[3]) * iS; q[2] = (real)0.25 * S; q[3] = (r[5] + r[7]) * iS;
+    } else {
+        real S = M<real>::sqrt((real)1 + r[8] - r[0] - r[4]) * (real)2, iS = (real)1 / S;
+        q[0] = (r[3] - r[1]) * iS; q[1] = (r[2] + r[6]) * iS; q[2] = (r[5] + r[7]) * iS; q[3] = (real)0.25 * S;
+    }
+}
+
+// Self observation with sensor noise: get_state.py:6-72 + sensor_noise.py:112-218,:235-261.
+// Writes self_dim values to o[] (o may live in LDS).
+template <typename real>
+__device__ __forceinline__ void self_obs(const Consts<real> &c, const RngKey &key, int drone, int pass, const Drone<real> &d,
+                                         const real goal[3], real *o) {
+    real p[3], v[3], w[3], R[9];
+    if (!c.sense_noise) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { p[q] = d.pos[q]; v[q] = d.vel[q]; w[q] = d.omega[q]; }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R[q] = d.rot[q];
+    } else {
+        real z[3], u[3];
+        rng_normal<real, 3>(key, QS_SITE_SENS_POS_N, pass, drone, 0, z);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) p[q] = d.pos[q] + c.pos_norm_std * z[q];
+        if (c.pos_unif_range != (real)0) {
+            rng_uniform<real, 3>(key, QS_SITE_SENS_POS_U, pass, drone, 0, -c.pos_unif_range, c.pos_unif_range, u);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) p[q] += u[q];
+        }
+        rng_normal<real, 3>(key, QS_SITE_SENS_VEL_N, pass, drone, 0, z);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = d.vel[q] + c.vel_norm_std * z[q];
+        if (c.vel_unif_range != (real)0) {
+            rng_uniform<real, 3>(key, QS_SITE_SENS_VEL_U, pass, drone, 0, -c.vel_unif_range, c.vel_unif_range, u);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) v[q] += u[q];
+        }
+        rng_normal<real, 3>(key, QS_SITE_SENS_OMEGA_N, pass, drone, 0, z);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w[q] = d.omega[q] + c.gyro_noise_density * z[q];
+        real th[3] = {0, 0, 0};
+        if (c.quat_norm_std != (real)0) {
+            rng_normal<real, 3>(key, QS_SITE_SENS_THETA_N, pass, drone, 0, z);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) th[q] = c.quat_norm_std * z[q];
+        }
+        if (c.quat_unif_range != (real)0) {
+            rng_uniform<real, 3>(key, QS_SITE_SENS_THETA_U, pass, drone, 0, -c.quat_unif_range, c.quat_unif_range, u);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) th[q] += u[q];
+        }
+        // R -> quat -> quat (x) dq(theta) -> R  (sensor_noise.py:205-210; identity dq still re-derives R)
+        real nt = norm3<real>(th), qsq = nt * nt / (real)4, qt[4];
+        if (qsq < (real)1) { qt[0] = M<real>::sqrt((real)1 - qsq); qt[1] = th[0] * (real)0.5; qt[2] = th[1] * (real)0.5; qt[3] = th[2] * (real)0.5; }
+        else { real ww = (real)1 / M<real>::sqrt((real)1 + qsq), f = (real)0.5 * ww; qt[0] = ww; qt[1] = th[0] * f; qt[2] = th[1] * f; qt[3] = th[2] * f; }
+        real qn = M<real>::sqrt(qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qt[q] /= qn;
+        real q[4];
+        rot2quat<real>(d.rot, q);
+        real qw = q[0] * qt[0] - q[1] * qt[1] - q[2] * qt[2] - q[3] * qt[3];
+        real qx = q[0] * qt[1] + q[1] * qt[0] - q[2] * qt[3] + q[3] * qt[2];
+        real qy = q[0] * qt[2] + q[1] * qt[3] + q[2] * qt[0] - q[3] * qt[1];
+        real qz = q[0] * qt[3] - q[1] * qt[2] + q[2] * qt[1] + q[3] * qt[0];
+        R[0] = (real)1 - 2 * qy * qy - 2 * qz * qz; R[1] = 2 * qx * qy - 2 * qz * qw; R[2] = 2 * qx * qz + 2 * qy * qw;
+        R[3] = 2 * qx * qy + 2 * qz * qw; R[4] = (real)1 - 2 * qx * qx - 2 * qz * qz; R[5] = 2 * qy * qz - 2 * qx * qw;
+        R[6] = 2 * qx * qz - 2 * qy * qw; R[7] = 2 * qy * qz + 2 * qx * qw; R[8] = (real)1 - 2 * qx * qx - 2 * qy * qy;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { o[q] = p[q] - goal[q]; o[3 + q] = v[q]; o[15 + q] = w[q]; }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) o[6 + q] = R[q];
+    if (c.obs_repr == QS_OBS_XYZ_VXYZ_R_OMEGA_FLOOR) o[18] = p[2];
+    else if (c.obs_repr == QS_OBS_XYZ_VXYZ_R_OMEGA_WALL) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { o[18 + q] = clipr<real>(p[q] - c.room_lo[q], (real)0, (real)5); o[21 + q] = clipr<real>(c.room_hi[q] - p[q], (real)0, (real)5); }
+    }
+}
+
+// compute_new_vel collisions/utils.py:8-18
+template <typename real> __device__ __forceinline__ void compute_new_vel(real max_vel_magn, real vel[3], const real shift[3], real decay) {
+    real vn[3] = {vel[0] + shift[0], vel[1] + shift[1], vel[2] + shift[2]};
+    real mag = norm3<real>(vn), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
+    real nm = M<real>::fmin(mag * decay, max_vel_magn);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { real nv = (vn[q] / den) * nm; real sh = nv - vel[q]; vel[q] += sh; }
+}
+// compute_new_omega collisions/utils.py:22-34
+template <typename real> __device__ __forceinline__ void compute_new_omega(const real u[4], real out[3]) {
+    real mag = norm3<real>(u), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) out[q] = (u[q] / den) * u[3];
+}
+
+// perform_collision_with_obstacle collisions/obstacles.py:23-50 (+ :9-20)
+template <typename real>
+__device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const RngKey &key, int drone, Drone<real> &d, real ox, real oy) {
+    real n[3] = {d.pos[0] - ox, d.pos[1] - oy, 0};
+    real mag = norm3<real>(n), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
+    n[0] /= den; n[1] /= den;
+    real vmag = norm3<real>(d.vel), nv[3] = {vmag * n[0], vmag * n[1], vmag * n[2]}, noise[3] = {0, 0, 0};
+    for (int t = 0; t < 3; ++t) {
+        real cons[3], n1[3], tmp[3], chk[3];
+        rng_normal<real, 3>(key, QS_SITE_OBST_N, t * 2 + 0, drone, 0, cons);
+        rng_normal<real, 3>(key, QS_SITE_OBST_N, t * 2 + 1, drone, 0, n1);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { tmp[q] = (real)0.1 * cons[q] + (real)0.05 * n1[q]; chk[q] = nv[q] + tmp[q]; }
+        if (dot3<real>(chk, n) > (real)0) { noise[0] = tmp[0]; noise[1] = tmp[1]; noise[2] = tmp[2]; break; }
+    }
+    real diff[3] = {d.pos[0] - ox, d.pos[1] - oy, d.pos[2] - c.room_mid_z};
+    bool inside = norm3<real>(diff) < c.obst_size / (real)2;
+    real decay = inside ? rng_uniform1<real>(key, QS_SITE_OBST_U, 0, drone, 0, (real)1, (real)1)
+                        : rng_uniform1<real>(key, QS_SITE_OBST_U, 0, drone, 0, (real)0.2, (real)0.8);
+    real shift[3] = {nv[0] - d.vel[0] + noise[0], nv[1] - d.vel[1] + noise[1], nv[2] - d.vel[2] + noise[2]};
+    compute_new_vel<real>(vmag, d.vel, shift, decay);
+    uint32_t w[4]; rng_words(key, QS_SITE_OBST_W, 0, drone, 0, w);
+    real u[4] = {(real)-1 + (real)2 * u01<real>(w[0]), (real)-1 + (real)2 * u01<real>(w[1]), (real)-1 + (real)2 * u01<real>(w[2]),
+                 (real)(0.5 * QS_PI_D) + (real)(QS_PI_D - 0.5 * QS_PI_D) * u01<real>(w[3])};
+    real dw[3]; compute_new_omega<real>(u, dw);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) d.omega[q] += dw[q];
+}
+
+// perform_collision_with_wall collisions/room.py:6-44 / perform_collision_with_ceiling :91-113
+template <typename real>
+__device__ __forceinline__ void collide_room(const Consts<real> &c, const RngKey &key, int drone, Drone<real> &d, bool is_wall) {
+    int site = is_wall ? QS_SITE_WALL : QS_SITE_CEIL;
+    real speed = norm3<real>(d.vel), dir[3];
+    uint32_t w[4]; rng_words(key, site, 0, drone, 0, w);
+    real rs = (real)0.2 * speed + ((real)0.8 * speed - (real)0.2 * speed) * u01<real>(w[0]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) dir[q] = (real)-1 + (real)2 * u01<real>(w[1 + q]);
+    rs = clipr<real>(rs, (real)0.1, (real)6);
+    uint32_t w1[4]; rng_words(key, site, 1, drone, 0, w1);
+    if (is_wall) {
+        if (d.pos[0] == c.room_lo[0]) dir[0] = (real)0.1 + (real)0.9 * u01<real>(w1[0]);
+        else if (d.pos[0] == c.room_hi[0]) dir[0] = (real)-1 + (real)0.9 * u01<real>(w1[0]);
+        if (d.pos[1] == c.room_lo[1]) dir[1] = (real)0.1 + (real)0.9 * u01<real>(w1[1]);
+        else if (d.pos[1] == c.room_hi[1]) dir[1] = (real)-1 + (real)0.9 * u01<real>(w1[1]);
+    }
+    dir[2] = (real)-1 + (real)0.5 * u01<real>(w1[2]);
+    real dm = norm3<real>(dir);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) d.vel[q] = rs * (dir[q] / (dm + (real)1e-5));
+    rng_words(key, site, 2, drone, 0, w);
+    real u[4] = {(real)-1 + (real)2 * u01<real>(w[0]), (real)-1 + (real)2 * u01<real>(w[1]), (real)-1 + (real)2 * u01<real>(w[2]),
+                 (real)(10.0 * QS_PI_D) + (real)(10.0 * QS_PI_D) * u01<real>(w[3])};
+    real um = norm3<real>(u);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { real dwq = u[q] / (um + (real)1e-5); dwq *= u[3]; d.omega[q] += dwq; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scenarios (per-environment, executed by one lane at episode boundaries / goal switches)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool f_is_circle(int f) { return f <= 2; }
+__device__ __forceinline__ bool f_is_grid(int f) { return f >= 4 && f <= 6; }
+__device__ __forceinline__ int f_suffix(int f) { return (f == 0 || f == 4) ? 0 : ((f == 1 || f == 5) ? 1 : ((f == 2 || f == 6) ? 2 : -1)); }
+__device__ __forceinline__ void grid_dim(int num, int *d1, int *d2) {  // scenarios/utils.py:117-128
+    int a = (int)floorf(sqrtf((float)num));
+    while (a * a > num) --a;
+    while ((a + 1) * (a + 1) <= num) ++a;
+    while (a > 1) { if (num % a == 0) break; --a; }
+    *d1 = a; *d2 = num / a;
+}
+template <typename real> struct Formation { int f, per_layer; real lo, hi, size, layer_dist; };
+
+template <typename real> __device__ __forceinline__ void goal_by_formation(int f, real p0, real p1, real layer, real g[3]) {
+    int s = f_suffix(f);
+    if (s == 0) { g[0] = p0; g[1] = p1; g[2] = layer; }
+    else if (s == 1) { g[0] = p0; g[1] = layer; g[2] = p1; }
+    else { g[0] = layer; g[1] = p0; g[2] = p1; }
+}
+
+// QuadrotorScenario.generate_goals scenarios/base.py:39-113.  out: [rows][3] with stride `ld` reals per row.
+template <typename real>
+__device__ int generate_goals(const Formation<real> &F, int n, int fd, const real center[3], real *out, int ld) {
+    int f = F.f, per = F.per_layer, rows = n;
+    real size = F.size;
+    if (f_is_circle(f)) {
+        for (int i = 0; i < n; ++i) {
+            int layer = i / per, cur = (n <= per) ? n : ((layer < n / per) ? per : n % per);
+            real deg = (real)2 * (real)QS_PI_D * (real)(i % cur) / (real)cur, s, cs;
+            M<real>::sincos(deg, &s, &cs);
+            real g[3];
+            goal_by_formation<real>(f, size * cs, size * s, (real)layer * F.layer_dist, g);
+            for (int q = 0; q < 3; ++q) out[i * ld + q] = g[q] + center[q];
+        }
+    } else if (f == 3) {
+        int m = n < 3 ? 3 : n;
+        real x = (real)0.1 + (real)1.2 * m, start = (real)-1 + (real)1 / (m - (real)1), inc = ((real)2 - (real)2 / (m - (real)1)) / (m - (real)1);
+        for (int j = 0; j < m; ++j) {
+            real s = start + j * inc, sg = (real)((s > 0) - (s < 0));
+            real xx = s * x, yy = (real)(QS_PI_D / 2.) * sg * ((real)1 - M<real>::sqrt((real)1 - M<real>::fabs(s)));
+            real sx, cx, sy, cy; M<real>::sincos(xx, &sx, &cx); M<real>::sincos(yy, &sy, &cy);
+            out[j * ld + 0] = size * (cx * cy) + center[0];
+            out[j * ld + 1] = size * (sx * cy) + center[1];
+            out[j * ld + 2] = size * sy + center[2];
+        }
+        rows = m;
+    } else if (f_is_grid(f)) {
+        real mean[3] = {0, 0, 0};
+        for (int i = 0; i < n; ++i) {
+            int layer = i / per, d1, d2;
+            int cnt = (n <= per) ? n : ((layer < n / per) ? per : n % per);
+            grid_dim(cnt, &d1, &d2);
+            real g[3];
+            goal_by_formation<real>(f, size * (real)(i % d2), size * (real)((i / d2) % d1), (real)layer * F.layer_dist, g);
+            for (int q = 0; q < 3; ++q) { out[i * ld + q] = g[q]; mean[q] += g[q]; }
+        }
+        for (int q = 0; q < 3; ++q) mean[q] /= (real)n;
+        for (int i = 0; i < n; ++i) for (int q = 0; q < 3; ++q) out[i * ld + q] = out[i * ld + q] - mean[q] + center[q];
+    } else {
+        real mean[3] = {0, 0, 0};
+        for (int i = 0; i < n; ++i) {
+            real g[3] = {center[2] + size * (real)(i / (fd * fd)), size * (real)((i / fd) % fd), size * (real)(i % fd)};
+            for (int q = 0; q < 3; ++q) { out[i * ld + q] = g[q]; mean[q] += g[q]; }
+        }
+        for (int q = 0; q < 3; ++q) mean[q] /= (real)n;
+        for (int i = 0; i < n; ++i) for (int q = 0; q < 3; ++q) out[i * ld + q] = out[i * ld + q] - mean[q] + center[q];
+    }
+    return rows;
+}
+
+// update_formation_and_relate_param scenarios/base.py:123-135
+template <typename real>
+__device__ void update_formation(const Consts<real> &c, const RngKey &key, int slot, int num_agents, Formation<real> &F) {
+    bool svs = c.scenario == QS_SCENARIO_SWARM_VS_SWARM;
+    int nform = svs ? 8 : 1;
+    real lo = svs ? (real)(5 * 0.05) : (real)0, hi = svs ? (real)(10 * 0.05) : (real)0;
+    int fi = (int)(rng_uniform1<real>(key, QS_SITE_SCEN, slot + 0, 0, 0, (real)0, (real)1) * (real)nform);
+    if (fi >= nform) fi = nform - 1;
+    F.f = fi;
+    F.per_layer = f_is_circle(fi) ? 8 : (f_is_grid(fi) ? 50 : 8);
+    int n = svs ? num_agents / 2 : num_agents;
+    if (f_is_circle(fi)) {
+        real theta = (real)2 * (real)QS_PI_D / (real)F.per_layer, sn = M<real>::sin(theta / (real)2);
+        F.lo = ((real)0.5 * lo) / sn; F.hi = ((real)0.5 * hi) / sn;
+    } else if (fi == 3) {
+        real A = (real)1.75388487222762, B = (real)0.860487305801679, C = (real)10.3632729642351, D = (real)0.0920858134405214;
+        real ratio = (A - D) / ((real)1 + M<real>::pow((real)n / C, B)) + D;
+        F.lo = lo / ratio; F.hi = hi / ratio;
+    } else { F.lo = lo; F.hi = hi; }
+    F.size = rng_uniform1<real>(key, QS_SITE_SCEN, slot + 1, 0, 0, F.lo, F.hi);
+    F.layer_dist = rng_uniform1<real>(key, QS_SITE_SCEN, slot + 2, 0, 0, F.lo, F.hi);
+}
+
+// np.random.shuffle on rows [0,n) of buf (stride ld): Fisher-Yates with the QS_SITE_SCEN_SHUFFLE stream
+template <typename real>
+__device__ void shuffle_rows(const RngKey &key, real *buf, int ld, int n, int slot_base) {
+    // the oracle builds perm by swapping from the top, then gathers rows[k] = old[perm[k]]; applying the same
+    // swaps directly to the rows is the identical permutation.
+    for (int i = n - 1; i >= 1; --i) {
+        int j = (int)(rng_uniform1<real>(key, QS_SITE_SCEN_SHUFFLE, slot_base + i, 0, 0, (real)0, (real)1) * (real)(i + 1));
+        if (j > i) j = i;
+        for (int q = 0; q < 3; ++q) { real t = buf[i * ld + q]; buf[i * ld + q] = buf[j * ld + q]; buf[j * ld + q] = t; }
+    }
+}
+
+// Scenario_swarm_vs_swarm.create_formations swarm_vs_swarm.py:52-57 (+ shuffle of update_goals :66-69).
+// goals: [>= 2*N+6][3] scratch rows (stride 3); the first N rows are the drones' goals afterwards.
+template <typename real>
+__device__ void svs_create_formations(const RngKey &key, const Formation<real> &F, int N, const int fd[2], const real c1[3],
+                                      const real c2[3], bool do_shuffle, real *goals) {
+    int n1 = N / 2, n2 = N - N / 2;
+    int r1 = generate_goals<real>(F, n1, fd[0], c1, goals, 3);
+    if (do_shuffle) shuffle_rows<real>(key, goals, 3, r1, 0);
+    int r2 = generate_goals<real>(F, n2, fd[1], c2, goals + r1 * 3, 3);
+    if (do_shuffle) shuffle_rows<real>(key, goals + r1 * 3, 3, r2, 256);
+}
+
+}  // namespace qs

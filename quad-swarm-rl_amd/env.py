@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's env interface on top of the HIP stepper.
+
+  * `QuadSwarmVecEnv`   - E envs x N drones, device tensors in / out (the production, batched view);
+  * `QuadrotorEnvMulti` - drop-in for gym_art/quadrotor_multi/quadrotor_multi.py:23 (one env, python lists /
+                          numpy in and out, same constructor keywords, same `infos` keys, auto-reset in step).
+
+Both raise if the HIP extension or a GPU is missing: there is no CPU fallback on the product path.
+"""
+import numpy as np
+
+from . import config as qcfg
+from . import native
+
+try:  # gymnasium is optional on the box that only steps envs
+    from gymnasium import spaces as _spaces
+    _Box = _spaces.Box
+except Exception:  # pragma: no cover - minimal stand-in with the attributes SF / the wrappers read
+    class _Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low = np.asarray(low, dtype=dtype)
+            self.high = np.asarray(high, dtype=dtype)
+            self.shape = self.low.shape
+            self.dtype = np.dtype(dtype)
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+class _Scenario:
+    """Just enough of scenarios/base.py for the wrappers (`scenario.name()`, `.approch_goal_metric`)."""
+
+    def __init__(self, cfg):
+        self._name = qcfg.SCENARIO_CLASS_NAMES[cfg.scenario]
+        self.approch_goal_metric = cfg.approach_goal_metric
+
+    def name(self):
+        return self._name
+
+
+class QuadSwarmVecEnv:
+    """Batched env: all E*N agents stepped by one kernel launch; observations are born in HBM.
+
+    reset() -> obs[E*N, D];  step(actions[E*N, 4]) -> obs, rewards[E*N], dones[E*N] (uint8), infos (lazy)
+    `actions` is a torch tensor on the stepper's device with the stepper's dtype (float32 by default).
+    """
+
+    def __init__(self, num_envs, device=0, seed=0, env_id_offset=0, precision="f32", **env_kwargs):
+        self.cfg = qcfg.make_config(num_envs=num_envs, seed=seed, env_id_offset=env_id_offset, precision=precision, **env_kwargs)
+        self.stepper = native.Stepper(self.cfg, device=device)
+        self.num_envs = num_envs
+        self.num_agents_per_env = self.cfg.num_agents
+        self.num_agents = num_envs * self.cfg.num_agents
+        self.is_multiagent = True
+        low, high = qcfg.obs_bounds(self.cfg)
+        self.observation_space = _Box(low, high, dtype=np.float32)
+        self.action_space = _Box(-np.ones(4), np.ones(4), dtype=np.float32)   # quadrotor_control.py:37-49
+        self.rew_coeff = dict(qcfg.REW_COEFF_DEFAULT)
+        self.rew_coeff.update({k: self.cfg.rew_coeff[i] for i, k in enumerate(qcfg.REW_COEFF_KEYS)})
+        self._pushed_coeff = [self.rew_coeff[k] for k in qcfg.REW_COEFF_KEYS]
+        self.scenario = _Scenario(self.cfg)
+        self._t = self.stepper.tensor
+
+    def _sync_rew_coeff(self):
+        cur = [float(self.rew_coeff[k]) for k in qcfg.REW_COEFF_KEYS]
+        if cur != self._pushed_coeff:   # the SF wrapper mutates env.rew_coeff in place (reward_shaping.py:57-59)
+            self.stepper.set_reward_coeffs(cur)
+            self._pushed_coeff = cur
+
+    def reset(self, env_mask=None):
+        import torch
+        self.stepper.reset(env_mask, stream=torch.cuda.current_stream(self.stepper.device))
+        return self._t("obs")
+
+    def step(self, actions):
+        import torch
+        self._sync_rew_coeff()
+        assert actions.is_cuda and actions.is_contiguous() and actions.numel() == self.num_agents * 4
+        assert actions.element_size() == self.stepper.real_size, "actions dtype must match the stepper precision"
+        self.stepper.step(actions.data_ptr(), stream=torch.cuda.current_stream(self.stepper.device))
+        return self._t("obs"), self._t("reward"), self._t("done"), None
+
+    def reward_info(self):
+        """[17, E*N] device tensor of the `infos[i]['rewards']` terms (row order: config.REW_INFO_KEYS)."""
+        return self._t("rew_info")
+
+    def close(self):
+        self.stepper.close()
+
+
+class QuadrotorEnvMulti:
+    """Reference-compatible single environment (constructor keywords of quadrotor_multi.py:24-41)."""
+
+    def __init__(self, num_agents, ep_time, rew_coeff, obs_repr,
+                 neighbor_visible_num, neighbor_obs_type, collision_hitbox_radius, collision_falloff_radius,
+                 use_obstacles, obst_density, obst_size, obst_spawn_area,
+                 use_downwash, use_numba, quads_mode, room_dims, use_replay_buffer=False, quads_view_mode=None,
+                 quads_render=False,
+                 dynamics_params="Crazyflie", raw_control=True, raw_control_zero_middle=True,
+                 dynamics_randomize_every=None, dynamics_change=None, dyn_sampler_1=None,
+                 sense_noise="default", init_random_state=False, render_mode="human",
+                 seed=0, device=0, precision="f32"):
+        if dynamics_params != "Crazyflie" or not raw_control or not raw_control_zero_middle or init_random_state \
+                or dynamics_randomize_every is not None or dyn_sampler_1 is not None:
+            raise NotImplementedError("only the configuration hard-coded by make_quadrotor_env_multi is supported "
+                                      "(swarm_rl/env_wrappers/quad_utils.py:22-31)")
+        if quads_render:
+            raise NotImplementedError("rendering is out of scope of the stepper")
+        tnr = 0.05
+        if dynamics_change is not None:
+            tnr = dynamics_change.get("noise", {}).get("thrust_noise_ratio", tnr)
+        self._vec = QuadSwarmVecEnv(
+            1, device=device, seed=seed, precision=precision,
+            num_agents=num_agents, ep_time=ep_time, rew_coeff=rew_coeff, obs_repr=obs_repr,
+            neighbor_visible_num=neighbor_visible_num, neighbor_obs_type=neighbor_obs_type,
+            collision_hitbox_radius=collision_hitbox_radius, collision_falloff_radius=collision_falloff_radius,
+            use_obstacles=use_obstacles, obst_density=obst_density, obst_size=obst_size, obst_spawn_area=obst_spawn_area,
+            use_downwash=use_downwash, use_numba=use_numba, quads_mode=quads_mode, room_dims=room_dims,
+            sense_noise=sense_noise, thrust_noise_ratio=tnr)
+        v = self._vec
+        self.num_agents = num_agents
+        self.is_multiagent = True
+        self.observation_space, self.action_space = v.observation_space, v.action_space
+        self.rew_coeff = v.rew_coeff          # same dict object: outside mutation reaches the device constants
+        self.scenario = v.scenario
+        self.use_obstacles, self.use_replay_buffer = use_obstacles, use_replay_buffer
+        self.room_dims, self.quads_mode = room_dims, quads_mode
+        self.control_freq = 1.0 / (v.cfg.dt * v.cfg.sim_steps)
+        self.last_step_unique_collisions = np.array([], dtype=np.int64)
+        self.curr_quad_col = np.array([], dtype=np.int64)
+        self._real = v.stepper.np_real
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def reset(self, obst_density=None, obst_size=None):
+        self._vec.stepper.reset()
+        return self._vec.stepper.to_host("obs").astype(np.float64)
+
+    def step(self, actions):
+        st = self._vec.stepper
+        self._vec._sync_rew_coeff()
+        a = np.ascontiguousarray(np.asarray(actions, dtype=self._real).reshape(self.num_agents, 4))
+        st.from_host("actions", a)
+        st.step()
+        st.sync()
+        st.check_errors()          # ValueError('QuadEnv: reward is Nan'), quadrotor_single.py:87-90
+        obs = st.to_host("obs").astype(np.float64)
+        rewards = [float(r) for r in st.to_host("reward")]
+        dones = [bool(d) for d in st.to_host("done")]
+        ri = st.to_host("rew_info")
+        keys = qcfg.REW_INFO_KEYS if self.use_obstacles else qcfg.REW_INFO_KEYS[:15]
+        infos = [{"rewards": {k: float(ri[j, i]) for j, k in enumerate(keys)}} for i in range(self.num_agents)]
+        ids = int(st.to_host("unique_col_mask")[0])
+        self.last_step_unique_collisions = np.array([i for i in range(self.num_agents) if ids >> i & 1], dtype=np.int64)
+        if self.use_obstacles:
+            ids = int(st.to_host("obst_new_mask")[0])
+            self.curr_quad_col = np.array([i for i in range(self.num_agents) if ids >> i & 1], dtype=np.int64)
+        if any(dones):
+            stats = self.episode_extra_stats()
+            for i in range(self.num_agents):
+                infos[i]["episode_extra_stats"] = stats[i]
+        return obs, rewards, dones, infos
+
+    def episode_extra_stats(self):
+        """Per-agent dicts with the keys of quadrotor_multi.py:637-718, from the device-side episode snapshot."""
+        st, n = self._vec.stepper, self.num_agents
+        eps, cnt = st.to_host("ep_stats").astype(np.float64), st.to_host("ep_counters")[:, 0]
+        name = self.scenario.name()[9:]
+        ok = np.logical_and(eps[4], eps[5])
+        succ = float(np.sum(np.logical_and(ok, eps[3])) / n)
+        dead = float(np.sum(np.logical_and(ok, 1 - eps[3])) / n)
+        col, ncol, ocol = float(1.0 - np.sum(ok) / n), float(1.0 - np.sum(eps[4]) / n), float(1.0 - np.sum(eps[5]) / n)
+        out = []
+        for i in range(n):
+            d = {
+                "num_collisions": int(cnt[0]), "num_collisions_with_room": int(cnt[3]), "num_collisions_with_floor": int(cnt[4]),
+                "num_collisions_with_wall": int(cnt[5]), "num_collisions_with_ceiling": int(cnt[6]),
+                "num_collisions_after_settle": int(cnt[1]), f"{name}/num_collisions": int(cnt[1]),
+                "num_collisions_final_5_s": int(cnt[2]), f"{name}/num_collisions_final_5_s": int(cnt[2]),
+                "distance_to_goal_1s": float(eps[0, i]), "distance_to_goal_3s": float(eps[1, i]), "distance_to_goal_5s": float(eps[2, i]),
+                f"{name}/distance_to_goal_1s": float(eps[0, i]), f"{name}/distance_to_goal_3s": float(eps[1, i]),
+                f"{name}/distance_to_goal_5s": float(eps[2, i]),
+                "metric/agent_success_rate": succ, f"{name}/agent_success_rate": succ,
+                "metric/agent_deadlock_rate": dead, f"{name}/agent_deadlock_rate": dead,
+                "metric/agent_col_rate": col, f"{name}/agent_col_rate": col,
+                "metric/agent_neighbor_col_rate": ncol, f"{name}/agent_neighbor_col_rate": ncol,
+                "metric/agent_obst_col_rate": ocol, f"{name}/agent_obst_col_rate": ocol,
+            }
+            if self.use_obstacles:
+                d.update({"num_collisions_obst_quad": int(cnt[7]), "num_collisions_obst_quad_after_settle": int(cnt[8]),
+                          f"{name}/num_collisions_obst": int(cnt[7]), "num_collisions_obst_quad_3_5": int(cnt[9]),
+                          f"{name}/num_collisions_obst_quad_3_5": int(cnt[9]), "num_collisions_obst_quad_5": int(cnt[10]),
+                          f"{name}/num_collisions_obst_quad_5": int(cnt[10])})
+            out.append(d)
+        return out
+
+    def render(self, *a, **k):
+        raise NotImplementedError("rendering is out of scope of the stepper")
+
+    def close(self):
+        self._vec.close()

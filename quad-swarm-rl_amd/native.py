@@ -1,0 +1,223 @@
+"""ctypes binding of the HIP stepper's C ABI (include/quadswarm.h -> csrc/libquadswarm_hip.so).
+
+The product path: there is NO CPU fallback here.  If the HIP extension is missing, cannot be built, or no
+GPU is visible, the constructor raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import config as qcfg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libquadswarm_hip.so")
+SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_device.h"),
+           os.path.join(os.path.dirname(HERE), "include", "quadswarm.h")]
+
+QS_OK = 0
+QS_ERR_NAN_REWARD = -3
+
+
+class QsBuffers(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name in (
+        "obs", "reward", "done", "rew_info", "actions", "pos", "vel", "omega", "rot", "thrust_rot_damp",
+        "thrust_cmds_damp", "ou_state", "goal", "flags", "obst_hit_idx", "col_pair_mask", "new_pair_mask",
+        "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_pos", "ep_stats",
+        "ep_counters", "error_flag")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    newest = max(os.path.getmtime(s) for s in SOURCES)
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, SOURCES[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.qs_version.restype = C.c_int
+        L.qs_sizeof_config.restype = C.c_size_t
+        L.qs_last_error.restype = C.c_char_p
+        L.qs_default_config.argtypes = [C.POINTER(qcfg.QsConfig), C.c_int32, C.c_int32]
+        L.qs_obs_dim.argtypes = [C.POINTER(qcfg.QsConfig)]
+        L.qs_create.argtypes = [C.POINTER(qcfg.QsConfig), C.c_int, C.POINTER(vp)]
+        L.qs_destroy.argtypes = [vp]
+        L.qs_reset.argtypes = [vp, C.POINTER(C.c_uint8), vp]
+        L.qs_step.argtypes = [vp, vp, vp]
+        L.qs_step_many.argtypes = [vp, vp, C.c_int32, vp]
+        L.qs_sync.argtypes = [vp, vp]
+        L.qs_get_buffers.argtypes = [vp, C.POINTER(QsBuffers)]
+        L.qs_set_reward_coeffs.argtypes = [vp, C.POINTER(C.c_double)]
+        L.qs_get_state.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+        L.qs_set_state.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_int32]
+        L.qs_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+        L.qs_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.qs_check_errors.argtypes = [vp]
+        L.qs_set_profiling.argtypes = [vp, C.c_int32]
+        L.qs_get_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
+            raise RuntimeError("qs_config layout mismatch between config.py and libquadswarm_hip.so")
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
+                    "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
+                    "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_check_errors", "qs_set_profiling",
+                    "qs_get_kernel_time"]
+
+
+class QsError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != QS_OK:
+        msg = lib().qs_last_error().decode()
+        if rc == QS_ERR_NAN_REWARD:
+            raise ValueError("QuadEnv: reward is Nan")   # quadrotor_single.py:87-90
+        raise QsError(f"quadswarm error {rc}: {msg}")
+
+
+class _DevArray:
+    """Zero-copy view of a library-owned device buffer for torch.as_tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2,
+                                             strides=None)
+
+
+class Stepper:
+    """E envs x N drones stepped by the HIP kernels.  Thin, allocation-free per step."""
+
+    def __init__(self, cfg, device=0):
+        self.cfg = cfg
+        self.device = device
+        self._h = C.c_void_p()
+        _check(lib().qs_create(C.byref(cfg), device, C.byref(self._h)))
+        self.bufs = QsBuffers()
+        _check(lib().qs_get_buffers(self._h, C.byref(self.bufs)))
+        self.E, self.N = cfg.num_envs, cfg.num_agents
+        self.T = self.E * self.N
+        self.obs_dim = self.bufs.obs_dim
+        self.real_size = self.bufs.real_size
+        self.np_real = np.float64 if self.real_size == 8 else np.float32
+        self._shapes = dict(
+            obs=((self.T, self.obs_dim), "real"), reward=((self.T,), "real"), done=((self.T,), "u1"),
+            rew_info=((17, self.T), "real"), actions=((self.T, 4), "real"),
+            pos=((3, self.T), "real"), vel=((3, self.T), "real"), omega=((3, self.T), "real"), rot=((9, self.T), "real"),
+            thrust_rot_damp=((4, self.T), "real"), thrust_cmds_damp=((4, self.T), "real"), ou_state=((4, self.T), "real"),
+            goal=((3, self.T), "real"), flags=((self.T,), "u4"), obst_hit_idx=((self.T,), "i4"),
+            col_pair_mask=((self.T,), "u8"), new_pair_mask=((self.T,), "u8"), unique_col_mask=((self.E,), "u8"),
+            obst_new_mask=((self.E,), "u8"), room_new_mask=((self.E,), "u8"), counters=((11, self.E), "i4"),
+            tick=((self.E,), "i4"), obst_pos=((2, self.E * max(cfg.num_obstacles, 1)), "real"),
+            ep_stats=((6, self.T), "real"), ep_counters=((11, self.E), "i4"), error_flag=((1,), "u4"))
+        self._torch_cache = {}
+
+    # ---- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            lib().qs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stepping ----------------------------------------------------------------------------
+    @staticmethod
+    def _stream_ptr(stream):
+        if stream is None:
+            return None
+        return C.c_void_p(int(getattr(stream, "cuda_stream", stream)))
+
+    def reset(self, env_mask=None, stream=None):
+        m = None
+        if env_mask is not None:
+            arr = np.ascontiguousarray(env_mask, dtype=np.uint8)
+            assert arr.size == self.E
+            m = arr.ctypes.data_as(C.POINTER(C.c_uint8))
+        _check(lib().qs_reset(self._h, m, self._stream_ptr(stream)))
+
+    def step(self, actions_ptr=None, stream=None):
+        """actions_ptr: device address of real[T,4] (int) or None to use the staging buffer `actions`."""
+        _check(lib().qs_step(self._h, C.c_void_p(actions_ptr) if actions_ptr else None, self._stream_ptr(stream)))
+
+    def step_many(self, actions_ptr, k, stream=None):
+        _check(lib().qs_step_many(self._h, C.c_void_p(actions_ptr), k, self._stream_ptr(stream)))
+
+    def sync(self, stream=None):
+        _check(lib().qs_sync(self._h, self._stream_ptr(stream)))
+
+    def check_errors(self):
+        _check(lib().qs_check_errors(self._h))
+
+    def set_reward_coeffs(self, coeffs):
+        arr = (C.c_double * 8)(*[float(x) for x in coeffs])
+        _check(lib().qs_set_reward_coeffs(self._h, arr))
+
+    def set_profiling(self, enable):
+        _check(lib().qs_set_profiling(self._h, int(enable)))
+
+    def kernel_time(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        _check(lib().qs_get_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- data access ---------------------------------------------------------------------------
+    def _dtype(self, kind):
+        return {"real": self.np_real, "u1": np.uint8, "u4": np.uint32, "i4": np.int32, "u8": np.uint64}[kind]
+
+    def ptr(self, name):
+        return getattr(self.bufs, name)
+
+    def to_host(self, name):
+        shape, kind = self._shapes[name]
+        out = np.empty(shape, dtype=self._dtype(kind))
+        _check(lib().qs_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr(name)), out.nbytes))
+        return out
+
+    def from_host(self, name, arr):
+        shape, kind = self._shapes[name]
+        a = np.ascontiguousarray(arr, dtype=self._dtype(kind)).reshape(shape)
+        _check(lib().qs_memcpy_h2d(self._h, C.c_void_p(self.ptr(name)), a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def tensor(self, name):
+        """Zero-copy torch view (device tensor) of a library buffer."""
+        import torch
+        if name not in self._torch_cache:
+            shape, kind = self._shapes[name]
+            typestr = {"real": "<f8" if self.real_size == 8 else "<f4", "u1": "|u1", "u4": "<u4", "i4": "<i4", "u8": "<u8"}[kind]
+            if kind in ("u4", "u8"):   # torch has no unsigned 32/64 views everywhere: expose as signed
+                typestr = typestr.replace("u", "i")
+            self._torch_cache[name] = torch.as_tensor(_DevArray(self.ptr(name), shape, typestr), device=f"cuda:{self.device}")
+        return self._torch_cache[name]
+
+    def get_state(self, env):
+        s = np.zeros((self.N, qcfg.QS_STATE_STRIDE))
+        tick = C.c_int32(0)
+        _check(lib().qs_get_state(self._h, env, s.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tick)))
+        return s, tick.value
+
+    def set_state(self, env, s, tick=-1):
+        a = np.ascontiguousarray(s, dtype=np.float64).reshape(self.N, qcfg.QS_STATE_STRIDE)
+        _check(lib().qs_set_state(self._h, env, a.ctypes.data_as(C.POINTER(C.c_double)), tick))

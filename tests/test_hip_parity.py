@@ -1,0 +1,269 @@
+"""GPU parity tests proper: the HIP stepper (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Both sides draw every stochastic term from the same counter-based Philox stream (include/quadswarm.h), so
+"same seed" literally means same noise.  Two modes:
+  * f64 instantiation, free-running rollouts: floats to 1e-8, every flag / index / mask / counter exact;
+  * f32 instantiation (the production precision), teacher-forced: before each step the device state is
+    overwritten with the oracle's, one control step is taken, outputs must agree to 1e-5 (the tolerance
+    north_star states for fp32 dynamics state) and the discrete outputs exactly.
+"""
+import numpy as np
+import pytest
+
+from quad_swarm_rl_amd import config as qcfg
+
+pytestmark = pytest.mark.gpu
+
+REW = dict(pos=1.0, effort=0.05, spin=0.1, crash=1.0, orient=1.0, quadcol_bin=5.0, quadcol_bin_smooth_max=10.0,
+           quadcol_bin_obst=5.0)
+
+CASES = {
+    "c1_single": dict(num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none", use_numba=False),
+    "c2_n8_dw": dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                     collision_falloff_radius=4.0, rew_coeff=REW),
+    "c2_n8_k2_numpy_wall": dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_downwash=True,
+                                use_numba=False, collision_falloff_radius=4.0, rew_coeff=REW, obs_repr="xyz_vxyz_R_omega_wall"),
+    "c2_n5_kall_short": dict(num_agents=5, neighbor_visible_num=-1, neighbor_obs_type="pos_vel", use_downwash=True,
+                             use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW, ep_time=0.4),
+    "c3_n8_obst": dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                       collision_falloff_radius=4.0, rew_coeff=dict(REW, quadcol_bin_smooth_max=4.0), use_obstacles=True,
+                       obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_static_same_goal",
+                       obs_repr="xyz_vxyz_R_omega_floor"),
+    "c3_n8_obst_short": dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_downwash=False,
+                             use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW, use_obstacles=True,
+                             obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_static_same_goal",
+                             obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.5),
+    "c4_n32_svs": dict(num_agents=32, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                       collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swarm_vs_swarm"),
+    "c4_n12_svs_short": dict(num_agents=12, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True,
+                             use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swarm_vs_swarm", ep_time=0.1),
+}
+
+
+def soa(a, E, N):
+    """[C, E*N] -> [E, N, C]"""
+    return np.ascontiguousarray(a.reshape(a.shape[0], E, N).transpose(1, 2, 0))
+
+
+def force_events(t, e, s, n, obst_xy=None, obst_r=0.3):
+    """Crafted states (same idea as oracle/ref_harness/capture.py) applied to env e before step t."""
+    changed = False
+    yaw = lambda th: np.array([np.cos(th), -np.sin(th), 0, np.sin(th), np.cos(th), 0, 0, 0, 1.0])
+    if n >= 8 and t == 6 and e % 2 == 0:
+        s[1, 0:3] = [1.0, 1.0, 3.0]; s[1, 3:6] = [0.8, 0.0, 0.0]
+        s[2, 0:3] = [1.12, 1.0, 3.0]; s[2, 3:6] = [-0.8, 0.1, 0.0]
+        s[3, 0:3] = [-1.0, 1.0, 2.5]; s[3, 3:6] = [0.0, 0.3, 0.0]
+        s[5, 0:3] = [-1.0, 1.05, 2.52]; s[5, 3:6] = [0.0, -0.3, 0.1]
+        s[0, 0:3] = [2.0, -2.0, 2.0]; s[4, 0:3] = [2.0, -1.85, 2.0]
+        s[6, 0:3] = [-2.0, -2.0, 3.0]; s[6, 6:15] = yaw(0.3)
+        s[7, 0:3] = [-2.03, -1.98, 2.6]
+        changed = True
+    if n >= 3 and t in (14, 16) and e % 2 == 1:      # ids {0}: the `.any()` quirk
+        s[0, 0:3] = [0.0, 0.0, 4.0]; s[1, 0:3] = [0.05, 0.0, 4.0]; s[2, 0:3] = [0.10, 0.0, 4.0]
+        s[0:3, 3:6] = 0
+        changed = True
+    if n >= 3 and t == 15 and e % 2 == 1:
+        s[0, 0:3] = [3.0, 3.0, 4.0]; s[1, 0:3] = [0.05, 0.0, 4.0]; s[2, 0:3] = [0.10, 0.0, 4.0]
+        s[0:3, 3:6] = 0
+        changed = True
+    if t == 22:
+        s[0, 0:3] = [4.99, 0.0, 3.0]; s[0, 3:6] = [3.0, 0.5, 0.0]
+        if n >= 6:
+            s[1, 0:3] = [-4.995, -4.99, 3.0]; s[1, 3:6] = [-2.0, -2.5, 0.2]
+            s[2, 0:3] = [0.0, 1.0, 9.99]; s[2, 3:6] = [0.2, 0.0, 4.0]
+            s[3, 0:3] = [1.0, 4.99, 9.99]; s[3, 3:6] = [0.0, 3.0, 3.0]
+            s[4, 0:3] = [0.5, 0.5, 0.2]; s[4, 3:6] = [0.3, 0.1, -2.0]
+            s[5, 0:3] = [-1.5, 0.5, 0.2]; s[5, 3:6] = [0.0, 0.4, -2.0]; s[5, 6:15] = [1, 0, 0, 0, -1, 0, 0, 0, -1.0]
+        changed = True
+    if obst_xy is not None and t in (30, 31) and n >= 3:
+        s[0, 0:3] = [obst_xy[3, 0] + obst_r + 0.06, obst_xy[3, 1], 2.0]; s[0, 3:6] = [-1.5, 0.2, 0.0]
+        s[1, 0:3] = [obst_xy[5, 0] + 0.1, obst_xy[5, 1] - 0.05, 5.05]; s[1, 3:6] = [0.3, 0.0, 0.0]   # inside (z ~ room mid)
+        s[2, 0:3] = [obst_xy[0, 0], obst_xy[0, 1] - obst_r - 0.03, 3.0]; s[2, 3:6] = [0.0, 0.5, 0.0]
+        changed = True
+    return changed
+
+
+class Pair:
+    """An oracle batch and a HIP stepper built from the same configuration."""
+
+    def __init__(self, case, E, precision, seed=1234, env_id_offset=3):
+        from oracle import oracle as orc
+        from quad_swarm_rl_amd import native
+        kw = dict(CASES[case])
+        self.cfg = qcfg.make_config(num_envs=E, seed=seed, env_id_offset=env_id_offset, precision=precision, **kw)
+        self.E, self.N = E, self.cfg.num_agents
+        self.oenvs = [orc.OracleEnv(self.cfg, env_global_id=env_id_offset + e) for e in range(E)]
+        self.hip = native.Stepper(self.cfg, device=0)
+        self.D = self.hip.obs_dim
+
+    def reset(self):
+        oobs = np.stack([o.reset() for o in self.oenvs])
+        self.hip.reset()
+        return oobs, self.hip.to_host("obs").reshape(self.E, self.N, self.D)
+
+    def step(self, actions):
+        o_obs, o_rew, o_done, o_ri = zip(*[o.step(actions[e]) for e, o in enumerate(self.oenvs)])
+        self.hip.from_host("actions", actions.reshape(-1, 4))
+        self.hip.step()
+        self.hip.sync()
+        h = self.hip
+        return (np.stack(o_obs), np.stack(o_rew), np.stack(o_done), np.stack(o_ri)), \
+               (h.to_host("obs").reshape(self.E, self.N, self.D), h.to_host("reward").reshape(self.E, self.N),
+                h.to_host("done").reshape(self.E, self.N), soa(h.to_host("rew_info"), self.E, self.N))
+
+    def compare_discrete(self, t):
+        h, E, N = self.hip, self.E, self.N
+        flags = h.to_host("flags").reshape(E, N)
+        cp, npm = h.to_host("col_pair_mask").reshape(E, N), h.to_host("new_pair_mask").reshape(E, N)
+        uq, on, rn = h.to_host("unique_col_mask"), h.to_host("obst_new_mask"), h.to_host("room_new_mask")
+        cnt, tick, ohi = h.to_host("counters"), h.to_host("tick"), h.to_host("obst_hit_idx").reshape(E, N)
+        for e, o in enumerate(self.oenvs):
+            info = o.info()
+            assert tick[e] == info.tick, f"tick step {t} env {e}"
+            np.testing.assert_array_equal(flags[e] & 0x7ff, np.array(info.flags[:N]) & 0x7ff, err_msg=f"flags step {t} env {e}")
+            np.testing.assert_array_equal(cnt[:, e], np.array(info.counters), err_msg=f"counters step {t} env {e}")
+            if info.tick != 0:     # (masks are cleared by the reset that ends an episode)
+                assert uq[e] == info.unique_col_mask, f"unique collision ids step {t} env {e}"
+                assert on[e] == info.obst_new_mask and rn[e] == info.room_new_mask, f"obst/room masks step {t} env {e}"
+                np.testing.assert_array_equal(cp[e], np.array(info.col_pair_mask[:N], dtype=np.uint64))
+                np.testing.assert_array_equal(npm[e], np.array(info.new_pair_mask[:N], dtype=np.uint64))
+                if self.cfg.use_obstacles:
+                    np.testing.assert_array_equal(ohi[e], np.array(info.obst_hit_idx[:N]))
+
+    def compare_state(self, t, tol):
+        h, E, N = self.hip, self.E, self.N
+        pos, vel, om, rot = soa(h.to_host("pos"), E, N), soa(h.to_host("vel"), E, N), soa(h.to_host("omega"), E, N), soa(h.to_host("rot"), E, N)
+        goal = soa(h.to_host("goal"), E, N)
+        worst = 0.0
+        for e, o in enumerate(self.oenvs):
+            s, _ = o.get_state()
+            for nm, a, b in (("pos", pos[e], s[:, 0:3]), ("vel", vel[e], s[:, 3:6]), ("rot", rot[e], s[:, 6:15]),
+                             ("omega", om[e], s[:, 15:18]), ("goal", goal[e], s[:, 32:35])):
+                err = np.abs(a - b).max()
+                worst = max(worst, err)
+                assert err <= tol * (1.0 + np.abs(b).max()), f"{nm} step {t} env {e}: {err}"
+        return worst
+
+    def compare_ep_stats(self, t, tol):
+        h, E, N = self.hip, self.E, self.N
+        eps, epc = soa(h.to_host("ep_stats"), E, N), h.to_host("ep_counters")
+        for e, o in enumerate(self.oenvs):
+            info = o.info()
+            np.testing.assert_allclose(eps[e], np.array(info.ep_stats)[:N], rtol=tol, atol=tol, err_msg=f"episode stats step {t} env {e}")
+            np.testing.assert_array_equal(epc[:, e], np.array(info.ep_counters))
+
+    def obst_xy(self, e):
+        M = self.cfg.num_obstacles
+        op = self.hip.to_host("obst_pos")
+        return np.stack([op[0, e * M:(e + 1) * M], op[1, e * M:(e + 1) * M]], axis=1)
+
+    def close(self):
+        self.hip.close()
+        for o in self.oenvs:
+            o.close()
+
+
+def check_floats(t, tol, o, h, what):
+    for nm, a, b in zip(("obs", "reward", "done", "rew_info"), o, h):
+        if nm == "done":
+            np.testing.assert_array_equal(a, b, err_msg=f"done step {t}")
+            continue
+        err = np.abs(a - b).max()
+        assert err <= tol * (1.0 + np.abs(a).max()), f"{what}: {nm} step {t}: max abs err {err}"
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_rollout_f64_bit_exact_discrete(case):
+    E, steps, tol = 11, 70, 1e-8
+    pr = Pair(case, E, "f64")
+    rng = np.random.RandomState(5)
+    oobs, hobs = pr.reset()
+    np.testing.assert_allclose(hobs, oobs, rtol=0, atol=tol)
+    if pr.cfg.use_obstacles:
+        for e, o in enumerate(pr.oenvs):
+            np.testing.assert_allclose(pr.obst_xy(e), np.array(o.info().obst_pos)[:pr.cfg.num_obstacles], atol=1e-12)
+    for t in range(steps):
+        for e, o in enumerate(pr.oenvs):
+            s, tick = o.get_state()
+            oxy = pr.obst_xy(e) if pr.cfg.use_obstacles else None
+            if force_events(t, e, s, pr.N, oxy, pr.cfg.obst_size / 2):
+                o.set_state(s, tick)
+                pr.hip.set_state(e, s, tick)
+        gentle = (t // 10) % 2 == 1
+        act = rng.uniform(-1, 1, size=(E, pr.N, 4)) if not gentle else 0.06 + rng.uniform(-0.05, 0.05, size=(E, pr.N, 4))
+        o, h = pr.step(act)
+        check_floats(t, tol, o, h, case)
+        pr.compare_discrete(t)
+        pr.compare_state(t, tol)
+        if o[2].any():
+            pr.compare_ep_stats(t, 1e-7)
+    pr.hip.check_errors()
+    pr.close()
+
+
+@pytest.mark.parametrize("case", ["c1_single", "c2_n8_dw", "c3_n8_obst", "c4_n32_svs", "c2_n8_k2_numpy_wall"])
+def test_teacher_forced_f32(case):
+    E, steps, tol = 7, 60, 1e-5
+    pr = Pair(case, E, "f32")
+    rng = np.random.RandomState(9)
+    oobs, hobs = pr.reset()
+    np.testing.assert_allclose(hobs, oobs, rtol=0, atol=2e-5)
+    worst = 0.0
+    for t in range(steps):
+        for e, o in enumerate(pr.oenvs):
+            s, tick = o.get_state()
+            oxy = pr.obst_xy(e).astype(np.float64) if pr.cfg.use_obstacles else None
+            if force_events(t, e, s, pr.N, oxy, pr.cfg.obst_size / 2):
+                o.set_state(s, tick)
+            pr.hip.set_state(e, s, tick)          # teacher forcing: device state <- oracle state (rounded to f32)
+        gentle = (t // 10) % 2 == 1
+        act = rng.uniform(-1, 1, size=(E, pr.N, 4)) if not gentle else 0.06 + rng.uniform(-0.05, 0.05, size=(E, pr.N, 4))
+        act = act.astype(np.float32).astype(np.float64)
+        o, h = pr.step(act)
+        check_floats(t, tol, o, h, case)
+        pr.compare_discrete(t)
+        worst = max(worst, pr.compare_state(t, tol))
+    print(f"{case}: worst f32 state error {worst:.2e}")
+    pr.hip.check_errors()
+    pr.close()
+
+
+def test_c_abi_error_paths():
+    import ctypes as C
+    from quad_swarm_rl_amd import native
+    L = native.lib()
+    cfg = qcfg.make_config(num_envs=2, num_agents=4)
+    cfg.num_agents = 100
+    h = C.c_void_p()
+    assert L.qs_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert b"num_agents" in L.qs_last_error()
+    cfg = qcfg.make_config(num_envs=2, num_agents=4)
+    assert L.qs_create(C.byref(cfg), 99, C.byref(h)) == -2
+
+
+def test_determinism_and_sharding_invariance():
+    """Same seed twice => bit-identical; env shards with env_id_offset reproduce the un-sharded run."""
+    from quad_swarm_rl_amd import native
+    kw = dict(CASES["c2_n8_dw"])
+    E = 16
+    rng = np.random.RandomState(3)
+    acts = rng.uniform(-1, 1, size=(20, E, 8, 4)).astype(np.float32)
+
+    def run(num_envs, offset, sl):
+        st = native.Stepper(qcfg.make_config(num_envs=num_envs, seed=77, env_id_offset=offset, **kw))
+        st.reset()
+        out = [st.to_host("obs").copy()]
+        for t in range(acts.shape[0]):
+            st.from_host("actions", acts[t, sl].reshape(-1, 4))
+            st.step()
+            out.append(st.to_host("obs").copy())
+            out.append(st.to_host("reward").copy())
+        st.close()
+        return out
+
+    full1, full2 = run(E, 0, slice(0, E)), run(E, 0, slice(0, E))
+    for a, b in zip(full1, full2):
+        np.testing.assert_array_equal(a, b)
+    lo, hi = run(E // 2, 0, slice(0, E // 2)), run(E // 2, E // 2, slice(E // 2, E))
+    for a, b, c in zip(full1, lo, hi):
+        np.testing.assert_array_equal(a, np.concatenate([b, c], axis=0))
