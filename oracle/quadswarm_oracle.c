@@ -1161,6 +1161,7 @@ void qso_step(qso_env *e, const double *actions, double *obs, double *rew, uint8
         }
         memcpy(e->info.ep_counters, e->info.counters, sizeof e->info.counters);
         env_reset(e, obs);
+        for (int i = 0; i < N; ++i) e->info.flags[i] = e->d[i].flags;
     }
     e->info.tick = e->tick;
 }
