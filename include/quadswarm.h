@@ -110,6 +110,10 @@ typedef struct qs_config {
     double obst_size, obst_density;
     int32_t obst_area[2];      /* int(obst_spawn_area) */
     int32_t num_obstacles;     /* int(density*area0*area1) */
+
+    /* ---- outputs ---- */
+    int32_t write_rew_info;    /* 1: fill qs_buffers.rew_info every step (the infos[i]['rewards'] terms the SF
+                                  reward-shaping wrapper logs); 0: skip those 17 stores per drone */
 } qs_config;
 
 /* Device pointers (element type = float for QS_PRECISION_F32, double for QS_PRECISION_F64 where

@@ -16,6 +16,7 @@ enum : uint32_t {
     F_ON_FLOOR = 1u << 0, F_CRASH_FLOOR = 1u << 1, F_CRASH_WALL = 1u << 2, F_CRASH_CEIL = 1u << 3,
     F_PREV_WALL = 1u << 4, F_PREV_CEIL = 1u << 5, F_PREV_ROOM = 1u << 6, F_PREV_OBST = 1u << 7,
     F_REACHED = 1u << 8, F_COL_AGENT_OK = 1u << 9, F_COL_OBST_OK = 1u << 10,
+    F_IN_COL = 1u << 11,   // this drone's id was in a colliding pair last step (prev_ids of quadrotor_multi.py:440)
     F_SVD_SHIFT = 16, F_SVD_MASK = 0xffu << 16
 };
 
@@ -35,6 +36,16 @@ template <> struct M<float> {
     static __device__ __forceinline__ void sincos(float x, float *s, float *c) { sincosf(x, s, c); }
     static __device__ __forceinline__ float atan2(float y, float x) { return atan2f(y, x); }
     static __device__ __forceinline__ float log(float x) { return logf(x); }
+    // ln(u) for u in (0,1) via v_log_f32 (abs err ~1e-7 * |ln u|: noise amplitudes are 1e-2..1e-4, tolerance 1e-5)
+    static __device__ __forceinline__ float log_u01(float u) { return __builtin_amdgcn_logf(u) * 0.69314718055994531f; }
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    // sin(x), 1-cos(x) for |x| <= ~0.4 (the Rodrigues angle is |omega| dt <= 40*sqrt(3)*0.005 = 0.35): Taylor series;
+    // computing 1-cos directly avoids the cancellation of 1 - cosf(x) in fp32
+    static __device__ __forceinline__ void sin_omcos_small(float x, float *s, float *omc) {
+        float x2 = x * x;
+        *s = x * (1.0f + x2 * (-1.0f / 6 + x2 * (1.0f / 120 + x2 * (-1.0f / 5040 + x2 * (1.0f / 362880)))));
+        *omc = x2 * (0.5f + x2 * (-1.0f / 24 + x2 * (1.0f / 720 + x2 * (-1.0f / 40320 + x2 * (1.0f / 3628800)))));
+    }
     static __device__ __forceinline__ float pow(float x, float y) { return powf(x, y); }
     static __device__ __forceinline__ float fabs(float x) { return fabsf(x); }
     static __device__ __forceinline__ float fmax(float a, float b) { return fmaxf(a, b); }
@@ -52,6 +63,9 @@ template <> struct M<double> {
     static __device__ __forceinline__ void sincos(double x, double *s, double *c) { *s = ::sin(x); *c = ::cos(x); }
     static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
+    static __device__ __forceinline__ double log_u01(double u) { return ::log(u); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ void sin_omcos_small(double x, double *s, double *omc) { *s = ::sin(x); *omc = 1.0 - ::cos(x); }
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
     static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
     static __device__ __forceinline__ double fmax(double a, double b) { return ::fmax(a, b); }
@@ -91,12 +105,12 @@ template <typename real> __device__ __forceinline__ real u01(uint32_t x) { retur
 template <typename real, int NN> __device__ __forceinline__ void rng_normal(const RngKey &k, int site, int slot, int i, int j, real z[NN]) {
     uint32_t w[4];
     rng_words(k, site, slot, i, j, w);
-    real r0 = M<real>::sqrt((real)-2.0 * M<real>::log(u01<real>(w[0]))), s0, c0;
+    real r0 = M<real>::sqrt((real)-2.0 * M<real>::log_u01(u01<real>(w[0]))), s0, c0;
     M<real>::sincos2pi(u01<real>(w[1]), &s0, &c0);
     z[0] = r0 * c0;
     if (NN > 1) z[1] = r0 * s0;
     if (NN > 2) {
-        real r1 = M<real>::sqrt((real)-2.0 * M<real>::log(u01<real>(w[2]))), s1, c1;
+        real r1 = M<real>::sqrt((real)-2.0 * M<real>::log_u01(u01<real>(w[2]))), s1, c1;
         M<real>::sincos2pi(u01<real>(w[3]), &s1, &c1);
         z[2] = r1 * c1;
         if (NN > 3) z[3] = r1 * s1;
@@ -135,6 +149,7 @@ template <typename real> struct Consts {
     int32_t cube_fd[2];   // int(n ** (1/3)) for the two half-swarms, evaluated on the host with libm's pow (scenarios/base.py:98-99)
     uint32_t seed_lo, seed_hi;
     int32_t env_id_offset, num_envs, num_agents;
+    int32_t write_rew_info;   // 0: skip the 17-term reward-info matrix (it is logging, not part of obs/reward/done)
 };
 
 // per-drone dynamic state held in registers
@@ -156,6 +171,19 @@ template <typename real> __device__ __forceinline__ void matmul3(const real a[9]
 template <typename real> __device__ __forceinline__ void yaw_rot(real theta, real r[9]) {
     real s, c; M<real>::sincos(theta, &s, &c);
     r[0] = c; r[1] = -s; r[2] = 0; r[3] = s; r[4] = c; r[5] = 0; r[6] = 0; r[7] = 0; r[8] = 1;
+}
+
+// yaw_rot(atan2(y, x)) without the transcendental round trip: cos(atan2(y,x)) = x/hypot(x,y), sin = y/hypot(x,y);
+// atan2(0,0) = 0 -> identity yaw.
+template <typename real> __device__ __forceinline__ void yaw_rot_xy(real x, real y, real r[9]) {
+    real h2 = x * x + y * y, c = 1, s = 0;
+    if (h2 > (real)0) { real ih = (real)1 / M<real>::sqrt(h2); c = x * ih; s = y * ih; }
+    r[0] = c; r[1] = -s; r[2] = 0; r[3] = s; r[4] = c; r[5] = 0; r[6] = 0; r[7] = 0; r[8] = 1;
+}
+template <typename real> __device__ __forceinline__ void unit_xy(real x, real y, real *c, real *s) {
+    real h2 = x * x + y * y;
+    *c = 1; *s = 0;
+    if (h2 > (real)0) { real ih = (real)1 / M<real>::sqrt(h2); *c = x * ih; *s = y * ih; }
 }
 
 // nearest rotation (orthogonal polar factor) == U V^T of the SVD, quadrotor_dynamics.py:546-551.
@@ -210,8 +238,7 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
         real iw = (real)1 / wn;
         real kx = wv[0] * iw, ky = wv[1] * iw, kz = wv[2] * iw;
         real K[9] = {0, -kz, ky, kz, 0, -kx, -ky, kx, 0};
-        real s, cc; M<real>::sincos(wn * dt, &s, &cc);
-        cc = (real)1 - cc;
+        real s, cc; M<real>::sin_omcos_small(wn * dt, &s, &cc);
         real KK[9], dR[9];
         matmul3<real>(K, K, KK);
 #pragma unroll
@@ -244,8 +271,7 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
     if (d.pos[2] <= c.floor_threshold) {
         d.pos[2] = c.floor_threshold;
         if (f & F_ON_FLOOR) {
-            real theta = M<real>::atan2(R[3], R[0] + (real)1e-6);
-            yaw_rot<real>(theta, R);
+            yaw_rot_xy<real>(R[0] + (real)1e-6, R[3], R);
             real fr = (real)0.6 * (c.mass * (real)9.81 - force[2]);
             real vn = norm3<real>(d.vel);
             bool is_static = (c.floor_mode == QS_FLOOR_NUMPY) ? (vn == (real)0) : (vn < (real)1e-6);
@@ -254,20 +280,20 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
                 fxy = M<real>::fmax(fxy - fr, (real)0);
                 if (fxy == (real)0) { force[0] = 0; force[1] = 0; }
                 else {
-                    real ang = M<real>::atan2(force[1], force[0]), s, cs; M<real>::sincos(ang, &s, &cs);
+                    real s, cs; unit_xy<real>(force[0], force[1], &cs, &s);
                     force[0] = fxy * cs; force[1] = fxy * s;
                 }
             } else {
-                real ang = (c.floor_mode == QS_FLOOR_NUMPY) ? M<real>::atan2((real)-1 * d.vel[1], (real)-1 * d.vel[0])
-                                                            : M<real>::atan2(d.vel[1], d.vel[0]);
-                real s, cs; M<real>::sincos(ang, &s, &cs);
+                real s, cs;
+                if (c.floor_mode == QS_FLOOR_NUMPY) unit_xy<real>((real)-1 * d.vel[0], (real)-1 * d.vel[1], &cs, &s);
+                else unit_xy<real>(d.vel[0], d.vel[1], &cs, &s);
                 force[0] = force[0] - cs * fr; force[1] = force[1] - s * fr;
             }
         } else {
             f |= F_ON_FLOOR | F_CRASH_FLOOR;
 #pragma unroll
             for (int q = 0; q < 3; ++q) { d.vel[q] = 0; om[q] = 0; }
-            real theta = M<real>::atan2(R[3], R[0] + (real)1e-6);
+            real theta;
             if (R[8] < (real)0) {
                 if (c.floor_mode != QS_FLOOR_NUMPY) {
                     theta = rng_uniform1<real>(key, QS_SITE_FLOOR_YAW, sub * 64, drone, 0, (real)-QS_PI_D, (real)QS_PI_D);
@@ -282,7 +308,7 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
                     }
                 }
             } else {
-                yaw_rot<real>(theta, R);
+                yaw_rot_xy<real>(R[0] + (real)1e-6, R[3], R);
             }
 #pragma unroll
             for (int m = 0; m < 4; ++m) { d.cmds_damp[m] = 0; d.rot_damp[m] = 0; }

@@ -46,25 +46,26 @@ template <typename real> struct Ptrs {
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
 };
 
-struct LdsLayout { int off_prev, off_curr, off_bits, off_envflag, off_pos, off_vel, off_zax, off_om, off_goal, off_obs, obs_ld, goal_rows, total; };
+struct LdsLayout { int off_mask, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total; };
+#define QS_RESET_SCRATCH_INTS 160   // per env: virtual-pool index/value lists (2x64) + two DP rows (2x16)
 
-static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim) {
+static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K) {
     LdsLayout L;
     int o = 0;
-    L.off_prev = o; o += 8 * B;
-    L.off_curr = o; o += 8 * B;
-    L.off_bits = o; o += 4 * B;
+    L.off_mask = o; o += 8 * B;                       // u64 per lane: new-pair masks for the serial response path
     L.off_envflag = o; o += 4 * ((epb + 3) & ~3);
+    L.off_scratch = o; o += 4 * QS_RESET_SCRATCH_INTS * epb;
     o = (o + 15) & ~15;
     L.off_pos = o; o += real_size * 3 * B;
     L.off_vel = o; o += real_size * 3 * B;
-    L.off_zax = o; o += real_size * 3 * B;
+    L.off_zax = o; o += real_size * 3 * B;            // body z axes (downwash); spawn points in the reset tail
     L.off_om = o; o += real_size * 3 * B;
     L.goal_rows = 2 * N + 8;
     L.off_goal = o; o += real_size * 3 * L.goal_rows * epb;
+    L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
+    L.off_metric = o; o += (K > 0 && K < N - 1) ? real_size * N * B : 0;         // neighbour metric rows, [N][B]
     o = (o + 15) & ~15;
-    L.obs_ld = obs_dim | 1;
-    L.off_obs = o; o += real_size * L.obs_ld * B;
+    L.off_obs = o; o += real_size * obs_dim * B;      // observation staging, row-major, contiguous
     L.total = (o + 15) & ~15;
     return L;
 }
@@ -72,29 +73,43 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim) {
 // ------------------------------------------------------------------------------------------------
 // K-nearest neighbour observation for one drone (neighborhood_indices quadrotor_multi.py:247-274,
 // extend_obs_space :233-245).  pos/vel of the env's drones are in LDS (component-major, stride B).
+// The N-1 metrics are evaluated once into an LDS row, then K rounds of arg-min (lowest index wins ties,
+// like the stable ordering of argsort on distinct keys).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i, int base, int B, const real *s_pos, const real *s_vel,
-                                             const real mypos[3], const real myvel[3], real *o) {
+__device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
+                                             real *s_metric, const real mypos[3], const real myvel[3], real *o) {
     const int K = c.num_neighbors;
     if (K <= 0) return;
-    uint64_t taken = 1ull << i;
-    for (int k = 0; k < K; ++k) {
-        int best = -1;
-        if (K == N - 1) {
-            best = (k < i) ? k : k + 1;
-        } else {
-            real bm = 0;
-            for (int j = 0; j < N; ++j) {
-                if (taken >> j & 1) continue;
-                real rp[3] = {s_pos[0 * B + base + j] - mypos[0], s_pos[1 * B + base + j] - mypos[1], s_pos[2 * B + base + j] - mypos[2]};
-                real rv[3] = {s_vel[0 * B + base + j] - myvel[0], s_vel[1 * B + base + j] - myvel[1], s_vel[2 * B + base + j] - myvel[2]};
-                real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
-                real m = rd + ((rp[0] / rd) * rv[0] + (rp[1] / rd) * rv[1] + (rp[2] / rd) * rv[2]);
-                if (best < 0 || m < bm) { best = j; bm = m; }
+    if (K == N - 1) {
+        for (int k = 0; k < K; ++k) {
+            const int j = (k < i) ? k : k + 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                o[k * 6 + a] = clipr<real>(s_pos[a * B + base + j] - mypos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
+                o[k * 6 + 3 + a] = clipr<real>(s_vel[a * B + base + j] - myvel[a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
             }
-            taken |= 1ull << best;
         }
+        return;
+    }
+    for (int j = 0; j < N; ++j) {
+        real rp[3] = {s_pos[0 * B + base + j] - mypos[0], s_pos[1 * B + base + j] - mypos[1], s_pos[2 * B + base + j] - mypos[2]};
+        real rv[3] = {s_vel[0 * B + base + j] - myvel[0], s_vel[1 * B + base + j] - myvel[1], s_vel[2 * B + base + j] - myvel[2]};
+        real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
+        real m = rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) / rd;
+        s_metric[j * B + tid] = (j == i) ? (real)3.0e38 : m;
+    }
+    uint64_t taken = 0;
+    for (int k = 0; k < K; ++k) {
+        int best = 0;
+        real bm = (real)3.4e38;
+        for (int j = 0; j < N; ++j) {
+            real m = s_metric[j * B + tid];
+            bool better = !(taken >> j & 1) && m < bm;
+            best = better ? j : best;
+            bm = better ? m : bm;
+        }
+        taken |= 1ull << best;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             o[k * 6 + a] = clipr<real>(s_pos[a * B + base + best] - mypos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
@@ -103,7 +118,7 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
     }
 }
 
-// get_surround_sdfs obstacles/utils.py:5-27
+// get_surround_sdfs obstacles/utils.py:5-27 (obstacle xy of the env in LDS)
 template <typename real>
 __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o) {
     const real res = (real)0.1;
@@ -118,7 +133,7 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
                 real dx = gx[a] - x, dy = gy[b] - y, dist = M<real>::sqrt(dx * dx + dy * dy);
-                if (dist < mind[a * 3 + b]) mind[a * 3 + b] = dist;
+                mind[a * 3 + b] = dist < mind[a * 3 + b] ? dist : mind[a * 3 + b];
             }
     }
 #pragma unroll
@@ -127,7 +142,7 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
 
 // perform_collision_between_drones collisions/quadrotors.py:24-59 on LDS-resident vel/omega (serial per env)
 template <typename real>
-__device__ void collide_drones_lds(const RngKey &key, int i, int j, int base, int B, const real *s_pos, real *s_vel, real *s_om) {
+__device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int j, int base, int B, const real *s_pos, real *s_vel, real *s_om) {
     real p1[3], p2[3], v1[3], v2[3];
     for (int q = 0; q < 3; ++q) { p1[q] = s_pos[q * B + base + i]; p2[q] = s_pos[q * B + base + j]; v1[q] = s_vel[q * B + base + i]; v2[q] = s_vel[q * B + base + j]; }
     real n[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
@@ -162,415 +177,69 @@ __device__ void collide_drones_lds(const RngKey &key, int i, int j, int base, in
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// THE step kernel: one control step of every environment (QuadrotorEnvMulti.step without the reset tail)
-// ------------------------------------------------------------------------------------------------
+// rare per-drone responses kept out of line so the hot path stays compact
 template <typename real>
-__global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__restrict__ cp, Ptrs<real> p, const real *__restrict__ actions,
-                                                          LdsLayout L, int epb) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, const RngKey &key, int i, uint32_t bits, real ox, real oy, real pos[3], real vel[3], real omega[3]) {
     const Consts<real> &c = *cp;
-    const int B = QS_WAVE, N = c.num_agents, E = c.num_envs, T = E * N;
-    uint64_t *s_prev = (uint64_t *)(smem + L.off_prev), *s_curr = (uint64_t *)(smem + L.off_curr);
-    uint32_t *s_bits = (uint32_t *)(smem + L.off_bits), *s_envflag = (uint32_t *)(smem + L.off_envflag);
-    real *s_pos = (real *)(smem + L.off_pos), *s_vel = (real *)(smem + L.off_vel), *s_zax = (real *)(smem + L.off_zax);
-    real *s_om = (real *)(smem + L.off_om), *s_goal = (real *)(smem + L.off_goal), *s_obs = (real *)(smem + L.off_obs);
-
-    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
-    const bool active = (le < epb) && (e < E);
-    const int g = active ? e * N + i : 0;
-
     Drone<real> d;
-    real goal[3], act[4], rew = 0, ri[QS_RI_COUNT];
-    uint64_t prev_pair = 0, curr_pair = 0, new_pair = 0;
-    int tick = 0;
-    RngKey key = {c.seed_lo, c.seed_hi, 0, 0};
-    real *myobs = s_obs + tid * L.obs_ld;
-    bool done = false;
-    uint32_t bits = 0;
-    int obst_idx = -1;
-
-    if (active) {
-        // ---- load (coalesced: component-major SoA) ----
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { d.pos[q] = p.pos[q * T + g]; d.vel[q] = p.vel[q * T + g]; d.omega[q] = p.omega[q * T + g]; goal[q] = p.goal[q * T + g]; }
+    for (int q = 0; q < 3; ++q) { d.pos[q] = pos[q]; d.vel[q] = vel[q]; d.omega[q] = omega[q]; }
+    if (bits & B_OBST_NEW) collide_obstacle<real>(c, key, i, d, ox, oy);      // collisions/obstacles.py:23-50
+    if (bits & B_WALL_NEW) collide_room<real>(c, key, i, d, true);            // collisions/room.py:6-44
+    if (bits & B_CEIL_NEW) collide_room<real>(c, key, i, d, false);           // collisions/room.py:91-113
 #pragma unroll
-        for (int q = 0; q < 9; ++q) d.rot[q] = p.rot[q * T + g];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { d.rot_damp[q] = p.rot_damp[q * T + g]; d.cmds_damp[q] = p.cmds_damp[q * T + g]; d.ou[q] = p.ou[q * T + g]; }
-        d.flags = p.flags[g];
-        prev_pair = p.pair_mask[g];
-        {   // actions are row-major [T,4]: one 16/32-byte vector load per lane
-            const real *a = actions + (size_t)g * 4;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) act[q] = a[q];
-        }
-        const int tick_before = p.tick[e];
-        key.env = (uint32_t)(c.env_id_offset + e);
-        key.step = p.step_ctr[e] + 1;
-
-        // ---- A. per-drone step: RawControl quadrotor_control.py:53-57, OU noise quad_utils.py:275-279,
-        //         2 sub-steps, reward quadrotor_single.py:34-92, tick/done :352-353, self obs ----
-        real cmds[4], z[4], acc[3];
-        rng_normal<real, 4>(key, QS_SITE_OU, 0, i, 0, z);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            cmds[m] = (real)0.5 * (clipr<real>(act[m], (real)-1, (real)1) + (real)1);
-            real x = d.ou[m];
-            d.ou[m] = x + (c.ou_theta * ((real)0 - x) + c.thrust_noise_sigma * z[m]);
-        }
-        for (int s = 0; s < c.sim_steps; ++s) substep<real>(c, key, i, s, d, cmds, acc);
-
-        {
-            const real dt = c.dt;
-            real diff[3] = {goal[0] - d.pos[0], goal[1] - d.pos[1], goal[2] - d.pos[2]};
-            real cpr = norm3<real>(diff), cpos = c.rew_coeff[QS_REW_POS] * cpr;
-            real cer = M<real>::sqrt(act[0] * act[0] + act[1] * act[1] + act[2] * act[2] + act[3] * act[3]), cef = c.rew_coeff[QS_REW_EFFORT] * cer;
-            bool on_floor = (d.flags & F_ON_FLOOR) != 0;
-            real cor = on_floor ? (real)1 : -d.rot[8], cori = c.rew_coeff[QS_REW_ORIENT] * cor;
-            real csr = M<real>::sqrt(d.omega[0] * d.omega[0] + d.omega[1] * d.omega[1] + d.omega[2] * d.omega[2]), cspin = c.rew_coeff[QS_REW_SPIN] * csr;
-            real ccr = on_floor ? (real)1 : (real)0, ccrash = c.rew_coeff[QS_REW_CRASH] * ccr;
-            rew = -dt * ((((cpos + cef) + ccrash) + cori) + cspin);
-            ri[QS_RI_REW_MAIN] = dt * -cpos; ri[QS_RI_REW_POS] = dt * -cpos; ri[QS_RI_REW_ACTION] = dt * -cef;
-            ri[QS_RI_REW_CRASH] = dt * -ccrash; ri[QS_RI_REW_ORIENT] = dt * -cori; ri[QS_RI_REW_SPIN] = dt * -cspin;
-            ri[QS_RI_RAW_MAIN] = dt * -cpr; ri[QS_RI_RAW_POS] = dt * -cpr; ri[QS_RI_RAW_ACTION] = dt * -cer;
-            ri[QS_RI_RAW_CRASH] = dt * -ccr; ri[QS_RI_RAW_ORIENT] = dt * -cor; ri[QS_RI_RAW_SPIN] = dt * -csr;
-            ri[QS_RI_REW_QUADCOL_OBST] = 0; ri[QS_RI_RAW_QUADCOL_OBST] = 0;
-            if (!(rew == rew) || M<real>::fabs(rew) > (real)3.0e38) atomicOr(p.error_flag, 1u);
-        }
-        tick = tick_before + 1;
-        done = tick > c.ep_len;
-        self_obs<real>(c, key, i, 0, d, goal, myobs);
-
-        // ---- publish for the per-env phases ----
-#pragma unroll
-        for (int q = 0; q < 3; ++q) s_pos[q * B + tid] = d.pos[q];
-        s_zax[0 * B + tid] = d.rot[2]; s_zax[1 * B + tid] = d.rot[5]; s_zax[2 * B + tid] = d.rot[8];
-        s_prev[tid] = prev_pair;
-    }
-    __syncthreads();
-
-    real prox = 0;
-    bool in_curr = false;
-    if (active) {
-        // ---- B. drone-drone pair scan: calculate_collision_matrix collisions/quadrotors.py:63-91,
-        //         proximity penalties :95-103 ----
-        const real pr = -c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX] / c.collision_falloff_threshold;
-        for (int j = 0; j < N; ++j) {
-            if (j == i) continue;
-            real dx = d.pos[0] - s_pos[0 * B + base + j], dy = d.pos[1] - s_pos[1 * B + base + j], dz = d.pos[2] - s_pos[2 * B + base + j];
-            real dist = M<real>::sqrt(dx * dx + dy * dy + dz * dz);
-            if (dist <= c.collision_threshold) { in_curr = true; if (j > i) curr_pair |= 1ull << j; }
-            if (dist <= c.collision_falloff_threshold) prox += pr * dist + c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX];
-        }
-        // ---- obstacles: first hit in index order, obstacles/utils.py:31-43 ----
-        if (c.use_obstacles) {
-            const int M_ = c.num_obstacles;
-            const real *ox = p.obst_pos + (size_t)e * M_, *oy = p.obst_pos + (size_t)E * M_ + (size_t)e * M_;
-            for (int k = 0; k < M_; ++k) {
-                real dx = d.pos[0] - ox[k], dy = d.pos[1] - oy[k];
-                if (M<real>::sqrt(dx * dx + dy * dy) <= c.obst_hit_threshold) { obst_idx = k; break; }
-            }
-            if (obst_idx >= 0) { bits |= B_OBST_HIT; if (!(d.flags & F_PREV_OBST)) bits |= B_OBST_NEW; d.flags |= F_PREV_OBST; }
-            else d.flags &= ~F_PREV_OBST;
-        }
-        // ---- room lists: calculate_room_collision quadrotor_multi.py:289-302, :491-497 ----
-        uint32_t f = d.flags;
-        if (f & F_CRASH_FLOOR) bits |= B_FLOOR;
-        if ((f & F_CRASH_WALL) && !(f & F_PREV_WALL)) bits |= B_WALL_NEW;
-        if ((f & F_CRASH_CEIL) && !(f & F_PREV_CEIL)) bits |= B_CEIL_NEW;
-        if ((bits & (B_FLOOR | B_WALL_NEW | B_CEIL_NEW)) && !(f & F_PREV_ROOM)) bits |= B_ROOM_NEW;
-        f &= ~(F_PREV_WALL | F_PREV_CEIL | F_PREV_ROOM);
-        if (bits & B_WALL_NEW) f |= F_PREV_WALL;
-        if (bits & B_CEIL_NEW) f |= F_PREV_CEIL;
-        if (bits & B_ROOM_NEW) f |= F_PREV_ROOM;
-        d.flags = f;
-        s_curr[tid] = curr_pair;
-        s_bits[tid] = bits;
-    }
-    __syncthreads();
-
-    uint64_t unique = 0, m_obst_hit = 0, m_obst_new = 0, m_floor = 0, m_wall = 0, m_ceil = 0, m_room = 0, m_newpair_any = 0;
-    if (active) {
-        // ---- env-level id sets (quadrotor_multi.py:432-459, :462-488): every lane derives them redundantly ----
-        uint64_t curr_ids = 0, prev_ids = 0;
-        for (int j = 0; j < N; ++j) {
-            uint64_t cpj = s_curr[base + j], ppj = s_prev[base + j];
-            if (cpj) curr_ids |= (1ull << j) | cpj;
-            if (ppj) prev_ids |= (1ull << j) | ppj;
-            m_newpair_any |= cpj & ~ppj;
-            uint32_t b = s_bits[base + j];
-            uint64_t bj = 1ull << j;
-            if (b & B_OBST_HIT) m_obst_hit |= bj;
-            if (b & B_OBST_NEW) m_obst_new |= bj;
-            if (b & B_FLOOR) m_floor |= bj;
-            if (b & B_WALL_NEW) m_wall |= bj;
-            if (b & B_CEIL_NEW) m_ceil |= bj;
-            if (b & B_ROOM_NEW) m_room |= bj;
-        }
-        unique = curr_ids & ~prev_ids;                       // np.setdiff1d on flattened ids (:440)
-        new_pair = curr_pair & ~prev_pair;                   // pair-level novelty (:437-438)
-        const int col_tick = __popcll(unique) / 2;           // :448
-        const int obst_cnt = __popcll(m_obst_new);
-        const bool settled = tick >= c.grace_steps;
-        const int time_remain = c.ep_len - (tick - 1);
-        if (col_tick > 0 && settled && (unique >> i & 1)) d.flags &= ~F_COL_AGENT_OK;
-        if (obst_cnt > 0 && settled && (bits & B_OBST_NEW)) d.flags &= ~F_COL_OBST_OK;
-
-        // ---- rewards (:499-546) ----
-        const bool any_nonzero_id = (unique & ~1ull) != 0;   // `.any()` of the id array
-        real raw = (any_nonzero_id && (unique >> i & 1)) ? (real)-1 : (real)0;
-        real rc = c.rew_coeff[QS_REW_QUADCOL_BIN] * raw;
-        real rp = (real)-1 * (c.control_dt * prox);
-        rew += rc;
-        rew += rp;
-        ri[QS_RI_REW_QUADCOL] = rc; ri[QS_RI_REW_PROXIMITY] = rp; ri[QS_RI_RAW_QUADCOL] = raw;
-        if (c.use_obstacles) {
-            real ro_raw = (m_obst_hit && (bits & B_OBST_NEW)) ? (real)-1 : (real)0;
-            real ro = c.rew_coeff[QS_REW_QUADCOL_OBST] * ro_raw;
-            rew += ro;
-            ri[QS_RI_REW_QUADCOL_OBST] = ro; ri[QS_RI_RAW_QUADCOL_OBST] = ro_raw;
-        }
-        // ---- distance-to-goal log, reached_goal (:542-546), windowed sums for the episode stats (:649-661) ----
-        {
-            real dnow = -ri[QS_RI_RAW_POS];
-            real r0 = p.dist_ring[0 * T + g], r1 = p.dist_ring[1 * T + g], r2 = p.dist_ring[2 * T + g], r3 = p.dist_ring[3 * T + g];
-            if (tick >= 5 && !(d.flags & F_REACHED)) {
-                real mean5 = ((((r3 + r2) + r1) + r0) + dnow) / (real)5;
-                if (mean5 / c.dt < c.approach_goal_metric) d.flags |= F_REACHED;
-            }
-            p.dist_ring[3 * T + g] = r2; p.dist_ring[2 * T + g] = r1; p.dist_ring[1 * T + g] = r0; p.dist_ring[0 * T + g] = dnow;
-            const int total = c.ep_len + 1;
-#pragma unroll
-            for (int w = 0; w < 3; ++w) {
-                int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * c.control_freq;
-                real sum = (tick == 1) ? (real)0 : p.dist_sums[w * T + g];
-                if (tick > total - win) sum += dnow;
-                p.dist_sums[w * T + g] = sum;
-                if (done) {
-                    int cnt = total < win ? total : win;
-                    p.ep_stats[w * T + g] = ((real)1 / c.dt) * (sum / (real)cnt);
-                }
-            }
-        }
-        // ---- per-env counters and masks, lane 0 of the env ----
-        if (i == 0) {
-            int32_t cnt[QS_CNT_COUNT];
-#pragma unroll
-            for (int q = 0; q < QS_CNT_COUNT; ++q) cnt[q] = p.counters[q * E + e];
-            cnt[QS_CNT_COLLISIONS] += col_tick;
-            if (col_tick > 0 && settled) cnt[QS_CNT_COLLISIONS_AFTER_SETTLE] += col_tick;
-            if (col_tick > 0 && time_remain <= c.final_steps) cnt[QS_CNT_COLLISIONS_FINAL_5S] += col_tick;
-            cnt[QS_CNT_OBST] += obst_cnt;
-            if (obst_cnt > 0 && settled) cnt[QS_CNT_OBST_AFTER_SETTLE] += obst_cnt;
-            if (settled) {
-                cnt[QS_CNT_ROOM] += __popcll(m_room); cnt[QS_CNT_FLOOR] += __popcll(m_floor);
-                cnt[QS_CNT_WALL] += __popcll(m_wall); cnt[QS_CNT_CEILING] += __popcll(m_ceil);
-            }
-            if (obst_cnt > 0 && settled) {
-                // distance_to_goal_3_5 / _5 use the NOISY relative position of the self obs (:474-478)
-                for (int j = 0; j < N; ++j) if (m_obst_new >> j & 1) {
-                    const real *oj = s_obs + (base + j) * L.obs_ld;
-                    real q = M<real>::sqrt(oj[0] * oj[0] + oj[1] * oj[1] + oj[2] * oj[2]);
-                    if (q > (real)3.5) cnt[QS_CNT_OBST_DIST_3_5] += 1;
-                    if (q > (real)5.0) cnt[QS_CNT_OBST_DIST_5] += 1;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < QS_CNT_COUNT; ++q) { p.counters[q * E + e] = cnt[q]; if (done) p.ep_counters[q * E + e] = cnt[q]; }
-            p.unique_col[e] = unique; p.obst_new[e] = m_obst_new; p.room_new[e] = m_room;
-            p.tick[e] = tick;
-            p.step_ctr[e] = key.step;
-            if (done) p.reset_mask[e] = 1;
-        }
-
-        // ---- C. physical interactions, in the reference's order (:548-587) ----
-        // 1) downwash aerodynamics/downwash.py:4-66: this lane is the LOWER drone j, loops upper drones ii
-        if (c.use_downwash) {
-            for (int ii = 0; ii < N; ++ii) {
-                if (ii == i) continue;
-                real rel[3] = {d.pos[0] - s_pos[0 * B + base + ii], d.pos[1] - s_pos[1 * B + base + ii], d.pos[2] - s_pos[2 * B + base + ii]};
-                real zx[3] = {s_zax[0 * B + base + ii], s_zax[1 * B + base + ii], s_zax[2 * B + base + ii]};
-                real dist = norm3<real>(rel), rz = dot3<real>(rel, zx), rxy = M<real>::sqrt(dist * dist - rz * rz);
-                if ((real)-0.7 < rz && rz < (real)0 && rxy < (real)0.1) {
-                    uint32_t w[4];
-                    rng_words(key, QS_SITE_DW_I, 0, ii, 0, w);
-                    real ua = (real)-0.1 + (real)0.2 * u01<real>(w[0]), uw = (real)-0.01 + (real)0.02 * u01<real>(w[1]);
-                    real a = M<real>::fmax((real)1e-6, (real)(6.0 / 17.0) * ((real)-10 * dist + (real)7) + ua);
-                    real ow = M<real>::fmax((real)1e-6, (real)0.3 * ((dist - (real)1) * (dist - (real)1)) + uw);
-                    real nz[3], dirw[3];
-                    rng_words(key, QS_SITE_DW_IJ_V, 0, ii, i, w);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) nz[q] = zx[q] + ((real)-0.1 + (real)0.2 * u01<real>(w[q]));
-                    rng_words(key, QS_SITE_DW_IJ_W, 0, ii, i, w);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) dirw[q] = (real)-1 + (real)2 * u01<real>(w[q]);
-                    real mz = norm3<real>(nz), dz = (mz == (real)0) ? mz + (real)1e-6 : mz;
-                    real mw = norm3<real>(dirw), dwn = (mw == (real)0) ? mw + (real)1e-6 : mw;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        real down = (real)-1 * (nz[q] / dz);
-                        d.vel[q] += a * down * c.control_dt;
-                        d.omega[q] += ow * (dirw[q] / dwn) * c.control_dt;
-                    }
-                    bits |= B_DOWNWASH;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { s_vel[q * B + tid] = d.vel[q]; s_om[q * B + tid] = d.omega[q]; }
-        s_bits[tid] = bits;
-    }
-    __syncthreads();
-
-    bool update_flag = false;
-    if (active) {
-        // 2) drone-drone responses for the NEW pairs in lexicographic order (collisions/quadrotors.py:24-59);
-        //    order-dependent, so one lane per env walks the pair list on the LDS-resident vel/omega
-        if (m_newpair_any && i == 0) {
-            for (int a = 0; a < N; ++a) {
-                uint64_t np = s_curr[base + a] & ~s_prev[base + a];
-                while (np) {
-                    int b = __ffsll((long long)np) - 1;
-                    np &= np - 1;
-                    collide_drones_lds<real>(key, a, b, base, B, s_pos, s_vel, s_om);
-                }
-            }
-        }
-        bool any_dw = false;
-        for (int j = 0; j < N; ++j) any_dw |= (s_bits[base + j] & B_DOWNWASH) != 0;
-        update_flag = any_dw || (m_newpair_any != 0) || (m_obst_new != 0) || (m_wall != 0) || (m_ceil != 0);
-    }
-    __syncthreads();
-
-    if (active) {
-        if (m_newpair_any) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { d.vel[q] = s_vel[q * B + tid]; d.omega[q] = s_om[q * B + tid]; }
-        }
-        // 3) obstacle response (collisions/obstacles.py:23-50), 4) wall then ceiling (collisions/room.py)
-        if (bits & B_OBST_NEW) {
-            const int M_ = c.num_obstacles;
-            collide_obstacle<real>(c, key, i, d, p.obst_pos[(size_t)e * M_ + obst_idx], p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + obst_idx]);
-        }
-        if (bits & B_WALL_NEW) collide_room<real>(c, key, i, d, true);
-        if (bits & B_CEIL_NEW) collide_room<real>(c, key, i, d, false);
-    }
-
-    // ---- D. scenario.step(): swarm_vs_swarm swaps the two formations every U(4,6) s (swarm_vs_swarm.py:59-79) ----
-    if (c.scenario == QS_SCENARIO_SWARM_VS_SWARM) {
-        if (active && i == 0) {
-            const int period = p.scen_int[e];
-            uint32_t sw = 0;
-            if (period > 0 && tick % period == 0 && tick > 0) {
-                real c1[3], c2[3];
-                for (int q = 0; q < 3; ++q) { c1[q] = p.scen_real[(3 + q) * E + e]; c2[q] = p.scen_real[q * E + e]; }
-                for (int q = 0; q < 3; ++q) { p.scen_real[q * E + e] = c1[q]; p.scen_real[(3 + q) * E + e] = c2[q]; }
-                Formation<real> F;
-                update_formation<real>(c, key, 32, N, F);
-                svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, true, s_goal + le * L.goal_rows * 3);
-                sw = 1;
-            }
-            s_envflag[le] = sw;
-        }
-        __syncthreads();
-        if (active && s_envflag[le]) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) goal[q] = s_goal[(le * L.goal_rows + i) * 3 + q];
-        }
-    }
-
-    if (active) {
-        // ---- E. final observations (:592-607) ----
-#pragma unroll
-        for (int q = 0; q < 3; ++q) s_vel[q * B + tid] = d.vel[q];
-        if (update_flag) self_obs<real>(c, key, i, 1, d, goal, myobs);   // fresh sensor noise, new goal (:598-599)
-    }
-    __syncthreads();
-
-    if (active) {
-        neighbor_obs<real>(c, N, i, base, B, s_pos, s_vel, d.pos, d.vel, myobs + c.self_dim);
-        if (c.use_obstacles) {
-            const int M_ = c.num_obstacles;
-            sdf_obs<real>(c, p.obst_pos + (size_t)e * M_, p.obst_pos + (size_t)E * M_ + (size_t)e * M_, M_, d.pos[0], d.pos[1],
-                          myobs + c.self_dim + 6 * c.num_neighbors);
-        }
-        // ---- G. write back ----
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = d.vel[q]; p.omega[q * T + g] = d.omega[q]; p.goal[q * T + g] = goal[q]; }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) p.rot[q * T + g] = d.rot[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { p.rot_damp[q * T + g] = d.rot_damp[q]; p.cmds_damp[q * T + g] = d.cmds_damp[q]; p.ou[q * T + g] = d.ou[q]; }
-        p.flags[g] = d.flags;
-        p.pair_mask[g] = curr_pair;
-        p.new_pair_mask[g] = new_pair;
-        p.obst_hit_idx[g] = obst_idx;
-        p.reward[g] = rew;
-        p.done[g] = done ? 1 : 0;
-#pragma unroll
-        for (int q = 0; q < QS_RI_COUNT; ++q) p.rew_info[q * T + g] = ri[q];
-        if (done) {
-            p.ep_stats[QS_EPS_REACHED_GOAL * T + g] = (d.flags & F_REACHED) ? (real)1 : (real)0;
-            p.ep_stats[QS_EPS_COL_AGENT_OK * T + g] = (d.flags & F_COL_AGENT_OK) ? (real)1 : (real)0;
-            p.ep_stats[QS_EPS_COL_OBST_OK * T + g] = (d.flags & F_COL_OBST_OK) ? (real)1 : (real)0;
-        }
-    }
-    __syncthreads();
-    {   // obs copy-out: the workgroup's rows form one contiguous [rows*obs_dim] block in HBM
-        const int D = c.obs_dim, first_env = blockIdx.x * epb;
-        int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
-        const int total = nenv * N * D;
-        real *dst = p.obs + (size_t)first_env * N * D;
-        for (int idx = tid; idx < total; idx += B) {
-            int row = idx / D, col = idx - row * D;
-            dst[idx] = s_obs[row * L.obs_ld + col];
-        }
-    }
+    for (int q = 0; q < 3; ++q) { vel[q] = d.vel[q]; omega[q] = d.omega[q]; }
 }
 
 // ------------------------------------------------------------------------------------------------
-// reset kernel: QuadrotorEnvMulti.reset quadrotor_multi.py:339-411 for the envs flagged in reset_mask
+// Episode reset of the envs whose lanes have `do_reset` set: QuadrotorEnvMulti.reset quadrotor_multi.py:339-411
+// (+ QuadrotorSingle._reset quadrotor_single.py:387-447, obst_generation_given_density quadrotor_multi.py:304-325,
+// scenario.reset()).  Shared by the reset kernel and the tail of the step kernel (auto-reset inside step, :720).
+// Must be entered by the whole workgroup (contains barriers).  Outputs: d / goal (registers), the obs row in LDS,
+// per-env global scratch (obstacle positions, scenario state).  `stale_vel` are the previous episode's final
+// velocities: the first neighbour obs of an episode is computed from them (SURVEY App. A reset quirk).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *__restrict__ cp, Ptrs<real> p, LdsLayout L, int epb) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem, int epb, const RngKey &key,
+                                        bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3]) {
     const Consts<real> &c = *cp;
-    const int B = QS_WAVE, N = c.num_agents, E = c.num_envs, T = E * N;
-    real *s_pos = (real *)(smem + L.off_pos), *s_vel = (real *)(smem + L.off_vel);
-    real *s_goal = (real *)(smem + L.off_goal), *s_obs = (real *)(smem + L.off_obs);
-    real *s_spawn = (real *)(smem + L.off_zax);   // [3][B] spawn points (obstacle scenarios)
+    const Ptrs<real> &p = *pp;
+    const LdsLayout &L = *Lp;
+    Drone<real> &d = *dp;
+    const int B = QS_WAVE, N = c.num_agents, E = c.num_envs;
+    real *s_pos = (real *)(smem + L.off_pos), *s_vel = (real *)(smem + L.off_vel), *s_spawn = (real *)(smem + L.off_zax);
+    real *s_goal = (real *)(smem + L.off_goal), *s_obs = (real *)(smem + L.off_obs), *s_obst = (real *)(smem + L.off_obst);
+    real *s_metric = (real *)(smem + L.off_metric);
     uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
-
     const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
-    const bool in_range = (le < epb) && (e < E);
-    const bool active = in_range && p.reset_mask[e] != 0;
-    const int g = in_range ? e * N + i : 0;
-    RngKey key = {c.seed_lo, c.seed_hi, 0, 0};
-    if (active) { key.env = (uint32_t)(c.env_id_offset + e); key.step = p.step_ctr[e]; }
+    const int M_ = c.num_obstacles;
+    real *myobs = s_obs + tid * c.obs_dim;
+    int *tidx = (int *)(smem + L.off_scratch) + le * QS_RESET_SCRATCH_INTS, *tval = tidx + 64, *prev_row = tidx + 128, *cur_row = tidx + 144;
 
-    // ---- per-env part (one lane): obstacle map (quadrotor_multi.py:304-325) + scenario.reset() ----
-    if (active && i == 0) {
+    // ---- per-env part (one lane): obstacle map + scenario.reset() ----
+    if (do_reset && i == 0) {
         real *goals = s_goal + le * L.goal_rows * 3;
         uint32_t have_spawn = 0;
         uint64_t omap[4] = {0, 0, 0, 0};   // obstacle map bitset, cell id = rid*W + cid
-        const int Lr = c.obst_area[0], W = c.obst_area[1], M_ = c.num_obstacles, cells = Lr * W;
+        const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W;
         if (c.use_obstacles) {
             // np.random.choice(cells, M, replace=False): partial Fisher-Yates on a virtual pool
-            int tidx[2 * QS_MAX_OBSTACLES], tval[2 * QS_MAX_OBSTACLES], nt = 0;
+            int nt = 0;
             for (int k = 0; k < M_; ++k) {
                 int j = k + (int)(rng_uniform1<real>(key, QS_SITE_OBST_MAP, k, 0, 0, (real)0, (real)1) * (real)(cells - k));
                 if (j >= cells) j = cells - 1;
-                int vk = k, vj = j, pk = -1, pj = -1;
-                for (int q = 0; q < nt; ++q) { if (tidx[q] == k) { vk = tval[q]; pk = q; } if (tidx[q] == j) { vj = tval[q]; pj = q; } }
-                if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }   // pool[j] = pool[k]
-                (void)pk;                                                                  // pool[k] = vj is the pick
+                int vk = k, vj = j, pj = -1;
+                for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
+                if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }   // pool[j] = pool[k]; the pick is old pool[j]
                 int id = vj, rid = id / W, cid = id - rid * W;
                 omap[id >> 6] |= 1ull << (id & 63);
                 // cell centre index rid + L*cid (quadrotor_multi.py:321); centres per obstacles/utils.py:47-58
                 int ci = rid + Lr * cid, ii = ci / W, jj = (W - 1) - (ci - ii * W);
-                p.obst_pos[(size_t)e * M_ + k] = (real)ii + (real)0.5 - (real)(Lr / 2);
-                p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + k] = (real)jj + (real)0.5 - (real)(W / 2);
+                real ox = (real)ii + (real)0.5 - (real)(Lr / 2), oy = (real)jj + (real)0.5 - (real)(W / 2);
+                p.obst_pos[(size_t)e * M_ + k] = ox;
+                p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + k] = oy;
+                s_obst[(le * 2 + 0) * M_ + k] = ox;
+                s_obst[(le * 2 + 1) * M_ + k] = oy;
             }
         }
         Formation<real> F;
@@ -581,15 +250,14 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *_
         } else if (c.scenario == QS_SCENARIO_O_STATIC_SAME_GOAL) {
             // obstacles/o_static_same_goal.py:27-48 + o_base.py:69-81,:124-153
             int nfree = cells - M_;
-            int tidx[2 * QS_MAX_AGENTS], tval[2 * QS_MAX_AGENTS], nt = 0;
+            int nt = 0;
             for (int k = 0; k < N; ++k) {
                 int j = k + (int)(rng_uniform1<real>(key, QS_SITE_SCEN, 16 + k, 0, 0, (real)0, (real)1) * (real)(nfree - k));
                 if (j >= nfree) j = nfree - 1;
                 int vk = k, vj = j, pj = -1;
                 for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
                 if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }
-                // vj-th free cell in row-major order (np.where(obst_map == 0))
-                int seen = 0, cell = 0;
+                int seen = 0, cell = 0;   // vj-th free cell in row-major order (np.where(obst_map == 0))
                 for (int id = 0; id < cells; ++id) if (!(omap[id >> 6] >> (id & 63) & 1)) { if (seen == vj) { cell = id; break; } ++seen; }
                 int x = cell / W, y = cell - x * W, index = x + Lr * y, ii = index / W, jj = (W - 1) - (index - ii * W);
                 s_spawn[0 * B + base + k] = (real)ii + (real)0.5 - (real)(Lr / 2);
@@ -598,7 +266,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *_
             }
             have_spawn = 1;
             // max_square_area_center o_base.py:124-153 (two-row dynamic programme)
-            int prev_row[16], cur_row[16], max_size = 0, cx = 0, cy = 0;
+            int max_size = 0, cx = 0, cy = 0;
             for (int q = 0; q < W; ++q) prev_row[q] = (int)(omap[q >> 6] >> (q & 63) & 1);
             for (int r = 1; r < Lr; ++r) {
                 int id0 = r * W;
@@ -646,17 +314,10 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *_
             svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, false, goals);
         }
         s_envflag[le] = have_spawn;
-        // per-env bookkeeping (:386-409)
-        for (int q = 0; q < QS_CNT_COUNT; ++q) p.counters[q * E + e] = 0;
-        p.tick[e] = 0;
-        p.unique_col[e] = 0; p.obst_new[e] = 0; p.room_new[e] = 0;
     }
     __syncthreads();
 
-    Drone<real> d;
-    real goal[3];
-    real *myobs = s_obs + tid * L.obs_ld;
-    if (active) {
+    if (do_reset) {
         // ---- per-drone part: QuadrotorSingle._reset quadrotor_single.py:387-447 ----
         real spawn[3];
 #pragma unroll
@@ -676,22 +337,410 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *_
             yaw_rot<real>(th, d.rot);
             if (!(d.rot[0] * xy[0] + d.rot[3] * xy[1] < (real)0.5)) break;
         }
-        // NB: the neighbour obs of the first step uses the PREVIOUS episode's final velocities (App. A reset quirk)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { s_vel[q * B + tid] = p.vel[q * T + g]; s_pos[q * B + tid] = d.pos[q]; d.vel[q] = 0; d.omega[q] = 0; }
-        const uint32_t old_flags = p.flags[g];
-        d.flags = F_COL_AGENT_OK | F_COL_OBST_OK | (old_flags & F_SVD_MASK);   // since_last_svd persists (App. A)
+        for (int q = 0; q < 3; ++q) { s_vel[q * B + tid] = stale_vel[q]; s_pos[q * B + tid] = d.pos[q]; d.vel[q] = 0; d.omega[q] = 0; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { d.rot_damp[q] = 0; d.cmds_damp[q] = 0; }
+        d.flags = F_COL_AGENT_OK | F_COL_OBST_OK | (d.flags & F_SVD_MASK);   // since_last_svd persists (App. A)
         self_obs<real>(c, key, i, 0, d, goal, myobs);
     }
     __syncthreads();
-    if (active) {
-        real stale_vel[3] = {s_vel[0 * B + tid], s_vel[1 * B + tid], s_vel[2 * B + tid]};
-        neighbor_obs<real>(c, N, i, base, B, s_pos, s_vel, d.pos, stale_vel, myobs + c.self_dim);
-        if (c.use_obstacles) {
-            const int M_ = c.num_obstacles;
-            sdf_obs<real>(c, p.obst_pos + (size_t)e * M_, p.obst_pos + (size_t)E * M_ + (size_t)e * M_, M_, d.pos[0], d.pos[1],
-                          myobs + c.self_dim + 6 * c.num_neighbors);
+    if (do_reset) {
+        neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, stale_vel, myobs + c.self_dim);
+        if (c.use_obstacles)
+            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE step kernel: one control step of every environment = QuadrotorEnvMulti.step incl. the auto-reset tail.
+// All global loads are issued at the top, all global stores at the bottom; in between the wave works in
+// registers + LDS only, so HBM latency is paid once per step.
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+__global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__restrict__ cp, Ptrs<real> p, const real *__restrict__ actions,
+                                                          LdsLayout L, int epb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Consts<real> &c = *cp;
+    const int B = QS_WAVE, N = c.num_agents, E = c.num_envs, T = E * N, M_ = c.num_obstacles;
+    uint64_t *s_mask = (uint64_t *)(smem + L.off_mask);
+    uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
+    real *s_pos = (real *)(smem + L.off_pos), *s_vel = (real *)(smem + L.off_vel), *s_zax = (real *)(smem + L.off_zax);
+    real *s_om = (real *)(smem + L.off_om), *s_goal = (real *)(smem + L.off_goal), *s_obs = (real *)(smem + L.off_obs);
+    real *s_obst = (real *)(smem + L.off_obst), *s_metric = (real *)(smem + L.off_metric);
+
+    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
+    const bool active = (le < epb) && (e < E);
+    const int g = active ? e * N + i : 0, ee = active ? e : 0;
+    const uint64_t nmask = (N >= 64) ? ~0ull : ((1ull << N) - 1);
+    real *myobs = s_obs + tid * c.obs_dim;
+
+    // ================= loads (coalesced: component-major SoA) =================
+    Drone<real> d;
+    real goal[3], act[4], ring[4], sums[3];
+    int32_t cnt[QS_CNT_COUNT];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { d.pos[q] = p.pos[q * T + g]; d.vel[q] = p.vel[q * T + g]; d.omega[q] = p.omega[q * T + g]; goal[q] = p.goal[q * T + g]; sums[q] = p.dist_sums[q * T + g]; }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) d.rot[q] = p.rot[q * T + g];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { d.rot_damp[q] = p.rot_damp[q * T + g]; d.cmds_damp[q] = p.cmds_damp[q * T + g]; d.ou[q] = p.ou[q * T + g]; ring[q] = p.dist_ring[q * T + g]; }
+    d.flags = p.flags[g];
+    const uint64_t prev_pair = p.pair_mask[g];
+    {   // actions are row-major [T,4]: one 16/32-byte vector load per lane
+        const real *a = actions + (size_t)g * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) act[q] = a[q];
+    }
+    const int tick_before = p.tick[ee];
+    const uint32_t step_no = p.step_ctr[ee] + 1;
+    const int svs_period = (c.scenario == QS_SCENARIO_SWARM_VS_SWARM) ? p.scen_int[ee] : 0;
+    if (active && i == 0) {
+#pragma unroll
+        for (int q = 0; q < QS_CNT_COUNT; ++q) cnt[q] = p.counters[q * E + ee];
+    }
+    if (c.use_obstacles && active) {   // stage the env's obstacle positions in LDS
+        for (int k = i; k < M_; k += N) {
+            s_obst[(le * 2 + 0) * M_ + k] = p.obst_pos[(size_t)e * M_ + k];
+            s_obst[(le * 2 + 1) * M_ + k] = p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + k];
         }
+    }
+    RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + ee), step_no};
+
+    // ================= A. per-drone step =================
+    // RawControl quadrotor_control.py:53-57, OU noise quad_utils.py:275-279, 2 sub-steps (qs_device.h),
+    // reward quadrotor_single.py:34-92, tick/done :352-353, self obs get_state.py + sensor_noise.py
+    real rew, ri[QS_RI_COUNT];
+    {
+        real cmds[4], z[4], acc[3];
+        rng_normal<real, 4>(key, QS_SITE_OU, 0, i, 0, z);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cmds[m] = (real)0.5 * (clipr<real>(act[m], (real)-1, (real)1) + (real)1);
+            real x = d.ou[m];
+            d.ou[m] = x + (c.ou_theta * ((real)0 - x) + c.thrust_noise_sigma * z[m]);
+        }
+        for (int s = 0; s < c.sim_steps; ++s) substep<real>(c, key, i, s, d, cmds, acc);
+        const real dt = c.dt;
+        real diff[3] = {goal[0] - d.pos[0], goal[1] - d.pos[1], goal[2] - d.pos[2]};
+        real cpr = norm3<real>(diff), cpos = c.rew_coeff[QS_REW_POS] * cpr;
+        real cer = M<real>::sqrt(act[0] * act[0] + act[1] * act[1] + act[2] * act[2] + act[3] * act[3]), cef = c.rew_coeff[QS_REW_EFFORT] * cer;
+        bool on_floor = (d.flags & F_ON_FLOOR) != 0;
+        real cor = on_floor ? (real)1 : -d.rot[8], cori = c.rew_coeff[QS_REW_ORIENT] * cor;
+        real csr = M<real>::sqrt(d.omega[0] * d.omega[0] + d.omega[1] * d.omega[1] + d.omega[2] * d.omega[2]), cspin = c.rew_coeff[QS_REW_SPIN] * csr;
+        real ccr = on_floor ? (real)1 : (real)0, ccrash = c.rew_coeff[QS_REW_CRASH] * ccr;
+        rew = -dt * ((((cpos + cef) + ccrash) + cori) + cspin);
+        ri[QS_RI_REW_MAIN] = dt * -cpos; ri[QS_RI_REW_POS] = dt * -cpos; ri[QS_RI_REW_ACTION] = dt * -cef;
+        ri[QS_RI_REW_CRASH] = dt * -ccrash; ri[QS_RI_REW_ORIENT] = dt * -cori; ri[QS_RI_REW_SPIN] = dt * -cspin;
+        ri[QS_RI_RAW_MAIN] = dt * -cpr; ri[QS_RI_RAW_POS] = dt * -cpr; ri[QS_RI_RAW_ACTION] = dt * -cer;
+        ri[QS_RI_RAW_CRASH] = dt * -ccr; ri[QS_RI_RAW_ORIENT] = dt * -cor; ri[QS_RI_RAW_SPIN] = dt * -csr;
+        ri[QS_RI_REW_QUADCOL_OBST] = 0; ri[QS_RI_RAW_QUADCOL_OBST] = 0;
+    }
+    const bool nan_rew = !(rew == rew) || M<real>::fabs(rew) > (real)3.0e38;
+    const int tick = tick_before + 1;
+    const bool done = tick > c.ep_len;
+    self_obs<real>(c, key, i, 0, d, goal, myobs);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s_pos[q * B + tid] = d.pos[q];
+    s_zax[0 * B + tid] = d.rot[2]; s_zax[1 * B + tid] = d.rot[5]; s_zax[2 * B + tid] = d.rot[8];
+    __syncthreads();
+
+    // ================= B. pair scan, obstacle first hit, room lists =================
+    uint64_t curr_pair = 0;
+    bool in_curr = false;
+    real prox = 0;
+    uint32_t bits = 0;
+    int obst_idx = -1;
+    if (active) {
+        // calculate_collision_matrix collisions/quadrotors.py:63-91, proximity penalties :95-103
+        const real pr = -c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX] / c.collision_falloff_threshold;
+        for (int j = 0; j < N; ++j) {
+            real dx = d.pos[0] - s_pos[0 * B + base + j], dy = d.pos[1] - s_pos[1 * B + base + j], dz = d.pos[2] - s_pos[2 * B + base + j];
+            real dist = M<real>::sqrt(dx * dx + dy * dy + dz * dz);
+            const bool other = j != i;
+            if (other && dist <= c.collision_threshold) { in_curr = true; if (j > i) curr_pair |= 1ull << j; }
+            if (other && dist <= c.collision_falloff_threshold) prox += pr * dist + c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX];
+        }
+        if (c.use_obstacles) {   // first hit in index order, obstacles/utils.py:31-43
+            const real *ox = s_obst + (le * 2 + 0) * M_, *oy = s_obst + (le * 2 + 1) * M_;
+            for (int k = M_ - 1; k >= 0; --k) {
+                real dx = d.pos[0] - ox[k], dy = d.pos[1] - oy[k];
+                obst_idx = (M<real>::sqrt(dx * dx + dy * dy) <= c.obst_hit_threshold) ? k : obst_idx;
+            }
+            if (obst_idx >= 0) { bits |= B_OBST_HIT; if (!(d.flags & F_PREV_OBST)) bits |= B_OBST_NEW; d.flags |= F_PREV_OBST; }
+            else d.flags &= ~F_PREV_OBST;
+        }
+        // calculate_room_collision quadrotor_multi.py:289-302, :491-497
+        uint32_t f = d.flags;
+        if (f & F_CRASH_FLOOR) bits |= B_FLOOR;
+        if ((f & F_CRASH_WALL) && !(f & F_PREV_WALL)) bits |= B_WALL_NEW;
+        if ((f & F_CRASH_CEIL) && !(f & F_PREV_CEIL)) bits |= B_CEIL_NEW;
+        if ((bits & (B_FLOOR | B_WALL_NEW | B_CEIL_NEW)) && !(f & F_PREV_ROOM)) bits |= B_ROOM_NEW;
+        f &= ~(F_PREV_WALL | F_PREV_CEIL | F_PREV_ROOM);
+        if (bits & B_WALL_NEW) f |= F_PREV_WALL;
+        if (bits & B_CEIL_NEW) f |= F_PREV_CEIL;
+        if (bits & B_ROOM_NEW) f |= F_PREV_ROOM;
+        d.flags = f;
+    }
+    // ---- env-level id sets by wave ballots (quadrotor_multi.py:432-459, :462-488) ----
+    const bool was_in_col = active && (d.flags & F_IN_COL);
+    const uint64_t new_pair = curr_pair & ~prev_pair;                                  // pair-level novelty (:437-438)
+    const uint64_t curr_ids = (__ballot(active && in_curr) >> base) & nmask;
+    const uint64_t prev_ids = (__ballot(was_in_col) >> base) & nmask;
+    const uint64_t m_obst_hit = (__ballot(active && (bits & B_OBST_HIT)) >> base) & nmask;
+    const uint64_t m_obst_new = (__ballot(active && (bits & B_OBST_NEW)) >> base) & nmask;
+    const uint64_t m_floor = (__ballot(active && (bits & B_FLOOR)) >> base) & nmask;
+    const uint64_t m_wall = (__ballot(active && (bits & B_WALL_NEW)) >> base) & nmask;
+    const uint64_t m_ceil = (__ballot(active && (bits & B_CEIL_NEW)) >> base) & nmask;
+    const uint64_t m_room = (__ballot(active && (bits & B_ROOM_NEW)) >> base) & nmask;
+    const uint64_t wave_newpair = __ballot(active && new_pair != 0);
+    const uint64_t m_newpair_any = (wave_newpair >> base) & nmask;
+    const uint64_t unique = curr_ids & ~prev_ids;                                      // np.setdiff1d on flattened ids (:440)
+    if (in_curr) d.flags |= F_IN_COL; else d.flags &= ~F_IN_COL;
+    const int col_tick = __popcll(unique) / 2;                                         // :448
+    const int obst_cnt = __popcll(m_obst_new);
+    const bool settled = tick >= c.grace_steps;
+    const int time_remain = c.ep_len - tick_before;
+    if (col_tick > 0 && settled && (unique >> i & 1)) d.flags &= ~F_COL_AGENT_OK;
+    if (obst_cnt > 0 && settled && (bits & B_OBST_NEW)) d.flags &= ~F_COL_OBST_OK;
+    // distance_to_goal_3_5 / _5 use the NOISY relative position of the self obs (:474-478)
+    const real qrel = M<real>::sqrt(myobs[0] * myobs[0] + myobs[1] * myobs[1] + myobs[2] * myobs[2]);
+    const int n35 = __popcll((__ballot(active && (bits & B_OBST_NEW) && qrel > (real)3.5) >> base) & nmask);
+    const int n5 = __popcll((__ballot(active && (bits & B_OBST_NEW) && qrel > (real)5.0) >> base) & nmask);
+
+    // ---- rewards (:499-546) ----
+    {
+        const bool any_nonzero_id = (unique & ~1ull) != 0;   // `.any()` of the id array
+        real raw = (any_nonzero_id && (unique >> i & 1)) ? (real)-1 : (real)0;
+        real rc = c.rew_coeff[QS_REW_QUADCOL_BIN] * raw;
+        real rp = (real)-1 * (c.control_dt * prox);
+        rew += rc;
+        rew += rp;
+        ri[QS_RI_REW_QUADCOL] = rc; ri[QS_RI_REW_PROXIMITY] = rp; ri[QS_RI_RAW_QUADCOL] = raw;
+        if (c.use_obstacles) {
+            real ro_raw = (m_obst_hit && (bits & B_OBST_NEW)) ? (real)-1 : (real)0;
+            real ro = c.rew_coeff[QS_REW_QUADCOL_OBST] * ro_raw;
+            rew += ro;
+            ri[QS_RI_REW_QUADCOL_OBST] = ro; ri[QS_RI_RAW_QUADCOL_OBST] = ro_raw;
+        }
+    }
+    // ---- distance-to-goal log, reached_goal (:542-546), windowed sums for the episode stats (:649-661) ----
+    real eps_dist[3] = {0, 0, 0};
+    {
+        const real dnow = -ri[QS_RI_RAW_POS];
+        if (tick >= 5 && !(d.flags & F_REACHED)) {
+            real mean5 = ((((ring[3] + ring[2]) + ring[1]) + ring[0]) + dnow) / (real)5;
+            if (mean5 / c.dt < c.approach_goal_metric) d.flags |= F_REACHED;
+        }
+        ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = dnow;
+        const int total = c.ep_len + 1;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * c.control_freq;
+            real sum = (tick == 1) ? (real)0 : sums[w];
+            if (tick > total - win) sum += dnow;
+            sums[w] = sum;
+            const int n = total < win ? total : win;
+            eps_dist[w] = ((real)1 / c.dt) * (sum / (real)n);
+        }
+    }
+    // ---- per-env counters (lane 0 of the env keeps them in registers) ----
+    if (active && i == 0) {
+        cnt[QS_CNT_COLLISIONS] += col_tick;
+        if (col_tick > 0 && settled) cnt[QS_CNT_COLLISIONS_AFTER_SETTLE] += col_tick;
+        if (col_tick > 0 && time_remain <= c.final_steps) cnt[QS_CNT_COLLISIONS_FINAL_5S] += col_tick;
+        cnt[QS_CNT_OBST] += obst_cnt;
+        if (obst_cnt > 0 && settled) { cnt[QS_CNT_OBST_AFTER_SETTLE] += obst_cnt; cnt[QS_CNT_OBST_DIST_3_5] += n35; cnt[QS_CNT_OBST_DIST_5] += n5; }
+        if (settled) {
+            cnt[QS_CNT_ROOM] += __popcll(m_room); cnt[QS_CNT_FLOOR] += __popcll(m_floor);
+            cnt[QS_CNT_WALL] += __popcll(m_wall); cnt[QS_CNT_CEILING] += __popcll(m_ceil);
+        }
+    }
+
+    // ================= C. physical interactions, in the reference's order (:548-587) =================
+    // 1) downwash aerodynamics/downwash.py:4-66: this lane is the LOWER drone j, loops upper drones ii
+    if (c.use_downwash && active) {
+        for (int ii = 0; ii < N; ++ii) {
+            real rel[3] = {d.pos[0] - s_pos[0 * B + base + ii], d.pos[1] - s_pos[1 * B + base + ii], d.pos[2] - s_pos[2 * B + base + ii]};
+            real zx[3] = {s_zax[0 * B + base + ii], s_zax[1 * B + base + ii], s_zax[2 * B + base + ii]};
+            real d2 = rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2], rz = dot3<real>(rel, zx);
+            real dist = M<real>::sqrt(d2), rxy = M<real>::sqrt(dist * dist - rz * rz);
+            if (ii != i && (real)-0.7 < rz && rz < (real)0 && rxy < (real)0.1) {
+                uint32_t w[4];
+                rng_words(key, QS_SITE_DW_I, 0, ii, 0, w);
+                real ua = (real)-0.1 + (real)0.2 * u01<real>(w[0]), uw = (real)-0.01 + (real)0.02 * u01<real>(w[1]);
+                real a = M<real>::fmax((real)1e-6, (real)(6.0 / 17.0) * ((real)-10 * dist + (real)7) + ua);
+                real ow = M<real>::fmax((real)1e-6, (real)0.3 * ((dist - (real)1) * (dist - (real)1)) + uw);
+                real nz[3], dirw[3];
+                rng_words(key, QS_SITE_DW_IJ_V, 0, ii, i, w);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) nz[q] = zx[q] + ((real)-0.1 + (real)0.2 * u01<real>(w[q]));
+                rng_words(key, QS_SITE_DW_IJ_W, 0, ii, i, w);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) dirw[q] = (real)-1 + (real)2 * u01<real>(w[q]);
+                real mz = norm3<real>(nz), dz = (mz == (real)0) ? mz + (real)1e-6 : mz;
+                real mw = norm3<real>(dirw), dwn = (mw == (real)0) ? mw + (real)1e-6 : mw;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    real down = (real)-1 * (nz[q] / dz);
+                    d.vel[q] += a * down * c.control_dt;
+                    d.omega[q] += ow * (dirw[q] / dwn) * c.control_dt;
+                }
+                bits |= B_DOWNWASH;
+            }
+        }
+    }
+    const bool any_dw = ((__ballot(active && (bits & B_DOWNWASH)) >> base) & nmask) != 0;
+    // 2) drone-drone responses for the NEW pairs in lexicographic order (collisions/quadrotors.py:24-59);
+    //    order-dependent and rare: one lane per env walks the pair list on LDS-resident vel/omega
+    if (wave_newpair) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { s_vel[q * B + tid] = d.vel[q]; s_om[q * B + tid] = d.omega[q]; }
+        s_mask[tid] = new_pair;
+        __syncthreads();
+        if (active && m_newpair_any && i == 0) {
+            for (int a = 0; a < N; ++a) {
+                uint64_t np = s_mask[base + a];
+                while (np) {
+                    int b = __ffsll((long long)np) - 1;
+                    np &= np - 1;
+                    collide_drones_lds<real>(key, a, b, base, B, s_pos, s_vel, s_om);
+                }
+            }
+        }
+        __syncthreads();
+        if (m_newpair_any) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { d.vel[q] = s_vel[q * B + tid]; d.omega[q] = s_om[q * B + tid]; }
+        }
+    }
+    // 3) obstacle response, 4) wall then ceiling (out of line: rare)
+    if (active && (bits & (B_OBST_NEW | B_WALL_NEW | B_CEIL_NEW))) {
+        real ox = 0, oy = 0;
+        if (bits & B_OBST_NEW) { ox = s_obst[(le * 2 + 0) * M_ + obst_idx]; oy = s_obst[(le * 2 + 1) * M_ + obst_idx]; }
+        room_obst_responses<real>(cp, key, i, bits, ox, oy, d.pos, d.vel, d.omega);
+    }
+    const bool update_flag = any_dw || (m_newpair_any != 0) || (m_obst_new != 0) || (m_wall != 0) || (m_ceil != 0);
+
+    // ================= D. scenario.step(): swarm_vs_swarm swaps the formations every U(4,6) s =================
+    if (c.scenario == QS_SCENARIO_SWARM_VS_SWARM) {   // swarm_vs_swarm.py:59-79
+        const bool sw = active && svs_period > 0 && tick % svs_period == 0 && tick > 0;
+        if (__ballot(sw)) {
+            if (sw && i == 0) {
+                real c1[3], c2[3];
+                for (int q = 0; q < 3; ++q) { c1[q] = p.scen_real[(3 + q) * E + e]; c2[q] = p.scen_real[q * E + e]; }
+                for (int q = 0; q < 3; ++q) { p.scen_real[q * E + e] = c1[q]; p.scen_real[(3 + q) * E + e] = c2[q]; }
+                Formation<real> F;
+                update_formation<real>(c, key, 32, N, F);
+                svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, true, s_goal + le * L.goal_rows * 3);
+            }
+            __syncthreads();
+            if (sw) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) goal[q] = s_goal[(le * L.goal_rows + i) * 3 + q];
+            }
+        }
+    }
+
+    // ================= E. final observations (:592-607) =================
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s_vel[q * B + tid] = d.vel[q];
+    if (update_flag && active) self_obs<real>(c, key, i, 1, d, goal, myobs);   // fresh sensor noise, new goal (:598-599)
+    __syncthreads();
+    if (active) {
+        neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, d.vel, myobs + c.self_dim);
+        if (c.use_obstacles)
+            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors);
+    }
+
+    // ================= F. done: episode snapshot + auto-reset (:626-722) =================
+    uint64_t out_unique = unique, out_obst_new = m_obst_new, out_room = m_room, out_curr_pair = curr_pair, out_new_pair = new_pair;
+    int out_tick = tick, out_obst_idx = obst_idx;
+    const bool do_reset = active && done;
+    if (__ballot(do_reset)) {
+        if (do_reset) {
+            p.ep_stats[QS_EPS_DIST_1S * T + g] = eps_dist[0]; p.ep_stats[QS_EPS_DIST_3S * T + g] = eps_dist[1]; p.ep_stats[QS_EPS_DIST_5S * T + g] = eps_dist[2];
+            p.ep_stats[QS_EPS_REACHED_GOAL * T + g] = (d.flags & F_REACHED) ? (real)1 : (real)0;
+            p.ep_stats[QS_EPS_COL_AGENT_OK * T + g] = (d.flags & F_COL_AGENT_OK) ? (real)1 : (real)0;
+            p.ep_stats[QS_EPS_COL_OBST_OK * T + g] = (d.flags & F_COL_OBST_OK) ? (real)1 : (real)0;
+            if (i == 0) {
+#pragma unroll
+                for (int q = 0; q < QS_CNT_COUNT; ++q) { p.ep_counters[q * E + e] = cnt[q]; cnt[q] = 0; }
+            }
+        }
+        real stale_vel[3] = {d.vel[0], d.vel[1], d.vel[2]};
+        __syncthreads();
+        reset_body<real>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);
+        if (do_reset) {
+            out_unique = 0; out_obst_new = 0; out_room = 0; out_curr_pair = 0; out_new_pair = 0; out_tick = 0; out_obst_idx = -1;
+            ring[0] = ring[1] = ring[2] = ring[3] = 0;
+        }
+    }
+
+    // ================= G. stores =================
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = d.vel[q]; p.omega[q * T + g] = d.omega[q]; p.goal[q * T + g] = goal[q]; p.dist_sums[q * T + g] = sums[q]; }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p.rot[q * T + g] = d.rot[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { p.rot_damp[q * T + g] = d.rot_damp[q]; p.cmds_damp[q * T + g] = d.cmds_damp[q]; p.ou[q * T + g] = d.ou[q]; p.dist_ring[q * T + g] = ring[q]; }
+        p.flags[g] = d.flags;
+        p.pair_mask[g] = out_curr_pair;
+        p.new_pair_mask[g] = out_new_pair;
+        p.obst_hit_idx[g] = out_obst_idx;
+        p.reward[g] = rew;
+        p.done[g] = done ? 1 : 0;
+        if (c.write_rew_info) {
+#pragma unroll
+            for (int q = 0; q < QS_RI_COUNT; ++q) p.rew_info[q * T + g] = ri[q];
+        }
+        if (nan_rew) atomicOr(p.error_flag, 1u);
+        if (i == 0) {
+#pragma unroll
+            for (int q = 0; q < QS_CNT_COUNT; ++q) p.counters[q * E + e] = cnt[q];
+            p.unique_col[e] = out_unique; p.obst_new[e] = out_obst_new; p.room_new[e] = out_room;
+            p.tick[e] = out_tick;
+            p.step_ctr[e] = step_no;
+        }
+    }
+    __syncthreads();
+    {   // obs copy-out: the workgroup's rows form one contiguous [rows*obs_dim] block in LDS and in HBM
+        const int D = c.obs_dim, first_env = blockIdx.x * epb;
+        int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
+        const int total = nenv * N * D;
+        real *dst = p.obs + (size_t)first_env * N * D;
+        if ((total & 3) == 0 && ((((size_t)first_env * N * D) * sizeof(real)) & 15) == 0 && sizeof(real) == 4) {
+            const float4 *src4 = (const float4 *)s_obs;
+            float4 *dst4 = (float4 *)dst;
+            for (int idx = tid; idx < total / 4; idx += B) dst4[idx] = src4[idx];
+        } else {
+            for (int idx = tid; idx < total; idx += B) dst[idx] = s_obs[idx];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reset kernel (qs_reset): resets the envs flagged in reset_mask
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+__global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *__restrict__ cp, Ptrs<real> p, LdsLayout L, int epb) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Consts<real> &c = *cp;
+    const int N = c.num_agents, E = c.num_envs, T = E * N;
+    real *s_obs = (real *)(smem + L.off_obs);
+    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le;
+    const bool in_range = (le < epb) && (e < E);
+    const bool do_reset = in_range && p.reset_mask[e] != 0;
+    const int g = in_range ? e * N + i : 0;
+    RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + (in_range ? e : 0)), in_range ? p.step_ctr[e] : 0u};
+    Drone<real> d;
+    real goal[3] = {0, 0, 0}, stale_vel[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) stale_vel[q] = p.vel[q * T + g];
+    d.flags = p.flags[g];
+    reset_body<real>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);
+    if (do_reset) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = 0; p.omega[q * T + g] = 0; p.goal[q * T + g] = goal[q]; }
 #pragma unroll
@@ -702,11 +751,16 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *_
         p.pair_mask[g] = 0;
         p.new_pair_mask[g] = 0;
         p.obst_hit_idx[g] = -1;
+        const real *myobs = s_obs + tid * c.obs_dim;
         real *dst = p.obs + (size_t)g * c.obs_dim;
         for (int q = 0; q < c.obs_dim; ++q) dst[q] = myobs[q];
+        if (i == 0) {
+            for (int q = 0; q < QS_CNT_COUNT; ++q) p.counters[q * E + e] = 0;
+            p.tick[e] = 0;
+            p.unique_col[e] = 0; p.obst_new[e] = 0; p.room_new[e] = 0;
+            p.reset_mask[e] = 0;
+        }
     }
-    __syncthreads();
-    if (active && i == 0) p.reset_mask[e] = 0;
 }
 
 // state get/set for one env (qs_get_state / qs_set_state)
@@ -758,9 +812,11 @@ struct qs_handle {
     void *d_actions = nullptr;
     double *d_state_buf = nullptr;
     int32_t *d_tick_io = nullptr;
-    std::vector<int32_t> host_tick;   // host mirror of the per-env tick (deterministic), used when ticks differ
-    bool ticks_uniform = true;        // all envs share `utick` (the normal case): O(1) bookkeeping per step
-    int32_t utick = 0;
+    // cached hipGraph of a K-step rollout (qs_step_many): K identical step-kernel nodes
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    const void *graph_actions = nullptr;
+    int32_t graph_k = 0;
     uint8_t *h_mask = nullptr;   // pinned staging for qs_reset masks
     // profiling of the step kernel
     bool profiling = false;
@@ -800,6 +856,7 @@ template <typename real> static void fill_consts(const qs_config &c, Consts<real
     k.cube_fd[1] = (int)pow((double)(c.num_agents - c.num_agents / 2), 1.0 / 3);
     k.seed_lo = (uint32_t)(c.seed & 0xffffffffu); k.seed_hi = (uint32_t)(c.seed >> 32);
     k.env_id_offset = c.env_id_offset; k.num_envs = c.num_envs; k.num_agents = c.num_agents;
+    k.write_rew_info = c.write_rew_info;
 }
 
 extern "C" int qs_obs_dim(const qs_config *c);
@@ -818,7 +875,7 @@ static int validate(const qs_config *c) {
         if (c->obst_area[0] * c->obst_area[1] - c->num_obstacles < c->num_agents) return fail(QS_ERR_INVALID, "not enough free cells to spawn the drones");
     }
     {
-        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents, qs_obs_dim(c));
+        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents, qs_obs_dim(c), c->num_obstacles, c->num_neighbors);
         if (L.total > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "observation staging does not fit the 160 KiB LDS of a CU");
     }
     if (c->sim_steps < 1 || c->ep_len < 1 || c->svd_period < 1 || c->svd_period > 255) return fail(QS_ERR_INVALID, "bad sim_steps/ep_len/svd_period");
@@ -917,6 +974,7 @@ int qs_default_config(qs_config *c, int32_t num_envs, int32_t num_agents) {
     c->spawn_box = 2.0; c->approach_goal_metric = 0.5;
     for (int q = 0; q < 3; ++q) { c->nbr_clip_pos[q] = 10.0; c->nbr_clip_vel[q] = 6.0; }
     c->obst_size = 1.0; c->obst_density = 0.2; c->obst_area[0] = 6; c->obst_area[1] = 6; c->num_obstacles = 0;
+    c->write_rew_info = 1;
     return QS_OK;
 }
 
@@ -935,7 +993,7 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
     h->obs_dim = qs_obs_dim(cfg);
     h->epb = QS_WAVE / cfg->num_agents;
     h->blocks = (cfg->num_envs + h->epb - 1) / h->epb;
-    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim);
+    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors);
     rc = (h->real_size == 8) ? create_typed<double>(h) : create_typed<float>(h);
     if (rc == QS_OK) {
         if (hipMalloc((void **)&h->d_state_buf, sizeof(double) * QS_MAX_AGENTS * QS_STATE_STRIDE) != hipSuccess ||
@@ -944,7 +1002,6 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
             rc = fail(QS_ERR_HIP, "allocation failed");
     }
     if (rc != QS_OK) { qs_destroy(h); return rc; }
-    h->host_tick.assign(cfg->num_envs, 0);
     if (h->lds.total > 64 * 1024) {
         hipError_t e1 = (h->real_size == 8)
             ? hipFuncSetAttribute((const void *)qs_step_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total)
@@ -967,6 +1024,8 @@ int qs_destroy(qs_handle *h) {
     if (h->d_tick_io) (void)hipFree(h->d_tick_io);
     if (h->h_mask) (void)hipHostFree(h->h_mask);
     for (auto &ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     delete h;
     return QS_OK;
 }
@@ -987,13 +1046,7 @@ int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream) {
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     const int E = h->cfg.num_envs;
-    if (h->ticks_uniform) for (int e = 0; e < E; ++e) h->host_tick[e] = h->utick;
-    bool all = true;
-    for (int e = 0; e < E; ++e) {
-        h->h_mask[e] = env_mask_host ? (env_mask_host[e] ? 1 : 0) : 1;
-        if (h->h_mask[e]) h->host_tick[e] = 0; else all = false;
-    }
-    if (all) { h->ticks_uniform = true; h->utick = 0; } else h->ticks_uniform = false;
+    for (int e = 0; e < E; ++e) h->h_mask[e] = env_mask_host ? (env_mask_host[e] ? 1 : 0) : 1;
     HIP_TRY(hipMemcpyAsync(h->pf.reset_mask, h->h_mask, (size_t)E, hipMemcpyHostToDevice, s));
     int rc = launch_reset(h, s);
     if (rc != QS_OK) return rc;
@@ -1023,12 +1076,7 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s) {
     }
     HIP_TRY(hipGetLastError());
     if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
-    // host mirror of the (deterministic) tick: launch the reset kernel when an episode ends in this step
-    bool any_done = false;
-    if (h->ticks_uniform) { h->utick += 1; if (h->utick > h->cfg.ep_len) { any_done = true; h->utick = 0; } }
-    else for (auto &t : h->host_tick) { t += 1; if (t > h->cfg.ep_len) { any_done = true; t = 0; } }
-    if (any_done) return launch_reset(h, s);
-    return QS_OK;
+    return QS_OK;   // the auto-reset is the tail of the step kernel itself
 }
 
 int qs_step(qs_handle *h, const void *actions_dev, void *stream) {
@@ -1041,10 +1089,32 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
     if (!h || !actions_dev || k < 0) return fail(QS_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * h->real_size;
-    for (int32_t t = 0; t < k; ++t) {
-        int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream);
-        if (rc != QS_OK) return rc;
+    if (h->profiling || k < 4) {   // per-launch HIP events need eager launches
+        for (int32_t t = 0; t < k; ++t) {
+            int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream);
+            if (rc != QS_OK) return rc;
+        }
+        return QS_OK;
     }
+    // launch-bound inner loop: capture the K launches once into a hipGraph, replay it afterwards.  The auto-reset
+    // lives in the step kernel, so every node is the same kernel; only the action pointer differs.
+    if (!h->graph_exec || h->graph_actions != actions_dev || h->graph_k != k) {
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        int rc = QS_OK;
+        for (int32_t t = 0; t < k && rc == QS_OK; ++t) rc = launch_step(h, (const char *)actions_dev + stride * t, h->cap_stream);
+        hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+        if (rc != QS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ce != hipSuccess) return fail(QS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { h->graph_exec = nullptr; return fail(QS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
+        h->graph_actions = actions_dev;
+        h->graph_k = k;
+    }
+    HIP_TRY(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
     return QS_OK;
 }
 
@@ -1092,10 +1162,6 @@ static int state_io(qs_handle *h, int32_t env, double *host, int32_t *tick, int 
         HIP_TRY(hipMemcpy(host, h->d_state_buf, bytes, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(&t, h->d_tick_io, sizeof t, hipMemcpyDeviceToHost));
         if (tick) *tick = t;
-    } else if (t >= 0) {
-        if (h->ticks_uniform) for (auto &x : h->host_tick) x = h->utick;
-        h->host_tick[env] = t;
-        h->ticks_uniform = false;
     }
     return QS_OK;
 }
