@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=400, help="steps of the HIP-event kernel-duration pass")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step obs all-gather at N>1")
+    ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a workload keyword (python literal)")
+    ap.add_argument("--graph", type=int, default=0, help="replay the rollout as hipGraphs of this many steps (qs_step_many)")
     args = ap.parse_args()
 
     import torch
@@ -102,9 +105,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    import ast
     w = WORKLOADS[args.workload]
+    kw = dict(w["kw"])
+    for item in args.set:
+        key, val = item.split("=", 1)
+        kw[key] = ast.literal_eval(val)
     E = args.envs_per_gpu or w["num_envs"]
-    cfg = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f32", **w["kw"])
+    cfg = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f32", write_rew_info=args.rew_info, **kw)
     st = native.Stepper(cfg, device=local_rank)
     N, T, D = cfg.num_agents, E * cfg.num_agents, st.obs_dim
     stream = torch.cuda.current_stream(local_rank)
@@ -119,6 +127,16 @@ def main():
     gathered = torch.empty((world * T, D), device=f"cuda:{local_rank}", dtype=torch.float32) if world > 1 else None
 
     def run(k, offset=0):
+        if args.graph > 0 and gathered is None:
+            # launch-bound inner loop: K-step hipGraph replays over the action ring (qs_step_many)
+            g = min(args.graph, ring)
+            done_steps = 0
+            while done_steps + g <= k:
+                st.step_many(aptr, g, stream=stream)
+                done_steps += g
+            for t in range(k - done_steps):
+                st.step(aptr + (t % ring) * astride, stream=stream)
+            return
         for t in range(k):
             st.step(aptr + ((offset + t) % ring) * astride, stream=stream)
             if gathered is not None and not args.no_gather:
@@ -159,7 +177,9 @@ def main():
             "config": {"workload": f"{args.workload}: {N} drones x {E} envs per GPU, {WORKLOADS[args.workload]['kw'].get('quads_mode', 'static_same_goal')}, "
                                    f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
                        "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N,
-                       "obs_gather": "rccl all_gather_into_tensor per step" if (world > 1 and not args.no_gather) else "none"},
+                       "obs_gather": "rccl all_gather_into_tensor per step" if (world > 1 and not args.no_gather) else "none",
+                       "launch": f"hipGraph x{min(args.graph, ring)}" if args.graph > 0 and world == 1 else "eager", "rew_info": bool(args.rew_info),
+                       "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "qs_step_kernel<float>", "kernel_avg_us": kernel_ms * 1e3, "kernel_launches": launches,
                          "algorithmic_bytes_per_launch": algo * T},

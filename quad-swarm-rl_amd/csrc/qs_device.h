@@ -88,10 +88,10 @@ struct RngKey { uint32_t k0, k1, env, step; };
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t w[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        // one 32x32->64 multiply (v_mad_u64_u32) yields both halves of each product
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     w[0] = c0; w[1] = c1; w[2] = c2; w[3] = c3;
@@ -345,11 +345,48 @@ template <typename real> __device__ __forceinline__ void rot2quat(const real r[9
     }
 }
 
-// Self observation with sensor noise: get_state.py:6-72 + sensor_noise.py:112-218,:235-261.
-// Writes self_dim values to o[] (o may live in LDS).
+// Sensor-noise draws of one self observation (sensor_noise.py:235-261 order): additive noise on pos, vel, omega and the
+// small-angle rotation noise theta.  Independent of the dynamic state, so the step kernel draws them while the state
+// loads are still in flight.
+template <typename real> struct SensNoise { real p[3], v[3], w[3], th[3]; };
+
 template <typename real>
-__device__ __forceinline__ void self_obs(const Consts<real> &c, const RngKey &key, int drone, int pass, const Drone<real> &d,
-                                         const real goal[3], real *o) {
+__device__ __forceinline__ void sensor_noise_draw(const Consts<real> &c, const RngKey &key, int drone, int pass, SensNoise<real> &n) {
+    real z[3], u[3];
+    rng_normal<real, 3>(key, QS_SITE_SENS_POS_N, pass, drone, 0, z);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) n.p[q] = c.pos_norm_std * z[q];
+    if (c.pos_unif_range != (real)0) {
+        rng_uniform<real, 3>(key, QS_SITE_SENS_POS_U, pass, drone, 0, -c.pos_unif_range, c.pos_unif_range, u);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) n.p[q] += u[q];
+    }
+    rng_normal<real, 3>(key, QS_SITE_SENS_VEL_N, pass, drone, 0, z);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) n.v[q] = c.vel_norm_std * z[q];
+    if (c.vel_unif_range != (real)0) {
+        rng_uniform<real, 3>(key, QS_SITE_SENS_VEL_U, pass, drone, 0, -c.vel_unif_range, c.vel_unif_range, u);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) n.v[q] += u[q];
+    }
+    rng_normal<real, 3>(key, QS_SITE_SENS_OMEGA_N, pass, drone, 0, z);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { n.w[q] = c.gyro_noise_density * z[q]; n.th[q] = 0; }
+    if (c.quat_norm_std != (real)0) {
+        rng_normal<real, 3>(key, QS_SITE_SENS_THETA_N, pass, drone, 0, z);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) n.th[q] = c.quat_norm_std * z[q];
+    }
+    if (c.quat_unif_range != (real)0) {
+        rng_uniform<real, 3>(key, QS_SITE_SENS_THETA_U, pass, drone, 0, -c.quat_unif_range, c.quat_unif_range, u);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) n.th[q] += u[q];
+    }
+}
+
+// Self observation: get_state.py:6-72 + sensor_noise.py:112-218.  Writes self_dim values to o[] (LDS row).
+template <typename real>
+__device__ __forceinline__ void self_obs(const Consts<real> &c, const SensNoise<real> &n, const Drone<real> &d, const real goal[3], real *o) {
     real p[3], v[3], w[3], R[9];
     if (!c.sense_noise) {
 #pragma unroll
@@ -357,50 +394,25 @@ __device__ __forceinline__ void self_obs(const Consts<real> &c, const RngKey &ke
 #pragma unroll
         for (int q = 0; q < 9; ++q) R[q] = d.rot[q];
     } else {
-        real z[3], u[3];
-        rng_normal<real, 3>(key, QS_SITE_SENS_POS_N, pass, drone, 0, z);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) p[q] = d.pos[q] + c.pos_norm_std * z[q];
-        if (c.pos_unif_range != (real)0) {
-            rng_uniform<real, 3>(key, QS_SITE_SENS_POS_U, pass, drone, 0, -c.pos_unif_range, c.pos_unif_range, u);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) p[q] += u[q];
-        }
-        rng_normal<real, 3>(key, QS_SITE_SENS_VEL_N, pass, drone, 0, z);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) v[q] = d.vel[q] + c.vel_norm_std * z[q];
-        if (c.vel_unif_range != (real)0) {
-            rng_uniform<real, 3>(key, QS_SITE_SENS_VEL_U, pass, drone, 0, -c.vel_unif_range, c.vel_unif_range, u);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) v[q] += u[q];
-        }
-        rng_normal<real, 3>(key, QS_SITE_SENS_OMEGA_N, pass, drone, 0, z);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) w[q] = d.omega[q] + c.gyro_noise_density * z[q];
-        real th[3] = {0, 0, 0};
-        if (c.quat_norm_std != (real)0) {
-            rng_normal<real, 3>(key, QS_SITE_SENS_THETA_N, pass, drone, 0, z);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) th[q] = c.quat_norm_std * z[q];
-        }
-        if (c.quat_unif_range != (real)0) {
-            rng_uniform<real, 3>(key, QS_SITE_SENS_THETA_U, pass, drone, 0, -c.quat_unif_range, c.quat_unif_range, u);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) th[q] += u[q];
-        }
-        // R -> quat -> quat (x) dq(theta) -> R  (sensor_noise.py:205-210; identity dq still re-derives R)
-        real nt = norm3<real>(th), qsq = nt * nt / (real)4, qt[4];
-        if (qsq < (real)1) { qt[0] = M<real>::sqrt((real)1 - qsq); qt[1] = th[0] * (real)0.5; qt[2] = th[1] * (real)0.5; qt[3] = th[2] * (real)0.5; }
-        else { real ww = (real)1 / M<real>::sqrt((real)1 + qsq), f = (real)0.5 * ww; qt[0] = ww; qt[1] = th[0] * f; qt[2] = th[1] * f; qt[3] = th[2] * f; }
-        real qn = M<real>::sqrt(qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) qt[q] /= qn;
+        for (int q = 0; q < 3; ++q) { p[q] = d.pos[q] + n.p[q]; v[q] = d.vel[q] + n.v[q]; w[q] = d.omega[q] + n.w[q]; }
+        // R -> quat -> quat (x) dq(theta) -> R  (sensor_noise.py:205-210; an identity dq still re-derives R)
         real q[4];
         rot2quat<real>(d.rot, q);
-        real qw = q[0] * qt[0] - q[1] * qt[1] - q[2] * qt[2] - q[3] * qt[3];
-        real qx = q[0] * qt[1] + q[1] * qt[0] - q[2] * qt[3] + q[3] * qt[2];
-        real qy = q[0] * qt[2] + q[1] * qt[3] + q[2] * qt[0] - q[3] * qt[1];
-        real qz = q[0] * qt[3] - q[1] * qt[2] + q[2] * qt[1] + q[3] * qt[0];
+        real qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+        if (c.quat_norm_std != (real)0 || c.quat_unif_range != (real)0) {
+            const real *th = n.th;
+            real nt = norm3<real>(th), qsq = nt * nt / (real)4, qt[4];
+            if (qsq < (real)1) { qt[0] = M<real>::sqrt((real)1 - qsq); qt[1] = th[0] * (real)0.5; qt[2] = th[1] * (real)0.5; qt[3] = th[2] * (real)0.5; }
+            else { real ww = (real)1 / M<real>::sqrt((real)1 + qsq), f = (real)0.5 * ww; qt[0] = ww; qt[1] = th[0] * f; qt[2] = th[1] * f; qt[3] = th[2] * f; }
+            real qn = M<real>::sqrt(qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qt[k] /= qn;
+            qw = q[0] * qt[0] - q[1] * qt[1] - q[2] * qt[2] - q[3] * qt[3];
+            qx = q[0] * qt[1] + q[1] * qt[0] - q[2] * qt[3] + q[3] * qt[2];
+            qy = q[0] * qt[2] + q[1] * qt[3] + q[2] * qt[0] - q[3] * qt[1];
+            qz = q[0] * qt[3] - q[1] * qt[2] + q[2] * qt[1] + q[3] * qt[0];
+        }   // theta == 0: quat_from_small_angle gives exactly (1,0,0,0) and q (x) (1,0,0,0) == q bit for bit
         R[0] = (real)1 - 2 * qy * qy - 2 * qz * qz; R[1] = 2 * qx * qy - 2 * qz * qw; R[2] = 2 * qx * qz + 2 * qy * qw;
         R[3] = 2 * qx * qy + 2 * qz * qw; R[4] = (real)1 - 2 * qx * qx - 2 * qz * qz; R[5] = 2 * qy * qz - 2 * qx * qw;
         R[6] = 2 * qx * qz - 2 * qy * qw; R[7] = 2 * qy * qz + 2 * qx * qw; R[8] = (real)1 - 2 * qx * qx - 2 * qy * qy;

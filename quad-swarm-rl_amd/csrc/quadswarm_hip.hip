@@ -44,7 +44,14 @@ template <typename real> struct Ptrs {
     int32_t *scen_int;
     uint32_t *error_flag;
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
+    unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
 };
+
+#ifdef QS_TIMING
+#define QS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.timing[k] = clock64(); } while (0)
+#else
+#define QS_STAMP(k) do { } while (0)
+#endif
 
 struct LdsLayout { int off_mask, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total; };
 #define QS_RESET_SCRATCH_INTS 160   // per env: virtual-pool index/value lists (2x64) + two DP rows (2x16)
@@ -63,7 +70,7 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     L.goal_rows = 2 * N + 8;
     L.off_goal = o; o += real_size * 3 * L.goal_rows * epb;
     L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
-    L.off_metric = o; o += (K > 0 && K < N - 1) ? real_size * N * B : 0;         // neighbour metric rows, [N][B]
+    L.off_metric = o; o += (K > 8 && K < N - 1) ? real_size * N * B : 0;         // neighbour metric rows, [N][B]
     o = (o + 15) & ~15;
     L.off_obs = o; o += real_size * obs_dim * B;      // observation staging, row-major, contiguous
     L.total = (o + 15) & ~15;
@@ -76,6 +83,7 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
 // The N-1 metrics are evaluated once into an LDS row, then K rounds of arg-min (lowest index wins ties,
 // like the stable ordering of argsort on distinct keys).
 // ------------------------------------------------------------------------------------------------
+#define QS_TOPK 8
 template <typename real>
 __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
                                              real *s_metric, const real mypos[3], const real myvel[3], real *o) {
@@ -92,22 +100,71 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
         }
         return;
     }
+    if (K <= QS_TOPK) {
+        // one streaming pass: sorted top-K (metric, index) list in registers; a new candidate is inserted behind
+        // entries with an equal metric, i.e. lower index first = the stable order of argsort on distinct keys
+        real bm[QS_TOPK];
+        int bi[QS_TOPK];
+#pragma unroll
+        for (int k = 0; k < QS_TOPK; ++k) { bm[k] = (real)3.4e38; bi[k] = 0; }
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            real rp[4][3], rv[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // LDS reads of 4 candidates issued together
+                const int j = (j0 + u < N) ? j0 + u : N - 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                real rd = M<real>::fmax(norm3<real>(rp[u]), (real)0.01);
+                real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) / rd;
+                m = (j < N && j != i) ? m : (real)3.4e38;
+                int mi = j;
+#pragma unroll
+                for (int k = 0; k < QS_TOPK; ++k) {   // insertion by a compare-exchange chain
+                    const bool lt = m < bm[k];
+                    const real tm = lt ? bm[k] : m;
+                    const int ti = lt ? bi[k] : mi;
+                    bm[k] = lt ? m : bm[k];
+                    bi[k] = lt ? mi : bi[k];
+                    m = tm; mi = ti;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < QS_TOPK; ++k) {
+            if (k < K) {
+                const int best = bi[k];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    o[k * 6 + a] = clipr<real>(s_pos[a * B + base + best] - mypos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
+                    o[k * 6 + 3 + a] = clipr<real>(s_vel[a * B + base + best] - myvel[a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
+                }
+            }
+        }
+        return;
+    }
+    // generic K: metrics into an LDS row, then K rounds of arg-min (lowest index wins ties)
     for (int j = 0; j < N; ++j) {
         real rp[3] = {s_pos[0 * B + base + j] - mypos[0], s_pos[1 * B + base + j] - mypos[1], s_pos[2 * B + base + j] - mypos[2]};
         real rv[3] = {s_vel[0 * B + base + j] - myvel[0], s_vel[1 * B + base + j] - myvel[1], s_vel[2 * B + base + j] - myvel[2]};
         real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
         real m = rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) / rd;
-        s_metric[j * B + tid] = (j == i) ? (real)3.0e38 : m;
+        s_metric[j * B + tid] = (j == i) ? (real)3.4e38 : m;
     }
     uint64_t taken = 0;
     for (int k = 0; k < K; ++k) {
         int best = 0;
-        real bm = (real)3.4e38;
+        real bmin = (real)3.4e38;
+        bool found = false;
         for (int j = 0; j < N; ++j) {
             real m = s_metric[j * B + tid];
-            bool better = !(taken >> j & 1) && m < bm;
+            bool better = !(taken >> j & 1) && j != i && (!found || m < bmin);
             best = better ? j : best;
-            bm = better ? m : bm;
+            bmin = better ? m : bmin;
+            found = found || better;
         }
         taken |= 1ull << best;
 #pragma unroll
@@ -342,7 +399,9 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
 #pragma unroll
         for (int q = 0; q < 4; ++q) { d.rot_damp[q] = 0; d.cmds_damp[q] = 0; }
         d.flags = F_COL_AGENT_OK | F_COL_OBST_OK | (d.flags & F_SVD_MASK);   // since_last_svd persists (App. A)
-        self_obs<real>(c, key, i, 0, d, goal, myobs);
+        SensNoise<real> sn;
+        if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 0, sn);
+        self_obs<real>(c, sn, d, goal, myobs);
     }
     __syncthreads();
     if (do_reset) {
@@ -358,10 +417,10 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
 // registers + LDS only, so HBM latency is paid once per step.
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__restrict__ cp, Ptrs<real> p, const real *__restrict__ actions,
+__global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, Ptrs<real> p, const real *__restrict__ actions,
                                                           LdsLayout L, int epb) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const Consts<real> &c = *cp;
+    const Consts<real> *cp = &c;
     const int B = QS_WAVE, N = c.num_agents, E = c.num_envs, T = E * N, M_ = c.num_obstacles;
     uint64_t *s_mask = (uint64_t *)(smem + L.off_mask);
     uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
@@ -375,6 +434,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
     const uint64_t nmask = (N >= 64) ? ~0ull : ((1ull << N) - 1);
     real *myobs = s_obs + tid * c.obs_dim;
 
+    QS_STAMP(0);
     // ================= loads (coalesced: component-major SoA) =================
     Drone<real> d;
     real goal[3], act[4], ring[4], sums[3];
@@ -405,22 +465,31 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
             s_obst[(le * 2 + 1) * M_ + k] = p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + k];
         }
     }
+    // The random draws of the per-drone phase do not depend on the state: generating them here overlaps the
+    // Philox / Box-Muller arithmetic with the HBM latency of the loads above.  (step_no is uniform per env and
+    // the first value the wave waits for.)
     RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + ee), step_no};
+    real zou[4];
+    SensNoise<real> sn;
+    rng_normal<real, 4>(key, QS_SITE_OU, 0, i, 0, zou);
+    if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 0, sn);
 
+    QS_STAMP(1);
     // ================= A. per-drone step =================
     // RawControl quadrotor_control.py:53-57, OU noise quad_utils.py:275-279, 2 sub-steps (qs_device.h),
     // reward quadrotor_single.py:34-92, tick/done :352-353, self obs get_state.py + sensor_noise.py
     real rew, ri[QS_RI_COUNT];
     {
-        real cmds[4], z[4], acc[3];
-        rng_normal<real, 4>(key, QS_SITE_OU, 0, i, 0, z);
+        real cmds[4], acc[3];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             cmds[m] = (real)0.5 * (clipr<real>(act[m], (real)-1, (real)1) + (real)1);
             real x = d.ou[m];
-            d.ou[m] = x + (c.ou_theta * ((real)0 - x) + c.thrust_noise_sigma * z[m]);
+            d.ou[m] = x + (c.ou_theta * ((real)0 - x) + c.thrust_noise_sigma * zou[m]);
         }
+        QS_STAMP(2);
         for (int s = 0; s < c.sim_steps; ++s) substep<real>(c, key, i, s, d, cmds, acc);
+        QS_STAMP(3);
         const real dt = c.dt;
         real diff[3] = {goal[0] - d.pos[0], goal[1] - d.pos[1], goal[2] - d.pos[2]};
         real cpr = norm3<real>(diff), cpos = c.rew_coeff[QS_REW_POS] * cpr;
@@ -439,27 +508,43 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
     const bool nan_rew = !(rew == rew) || M<real>::fabs(rew) > (real)3.0e38;
     const int tick = tick_before + 1;
     const bool done = tick > c.ep_len;
-    self_obs<real>(c, key, i, 0, d, goal, myobs);
+    QS_STAMP(4);
+    self_obs<real>(c, sn, d, goal, myobs);
+    QS_STAMP(5);
 #pragma unroll
     for (int q = 0; q < 3; ++q) s_pos[q * B + tid] = d.pos[q];
     s_zax[0 * B + tid] = d.rot[2]; s_zax[1 * B + tid] = d.rot[5]; s_zax[2 * B + tid] = d.rot[8];
     __syncthreads();
 
     // ================= B. pair scan, obstacle first hit, room lists =================
-    uint64_t curr_pair = 0;
+    uint64_t curr_pair = 0, dw_mask = 0;
     bool in_curr = false;
     real prox = 0;
     uint32_t bits = 0;
     int obst_idx = -1;
     if (active) {
-        // calculate_collision_matrix collisions/quadrotors.py:63-91, proximity penalties :95-103
+        // calculate_collision_matrix collisions/quadrotors.py:63-91, proximity penalties :95-103 and the downwash
+        // cylinder test of aerodynamics/downwash.py:30-45 share the relative position; 4 partners per iteration so the
+        // LDS reads are issued together
         const real pr = -c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX] / c.collision_falloff_threshold;
-        for (int j = 0; j < N; ++j) {
-            real dx = d.pos[0] - s_pos[0 * B + base + j], dy = d.pos[1] - s_pos[1 * B + base + j], dz = d.pos[2] - s_pos[2 * B + base + j];
-            real dist = M<real>::sqrt(dx * dx + dy * dy + dz * dz);
-            const bool other = j != i;
-            if (other && dist <= c.collision_threshold) { in_curr = true; if (j > i) curr_pair |= 1ull << j; }
-            if (other && dist <= c.collision_falloff_threshold) prox += pr * dist + c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX];
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            real rel[4][3], zx[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = (j0 + u < N) ? j0 + u : N - 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { rel[u][a] = d.pos[a] - s_pos[a * B + base + j]; zx[u][a] = s_zax[a * B + base + j]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                const bool other = j < N && j != i;
+                real dist = M<real>::sqrt(rel[u][0] * rel[u][0] + rel[u][1] * rel[u][1] + rel[u][2] * rel[u][2]);
+                if (other && dist <= c.collision_threshold) { in_curr = true; if (j > i) curr_pair |= 1ull << j; }
+                if (other && dist <= c.collision_falloff_threshold) prox += pr * dist + c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX];
+                real rz = dot3<real>(rel[u], zx[u]), rxy = M<real>::sqrt(dist * dist - rz * rz);
+                if (other && (real)-0.7 < rz && rz < (real)0 && rxy < (real)0.1) dw_mask |= 1ull << j;   // drone j is above me
+            }
         }
         if (c.use_obstacles) {   // first hit in index order, obstacles/utils.py:31-43
             const real *ox = s_obst + (le * 2 + 0) * M_, *oy = s_obst + (le * 2 + 1) * M_;
@@ -482,6 +567,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
         if (bits & B_ROOM_NEW) f |= F_PREV_ROOM;
         d.flags = f;
     }
+    QS_STAMP(6);
     // ---- env-level id sets by wave ballots (quadrotor_multi.py:432-459, :462-488) ----
     const bool was_in_col = active && (d.flags & F_IN_COL);
     const uint64_t new_pair = curr_pair & ~prev_pair;                                  // pair-level novelty (:437-438)
@@ -557,39 +643,41 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
         }
     }
 
+    QS_STAMP(7);
     // ================= C. physical interactions, in the reference's order (:548-587) =================
     // 1) downwash aerodynamics/downwash.py:4-66: this lane is the LOWER drone j, loops upper drones ii
-    if (c.use_downwash && active) {
-        for (int ii = 0; ii < N; ++ii) {
+    if (c.use_downwash && dw_mask) {   // rare: ascending ii = the reference's outer-loop order
+        uint64_t mm = dw_mask;
+        while (mm) {
+            const int ii = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
             real rel[3] = {d.pos[0] - s_pos[0 * B + base + ii], d.pos[1] - s_pos[1 * B + base + ii], d.pos[2] - s_pos[2 * B + base + ii]};
             real zx[3] = {s_zax[0 * B + base + ii], s_zax[1 * B + base + ii], s_zax[2 * B + base + ii]};
-            real d2 = rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2], rz = dot3<real>(rel, zx);
-            real dist = M<real>::sqrt(d2), rxy = M<real>::sqrt(dist * dist - rz * rz);
-            if (ii != i && (real)-0.7 < rz && rz < (real)0 && rxy < (real)0.1) {
-                uint32_t w[4];
-                rng_words(key, QS_SITE_DW_I, 0, ii, 0, w);
-                real ua = (real)-0.1 + (real)0.2 * u01<real>(w[0]), uw = (real)-0.01 + (real)0.02 * u01<real>(w[1]);
-                real a = M<real>::fmax((real)1e-6, (real)(6.0 / 17.0) * ((real)-10 * dist + (real)7) + ua);
-                real ow = M<real>::fmax((real)1e-6, (real)0.3 * ((dist - (real)1) * (dist - (real)1)) + uw);
-                real nz[3], dirw[3];
-                rng_words(key, QS_SITE_DW_IJ_V, 0, ii, i, w);
+            real dist = norm3<real>(rel);
+            uint32_t w[4];
+            rng_words(key, QS_SITE_DW_I, 0, ii, 0, w);
+            real ua = (real)-0.1 + (real)0.2 * u01<real>(w[0]), uw = (real)-0.01 + (real)0.02 * u01<real>(w[1]);
+            real a = M<real>::fmax((real)1e-6, (real)(6.0 / 17.0) * ((real)-10 * dist + (real)7) + ua);
+            real ow = M<real>::fmax((real)1e-6, (real)0.3 * ((dist - (real)1) * (dist - (real)1)) + uw);
+            real nz[3], dirw[3];
+            rng_words(key, QS_SITE_DW_IJ_V, 0, ii, i, w);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) nz[q] = zx[q] + ((real)-0.1 + (real)0.2 * u01<real>(w[q]));
-                rng_words(key, QS_SITE_DW_IJ_W, 0, ii, i, w);
+            for (int q = 0; q < 3; ++q) nz[q] = zx[q] + ((real)-0.1 + (real)0.2 * u01<real>(w[q]));
+            rng_words(key, QS_SITE_DW_IJ_W, 0, ii, i, w);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) dirw[q] = (real)-1 + (real)2 * u01<real>(w[q]);
-                real mz = norm3<real>(nz), dz = (mz == (real)0) ? mz + (real)1e-6 : mz;
-                real mw = norm3<real>(dirw), dwn = (mw == (real)0) ? mw + (real)1e-6 : mw;
+            for (int q = 0; q < 3; ++q) dirw[q] = (real)-1 + (real)2 * u01<real>(w[q]);
+            real mz = norm3<real>(nz), dz = (mz == (real)0) ? mz + (real)1e-6 : mz;
+            real mw = norm3<real>(dirw), dwn = (mw == (real)0) ? mw + (real)1e-6 : mw;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    real down = (real)-1 * (nz[q] / dz);
-                    d.vel[q] += a * down * c.control_dt;
-                    d.omega[q] += ow * (dirw[q] / dwn) * c.control_dt;
-                }
-                bits |= B_DOWNWASH;
+            for (int q = 0; q < 3; ++q) {
+                real down = (real)-1 * (nz[q] / dz);
+                d.vel[q] += a * down * c.control_dt;
+                d.omega[q] += ow * (dirw[q] / dwn) * c.control_dt;
             }
+            bits |= B_DOWNWASH;
         }
     }
+    QS_STAMP(8);
     const bool any_dw = ((__ballot(active && (bits & B_DOWNWASH)) >> base) & nmask) != 0;
     // 2) drone-drone responses for the NEW pairs in lexicographic order (collisions/quadrotors.py:24-59);
     //    order-dependent and rare: one lane per env walks the pair list on LDS-resident vel/omega
@@ -642,10 +730,14 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
         }
     }
 
+    QS_STAMP(9);
     // ================= E. final observations (:592-607) =================
 #pragma unroll
     for (int q = 0; q < 3; ++q) s_vel[q * B + tid] = d.vel[q];
-    if (update_flag && active) self_obs<real>(c, key, i, 1, d, goal, myobs);   // fresh sensor noise, new goal (:598-599)
+    if (update_flag && active) {   // fresh sensor noise, new goal (:598-599)
+        if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 1, sn);
+        self_obs<real>(c, sn, d, goal, myobs);
+    }
     __syncthreads();
     if (active) {
         neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, d.vel, myobs + c.self_dim);
@@ -653,6 +745,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
             sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors);
     }
 
+    QS_STAMP(10);
     // ================= F. done: episode snapshot + auto-reset (:626-722) =================
     uint64_t out_unique = unique, out_obst_new = m_obst_new, out_room = m_room, out_curr_pair = curr_pair, out_new_pair = new_pair;
     int out_tick = tick, out_obst_idx = obst_idx;
@@ -677,7 +770,24 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
         }
     }
 
-    // ================= G. stores =================
+    QS_STAMP(11);
+    // ================= G. stores (nothing waits on them: they are the last instructions of the wave) =================
+    __syncthreads();
+    {   // obs copy-out: the workgroup's rows form one contiguous [rows*obs_dim] block in LDS and in HBM
+        const int D = c.obs_dim, first_env = blockIdx.x * epb;
+        int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
+        const int total = nenv * N * D;
+        real *dst = p.obs + (size_t)first_env * N * D;
+        if ((total & 3) == 0 && ((((size_t)first_env * N * D) * sizeof(real)) & 15) == 0 && sizeof(real) == 4) {
+            const float4 *src4 = (const float4 *)s_obs;
+            float4 *dst4 = (float4 *)dst;
+#pragma unroll 4
+            for (int idx = tid; idx < total / 4; idx += B) dst4[idx] = src4[idx];
+        } else {
+            for (int idx = tid; idx < total; idx += B) dst[idx] = s_obs[idx];
+        }
+    }
+    QS_STAMP(12);
     if (active) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = d.vel[q]; p.omega[q * T + g] = d.omega[q]; p.goal[q * T + g] = goal[q]; p.dist_sums[q * T + g] = sums[q]; }
@@ -704,29 +814,16 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> *__
             p.step_ctr[e] = step_no;
         }
     }
-    __syncthreads();
-    {   // obs copy-out: the workgroup's rows form one contiguous [rows*obs_dim] block in LDS and in HBM
-        const int D = c.obs_dim, first_env = blockIdx.x * epb;
-        int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
-        const int total = nenv * N * D;
-        real *dst = p.obs + (size_t)first_env * N * D;
-        if ((total & 3) == 0 && ((((size_t)first_env * N * D) * sizeof(real)) & 15) == 0 && sizeof(real) == 4) {
-            const float4 *src4 = (const float4 *)s_obs;
-            float4 *dst4 = (float4 *)dst;
-            for (int idx = tid; idx < total / 4; idx += B) dst4[idx] = src4[idx];
-        } else {
-            for (int idx = tid; idx < total; idx += B) dst[idx] = s_obs[idx];
-        }
-    }
+    QS_STAMP(13);
 }
 
 // ------------------------------------------------------------------------------------------------
 // reset kernel (qs_reset): resets the envs flagged in reset_mask
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> *__restrict__ cp, Ptrs<real> p, LdsLayout L, int epb) {
+__global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c, Ptrs<real> p, LdsLayout L, int epb) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const Consts<real> &c = *cp;
+    const Consts<real> *cp = &c;
     const int N = c.num_agents, E = c.num_envs, T = E * N;
     real *s_obs = (real *)(smem + L.off_obs);
     const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le;
@@ -805,7 +902,8 @@ struct qs_handle {
     int real_size = 4;
     int obs_dim = 0, epb = 1, blocks = 0;
     LdsLayout lds;
-    void *d_consts = nullptr;
+    Consts<float> kf;    // kernel constants, passed by value in the kernarg segment
+    Consts<double> kd;
     Ptrs<float> pf;     // same field layout for float/double: only the pointee type differs
     std::vector<void *> allocs;
     qs_buffers bufs;
@@ -905,20 +1003,15 @@ template <typename real> static int create_typed(qs_handle *h) {
     DA(obs, T * D); DA(reward, T); DA(rew_info, QS_RI_COUNT * T); DA(done, T); DA(obst_hit_idx, T);
     DA(unique_col, E); DA(obst_new, E); DA(room_new, E); DA(counters, QS_CNT_COUNT * E); DA(tick, E); DA(step_ctr, E);
     DA(obst_pos, 2 * E * (M_ ? M_ : 1)); DA(dist_ring, 4 * T); DA(dist_sums, 3 * T); DA(ep_stats, QS_EPS_COUNT * T); DA(ep_counters, QS_CNT_COUNT * E);
-    DA(scen_real, 6 * E); DA(scen_int, E); DA(error_flag, 1); DA(reset_mask, E);
+    DA(scen_real, 6 * E); DA(scen_int, E); DA(error_flag, 1); DA(reset_mask, E); DA(timing, 32);
 #undef DA
     real *act = nullptr;
     if ((rc = dalloc(h, &act, 4 * T)) != QS_OK) return rc;
     h->d_actions = act;
     static_assert(sizeof(Ptrs<float>) == sizeof(Ptrs<double>), "layout");
     memcpy(&h->pf, &p, sizeof p);
-    Consts<real> k;
-    fill_consts<real>(c, k);
-    void *dk = nullptr;
-    HIP_TRY(hipMalloc(&dk, sizeof k));
-    HIP_TRY(hipMemcpy(dk, &k, sizeof k, hipMemcpyHostToDevice));
-    h->allocs.push_back(dk);
-    h->d_consts = dk;
+    fill_consts<float>(c, h->kf);
+    fill_consts<double>(c, h->kd);
     qs_buffers &b = h->bufs;
     memset(&b, 0, sizeof b);
     b.obs = p.obs; b.reward = p.reward; b.done = p.done; b.rew_info = p.rew_info; b.actions = act;
@@ -1033,9 +1126,9 @@ int qs_destroy(qs_handle *h) {
 static int launch_reset(qs_handle *h, hipStream_t s) {
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
-        hipLaunchKernelGGL(qs_reset_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, (const Consts<double> *)h->d_consts, p, h->lds, h->epb);
+        hipLaunchKernelGGL(qs_reset_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
     } else {
-        hipLaunchKernelGGL(qs_reset_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, (const Consts<float> *)h->d_consts, h->pf, h->lds, h->epb);
+        hipLaunchKernelGGL(qs_reset_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, h->lds, h->epb);
     }
     HIP_TRY(hipGetLastError());
     return QS_OK;
@@ -1068,10 +1161,10 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s) {
     }
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
-        hipLaunchKernelGGL(qs_step_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, (const Consts<double> *)h->d_consts, p,
+        hipLaunchKernelGGL(qs_step_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p,
                            (const double *)actions, h->lds, h->epb);
     } else {
-        hipLaunchKernelGGL(qs_step_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, (const Consts<float> *)h->d_consts, h->pf,
+        hipLaunchKernelGGL(qs_step_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf,
                            (const float *)actions, h->lds, h->epb);
     }
     HIP_TRY(hipGetLastError());
@@ -1136,8 +1229,9 @@ int qs_set_reward_coeffs(qs_handle *h, const double *coeffs) {
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     for (int q = 0; q < QS_REW_COUNT; ++q) h->cfg.rew_coeff[q] = coeffs[q];
-    if (h->real_size == 8) { Consts<double> k; fill_consts<double>(h->cfg, k); HIP_TRY(hipMemcpy(h->d_consts, &k, sizeof k, hipMemcpyHostToDevice)); }
-    else { Consts<float> k; fill_consts<float>(h->cfg, k); HIP_TRY(hipMemcpy(h->d_consts, &k, sizeof k, hipMemcpyHostToDevice)); }
+    fill_consts<float>(h->cfg, h->kf);
+    fill_consts<double>(h->cfg, h->kd);
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // constants are baked into the nodes
     return QS_OK;
 }
 
@@ -1182,6 +1276,15 @@ int qs_memcpy_h2d(qs_handle *h, void *dev_dst, const void *host_src, size_t byte
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return QS_OK;
+}
+
+/* debug: phase time stamps (shader clock) of workgroup 0; all zero unless built with -DQS_TIMING */
+int qs_debug_timing(qs_handle *h, unsigned long long *out32) {
+    if (!h || !out32) return fail(QS_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out32, h->pf.timing, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return QS_OK;
 }
 
