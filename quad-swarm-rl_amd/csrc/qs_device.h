@@ -38,7 +38,8 @@ template <> struct M<float> {
     static __device__ __forceinline__ float log(float x) { return logf(x); }
     // ln(u) for u in (0,1) via v_log_f32 (abs err ~1e-7 * |ln u|: noise amplitudes are 1e-2..1e-4, tolerance 1e-5)
     static __device__ __forceinline__ float log_u01(float u) { return __builtin_amdgcn_logf(u) * 0.69314718055994531f; }
-    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }      // 1 ulp; a/b costs ~50 cycles
+    static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
     // sin(x), 1-cos(x) for |x| <= ~0.4 (the Rodrigues angle is |omega| dt <= 40*sqrt(3)*0.005 = 0.35): Taylor series;
     // computing 1-cos directly avoids the cancellation of 1 - cosf(x) in fp32
     static __device__ __forceinline__ void sin_omcos_small(float x, float *s, float *omc) {
@@ -65,6 +66,7 @@ template <> struct M<double> {
     static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double log_u01(double u) { return ::log(u); }
     static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
     static __device__ __forceinline__ void sin_omcos_small(double x, double *s, double *omc) { *s = ::sin(x); *omc = 1.0 - ::cos(x); }
     static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
     static __device__ __forceinline__ double fabs(double x) { return ::fabs(x); }
@@ -99,6 +101,27 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 __device__ __forceinline__ void rng_words(const RngKey &k, int site, int slot, int i, int j, uint32_t w[4]) {
     philox4x32(k.env, k.step, (uint32_t)site | ((uint32_t)slot << 8), (uint32_t)i | ((uint32_t)j << 16), k.k0, k.k1, w);
 }
+// Four Philox blocks advanced in lockstep: the 10-round chains are independent, so issuing them round by round gives
+// the in-order wave 8 independent multiplies per round instead of 2 (a lone wave issues dependent VALU ops ~2x slower).
+__device__ __forceinline__ void philox4x32_x4(const uint32_t c0_in[4], uint32_t c1, const uint32_t c2_in[4], const uint32_t c3_in[4],
+                                              uint32_t k0, uint32_t k1, uint32_t w[4][4]) {
+    uint32_t c0[4], c1v[4], c2[4], c3[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { c0[s] = c0_in[s]; c1v[s] = c1; c2[s] = c2_in[s]; c3[s] = c3_in[s]; }
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * c0[s], p1 = (uint64_t)0xCD9E8D57u * c2[s];
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1v[s] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3[s] ^ k1;
+            c1v[s] = (uint32_t)p1; c3[s] = (uint32_t)p0; c0[s] = n0; c2[s] = n2;
+        }
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { w[s][0] = c0[s]; w[s][1] = c1v[s]; w[s][2] = c2[s]; w[s][3] = c3[s]; }
+}
+
 template <typename real> __device__ __forceinline__ real u01(uint32_t x) { return ((real)(x >> 9) + (real)0.5) * (real)(1.0 / 8388608.0); }
 
 // n <= 4 standard normals (Box-Muller on word pairs (0,1),(2,3))
@@ -116,6 +139,14 @@ template <typename real, int NN> __device__ __forceinline__ void rng_normal(cons
         if (NN > 3) z[3] = r1 * s1;
     }
 }
+template <typename real> __device__ __forceinline__ void box_muller4(const uint32_t w[4], real z[4]) {
+    real r0 = M<real>::sqrt((real)-2.0 * M<real>::log_u01(u01<real>(w[0]))), s0, c0;
+    M<real>::sincos2pi(u01<real>(w[1]), &s0, &c0);
+    real r1 = M<real>::sqrt((real)-2.0 * M<real>::log_u01(u01<real>(w[2]))), s1, c1;
+    M<real>::sincos2pi(u01<real>(w[3]), &s1, &c1);
+    z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
+}
+
 template <typename real, int NN> __device__ __forceinline__ void rng_uniform(const RngKey &k, int site, int slot, int i, int j, real lo, real hi, real u[NN]) {
     uint32_t w[4];
     rng_words(k, site, slot, i, j, w);
@@ -149,6 +180,8 @@ template <typename real> struct Consts {
     int32_t cube_fd[2];   // int(n ** (1/3)) for the two half-swarms, evaluated on the host with libm's pow (scenarios/base.py:98-99)
     uint32_t seed_lo, seed_hi;
     int32_t env_id_offset, num_envs, num_agents;
+    real inv_dt, prox_ratio;   // 1/dt; -quadcol_smooth_max / collision_falloff_threshold (collisions/quadrotors.py:97)
+    real inv_win[3];           // 1/min(ep_len+1, {1,3,5} s of control steps): episode-stat window sizes
     int32_t write_rew_info;   // 0: skip the 17-term reward-info matrix (it is logging, not part of obs/reward/done)
 };
 
@@ -177,13 +210,13 @@ template <typename real> __device__ __forceinline__ void yaw_rot(real theta, rea
 // atan2(0,0) = 0 -> identity yaw.
 template <typename real> __device__ __forceinline__ void yaw_rot_xy(real x, real y, real r[9]) {
     real h2 = x * x + y * y, c = 1, s = 0;
-    if (h2 > (real)0) { real ih = (real)1 / M<real>::sqrt(h2); c = x * ih; s = y * ih; }
+    if (h2 > (real)0) { real ih = M<real>::rsqrt(h2); c = x * ih; s = y * ih; }
     r[0] = c; r[1] = -s; r[2] = 0; r[3] = s; r[4] = c; r[5] = 0; r[6] = 0; r[7] = 0; r[8] = 1;
 }
 template <typename real> __device__ __forceinline__ void unit_xy(real x, real y, real *c, real *s) {
     real h2 = x * x + y * y;
     *c = 1; *s = 0;
-    if (h2 > (real)0) { real ih = (real)1 / M<real>::sqrt(h2); *c = x * ih; *s = y * ih; }
+    if (h2 > (real)0) { real ih = M<real>::rsqrt(h2); *c = x * ih; *s = y * ih; }
 }
 
 // nearest rotation (orthogonal polar factor) == U V^T of the SVD, quadrotor_dynamics.py:546-551.
@@ -235,7 +268,7 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
     for (int r = 0; r < 3; ++r) wv[r] = R[r * 3] * om[0] + R[r * 3 + 1] * om[1] + R[r * 3 + 2] * om[2];
     real wn = norm3<real>(wv);
     if (wn != (real)0) {
-        real iw = (real)1 / wn;
+        real iw = M<real>::rcp(wn);
         real kx = wv[0] * iw, ky = wv[1] * iw, kz = wv[2] * iw;
         real K[9] = {0, -kz, ky, kz, 0, -kx, -ky, kx, 0};
         real s, cc; M<real>::sin_omcos_small(wn * dt, &s, &cc);
@@ -331,16 +364,16 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
 template <typename real> __device__ __forceinline__ void rot2quat(const real r[9], real q[4]) {
     real trace = r[0] + r[4] + r[8];
     if (trace > (real)0) {
-        real S = M<real>::sqrt(trace + (real)1) * (real)2, iS = (real)1 / S;
+        real S = M<real>::sqrt(trace + (real)1) * (real)2, iS = M<real>::rcp(S);
         q[0] = (real)0.25 * S; q[1] = (r[7] - r[5]) * iS; q[2] = (r[2] - r[6]) * iS; q[3] = (r[3] - r[1]) * iS;
     } else if (r[0] > r[4] && r[0] > r[8]) {
-        real S = M<real>::sqrt((real)1 + r[0] - r[4] - r[8]) * (real)2, iS = (real)1 / S;
+        real S = M<real>::sqrt((real)1 + r[0] - r[4] - r[8]) * (real)2, iS = M<real>::rcp(S);
         q[0] = (r[7] - r[5]) * iS; q[1] = (real)0.25 * S; q[2] = (r[1] + r[3]) * iS; q[3] = (r[2] + r[6]) * iS;
     } else if (r[4] > r[8]) {
-        real S = M<real>::sqrt((real)1 + r[4] - r[0] - r[8]) * (real)2, iS = (real)1 / S;
+        real S = M<real>::sqrt((real)1 + r[4] - r[0] - r[8]) * (real)2, iS = M<real>::rcp(S);
         q[0] = (r[2] - r[6]) * iS; q[1] = (r[1] + r[3]) * iS; q[2] = (real)0.25 * S; q[3] = (r[5] + r[7]) * iS;
     } else {
-        real S = M<real>::sqrt((real)1 + r[8] - r[0] - r[4]) * (real)2, iS = (real)1 / S;
+        real S = M<real>::sqrt((real)1 + r[8] - r[0] - r[4]) * (real)2, iS = M<real>::rcp(S);
         q[0] = (r[3] - r[1]) * iS; q[1] = (r[2] + r[6]) * iS; q[2] = (r[5] + r[7]) * iS; q[3] = (real)0.25 * S;
     }
 }
@@ -381,6 +414,35 @@ __device__ __forceinline__ void sensor_noise_draw(const Consts<real> &c, const R
         rng_uniform<real, 3>(key, QS_SITE_SENS_THETA_U, pass, drone, 0, -c.quat_unif_range, c.quat_unif_range, u);
 #pragma unroll
         for (int q = 0; q < 3; ++q) n.th[q] += u[q];
+    }
+}
+
+// The four always-needed normal groups of a control step (OU thrust noise + sensor pos / vel / omega noise, pass 0)
+// from four Philox blocks advanced in lockstep.  Same sites / slots / values as the one-at-a-time draws.
+template <typename real>
+__device__ __forceinline__ void step_noise_draw(const Consts<real> &c, const RngKey &key, int drone, real zou[4], SensNoise<real> &n) {
+    const uint32_t c0[4] = {key.env, key.env, key.env, key.env};
+    const uint32_t c2[4] = {QS_SITE_OU, QS_SITE_SENS_POS_N, QS_SITE_SENS_VEL_N, QS_SITE_SENS_OMEGA_N};   // slot (pass) 0
+    const uint32_t c3[4] = {(uint32_t)drone, (uint32_t)drone, (uint32_t)drone, (uint32_t)drone};
+    uint32_t w[4][4];
+    philox4x32_x4(c0, key.step, c2, c3, key.k0, key.k1, w);
+    real z[4];
+    box_muller4<real>(w[0], zou);
+    box_muller4<real>(w[1], z);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) n.p[q] = c.pos_norm_std * z[q];
+    box_muller4<real>(w[2], z);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) n.v[q] = c.vel_norm_std * z[q];
+    box_muller4<real>(w[3], z);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { n.w[q] = c.gyro_noise_density * z[q]; n.th[q] = 0; }
+    if (c.pos_unif_range != (real)0 || c.vel_unif_range != (real)0 || c.quat_norm_std != (real)0 || c.quat_unif_range != (real)0) {
+        real u[3];   // non-default sensor model: the extra terms one group at a time
+        if (c.pos_unif_range != (real)0) { rng_uniform<real, 3>(key, QS_SITE_SENS_POS_U, 0, drone, 0, -c.pos_unif_range, c.pos_unif_range, u); for (int q = 0; q < 3; ++q) n.p[q] += u[q]; }
+        if (c.vel_unif_range != (real)0) { rng_uniform<real, 3>(key, QS_SITE_SENS_VEL_U, 0, drone, 0, -c.vel_unif_range, c.vel_unif_range, u); for (int q = 0; q < 3; ++q) n.v[q] += u[q]; }
+        if (c.quat_norm_std != (real)0) { rng_normal<real, 3>(key, QS_SITE_SENS_THETA_N, 0, drone, 0, z); for (int q = 0; q < 3; ++q) n.th[q] = c.quat_norm_std * z[q]; }
+        if (c.quat_unif_range != (real)0) { rng_uniform<real, 3>(key, QS_SITE_SENS_THETA_U, 0, drone, 0, -c.quat_unif_range, c.quat_unif_range, u); for (int q = 0; q < 3; ++q) n.th[q] += u[q]; }
     }
 }
 

@@ -83,34 +83,70 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
 // The N-1 metrics are evaluated once into an LDS row, then K rounds of arg-min (lowest index wins ties,
 // like the stable ordering of argsort on distinct keys).
 // ------------------------------------------------------------------------------------------------
-#define QS_TOPK 8
+// neighborhood_indices quadrotor_multi.py:247-274 + extend_obs_space :233-245.
+// pos/vel of the env's drones are in LDS (component-major, stride B).  Measured on MI355X (lone wave per SIMD, every
+// LDS round trip exposed): N <= 8 is fastest with all candidates in registers and rank-by-counting (independent
+// compares); larger N with a streaming sorted top-K list (insertion by compare-exchange).  Both give the first K
+// entries of the stable ascending order of the metric = argsort.
 template <typename real>
 __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
                                              real *s_metric, const real mypos[3], const real myvel[3], real *o) {
     const int K = c.num_neighbors;
     if (K <= 0) return;
-    if (K == N - 1) {
-        for (int k = 0; k < K; ++k) {
-            const int j = (k < i) ? k : k + 1;
+    if (K == N - 1 || N <= 8) {
+        const bool all_others = (K == N - 1);   // all other drones in index order (:253-254)
+        for (int j0 = 0; j0 < N; j0 += 8) {      // (a single chunk unless all_others with N > 8)
+            real rp[8][3], rv[8][3];
+            int rank[8];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                o[k * 6 + a] = clipr<real>(s_pos[a * B + base + j] - mypos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
-                o[k * 6 + 3 + a] = clipr<real>(s_vel[a * B + base + j] - myvel[a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
+            for (int u = 0; u < 8; ++u) {        // 48 LDS reads issued before the first use: one round trip
+                const int j = (j0 + u < N) ? j0 + u : N - 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+            }
+            if (all_others) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank[u] = (j0 + u < i) ? j0 + u : j0 + u - 1;
+            } else {
+                real mj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    real rd = M<real>::fmax(norm3<real>(rp[u]), (real)0.01);
+                    real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) * M<real>::rcp(rd);
+                    mj[u] = (u < N && u != i) ? m : (real)3.4e38;
+                    rank[u] = 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rank[u] += (mj[k] < mj[u] || (mj[k] == mj[u] && k < u)) ? 1 : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u;
+                if (j < N && j != i && rank[u] < K) {
+                    real *oo = o + rank[u] * 6;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        oo[a] = clipr<real>(rp[u][a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
+                        oo[3 + a] = clipr<real>(rv[u][a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
+                    }
+                }
             }
         }
         return;
     }
-    if (K <= QS_TOPK) {
-        // one streaming pass: sorted top-K (metric, index) list in registers; a new candidate is inserted behind
-        // entries with an equal metric, i.e. lower index first = the stable order of argsort on distinct keys
-        real bm[QS_TOPK];
-        int bi[QS_TOPK];
+    if (K <= 8) {
+        // streaming pass over the candidates, 4 per LDS round trip; sorted top-8 (metric, index) list in registers.  A new
+        // candidate is inserted behind entries with an equal metric, i.e. lower index first.
+        real bm[8];
+        int bi[8];
 #pragma unroll
-        for (int k = 0; k < QS_TOPK; ++k) { bm[k] = (real)3.4e38; bi[k] = 0; }
+        for (int k = 0; k < 8; ++k) { bm[k] = (real)3.4e38; bi[k] = 0; }
         for (int j0 = 0; j0 < N; j0 += 4) {
             real rp[4][3], rv[4][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {   // LDS reads of 4 candidates issued together
+            for (int u = 0; u < 4; ++u) {
                 const int j = (j0 + u < N) ? j0 + u : N - 1;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
@@ -119,11 +155,11 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
             for (int u = 0; u < 4; ++u) {
                 const int j = j0 + u;
                 real rd = M<real>::fmax(norm3<real>(rp[u]), (real)0.01);
-                real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) / rd;
+                real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) * M<real>::rcp(rd);
                 m = (j < N && j != i) ? m : (real)3.4e38;
                 int mi = j;
 #pragma unroll
-                for (int k = 0; k < QS_TOPK; ++k) {   // insertion by a compare-exchange chain
+                for (int k = 0; k < 8; ++k) {
                     const bool lt = m < bm[k];
                     const real tm = lt ? bm[k] : m;
                     const int ti = lt ? bi[k] : mi;
@@ -133,38 +169,43 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
                 }
             }
         }
+        real vals[8][6];
 #pragma unroll
-        for (int k = 0; k < QS_TOPK; ++k) {
+        for (int k = 0; k < 8; ++k) {
             if (k < K) {
-                const int best = bi[k];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { vals[k][a] = s_pos[a * B + base + bi[k]] - mypos[a]; vals[k][3 + a] = s_vel[a * B + base + bi[k]] - myvel[a]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k < K) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    o[k * 6 + a] = clipr<real>(s_pos[a * B + base + best] - mypos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
-                    o[k * 6 + 3 + a] = clipr<real>(s_vel[a * B + base + best] - myvel[a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
+                    o[k * 6 + a] = clipr<real>(vals[k][a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
+                    o[k * 6 + 3 + a] = clipr<real>(vals[k][3 + a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
                 }
             }
         }
         return;
     }
-    // generic K: metrics into an LDS row, then K rounds of arg-min (lowest index wins ties)
+    // 8 < K < N-1 (unusual): metrics into this lane's LDS column, then K rounds of arg-min (lowest index wins ties)
     for (int j = 0; j < N; ++j) {
         real rp[3] = {s_pos[0 * B + base + j] - mypos[0], s_pos[1 * B + base + j] - mypos[1], s_pos[2 * B + base + j] - mypos[2]};
         real rv[3] = {s_vel[0 * B + base + j] - myvel[0], s_vel[1 * B + base + j] - myvel[1], s_vel[2 * B + base + j] - myvel[2]};
         real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
-        real m = rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) / rd;
-        s_metric[j * B + tid] = (j == i) ? (real)3.4e38 : m;
+        real mm = rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) * M<real>::rcp(rd);
+        s_metric[j * B + tid] = (j == i) ? (real)3.4e38 : mm;
     }
-    uint64_t taken = 0;
+    uint64_t taken = 1ull << i;
     for (int k = 0; k < K; ++k) {
-        int best = 0;
+        int best = -1;
         real bmin = (real)3.4e38;
-        bool found = false;
         for (int j = 0; j < N; ++j) {
-            real m = s_metric[j * B + tid];
-            bool better = !(taken >> j & 1) && j != i && (!found || m < bmin);
+            real mm = s_metric[j * B + tid];
+            bool better = !(taken >> j & 1) && (best < 0 || mm < bmin);
             best = better ? j : best;
-            bmin = better ? m : bmin;
-            found = found || better;
+            bmin = better ? mm : bmin;
         }
         taken |= 1ull << best;
 #pragma unroll
@@ -471,8 +512,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, 
     RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + ee), step_no};
     real zou[4];
     SensNoise<real> sn;
-    rng_normal<real, 4>(key, QS_SITE_OU, 0, i, 0, zou);
-    if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 0, sn);
+    step_noise_draw<real>(c, key, i, zou, sn);
 
     QS_STAMP(1);
     // ================= A. per-drone step =================
@@ -524,19 +564,19 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, 
     int obst_idx = -1;
     if (active) {
         // calculate_collision_matrix collisions/quadrotors.py:63-91, proximity penalties :95-103 and the downwash
-        // cylinder test of aerodynamics/downwash.py:30-45 share the relative position; 4 partners per iteration so the
+        // cylinder test of aerodynamics/downwash.py:30-45 share the relative position; 8 partners per iteration so the
         // LDS reads are issued together
-        const real pr = -c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX] / c.collision_falloff_threshold;
-        for (int j0 = 0; j0 < N; j0 += 4) {
-            real rel[4][3], zx[4][3];
+        const real pr = c.prox_ratio;
+        for (int j0 = 0; j0 < N; j0 += 8) {
+            real rel[8][3], zx[8][3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int j = (j0 + u < N) ? j0 + u : N - 1;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) { rel[u][a] = d.pos[a] - s_pos[a * B + base + j]; zx[u][a] = s_zax[a * B + base + j]; }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int j = j0 + u;
                 const bool other = j < N && j != i;
                 real dist = M<real>::sqrt(rel[u][0] * rel[u][0] + rel[u][1] * rel[u][1] + rel[u][2] * rel[u][2]);
@@ -615,8 +655,8 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, 
     {
         const real dnow = -ri[QS_RI_RAW_POS];
         if (tick >= 5 && !(d.flags & F_REACHED)) {
-            real mean5 = ((((ring[3] + ring[2]) + ring[1]) + ring[0]) + dnow) / (real)5;
-            if (mean5 / c.dt < c.approach_goal_metric) d.flags |= F_REACHED;
+            real mean5 = ((((ring[3] + ring[2]) + ring[1]) + ring[0]) + dnow) * (real)0.2;
+            if (mean5 * c.inv_dt < c.approach_goal_metric) d.flags |= F_REACHED;
         }
         ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = dnow;
         const int total = c.ep_len + 1;
@@ -626,8 +666,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, 
             real sum = (tick == 1) ? (real)0 : sums[w];
             if (tick > total - win) sum += dnow;
             sums[w] = sum;
-            const int n = total < win ? total : win;
-            eps_dist[w] = ((real)1 / c.dt) * (sum / (real)n);
+            eps_dist[w] = c.inv_dt * (sum * c.inv_win[w]);
         }
     }
     // ---- per-env counters (lane 0 of the env keeps them in registers) ----
@@ -734,11 +773,14 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, 
     // ================= E. final observations (:592-607) =================
 #pragma unroll
     for (int q = 0; q < 3; ++q) s_vel[q * B + tid] = d.vel[q];
+    QS_STAMP(14);
     if (update_flag && active) {   // fresh sensor noise, new goal (:598-599)
         if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 1, sn);
         self_obs<real>(c, sn, d, goal, myobs);
     }
+    QS_STAMP(15);
     __syncthreads();
+    QS_STAMP(16);
     if (active) {
         neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, d.vel, myobs + c.self_dim);
         if (c.use_obstacles)
@@ -955,6 +997,12 @@ template <typename real> static void fill_consts(const qs_config &c, Consts<real
     k.seed_lo = (uint32_t)(c.seed & 0xffffffffu); k.seed_hi = (uint32_t)(c.seed >> 32);
     k.env_id_offset = c.env_id_offset; k.num_envs = c.num_envs; k.num_agents = c.num_agents;
     k.write_rew_info = c.write_rew_info;
+    k.inv_dt = (real)(1.0 / c.dt);
+    k.prox_ratio = (real)(-c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX] / c.collision_falloff_threshold);
+    for (int w = 0; w < 3; ++w) {
+        const int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * k.control_freq, total = c.ep_len + 1;
+        k.inv_win[w] = (real)(1.0 / (double)(total < win ? total : win));
+    }
 }
 
 extern "C" int qs_obs_dim(const qs_config *c);

@@ -39,10 +39,13 @@ for t in range(60):
     buf = (C.c_ulonglong * 32)()
     L.qs_debug_timing(st._h, buf)
     ts = np.array(buf[:14], dtype=np.float64)
+    extra = np.array(buf[14:17], dtype=np.float64)
     if t >= 10:
         acc += np.diff(ts)
+        ex = ex + np.array([extra[0] - ts[9], extra[1] - extra[0], extra[2] - extra[1], ts[10] - extra[2]]) if t > 10 else np.array([extra[0] - ts[9], extra[1] - extra[0], extra[2] - extra[1], ts[10] - extra[2]])
         n += 1
 acc /= n
 print(f"workload {wl} {args[1:]}: per-phase shader cycles (workgroup 0, lane 0), total {acc.sum():.0f}")
 for nm, v in zip(names, acc):
     print(f"  {nm:22s} {v:9.0f}")
+print("  final-obs split: publish vel %.0f | refresh self-obs %.0f | barrier %.0f | neighbour+sdf obs %.0f" % tuple(ex / n))
