@@ -49,28 +49,29 @@ WORKLOADS = {
 
 
 def cpu_baseline(workload, seconds):
-    """Times the oracle (kind 'port': validated C restatement of the reference) on the host cores."""
+    """Times the oracle (kind 'port': the validated C restatement of the reference) on the host cores.  Each env runs its
+    control steps back to back inside one OpenMP region (envs are independent), float64, all hardware threads."""
     from oracle import oracle as orc
     from quad_swarm_rl_amd import config as qcfg
     w = WORKLOADS[workload]
     threads = os.cpu_count() or 1
-    num_envs = min(w["num_envs"], max(64, 4 * threads))
+    num_envs = w["num_envs"]
     cfg = qcfg.make_config(num_envs=num_envs, seed=0, **w["kw"])
     batch = orc.OracleBatch(cfg, num_envs)
     batch.reset()
     n = cfg.num_agents
     rng = np.random.RandomState(0)
-    acts = rng.uniform(-1, 1, size=(8, num_envs, n, 4))
-    for t in range(3):
-        batch.step(acts[t % 8])
+    acts = rng.uniform(-1, 1, size=(16, num_envs, n, 4))
+    chunk = 50
+    batch.rollout(acts, chunk)                     # warm-up (thread pool, caches)
     steps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        for t in range(10):
-            batch.step(acts[(steps + t) % 8])
-        steps += 10
+        batch.rollout(acts, chunk)
+        steps += chunk
     dt = time.perf_counter() - t0
     return dict(value=num_envs * n * 2 * steps / dt, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{num_envs} envs x {n} drones x {steps} control steps ({dt:.1f} s), C oracle, OpenMP over envs, float64")
+                sample=f"{num_envs} envs x {n} drones x {steps} control steps ({dt:.1f} s), C oracle (float64), one OpenMP region, "
+                       f"{threads} threads")
 
 
 def main():

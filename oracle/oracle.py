@@ -58,6 +58,7 @@ def lib():
         _lib.qso_get_info.argtypes = [C.c_void_p, C.POINTER(QsoInfo)]
         _lib.qso_set_reward_coeffs.argtypes = [C.c_void_p, dp]
         _lib.qso_step_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, dp, dp, u8p]
+        _lib.qso_rollout_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, u8p]
         _lib.qso_sizeof_config.restype = C.c_size_t
         _lib.qso_sizeof_info.restype = C.c_size_t
         _lib.qso_obs_dim.argtypes = [C.c_void_p]
@@ -66,6 +67,7 @@ def lib():
         _lib.qso_surround_sdf.argtypes = [dp, dp, C.c_int32, C.c_double, C.c_double, dp]
         _lib.qso_obst_first_hit.argtypes = [dp, dp, C.c_int32, C.c_double]
         _lib.qso_collision_obstacle_kat.argtypes = [dp, dp, dp, dp, dp]
+        _lib.qso_collision_matrix.argtypes = [dp, C.c_int32, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         _lib.qso_philox4x32.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         assert _lib.qso_sizeof_info() == C.sizeof(QsoInfo), (_lib.qso_sizeof_info(), C.sizeof(QsoInfo))
     return _lib
@@ -154,6 +156,16 @@ class OracleBatch:
 
     def reset(self):
         return np.stack([e.reset() for e in self.envs])
+
+    def rollout(self, action_ring, steps):
+        """`steps` control steps of every env inside one OpenMP region (no per-step fork/join): the CPU baseline."""
+        a = np.ascontiguousarray(action_ring, dtype=np.float64).reshape(-1, self.e, self.n, 4)
+        obs = np.zeros((self.e, self.n, self.obs_dim))
+        rew = np.zeros((self.e, self.n))
+        done = np.zeros((self.e, self.n), dtype=np.uint8)
+        lib().qso_rollout_batch(self._handles, self.e, _dp(a), a.shape[0], steps, _dp(obs), _dp(rew),
+                                done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return obs, rew, done
 
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.e, self.n, 4)

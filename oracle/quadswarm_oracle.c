@@ -1174,6 +1174,17 @@ void qso_reset(qso_env *e, double *obs_out) {
     if (!obs_out) free(tmp);
 }
 
+/* calculate_collision_matrix collisions/quadrotors.py:63-91 as a stand-alone function (reference KAT
+ * collisions/test/unit_test/quadrotor.py:6-51): per-drone flag + masks of partners j>i within the threshold */
+void qso_collision_matrix(const double *pos, int32_t n, double thr, int32_t *flag, uint64_t *pair_mask) {
+    for (int i = 0; i < n; ++i) { flag[i] = 0; pair_mask[i] = 0; }
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            double dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+            if (pow(dx * dx + dy * dy + dz * dz, 0.5) <= thr) { flag[i] = 1; flag[j] = 1; pair_mask[i] |= 1ull << j; }
+        }
+}
+
 size_t qso_sizeof_config(void) { return sizeof(qs_config); }
 size_t qso_sizeof_info(void) { return sizeof(qso_info); }
 
@@ -1224,6 +1235,24 @@ void qso_set_state(qso_env *e, const double *s, int32_t tick) {
         d->flags &= ~F_OMEGA_F32;
     }
     if (tick >= 0) e->tick = tick;
+}
+
+/* CPU-baseline rollout: every env runs `steps` control steps back to back inside ONE parallel region (envs are
+ * independent, so there is no per-step fork/join).  actions: ring[ring_len][num][N*4]; obs/rew/done receive the last
+ * step's outputs ([num][N*obs_dim] etc.). */
+void qso_rollout_batch(qso_env **envs, int32_t num, const double *actions, int32_t ring_len, int32_t steps,
+                       double *obs, double *rew, uint8_t *done) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+    for (int32_t k = 0; k < num; ++k) {
+        qso_env *e = envs[k];
+        const int N = e->c.num_agents;
+        const size_t per_step = (size_t)num * N * 4;
+        for (int32_t t = 0; t < steps; ++t)
+            qso_step(e, actions + per_step * (size_t)(t % ring_len) + (size_t)k * N * 4, obs + (size_t)k * N * e->obs_dim,
+                     rew + (size_t)k * N, done + (size_t)k * N, NULL);
+    }
 }
 
 void qso_step_batch(qso_env **envs, int32_t num, const double *actions, double *obs, double *rew, uint8_t *done) {

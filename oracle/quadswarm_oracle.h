@@ -59,10 +59,14 @@ void qso_set_reward_coeffs(qso_env *e, const double *coeffs);
 /* Batched convenience for the CPU baseline: step `num` independent envs (OpenMP over envs if built with it). */
 void qso_step_batch(qso_env **envs, int32_t num, const double *actions, double *obs, double *rew, uint8_t *done);
 
+void qso_rollout_batch(qso_env **envs, int32_t num, const double *actions, int32_t ring_len, int32_t steps,
+                       double *obs, double *rew, uint8_t *done);
+
 /* exposed pieces for unit tests (known-answer tests of the reference's own test-suite) */
 void qso_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void qso_polar_rotation(const double r[9], double out[9]);
 int qso_obs_dim(const qs_config *cfg);
+void qso_collision_matrix(const double *pos, int32_t n, double thr, int32_t *flag, uint64_t *pair_mask);
 void qso_cell_centers(int32_t length, int32_t width, double *out /* [length*width][2] */);
 void qso_surround_sdf(const double qxy[2], const double *obst_xy, int32_t m, double radius, double res, double out[9]);
 int qso_obst_first_hit(const double qxy[2], const double *obst_xy, int32_t m, double thr);

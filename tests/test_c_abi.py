@@ -1,0 +1,85 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol that
+include/quadswarm.h declares, agrees with the ctypes mirror of qs_config, and fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from quad_swarm_rl_amd import config as qcfg, native
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_text():
+    return open(os.path.join(REPO, "include", "quadswarm.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    native.build()
+    lib = C.CDLL(native.LIB_PATH)
+    declared = sorted(set(re.findall(r"^(?:int|size_t|const char \*)\s*\*?(qs_\w+)\(", header_text(), flags=re.M)))
+    assert len(declared) >= 20, declared
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/quadswarm.h but not exported"
+    assert sorted(native.EXPORTED_SYMBOLS) == declared
+
+
+def test_config_struct_layout_matches():
+    L = native.lib()
+    assert L.qs_sizeof_config() == C.sizeof(qcfg.QsConfig)
+    assert L.qs_version() == int(re.search(r"#define QS_VERSION (\d+)", header_text()).group(1))
+
+
+def test_enums_match_header():
+    h = header_text()
+    assert int(re.search(r"#define QS_STATE_STRIDE (\d+)", h).group(1)) == qcfg.QS_STATE_STRIDE
+    assert int(re.search(r"#define QS_MAX_AGENTS (\d+)", h).group(1)) == qcfg.QS_MAX_AGENTS
+    ri = re.search(r"enum \{ QS_RI_REW_MAIN = 0,(.*?)QS_RI_COUNT \};", h, flags=re.S).group(1)
+    assert ri.count(",") + 1 == len(qcfg.REW_INFO_KEYS)
+    cnt = re.search(r"enum \{ QS_CNT_COLLISIONS = 0,(.*?)QS_CNT_COUNT \};", h, flags=re.S).group(1)
+    assert cnt.count(",") + 1 == len(qcfg.COUNTER_KEYS)
+
+
+def test_default_config_equals_host_derivation():
+    """qs_default_config (C, Appendix-C constants) == make_config (python, derived from the link geometry)."""
+    L = native.lib()
+    c = qcfg.QsConfig()
+    assert L.qs_default_config(C.byref(c), 4, 8) == 0
+    ref = qcfg.make_config(num_envs=4, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True,
+                           collision_falloff_radius=4.0, quads_mode="static_same_goal")
+    for name in ("mass", "arm", "motor_tau_up", "motor_tau_down", "omega_max", "dt", "thrust_noise_sigma", "ou_theta",
+                 "collision_threshold", "collision_falloff_threshold", "spawn_box", "approach_goal_metric"):
+        assert getattr(c, name) == pytest.approx(getattr(ref, name), rel=1e-15), name
+    for name in ("ep_len", "sim_steps", "svd_period", "num_neighbors", "floor_mode", "obs_repr", "sense_noise"):
+        assert getattr(c, name) == getattr(ref, name), name
+    np.testing.assert_allclose(list(c.inertia), list(ref.inertia), rtol=1e-14)
+    np.testing.assert_allclose(np.array(c.prop_cross), np.array(ref.prop_cross), atol=1e-17)
+    np.testing.assert_allclose(list(c.thrust_max), list(ref.thrust_max), rtol=1e-14)
+    np.testing.assert_allclose(list(c.torque_max), list(ref.torque_max), rtol=1e-14)
+    assert L.qs_obs_dim(C.byref(c)) == 54
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU box: covered by the gpu tests")
+def test_no_cpu_fallback_without_gpu():
+    """The product path must fail loudly when no GPU is visible."""
+    cfg = qcfg.make_config(num_envs=2, num_agents=2)
+    with pytest.raises(native.QsError):
+        native.Stepper(cfg)
+    from quad_swarm_rl_amd import env
+    with pytest.raises(native.QsError):
+        env.QuadSwarmVecEnv(2, num_agents=2)
+
+
+def test_invalid_arguments_rejected_before_touching_the_gpu():
+    L = native.lib()
+    h = C.c_void_p()
+    cfg = qcfg.make_config(num_envs=2, num_agents=4)
+    cfg.num_neighbors = 7
+    assert L.qs_create(C.byref(cfg), 0, C.byref(h)) == -1
+    assert b"neigbors" in L.qs_last_error()      # the reference's RuntimeError text (quadrotor_multi.py:274)
+    cfg = qcfg.make_config(num_envs=2, num_agents=4)
+    cfg.scenario = 9
+    assert L.qs_create(C.byref(cfg), 0, C.byref(h)) == -4
+    assert L.qs_step(None, None, None) == -1

@@ -1,0 +1,99 @@
+"""Known-answer tests the reference's own test-suite holds for this path, run against the oracle,
+plus the published Philox4x32-10 vectors that pin the shared random stream."""
+import ctypes as C
+
+import numpy as np
+
+from oracle import oracle as orc
+
+
+def dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def test_drone_collision_matrix_kat():
+    # collisions/test/unit_test/quadrotor.py:6-13: 8 drones, 7 at (1,1,1), one at (3,3,6), threshold 0.2
+    pos = np.ones((8, 3))
+    pos[3] = [3.0, 3.0, 6.0]
+    flag = np.zeros(8, dtype=np.int32)
+    mask = np.zeros(8, dtype=np.uint64)
+    orc.lib().qso_collision_matrix(dp(pos), 8, 0.2, flag.ctypes.data_as(C.POINTER(C.c_int32)), mask.ctypes.data_as(C.POINTER(C.c_uint64)))
+    brute = np.zeros(8, dtype=np.int32)
+    pairs = set()
+    for i in range(8):
+        for j in range(i + 1, 8):
+            if np.linalg.norm(pos[i] - pos[j]) <= 0.2:
+                brute[i] = brute[j] = 1
+                pairs.add((i, j))
+    np.testing.assert_array_equal(flag, brute)
+    got = {(i, j) for i in range(8) for j in range(8) if int(mask[i]) >> j & 1}
+    assert got == pairs and len(pairs) == 21 and flag[3] == 0
+
+
+def test_obstacle_collision_normal_kat():
+    # collisions/test/unit_test/obstacles.py:6-18: vnew = -sqrt(2)/2, normal (-sqrt(2)/2, -sqrt(2)/2, 0)
+    pos, vel, opos = np.zeros(3), np.array([1.0, 0.0, 0.0]), np.array([0.5, 0.5, 5.0])
+    vnew, n = C.c_double(0), np.zeros(3)
+    orc.lib().qso_collision_obstacle_kat(dp(pos), dp(vel), dp(opos), C.byref(vnew), dp(n))
+    assert round(vnew.value, 6) == round(-np.sqrt(2) / 2, 6)
+    np.testing.assert_allclose(n, [-np.sqrt(2) / 2, -np.sqrt(2) / 2, 0.0], atol=1e-12)
+
+
+def test_surround_sdf_kat():
+    # obstacles/test/unit_test.py:6-22: quad (0,0), obstacle (0.2,0), r 0.3, resolution 0.1
+    q, o, out = np.zeros(2), np.array([0.2, 0.0]), np.zeros(9)
+    orc.lib().qso_surround_sdf(dp(q), dp(o), 1, 0.3, 0.1, dp(out))
+    exp = [np.hypot(gx - 0.2, gy) - 0.3 for gx in (-0.1, 0.0, 0.1) for gy in (-0.1, 0.0, 0.1)]
+    np.testing.assert_allclose(out, exp, atol=1e-12)
+    assert out[4] == -0.09999999999999998 or abs(out[4] + 0.1) < 1e-12
+
+
+def test_obstacle_first_hit_lowest_index_wins():
+    # obstacles/utils.py:31-43: index order with `break`
+    o = np.array([[1.0, 1.0], [0.1, 0.0], [0.0, 0.1]])
+    assert orc.lib().qso_obst_first_hit(dp(np.zeros(2)), dp(o), 3, 0.346) == 1
+    assert orc.lib().qso_obst_first_hit(dp(np.array([5.0, 5.0])), dp(o), 3, 0.346) == -1
+
+
+def test_cell_centers_kat():
+    # obstacles/test/unit_test.py:35-47: 8x8 area, 1 m cells; obstacles/utils.py:47-58
+    out = np.zeros((64, 2))
+    orc.lib().qso_cell_centers(8, 8, dp(out))
+    exp = np.array([[i + 0.5 - 4, j + 0.5 - 4] for i in range(8) for j in range(7, -1, -1)])
+    np.testing.assert_array_equal(out, exp)
+    np.testing.assert_array_equal(out[0], [-3.5, 3.5])
+
+
+def test_polar_rotation_is_u_vt():
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] *= -1
+        a = q + 1e-3 * rng.normal(size=(3, 3))
+        u, s, vt = np.linalg.svd(a)
+        out = np.zeros(9)
+        orc.lib().qso_polar_rotation(dp(np.ascontiguousarray(a.reshape(-1))), dp(out))
+        np.testing.assert_allclose(out.reshape(3, 3), u @ vt, atol=1e-14)
+
+
+def test_philox4x32_10_known_answers():
+    # Random123 kat_vectors: philox4x32-10
+    vecs = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in vecs:
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        orc.lib().qso_philox4x32(c, k, o)
+        assert tuple(o) == exp
+
+
+def test_philox_mode_is_deterministic_and_keyed_by_global_env_id():
+    from quad_swarm_rl_amd import config as qcfg
+    cfg = qcfg.make_config(num_envs=1, num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", seed=5)
+    a, b, c = orc.OracleEnv(cfg, 3), orc.OracleEnv(cfg, 3), orc.OracleEnv(cfg, 4)
+    oa, ob, oc = a.reset(), b.reset(), c.reset()
+    np.testing.assert_array_equal(oa, ob)
+    assert np.abs(oa - oc).max() > 1e-3
+    act = np.random.RandomState(0).uniform(-1, 1, size=(4, 4))
+    np.testing.assert_array_equal(a.step(act)[0], b.step(act)[0])
