@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=400, help="steps of the HIP-event kernel-duration pass")
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step obs all-gather at N>1")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a workload keyword (python literal)")
     ap.add_argument("--graph", type=int, default=0, help="replay the rollout as hipGraphs of this many steps (qs_step_many)")
@@ -125,10 +126,13 @@ def main():
     actions = (torch.rand((ring, T, 4), device=f"cuda:{local_rank}", generator=gen, dtype=torch.float32) * 2.0 - 1.0).contiguous()
     aptr, astride = actions.data_ptr(), T * 4 * 4
     obs = st.tensor("obs")
-    gathered = torch.empty((world * T, D), device=f"cuda:{local_rank}", dtype=torch.float32) if world > 1 else None
+    gather = None
+    if world > 1 and not args.no_gather:
+        from quad_swarm_rl_amd import parallel
+        gather = parallel.ObsGather(obs, overlap=not args.no_overlap)   # ONE RCCL all-gather of the obs per rollout step
 
     def run(k, offset=0):
-        if args.graph > 0 and gathered is None:
+        if args.graph > 0 and gather is None:
             # launch-bound inner loop: K-step hipGraph replays over the action ring (qs_step_many)
             g = min(args.graph, ring)
             done_steps = 0
@@ -140,8 +144,10 @@ def main():
             return
         for t in range(k):
             st.step(aptr + ((offset + t) % ring) * astride, stream=stream)
-            if gathered is not None and not args.no_gather:
-                dist.all_gather_into_tensor(gathered, obs)
+            if gather is not None:
+                gather.gather()
+        if gather is not None:
+            gather.drain()
 
     st.reset(stream=stream)
     run(args.warmup)
@@ -178,7 +184,7 @@ def main():
             "config": {"workload": f"{args.workload}: {N} drones x {E} envs per GPU, {WORKLOADS[args.workload]['kw'].get('quads_mode', 'static_same_goal')}, "
                                    f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
                        "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N,
-                       "obs_gather": "rccl all_gather_into_tensor per step" if (world > 1 and not args.no_gather) else "none",
+                       "obs_gather": ("rccl all_gather_into_tensor per step" + ("" if args.no_overlap else ", overlapped with the next step")) if gather is not None else "none",
                        "launch": f"hipGraph x{min(args.graph, ring)}" if args.graph > 0 and world == 1 else "eager", "rew_info": bool(args.rew_info),
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -1,0 +1,218 @@
+"""Sample-Factory facing surface, mirroring swarm_rl/env_wrappers/ of the reference:
+
+  quad_utils.py:20-117        make_quadrotor_env_multi / make_quadrotor_env   -> make_quadrotor_env (same signature)
+  quadrotor_params.py:4-120   quadrotors_override_defaults / add_quadrotors_env_args (same flag names and defaults)
+  reward_shaping.py:52-123    QuadsRewardShapingWrapper   -> RewardShapingWrapper (same bookkeeping, no SF import needed)
+  compatibility.py:21-50      QuadEnvCompatibility        -> Compatibility (gymnasium 5-tuple, seed ignored)
+  swarm_rl/train.py:16-19     register_swarm_components
+
+The env underneath is the HIP stepper (env.QuadrotorEnvMulti); nothing here falls back to a CPU simulator.
+"""
+import copy
+
+import numpy as np
+
+from .env import QuadrotorEnvMulti
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if str(v).lower() in ("true", "1", "yes", "y", "t"):
+        return True
+    if str(v).lower() in ("false", "0", "no", "n", "f"):
+        return False
+    raise ValueError(f"boolean flag expected, got {v!r}")
+
+
+def quadrotors_override_defaults(env, parser):
+    parser.set_defaults(encoder_type="mlp", encoder_subtype="mlp_quads", rnn_size=256, encoder_extra_fc_layers=0, env_frameskip=1)
+
+
+def add_quadrotors_env_args(env, parser):
+    """Same names/defaults as swarm_rl/env_wrappers/quadrotor_params.py:15-120 (+ the stepper's own three flags)."""
+    p = parser
+    p.add_argument("--quads_num_agents", default=8, type=int)
+    p.add_argument("--quads_obs_repr", default="xyz_vxyz_R_omega", type=str,
+                   choices=["xyz_vxyz_R_omega", "xyz_vxyz_R_omega_floor", "xyz_vxyz_R_omega_wall"])
+    p.add_argument("--quads_episode_duration", default=15.0, type=float)
+    p.add_argument("--quads_encoder_type", default="corl", type=str)
+    p.add_argument("--quads_neighbor_visible_num", default=-1, type=int)
+    p.add_argument("--quads_neighbor_obs_type", default="none", type=str, choices=["none", "pos_vel"])
+    p.add_argument("--quads_neighbor_hidden_size", default=256, type=int)
+    p.add_argument("--quads_neighbor_encoder_type", default="attention", type=str,
+                   choices=["attention", "mean_embed", "mlp", "no_encoder"])
+    p.add_argument("--quads_collision_reward", default=0.0, type=float)
+    p.add_argument("--quads_collision_hitbox_radius", default=2.0, type=float)
+    p.add_argument("--quads_collision_falloff_radius", default=-1.0, type=float)
+    p.add_argument("--quads_collision_smooth_max_penalty", default=10.0, type=float)
+    p.add_argument("--quads_use_obstacles", default=False, type=str2bool)
+    p.add_argument("--quads_obstacle_obs_type", default="none", type=str, choices=["none", "octomap"])
+    p.add_argument("--quads_obst_density", default=0.2, type=float)
+    p.add_argument("--quads_obst_size", default=1.0, type=float)
+    p.add_argument("--quads_obst_spawn_area", nargs="+", default=[6.0, 6.0], type=float)
+    p.add_argument("--quads_domain_random", default=False, type=str2bool)
+    p.add_argument("--quads_obst_density_random", default=False, type=str2bool)
+    p.add_argument("--quads_obst_density_min", default=0.05, type=float)
+    p.add_argument("--quads_obst_density_max", default=0.2, type=float)
+    p.add_argument("--quads_obst_size_random", default=False, type=str2bool)
+    p.add_argument("--quads_obst_size_min", default=0.3, type=float)
+    p.add_argument("--quads_obst_size_max", default=0.6, type=float)
+    p.add_argument("--quads_obst_hidden_size", default=256, type=int)
+    p.add_argument("--quads_obst_encoder_type", default="mlp", type=str)
+    p.add_argument("--quads_obst_collision_reward", default=0.0, type=float)
+    p.add_argument("--quads_use_downwash", default=False, type=str2bool)
+    p.add_argument("--quads_use_numba", default=False, type=str2bool)
+    p.add_argument("--quads_mode", default="static_same_goal", type=str)
+    p.add_argument("--quads_room_dims", nargs="+", default=[10.0, 10.0, 10.0], type=float)
+    p.add_argument("--replay_buffer_sample_prob", default=0.0, type=float)
+    p.add_argument("--anneal_collision_steps", default=0.0, type=float)
+    p.add_argument("--quads_view_mode", nargs="+", default=["topdown", "chase", "global"], type=str)
+    p.add_argument("--quads_render", default=False, type=bool)
+    p.add_argument("--visualize_v_value", action="store_true")
+    p.add_argument("--quads_sim2real", default=False, type=str2bool)
+    # the stepper's own flags
+    p.add_argument("--quads_seed", default=0, type=int, help="seed of the counter-based noise stream")
+    p.add_argument("--quads_device", default=0, type=int, help="HIP device index")
+    p.add_argument("--quads_precision", default="f32", type=str, choices=["f32", "f64"])
+
+
+DEFAULT_QUAD_REWARD_SHAPING = dict(quad_rewards=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0,
+                                                     quadcol_bin=0.0, quadcol_bin_smooth_max=0.0, quadcol_bin_obst=0.0))
+
+
+class AnnealSchedule:
+    def __init__(self, coeff_name, final_value, anneal_env_steps):
+        self.coeff_name, self.final_value, self.anneal_env_steps = coeff_name, final_value, anneal_env_steps
+
+
+class _Wrapper:
+    def __init__(self, env):
+        self.env = env
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    @property
+    def unwrapped(self):
+        return self.env.unwrapped
+
+
+class RewardShapingWrapper(_Wrapper):
+    """reward_shaping.py:22-123: pushes the shaping scheme into env.rew_coeff, accumulates the rew_* terms per agent,
+    reports true_reward / episode stats at episode end, anneals the collision coefficients."""
+
+    def __init__(self, env, reward_shaping_scheme=None, annealing=None, with_pbt=False):
+        super().__init__(env)
+        self.reward_shaping_scheme = reward_shaping_scheme
+        self.cumulative_rewards = None
+        self.episode_actions = None
+        self.num_agents = env.num_agents if hasattr(env, "num_agents") else 1
+        self.reward_shaping_updated = True
+        self.annealing = annealing
+        self.training_info = {}
+
+    def set_training_info(self, training_info):
+        self.training_info = training_info
+
+    def reset(self):
+        obs = self.env.reset()
+        self.cumulative_rewards = [dict() for _ in range(self.num_agents)]
+        self.episode_actions = []
+        return obs
+
+    def step(self, action):
+        self.episode_actions.append(action)
+        if self.reward_shaping_updated:
+            env_reward_shaping = self.env.unwrapped.rew_coeff
+            for key, weight in self.reward_shaping_scheme["quad_rewards"].items():
+                if key in env_reward_shaping:
+                    env_reward_shaping[key] = weight
+            self.reward_shaping_updated = False
+        obs, rewards, dones, infos = self.env.step(action)
+        for i, info in enumerate(infos):
+            for key, value in info["rewards"].items():
+                if key.startswith("rew"):
+                    self.cumulative_rewards[i][key] = self.cumulative_rewards[i].get(key, 0) + value
+            if dones[i]:
+                true_reward = self.cumulative_rewards[i]["rewraw_main"] + 1000 * self.cumulative_rewards[i].get("rewraw_quadcol", 0)
+                info["true_reward"] = true_reward
+                self.cumulative_rewards[i]["rewraw_main"] = true_reward
+                extra_stats = info.setdefault("episode_extra_stats", dict())
+                extra_stats.update(self.cumulative_rewards[i])
+                approx = self.training_info.get("approx_total_training_steps", 0)
+                extra_stats["z_approx_total_training_steps"] = approx
+                scenario_name = self.env.unwrapped.scenario.name()
+                for rew_key in ("rew_pos", "rew_crash"):
+                    extra_stats[f"{scenario_name}/{rew_key}"] = self.cumulative_rewards[i][rew_key]
+                episode_actions = np.array(self.episode_actions).transpose()
+                for action_idx in range(episode_actions.shape[0]):
+                    extra_stats[f"z_action{action_idx}_mean"] = np.mean(episode_actions[action_idx])
+                    extra_stats[f"z_action{action_idx}_std"] = np.std(episode_actions[action_idx])
+                self.cumulative_rewards[i] = dict()
+                if self.annealing:
+                    env_reward_shaping = self.env.unwrapped.rew_coeff
+                    for sched in self.annealing:
+                        env_reward_shaping[sched.coeff_name] = min(sched.final_value * approx / sched.anneal_env_steps, sched.final_value)
+                        extra_stats[f"z_anneal_{sched.coeff_name}"] = env_reward_shaping[sched.coeff_name]
+        if any(dones):
+            self.episode_actions = []
+        return obs, rewards, dones, infos
+
+
+class Compatibility(_Wrapper):
+    """compatibility.py:21-50: old 4-tuple step -> gymnasium 5-tuple; reset(seed, options) ignores the seed."""
+
+    def reset(self, seed=None, options=None):
+        return self.env.reset(), {}
+
+    def step(self, action):
+        obs, reward, done, info = self.env.step(action)
+        done = np.array(done)
+        return obs, reward, done, np.zeros_like(done, dtype=bool), info
+
+
+def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
+    """quad_utils.py:20-110 on the HIP stepper (replay wrapper / V-value wrapper: SURVEY 8f 'next')."""
+    if getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0:
+        raise NotImplementedError("ExperienceReplayWrapper is not part of the stepper yet (SURVEY.md 8f)")
+    rew_coeff = DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]
+    env = QuadrotorEnvMulti(
+        num_agents=cfg.quads_num_agents, ep_time=cfg.quads_episode_duration,
+        rew_coeff=dict(rew_coeff),
+        obs_repr=cfg.quads_obs_repr,
+        neighbor_visible_num=cfg.quads_neighbor_visible_num, neighbor_obs_type=cfg.quads_neighbor_obs_type,
+        collision_hitbox_radius=cfg.quads_collision_hitbox_radius, collision_falloff_radius=cfg.quads_collision_falloff_radius,
+        use_obstacles=cfg.quads_use_obstacles, obst_density=cfg.quads_obst_density, obst_size=cfg.quads_obst_size,
+        obst_spawn_area=cfg.quads_obst_spawn_area, use_downwash=cfg.quads_use_downwash, use_numba=cfg.quads_use_numba,
+        quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims, use_replay_buffer=False,
+        quads_view_mode=getattr(cfg, "quads_view_mode", None), quads_render=getattr(cfg, "quads_render", False),
+        dynamics_params="Crazyflie", raw_control=True, raw_control_zero_middle=True, dynamics_randomize_every=None,
+        dynamics_change=dict(noise=dict(thrust_noise_ratio=0.05), damp=dict(vel=0, omega_quadratic=0)), dyn_sampler_1=None,
+        sense_noise="default", init_random_state=False, render_mode=render_mode,
+        seed=getattr(cfg, "quads_seed", 0), device=getattr(cfg, "quads_device", 0), precision=getattr(cfg, "quads_precision", "f32"))
+    reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
+    reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
+    reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty
+    reward_shaping["quad_rewards"]["quadcol_bin_obst"] = cfg.quads_obst_collision_reward
+    annealing = None
+    if cfg.anneal_collision_steps > 0:
+        for k in ("quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"):
+            reward_shaping["quad_rewards"][k] = 0.0
+        annealing = [AnnealSchedule("quadcol_bin", cfg.quads_collision_reward, cfg.anneal_collision_steps),
+                     AnnealSchedule("quadcol_bin_smooth_max", cfg.quads_collision_smooth_max_penalty, cfg.anneal_collision_steps),
+                     AnnealSchedule("quadcol_bin_obst", cfg.quads_obst_collision_reward, cfg.anneal_collision_steps)]
+    env = RewardShapingWrapper(env, reward_shaping_scheme=reward_shaping, annealing=annealing, with_pbt=getattr(cfg, "with_pbt", False))
+    return Compatibility(env)
+
+
+def make_quadrotor_env(env_name, cfg=None, _env_config=None, render_mode=None, **kwargs):
+    if env_name == "quadrotor_multi":
+        return make_quadrotor_env_multi(cfg, render_mode, **kwargs)
+    raise NotImplementedError
+
+
+def register_swarm_components():
+    """swarm_rl/train.py:16-19.  Needs sample_factory (not part of this repo)."""
+    from sample_factory.envs.env_utils import register_env   # raises ImportError where SF is not installed
+    register_env("quadrotor_multi", make_quadrotor_env)

@@ -1,0 +1,108 @@
+"""The reference-shaped python surface on top of the HIP stepper (needs the GPU)."""
+import argparse
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def parse(argv):
+    from quad_swarm_rl_amd import sf_env
+    p = argparse.ArgumentParser()
+    sf_env.add_quadrotors_env_args("quadrotor_multi", p)
+    p.add_argument("--with_pbt", default=False, type=sf_env.str2bool)
+    return p.parse_args(argv)
+
+
+def test_make_quadrotor_env_protocol():
+    """Mirrors swarm_rl/env_wrappers/tests/test_quads.py:15-31: construct through the factory, random actions, types."""
+    from quad_swarm_rl_amd import sf_env
+    cfg = parse(["--quads_num_agents=8", "--quads_neighbor_visible_num=6", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
+                 "--quads_collision_reward=5.0", "--quads_collision_falloff_radius=4.0", "--quads_use_downwash=True",
+                 "--quads_episode_duration=0.3", "--anneal_collision_steps=1000"])
+    env = sf_env.make_quadrotor_env("quadrotor_multi", cfg=cfg)
+    assert env.num_agents == 8 and env.is_multiagent
+    assert env.observation_space.shape == (54,) and env.action_space.shape == (4,)
+    obs, info = env.reset(seed=123)
+    assert obs.shape == (8, 54) and info == {}
+    saw_done = False
+    for t in range(40):
+        actions = [env.action_space.sample() for _ in range(8)]
+        obs, rew, term, trunc, infos = env.step(actions)
+        assert obs.shape == (8, 54) and len(rew) == 8 and term.shape == (8,) and not trunc.any() and len(infos) == 8
+        assert set(infos[0]["rewards"]) >= {"rew_main", "rew_pos", "rew_action", "rew_crash", "rew_orient", "rew_spin", "rewraw_main",
+                                            "rew_quadcol", "rew_proximity", "rewraw_quadcol"}
+        if term.any():
+            assert term.all()                         # all agents finish together (quadrotor_multi.py:720-722)
+            st = infos[0]["episode_extra_stats"]
+            for k in ("num_collisions", "distance_to_goal_1s", "metric/agent_success_rate", "static_same_goal/agent_col_rate",
+                      "z_anneal_quadcol_bin", "rewraw_main"):
+                assert k in st, k
+            assert "true_reward" in infos[0]
+            saw_done = True
+    assert saw_done
+    with pytest.raises(NotImplementedError):
+        sf_env.make_quadrotor_env("no_such_env", cfg=cfg)
+    env.close()
+
+
+def test_vec_env_device_tensors_and_coeff_push():
+    import torch
+    from quad_swarm_rl_amd.env import QuadSwarmVecEnv
+    env = QuadSwarmVecEnv(16, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True,
+                          collision_falloff_radius=4.0, seed=3)
+    obs = env.reset()
+    assert obs.is_cuda and tuple(obs.shape) == (128, 54) and env.num_agents == 128
+    a = torch.rand((128, 4), device="cuda") * 2 - 1
+    obs, rew, done, _ = env.step(a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and done.sum().item() == 0
+    r1 = rew.clone()
+    # the SF reward-shaping wrapper mutates env.rew_coeff: the next step must see the new coefficients
+    env2 = QuadSwarmVecEnv(16, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True,
+                           collision_falloff_radius=4.0, seed=3)
+    env2.reset()
+    env2.rew_coeff["pos"] = 3.0
+    _, rew2, _, _ = env2.step(a)
+    torch.cuda.synchronize()
+    assert (rew2 < r1 - 1e-4).all()
+    env.close(); env2.close()
+
+
+def test_nan_reward_raises_value_error():
+    """quadrotor_single.py:87-90: ValueError('QuadEnv: reward is Nan')"""
+    from quad_swarm_rl_amd import config as qcfg, native
+    st = native.Stepper(qcfg.make_config(num_envs=2, num_agents=2))
+    st.reset()
+    a = np.zeros((4, 4), dtype=np.float32)
+    a[1, 2] = np.nan
+    st.from_host("actions", a)
+    st.step()
+    st.sync()
+    with pytest.raises(ValueError, match="reward is Nan"):
+        st.check_errors()
+    st.close()
+
+
+def test_step_many_graph_equals_eager():
+    from quad_swarm_rl_amd import config as qcfg, native
+    import torch
+    kw = dict(num_envs=32, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, use_downwash=True,
+              collision_falloff_radius=4.0, seed=21, ep_time=0.2)
+    acts = (torch.rand((16, 256, 4), device="cuda") * 2 - 1).contiguous()
+    outs = []
+    for graph in (False, True):
+        st = native.Stepper(qcfg.make_config(**kw))
+        st.reset()
+        for rep in range(3):      # 48 steps with ep_len 20: auto-resets inside the captured graph
+            if graph:
+                st.step_many(acts.data_ptr(), 16)
+            else:
+                for t in range(16):
+                    st.step(acts.data_ptr() + t * 256 * 16)
+        st.sync()
+        outs.append((st.to_host("obs").copy(), st.to_host("reward").copy(), st.to_host("tick").copy()))
+        st.close()
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
