@@ -515,6 +515,15 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, 
     step_noise_draw<real>(c, key, i, zou, sn);
 
     QS_STAMP(1);
+#ifdef QS_SKIP_COMPUTE   // experiment: loads + stores only (memory/launch floor of the kernel)
+    real rew = act[0] + zou[0] + sn.p[0] + ring[0] + sums[0] + (real)prev_pair, ri[QS_RI_COUNT] = {};
+    const bool nan_rew = false, done = false;
+    const int tick = tick_before + 1;
+    uint64_t out_unique = 0, out_obst_new = 0, out_room = 0, out_curr_pair = 0, out_new_pair = 0;
+    int out_tick = tick, out_obst_idx = -1;
+    for (int q = 0; q < c.obs_dim; ++q) myobs[q] = d.pos[q % 3];
+    if (active && i == 0) cnt[0] += svs_period;
+#else
     // ================= A. per-drone step =================
     // RawControl quadrotor_control.py:53-57, OU noise quad_utils.py:275-279, 2 sub-steps (qs_device.h),
     // reward quadrotor_single.py:34-92, tick/done :352-353, self obs get_state.py + sensor_noise.py
@@ -812,6 +821,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, 
         }
     }
 
+#endif
     QS_STAMP(11);
     // ================= G. stores (nothing waits on them: they are the last instructions of the wave) =================
     __syncthreads();
