@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a workload keyword (python literal)")
-    ap.add_argument("--graph", type=int, default=0, help="replay the rollout as hipGraphs of this many steps (qs_step_many)")
+    ap.add_argument("--graph", type=int, default=0, help="headline mode: step the timed region as open-loop rollouts of this many steps per "
+                                                          "launch (qs_step_many: state stays in registers between the steps)")
+    ap.add_argument("--rollout-steps", type=int, default=64, help="steps per launch of the extra open-loop measurement (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -133,7 +135,7 @@ def main():
 
     def run(k, offset=0):
         if args.graph > 0 and gather is None:
-            # launch-bound inner loop: K-step hipGraph replays over the action ring (qs_step_many)
+            # open-loop rollout over the action ring: qs_step_many keeps the state in registers across the steps of a launch
             g = min(args.graph, ring)
             done_steps = 0
             while done_steps + g <= k:
@@ -166,6 +168,20 @@ def main():
         elapsed = float(tmax.item())
     st.check_errors()
 
+    # extra: the same workload as open-loop rollouts (pre-generated actions, K control steps per launch)
+    rollout = None
+    if world == 1 and args.rollout_steps > 0 and args.graph == 0:
+        kk = min(args.rollout_steps, ring)
+        reps = max(1, args.steps // kk)
+        st.step_many(aptr, kk, stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            st.step_many(aptr, kk, stream=stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rollout = {"steps_per_launch": kk, "value": T * 2 * reps * kk / dt, "unit": "env-steps/s", "us_per_step": 1e6 * dt / (reps * kk)}
+
     # dominant-kernel duration: HIP events recorded on the launch stream around every step-kernel launch
     st.set_profiling(True)
     for t in range(args.profile_steps):
@@ -185,7 +201,8 @@ def main():
                                    f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
                        "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N,
                        "obs_gather": ("rccl all_gather_into_tensor per step" + ("" if args.no_overlap else ", overlapped with the next step")) if gather is not None else "none",
-                       "launch": f"hipGraph x{min(args.graph, ring)}" if args.graph > 0 and world == 1 else "eager", "rew_info": bool(args.rew_info),
+                       "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and world == 1 else "one launch per control step",
+                       "open_loop_rollout": rollout, "rew_info": bool(args.rew_info),
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "qs_step_kernel<float>", "kernel_avg_us": kernel_ms * 1e3, "kernel_launches": launches,

@@ -60,7 +60,7 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     LdsLayout L;
     int o = 0;
     L.off_mask = o; o += 8 * B;                       // u64 per lane: new-pair masks for the serial response path
-    L.off_envflag = o; o += 4 * ((epb + 3) & ~3);
+    L.off_envflag = o; o += 4 * ((2 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods
     L.off_scratch = o; o += 4 * QS_RESET_SCRATCH_INTS * epb;
     o = (o + 15) & ~15;
     L.off_pos = o; o += real_size * 3 * B;
@@ -389,6 +389,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             // swarm_vs_swarm.py:80-94 (reset) + :17-50 (formation_centers) + scenarios/utils.py:170-181 (get_z_value)
             real dur = rng_uniform1<real>(key, QS_SITE_SCEN, 8, 0, 0, (real)4, (real)6);
             p.scen_int[e] = (int)(dur * (real)c.control_freq);
+            s_envflag[epb + le] = (uint32_t)(int)(dur * (real)c.control_freq);
             update_formation<real>(c, key, 0, N, F);
             real box = c.spawn_box, xy[2];
             rng_uniform<real, 2>(key, QS_SITE_SCEN, 9, 0, 0, -box, box, xy);
@@ -452,422 +453,12 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// THE step kernel: one control step of every environment = QuadrotorEnvMulti.step incl. the auto-reset tail.
-// All global loads are issued at the top, all global stores at the bottom; in between the wave works in
-// registers + LDS only, so HBM latency is paid once per step.
-// ------------------------------------------------------------------------------------------------
-template <typename real>
-__global__ void __launch_bounds__(QS_WAVE) qs_step_kernel(const Consts<real> c, Ptrs<real> p, const real *__restrict__ actions,
-                                                          LdsLayout L, int epb) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const Consts<real> *cp = &c;
-    const int B = QS_WAVE, N = c.num_agents, E = c.num_envs, T = E * N, M_ = c.num_obstacles;
-    uint64_t *s_mask = (uint64_t *)(smem + L.off_mask);
-    uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
-    real *s_pos = (real *)(smem + L.off_pos), *s_vel = (real *)(smem + L.off_vel), *s_zax = (real *)(smem + L.off_zax);
-    real *s_om = (real *)(smem + L.off_om), *s_goal = (real *)(smem + L.off_goal), *s_obs = (real *)(smem + L.off_obs);
-    real *s_obst = (real *)(smem + L.off_obst), *s_metric = (real *)(smem + L.off_metric);
-
-    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
-    const bool active = (le < epb) && (e < E);
-    const int g = active ? e * N + i : 0, ee = active ? e : 0;
-    const uint64_t nmask = (N >= 64) ? ~0ull : ((1ull << N) - 1);
-    real *myobs = s_obs + tid * c.obs_dim;
-
-    QS_STAMP(0);
-    // ================= loads (coalesced: component-major SoA) =================
-    Drone<real> d;
-    real goal[3], act[4], ring[4], sums[3];
-    int32_t cnt[QS_CNT_COUNT];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { d.pos[q] = p.pos[q * T + g]; d.vel[q] = p.vel[q * T + g]; d.omega[q] = p.omega[q * T + g]; goal[q] = p.goal[q * T + g]; sums[q] = p.dist_sums[q * T + g]; }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) d.rot[q] = p.rot[q * T + g];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { d.rot_damp[q] = p.rot_damp[q * T + g]; d.cmds_damp[q] = p.cmds_damp[q * T + g]; d.ou[q] = p.ou[q * T + g]; ring[q] = p.dist_ring[q * T + g]; }
-    d.flags = p.flags[g];
-    const uint64_t prev_pair = p.pair_mask[g];
-    {   // actions are row-major [T,4]: one 16/32-byte vector load per lane
-        const real *a = actions + (size_t)g * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) act[q] = a[q];
-    }
-    const int tick_before = p.tick[ee];
-    const uint32_t step_no = p.step_ctr[ee] + 1;
-    const int svs_period = (c.scenario == QS_SCENARIO_SWARM_VS_SWARM) ? p.scen_int[ee] : 0;
-    if (active && i == 0) {
-#pragma unroll
-        for (int q = 0; q < QS_CNT_COUNT; ++q) cnt[q] = p.counters[q * E + ee];
-    }
-    if (c.use_obstacles && active) {   // stage the env's obstacle positions in LDS
-        for (int k = i; k < M_; k += N) {
-            s_obst[(le * 2 + 0) * M_ + k] = p.obst_pos[(size_t)e * M_ + k];
-            s_obst[(le * 2 + 1) * M_ + k] = p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + k];
-        }
-    }
-    // The random draws of the per-drone phase do not depend on the state: generating them here overlaps the
-    // Philox / Box-Muller arithmetic with the HBM latency of the loads above.  (step_no is uniform per env and
-    // the first value the wave waits for.)
-    RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + ee), step_no};
-    real zou[4];
-    SensNoise<real> sn;
-    step_noise_draw<real>(c, key, i, zou, sn);
-
-    QS_STAMP(1);
-#ifdef QS_SKIP_COMPUTE   // experiment: loads + stores only (memory/launch floor of the kernel)
-    real rew = act[0] + zou[0] + sn.p[0] + ring[0] + sums[0] + (real)prev_pair, ri[QS_RI_COUNT] = {};
-    const bool nan_rew = false, done = false;
-    const int tick = tick_before + 1;
-    uint64_t out_unique = 0, out_obst_new = 0, out_room = 0, out_curr_pair = 0, out_new_pair = 0;
-    int out_tick = tick, out_obst_idx = -1;
-    for (int q = 0; q < c.obs_dim; ++q) myobs[q] = d.pos[q % 3];
-    if (active && i == 0) cnt[0] += svs_period;
-#else
-    // ================= A. per-drone step =================
-    // RawControl quadrotor_control.py:53-57, OU noise quad_utils.py:275-279, 2 sub-steps (qs_device.h),
-    // reward quadrotor_single.py:34-92, tick/done :352-353, self obs get_state.py + sensor_noise.py
-    real rew, ri[QS_RI_COUNT];
-    {
-        real cmds[4], acc[3];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            cmds[m] = (real)0.5 * (clipr<real>(act[m], (real)-1, (real)1) + (real)1);
-            real x = d.ou[m];
-            d.ou[m] = x + (c.ou_theta * ((real)0 - x) + c.thrust_noise_sigma * zou[m]);
-        }
-        QS_STAMP(2);
-        for (int s = 0; s < c.sim_steps; ++s) substep<real>(c, key, i, s, d, cmds, acc);
-        QS_STAMP(3);
-        const real dt = c.dt;
-        real diff[3] = {goal[0] - d.pos[0], goal[1] - d.pos[1], goal[2] - d.pos[2]};
-        real cpr = norm3<real>(diff), cpos = c.rew_coeff[QS_REW_POS] * cpr;
-        real cer = M<real>::sqrt(act[0] * act[0] + act[1] * act[1] + act[2] * act[2] + act[3] * act[3]), cef = c.rew_coeff[QS_REW_EFFORT] * cer;
-        bool on_floor = (d.flags & F_ON_FLOOR) != 0;
-        real cor = on_floor ? (real)1 : -d.rot[8], cori = c.rew_coeff[QS_REW_ORIENT] * cor;
-        real csr = M<real>::sqrt(d.omega[0] * d.omega[0] + d.omega[1] * d.omega[1] + d.omega[2] * d.omega[2]), cspin = c.rew_coeff[QS_REW_SPIN] * csr;
-        real ccr = on_floor ? (real)1 : (real)0, ccrash = c.rew_coeff[QS_REW_CRASH] * ccr;
-        rew = -dt * ((((cpos + cef) + ccrash) + cori) + cspin);
-        ri[QS_RI_REW_MAIN] = dt * -cpos; ri[QS_RI_REW_POS] = dt * -cpos; ri[QS_RI_REW_ACTION] = dt * -cef;
-        ri[QS_RI_REW_CRASH] = dt * -ccrash; ri[QS_RI_REW_ORIENT] = dt * -cori; ri[QS_RI_REW_SPIN] = dt * -cspin;
-        ri[QS_RI_RAW_MAIN] = dt * -cpr; ri[QS_RI_RAW_POS] = dt * -cpr; ri[QS_RI_RAW_ACTION] = dt * -cer;
-        ri[QS_RI_RAW_CRASH] = dt * -ccr; ri[QS_RI_RAW_ORIENT] = dt * -cor; ri[QS_RI_RAW_SPIN] = dt * -csr;
-        ri[QS_RI_REW_QUADCOL_OBST] = 0; ri[QS_RI_RAW_QUADCOL_OBST] = 0;
-    }
-    const bool nan_rew = !(rew == rew) || M<real>::fabs(rew) > (real)3.0e38;
-    const int tick = tick_before + 1;
-    const bool done = tick > c.ep_len;
-    QS_STAMP(4);
-    self_obs<real>(c, sn, d, goal, myobs);
-    QS_STAMP(5);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) s_pos[q * B + tid] = d.pos[q];
-    s_zax[0 * B + tid] = d.rot[2]; s_zax[1 * B + tid] = d.rot[5]; s_zax[2 * B + tid] = d.rot[8];
-    __syncthreads();
-
-    // ================= B. pair scan, obstacle first hit, room lists =================
-    uint64_t curr_pair = 0, dw_mask = 0;
-    bool in_curr = false;
-    real prox = 0;
-    uint32_t bits = 0;
-    int obst_idx = -1;
-    if (active) {
-        // calculate_collision_matrix collisions/quadrotors.py:63-91, proximity penalties :95-103 and the downwash
-        // cylinder test of aerodynamics/downwash.py:30-45 share the relative position; 8 partners per iteration so the
-        // LDS reads are issued together
-        const real pr = c.prox_ratio;
-        for (int j0 = 0; j0 < N; j0 += 8) {
-            real rel[8][3], zx[8][3];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = (j0 + u < N) ? j0 + u : N - 1;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { rel[u][a] = d.pos[a] - s_pos[a * B + base + j]; zx[u][a] = s_zax[a * B + base + j]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                const bool other = j < N && j != i;
-                real dist = M<real>::sqrt(rel[u][0] * rel[u][0] + rel[u][1] * rel[u][1] + rel[u][2] * rel[u][2]);
-                if (other && dist <= c.collision_threshold) { in_curr = true; if (j > i) curr_pair |= 1ull << j; }
-                if (other && dist <= c.collision_falloff_threshold) prox += pr * dist + c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX];
-                real rz = dot3<real>(rel[u], zx[u]), rxy = M<real>::sqrt(dist * dist - rz * rz);
-                if (other && (real)-0.7 < rz && rz < (real)0 && rxy < (real)0.1) dw_mask |= 1ull << j;   // drone j is above me
-            }
-        }
-        if (c.use_obstacles) {   // first hit in index order, obstacles/utils.py:31-43
-            const real *ox = s_obst + (le * 2 + 0) * M_, *oy = s_obst + (le * 2 + 1) * M_;
-            for (int k = M_ - 1; k >= 0; --k) {
-                real dx = d.pos[0] - ox[k], dy = d.pos[1] - oy[k];
-                obst_idx = (M<real>::sqrt(dx * dx + dy * dy) <= c.obst_hit_threshold) ? k : obst_idx;
-            }
-            if (obst_idx >= 0) { bits |= B_OBST_HIT; if (!(d.flags & F_PREV_OBST)) bits |= B_OBST_NEW; d.flags |= F_PREV_OBST; }
-            else d.flags &= ~F_PREV_OBST;
-        }
-        // calculate_room_collision quadrotor_multi.py:289-302, :491-497
-        uint32_t f = d.flags;
-        if (f & F_CRASH_FLOOR) bits |= B_FLOOR;
-        if ((f & F_CRASH_WALL) && !(f & F_PREV_WALL)) bits |= B_WALL_NEW;
-        if ((f & F_CRASH_CEIL) && !(f & F_PREV_CEIL)) bits |= B_CEIL_NEW;
-        if ((bits & (B_FLOOR | B_WALL_NEW | B_CEIL_NEW)) && !(f & F_PREV_ROOM)) bits |= B_ROOM_NEW;
-        f &= ~(F_PREV_WALL | F_PREV_CEIL | F_PREV_ROOM);
-        if (bits & B_WALL_NEW) f |= F_PREV_WALL;
-        if (bits & B_CEIL_NEW) f |= F_PREV_CEIL;
-        if (bits & B_ROOM_NEW) f |= F_PREV_ROOM;
-        d.flags = f;
-    }
-    QS_STAMP(6);
-    // ---- env-level id sets by wave ballots (quadrotor_multi.py:432-459, :462-488) ----
-    const bool was_in_col = active && (d.flags & F_IN_COL);
-    const uint64_t new_pair = curr_pair & ~prev_pair;                                  // pair-level novelty (:437-438)
-    const uint64_t curr_ids = (__ballot(active && in_curr) >> base) & nmask;
-    const uint64_t prev_ids = (__ballot(was_in_col) >> base) & nmask;
-    const uint64_t m_obst_hit = (__ballot(active && (bits & B_OBST_HIT)) >> base) & nmask;
-    const uint64_t m_obst_new = (__ballot(active && (bits & B_OBST_NEW)) >> base) & nmask;
-    const uint64_t m_floor = (__ballot(active && (bits & B_FLOOR)) >> base) & nmask;
-    const uint64_t m_wall = (__ballot(active && (bits & B_WALL_NEW)) >> base) & nmask;
-    const uint64_t m_ceil = (__ballot(active && (bits & B_CEIL_NEW)) >> base) & nmask;
-    const uint64_t m_room = (__ballot(active && (bits & B_ROOM_NEW)) >> base) & nmask;
-    const uint64_t wave_newpair = __ballot(active && new_pair != 0);
-    const uint64_t m_newpair_any = (wave_newpair >> base) & nmask;
-    const uint64_t unique = curr_ids & ~prev_ids;                                      // np.setdiff1d on flattened ids (:440)
-    if (in_curr) d.flags |= F_IN_COL; else d.flags &= ~F_IN_COL;
-    const int col_tick = __popcll(unique) / 2;                                         // :448
-    const int obst_cnt = __popcll(m_obst_new);
-    const bool settled = tick >= c.grace_steps;
-    const int time_remain = c.ep_len - tick_before;
-    if (col_tick > 0 && settled && (unique >> i & 1)) d.flags &= ~F_COL_AGENT_OK;
-    if (obst_cnt > 0 && settled && (bits & B_OBST_NEW)) d.flags &= ~F_COL_OBST_OK;
-    // distance_to_goal_3_5 / _5 use the NOISY relative position of the self obs (:474-478)
-    const real qrel = M<real>::sqrt(myobs[0] * myobs[0] + myobs[1] * myobs[1] + myobs[2] * myobs[2]);
-    const int n35 = __popcll((__ballot(active && (bits & B_OBST_NEW) && qrel > (real)3.5) >> base) & nmask);
-    const int n5 = __popcll((__ballot(active && (bits & B_OBST_NEW) && qrel > (real)5.0) >> base) & nmask);
-
-    // ---- rewards (:499-546) ----
-    {
-        const bool any_nonzero_id = (unique & ~1ull) != 0;   // `.any()` of the id array
-        real raw = (any_nonzero_id && (unique >> i & 1)) ? (real)-1 : (real)0;
-        real rc = c.rew_coeff[QS_REW_QUADCOL_BIN] * raw;
-        real rp = (real)-1 * (c.control_dt * prox);
-        rew += rc;
-        rew += rp;
-        ri[QS_RI_REW_QUADCOL] = rc; ri[QS_RI_REW_PROXIMITY] = rp; ri[QS_RI_RAW_QUADCOL] = raw;
-        if (c.use_obstacles) {
-            real ro_raw = (m_obst_hit && (bits & B_OBST_NEW)) ? (real)-1 : (real)0;
-            real ro = c.rew_coeff[QS_REW_QUADCOL_OBST] * ro_raw;
-            rew += ro;
-            ri[QS_RI_REW_QUADCOL_OBST] = ro; ri[QS_RI_RAW_QUADCOL_OBST] = ro_raw;
-        }
-    }
-    // ---- distance-to-goal log, reached_goal (:542-546), windowed sums for the episode stats (:649-661) ----
-    real eps_dist[3] = {0, 0, 0};
-    {
-        const real dnow = -ri[QS_RI_RAW_POS];
-        if (tick >= 5 && !(d.flags & F_REACHED)) {
-            real mean5 = ((((ring[3] + ring[2]) + ring[1]) + ring[0]) + dnow) * (real)0.2;
-            if (mean5 * c.inv_dt < c.approach_goal_metric) d.flags |= F_REACHED;
-        }
-        ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = dnow;
-        const int total = c.ep_len + 1;
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * c.control_freq;
-            real sum = (tick == 1) ? (real)0 : sums[w];
-            if (tick > total - win) sum += dnow;
-            sums[w] = sum;
-            eps_dist[w] = c.inv_dt * (sum * c.inv_win[w]);
-        }
-    }
-    // ---- per-env counters (lane 0 of the env keeps them in registers) ----
-    if (active && i == 0) {
-        cnt[QS_CNT_COLLISIONS] += col_tick;
-        if (col_tick > 0 && settled) cnt[QS_CNT_COLLISIONS_AFTER_SETTLE] += col_tick;
-        if (col_tick > 0 && time_remain <= c.final_steps) cnt[QS_CNT_COLLISIONS_FINAL_5S] += col_tick;
-        cnt[QS_CNT_OBST] += obst_cnt;
-        if (obst_cnt > 0 && settled) { cnt[QS_CNT_OBST_AFTER_SETTLE] += obst_cnt; cnt[QS_CNT_OBST_DIST_3_5] += n35; cnt[QS_CNT_OBST_DIST_5] += n5; }
-        if (settled) {
-            cnt[QS_CNT_ROOM] += __popcll(m_room); cnt[QS_CNT_FLOOR] += __popcll(m_floor);
-            cnt[QS_CNT_WALL] += __popcll(m_wall); cnt[QS_CNT_CEILING] += __popcll(m_ceil);
-        }
-    }
-
-    QS_STAMP(7);
-    // ================= C. physical interactions, in the reference's order (:548-587) =================
-    // 1) downwash aerodynamics/downwash.py:4-66: this lane is the LOWER drone j, loops upper drones ii
-    if (c.use_downwash && dw_mask) {   // rare: ascending ii = the reference's outer-loop order
-        uint64_t mm = dw_mask;
-        while (mm) {
-            const int ii = __ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            real rel[3] = {d.pos[0] - s_pos[0 * B + base + ii], d.pos[1] - s_pos[1 * B + base + ii], d.pos[2] - s_pos[2 * B + base + ii]};
-            real zx[3] = {s_zax[0 * B + base + ii], s_zax[1 * B + base + ii], s_zax[2 * B + base + ii]};
-            real dist = norm3<real>(rel);
-            uint32_t w[4];
-            rng_words(key, QS_SITE_DW_I, 0, ii, 0, w);
-            real ua = (real)-0.1 + (real)0.2 * u01<real>(w[0]), uw = (real)-0.01 + (real)0.02 * u01<real>(w[1]);
-            real a = M<real>::fmax((real)1e-6, (real)(6.0 / 17.0) * ((real)-10 * dist + (real)7) + ua);
-            real ow = M<real>::fmax((real)1e-6, (real)0.3 * ((dist - (real)1) * (dist - (real)1)) + uw);
-            real nz[3], dirw[3];
-            rng_words(key, QS_SITE_DW_IJ_V, 0, ii, i, w);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) nz[q] = zx[q] + ((real)-0.1 + (real)0.2 * u01<real>(w[q]));
-            rng_words(key, QS_SITE_DW_IJ_W, 0, ii, i, w);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) dirw[q] = (real)-1 + (real)2 * u01<real>(w[q]);
-            real mz = norm3<real>(nz), dz = (mz == (real)0) ? mz + (real)1e-6 : mz;
-            real mw = norm3<real>(dirw), dwn = (mw == (real)0) ? mw + (real)1e-6 : mw;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                real down = (real)-1 * (nz[q] / dz);
-                d.vel[q] += a * down * c.control_dt;
-                d.omega[q] += ow * (dirw[q] / dwn) * c.control_dt;
-            }
-            bits |= B_DOWNWASH;
-        }
-    }
-    QS_STAMP(8);
-    const bool any_dw = ((__ballot(active && (bits & B_DOWNWASH)) >> base) & nmask) != 0;
-    // 2) drone-drone responses for the NEW pairs in lexicographic order (collisions/quadrotors.py:24-59);
-    //    order-dependent and rare: one lane per env walks the pair list on LDS-resident vel/omega
-    if (wave_newpair) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { s_vel[q * B + tid] = d.vel[q]; s_om[q * B + tid] = d.omega[q]; }
-        s_mask[tid] = new_pair;
-        __syncthreads();
-        if (active && m_newpair_any && i == 0) {
-            for (int a = 0; a < N; ++a) {
-                uint64_t np = s_mask[base + a];
-                while (np) {
-                    int b = __ffsll((long long)np) - 1;
-                    np &= np - 1;
-                    collide_drones_lds<real>(key, a, b, base, B, s_pos, s_vel, s_om);
-                }
-            }
-        }
-        __syncthreads();
-        if (m_newpair_any) {
-#pragma unroll
-            for (int q = 0; q < 3; ++q) { d.vel[q] = s_vel[q * B + tid]; d.omega[q] = s_om[q * B + tid]; }
-        }
-    }
-    // 3) obstacle response, 4) wall then ceiling (out of line: rare)
-    if (active && (bits & (B_OBST_NEW | B_WALL_NEW | B_CEIL_NEW))) {
-        real ox = 0, oy = 0;
-        if (bits & B_OBST_NEW) { ox = s_obst[(le * 2 + 0) * M_ + obst_idx]; oy = s_obst[(le * 2 + 1) * M_ + obst_idx]; }
-        room_obst_responses<real>(cp, key, i, bits, ox, oy, d.pos, d.vel, d.omega);
-    }
-    const bool update_flag = any_dw || (m_newpair_any != 0) || (m_obst_new != 0) || (m_wall != 0) || (m_ceil != 0);
-
-    // ================= D. scenario.step(): swarm_vs_swarm swaps the formations every U(4,6) s =================
-    if (c.scenario == QS_SCENARIO_SWARM_VS_SWARM) {   // swarm_vs_swarm.py:59-79
-        const bool sw = active && svs_period > 0 && tick % svs_period == 0 && tick > 0;
-        if (__ballot(sw)) {
-            if (sw && i == 0) {
-                real c1[3], c2[3];
-                for (int q = 0; q < 3; ++q) { c1[q] = p.scen_real[(3 + q) * E + e]; c2[q] = p.scen_real[q * E + e]; }
-                for (int q = 0; q < 3; ++q) { p.scen_real[q * E + e] = c1[q]; p.scen_real[(3 + q) * E + e] = c2[q]; }
-                Formation<real> F;
-                update_formation<real>(c, key, 32, N, F);
-                svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, true, s_goal + le * L.goal_rows * 3);
-            }
-            __syncthreads();
-            if (sw) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) goal[q] = s_goal[(le * L.goal_rows + i) * 3 + q];
-            }
-        }
-    }
-
-    QS_STAMP(9);
-    // ================= E. final observations (:592-607) =================
-#pragma unroll
-    for (int q = 0; q < 3; ++q) s_vel[q * B + tid] = d.vel[q];
-    QS_STAMP(14);
-    if (update_flag && active) {   // fresh sensor noise, new goal (:598-599)
-        if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 1, sn);
-        self_obs<real>(c, sn, d, goal, myobs);
-    }
-    QS_STAMP(15);
-    __syncthreads();
-    QS_STAMP(16);
-    if (active) {
-        neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, d.vel, myobs + c.self_dim);
-        if (c.use_obstacles)
-            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors);
-    }
-
-    QS_STAMP(10);
-    // ================= F. done: episode snapshot + auto-reset (:626-722) =================
-    uint64_t out_unique = unique, out_obst_new = m_obst_new, out_room = m_room, out_curr_pair = curr_pair, out_new_pair = new_pair;
-    int out_tick = tick, out_obst_idx = obst_idx;
-    const bool do_reset = active && done;
-    if (__ballot(do_reset)) {
-        if (do_reset) {
-            p.ep_stats[QS_EPS_DIST_1S * T + g] = eps_dist[0]; p.ep_stats[QS_EPS_DIST_3S * T + g] = eps_dist[1]; p.ep_stats[QS_EPS_DIST_5S * T + g] = eps_dist[2];
-            p.ep_stats[QS_EPS_REACHED_GOAL * T + g] = (d.flags & F_REACHED) ? (real)1 : (real)0;
-            p.ep_stats[QS_EPS_COL_AGENT_OK * T + g] = (d.flags & F_COL_AGENT_OK) ? (real)1 : (real)0;
-            p.ep_stats[QS_EPS_COL_OBST_OK * T + g] = (d.flags & F_COL_OBST_OK) ? (real)1 : (real)0;
-            if (i == 0) {
-#pragma unroll
-                for (int q = 0; q < QS_CNT_COUNT; ++q) { p.ep_counters[q * E + e] = cnt[q]; cnt[q] = 0; }
-            }
-        }
-        real stale_vel[3] = {d.vel[0], d.vel[1], d.vel[2]};
-        __syncthreads();
-        reset_body<real>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);
-        if (do_reset) {
-            out_unique = 0; out_obst_new = 0; out_room = 0; out_curr_pair = 0; out_new_pair = 0; out_tick = 0; out_obst_idx = -1;
-            ring[0] = ring[1] = ring[2] = ring[3] = 0;
-        }
-    }
-
-#endif
-    QS_STAMP(11);
-    // ================= G. stores (nothing waits on them: they are the last instructions of the wave) =================
-    __syncthreads();
-    {   // obs copy-out: the workgroup's rows form one contiguous [rows*obs_dim] block in LDS and in HBM
-        const int D = c.obs_dim, first_env = blockIdx.x * epb;
-        int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
-        const int total = nenv * N * D;
-        real *dst = p.obs + (size_t)first_env * N * D;
-        if ((total & 3) == 0 && ((((size_t)first_env * N * D) * sizeof(real)) & 15) == 0 && sizeof(real) == 4) {
-            const float4 *src4 = (const float4 *)s_obs;
-            float4 *dst4 = (float4 *)dst;
-#pragma unroll 4
-            for (int idx = tid; idx < total / 4; idx += B) dst4[idx] = src4[idx];
-        } else {
-            for (int idx = tid; idx < total; idx += B) dst[idx] = s_obs[idx];
-        }
-    }
-    QS_STAMP(12);
-    if (active) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = d.vel[q]; p.omega[q * T + g] = d.omega[q]; p.goal[q * T + g] = goal[q]; p.dist_sums[q * T + g] = sums[q]; }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) p.rot[q * T + g] = d.rot[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { p.rot_damp[q * T + g] = d.rot_damp[q]; p.cmds_damp[q * T + g] = d.cmds_damp[q]; p.ou[q * T + g] = d.ou[q]; p.dist_ring[q * T + g] = ring[q]; }
-        p.flags[g] = d.flags;
-        p.pair_mask[g] = out_curr_pair;
-        p.new_pair_mask[g] = out_new_pair;
-        p.obst_hit_idx[g] = out_obst_idx;
-        p.reward[g] = rew;
-        p.done[g] = done ? 1 : 0;
-        if (c.write_rew_info) {
-#pragma unroll
-            for (int q = 0; q < QS_RI_COUNT; ++q) p.rew_info[q * T + g] = ri[q];
-        }
-        if (nan_rew) atomicOr(p.error_flag, 1u);
-        if (i == 0) {
-#pragma unroll
-            for (int q = 0; q < QS_CNT_COUNT; ++q) p.counters[q * E + e] = cnt[q];
-            p.unique_col[e] = out_unique; p.obst_new[e] = out_obst_new; p.room_new[e] = out_room;
-            p.tick[e] = out_tick;
-            p.step_ctr[e] = step_no;
-        }
-    }
-    QS_STAMP(13);
-}
+#define QS_MULTI 0
+#include "qs_step_kernel.inc"
+#undef QS_MULTI
+#define QS_MULTI 1
+#include "qs_step_kernel.inc"
+#undef QS_MULTI
 
 // ------------------------------------------------------------------------------------------------
 // reset kernel (qs_reset): resets the envs flagged in reset_mask
@@ -1157,6 +748,9 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         hipError_t e1 = (h->real_size == 8)
             ? hipFuncSetAttribute((const void *)qs_step_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total)
             : hipFuncSetAttribute((const void *)qs_step_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total);
+        if (e1 == hipSuccess) e1 = (h->real_size == 8)
+            ? hipFuncSetAttribute((const void *)qs_rollout_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total)
+            : hipFuncSetAttribute((const void *)qs_rollout_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total);
         hipError_t e2 = (h->real_size == 8)
             ? hipFuncSetAttribute((const void *)qs_reset_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total)
             : hipFuncSetAttribute((const void *)qs_reset_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total);
@@ -1205,7 +799,7 @@ int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream) {
     return QS_OK;
 }
 
-static int launch_step(qs_handle *h, const void *actions, hipStream_t s) {
+static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int ksteps = 1) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
         if (h->events_used == h->events.size()) {
@@ -1219,11 +813,11 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s) {
     }
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
-        hipLaunchKernelGGL(qs_step_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p,
-                           (const double *)actions, h->lds, h->epb);
+        if (ksteps == 1) hipLaunchKernelGGL(qs_step_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, (const double *)actions, h->lds, h->epb);
+        else hipLaunchKernelGGL(qs_rollout_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, (const double *)actions, h->lds, h->epb, ksteps);
     } else {
-        hipLaunchKernelGGL(qs_step_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf,
-                           (const float *)actions, h->lds, h->epb);
+        if (ksteps == 1) hipLaunchKernelGGL(qs_step_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, (const float *)actions, h->lds, h->epb);
+        else hipLaunchKernelGGL(qs_rollout_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, (const float *)actions, h->lds, h->epb, ksteps);
     }
     HIP_TRY(hipGetLastError());
     if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
@@ -1240,32 +834,19 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
     if (!h || !actions_dev || k < 0) return fail(QS_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * h->real_size;
-    if (h->profiling || k < 4) {   // per-launch HIP events need eager launches
+    if (h->profiling) {   // per-step HIP events: one launch per control step
         for (int32_t t = 0; t < k; ++t) {
-            int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream);
+            int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream, 1);
             if (rc != QS_OK) return rc;
         }
         return QS_OK;
     }
-    // launch-bound inner loop: capture the K launches once into a hipGraph, replay it afterwards.  The auto-reset
-    // lives in the step kernel, so every node is the same kernel; only the action pointer differs.
-    if (!h->graph_exec || h->graph_actions != actions_dev || h->graph_k != k) {
-        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-        if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-        hipGraph_t graph = nullptr;
-        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-        int rc = QS_OK;
-        for (int32_t t = 0; t < k && rc == QS_OK; ++t) rc = launch_step(h, (const char *)actions_dev + stride * t, h->cap_stream);
-        hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
-        if (rc != QS_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        if (ce != hipSuccess) return fail(QS_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
-        hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) { h->graph_exec = nullptr; return fail(QS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie)); }
-        h->graph_actions = actions_dev;
-        h->graph_k = k;
+    // open-loop rollout: the step kernel keeps the state in registers across up to QS_STEPS_PER_LAUNCH control steps
+    const int32_t per = 64;
+    for (int32_t t = 0; t < k; t += per) {
+        int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream, (k - t) < per ? (k - t) : per);
+        if (rc != QS_OK) return rc;
     }
-    HIP_TRY(hipGraphLaunch(h->graph_exec, (hipStream_t)stream));
     return QS_OK;
 }
 

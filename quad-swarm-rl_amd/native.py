@@ -14,7 +14,7 @@ from . import config as qcfg
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("QS_LIB", os.path.join(CSRC, "libquadswarm_hip.so"))   # QS_LIB: A/B builds (tools only)
-SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_device.h"),
+SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_device.h"),
            os.path.join(os.path.dirname(HERE), "include", "quadswarm.h")]
 
 QS_OK = 0

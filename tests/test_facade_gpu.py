@@ -85,7 +85,7 @@ def test_nan_reward_raises_value_error():
     st.close()
 
 
-def test_step_many_graph_equals_eager():
+def test_step_many_rollout_equals_stepwise():
     from quad_swarm_rl_amd import config as qcfg, native
     import torch
     kw = dict(num_envs=32, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, use_downwash=True,
@@ -104,5 +104,7 @@ def test_step_many_graph_equals_eager():
         st.sync()
         outs.append((st.to_host("obs").copy(), st.to_host("reward").copy(), st.to_host("tick").copy()))
         st.close()
-    for a, b in zip(*outs):
-        np.testing.assert_array_equal(a, b)
+    # the two kernels are separate instantiations: identical algorithm, fp32 results equal up to instruction selection
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=5e-6)
+    np.testing.assert_array_equal(outs[0][2], outs[1][2])
