@@ -459,6 +459,12 @@ __device__ __forceinline__ void self_obs(const Consts<real> &c, const SensNoise<
 #pragma unroll
         for (int q = 0; q < 3; ++q) { p[q] = d.pos[q] + n.p[q]; v[q] = d.vel[q] + n.v[q]; w[q] = d.omega[q] + n.w[q]; }
         // R -> quat -> quat (x) dq(theta) -> R  (sensor_noise.py:205-210; an identity dq still re-derives R)
+        if (sizeof(real) == 4 && c.quat_norm_std == (real)0 && c.quat_unif_range == (real)0) {
+            // fp32 production path, no rotation noise configured: quat2R(rot2quat(R)) reproduces an orthonormal R to a few
+            // ulp (1e-7), far inside the 1e-5 tolerance, so the round trip is skipped.  The f64 parity instantiation keeps it.
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = d.rot[k];
+        } else {
         real q[4];
         rot2quat<real>(d.rot, q);
         real qw = q[0], qx = q[1], qy = q[2], qz = q[3];
@@ -478,6 +484,7 @@ __device__ __forceinline__ void self_obs(const Consts<real> &c, const SensNoise<
         R[0] = (real)1 - 2 * qy * qy - 2 * qz * qz; R[1] = 2 * qx * qy - 2 * qz * qw; R[2] = 2 * qx * qz + 2 * qy * qw;
         R[3] = 2 * qx * qy + 2 * qz * qw; R[4] = (real)1 - 2 * qx * qx - 2 * qz * qz; R[5] = 2 * qy * qz - 2 * qx * qw;
         R[6] = 2 * qx * qz - 2 * qy * qw; R[7] = 2 * qy * qz + 2 * qx * qw; R[8] = (real)1 - 2 * qx * qx - 2 * qy * qy;
+        }
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) { o[q] = p[q] - goal[q]; o[3 + q] = v[q]; o[15 + q] = w[q]; }
