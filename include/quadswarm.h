@@ -35,7 +35,11 @@ extern "C" {
 /* obs_repr (quad_utils.py:30-34 QUADS_OBS_REPR) */
 enum { QS_OBS_XYZ_VXYZ_R_OMEGA = 0, QS_OBS_XYZ_VXYZ_R_OMEGA_FLOOR = 1, QS_OBS_XYZ_VXYZ_R_OMEGA_WALL = 2 };
 /* scenario (scenarios/mix.py:31 create_scenario) */
-enum { QS_SCENARIO_STATIC_SAME_GOAL = 0, QS_SCENARIO_O_STATIC_SAME_GOAL = 1, QS_SCENARIO_SWARM_VS_SWARM = 2 };
+enum { QS_SCENARIO_STATIC_SAME_GOAL = 0, QS_SCENARIO_O_STATIC_SAME_GOAL = 1, QS_SCENARIO_SWARM_VS_SWARM = 2,
+       QS_SCENARIO_STATIC_DIFF_GOAL = 3, QS_SCENARIO_DYNAMIC_SAME_GOAL = 4, QS_SCENARIO_DYNAMIC_DIFF_GOAL = 5,
+       QS_SCENARIO_DYNAMIC_FORMATIONS = 6, QS_SCENARIO_SWAP_GOALS = 7, QS_SCENARIO_EP_LISSAJOUS3D = 8,
+       QS_SCENARIO_EP_RAND_BEZIER = 9, QS_SCENARIO_O_RANDOM = 10, QS_SCENARIO_O_DYNAMIC_SAME_GOAL = 11,
+       QS_SCENARIO_O_SWAP_GOALS = 12, QS_SCENARIO_MIX = 13, QS_SCENARIO_COUNT = 14 };
 /* floor_mode: which of the two reference semantics */
 enum { QS_FLOOR_NUMBA = 0, QS_FLOOR_NUMPY = 1 };
 /* precision of the device state / arithmetic */

@@ -25,7 +25,7 @@ class QsoInfo(C.Structure):
         ("ep_stats", (C.c_double * QS_EPS_COUNT) * QS_MAX_AGENTS),
         ("obst_pos", (C.c_double * 2) * QS_MAX_OBSTACLES),
         ("acc", (C.c_double * 3) * QS_MAX_AGENTS),
-        ("nan_reward", C.c_int32), ("tape_underrun", C.c_int32),
+        ("nan_reward", C.c_int32), ("tape_underrun", C.c_int32), ("scenario", C.c_int32), ("ep_scenario", C.c_int32),
     ]
 
 

@@ -64,6 +64,8 @@ struct qso_env {
     double form_lo, form_hi, form_size, layer_dist;
     double center1[3], center2[3];
     int32_t control_step_for_sec;
+    int32_t scen, scen_constructed, duration_step, increase, bez_valid;
+    double speed, bez[9], end_point[3], approach_metric;
     /* rng */
     const double *tape;
     int64_t tape_n, tape_i;
@@ -782,18 +784,30 @@ static void shuffle_rows(qso_env *e, double rows[][3], int n, int slot_base) {
     for (int k = 0; k < n; ++k) memcpy(rows[k], tmp[k], sizeof tmp[k]);
 }
 
+/* per-scenario formation tables: QUADS_PARAMS_DICT scenarios/utils.py:33-51 */
+static void scen_params(int scen, int *nform, double *lo, double *hi) {
+    *nform = 1; *lo = 0.0; *hi = 0.0;
+    switch (scen) {
+    case QS_SCENARIO_STATIC_DIFF_GOAL: case QS_SCENARIO_DYNAMIC_DIFF_GOAL: case QS_SCENARIO_SWARM_VS_SWARM:
+        *nform = 8; *lo = 5 * 0.05; *hi = 10 * 0.05; break;
+    case QS_SCENARIO_SWAP_GOALS: *nform = 8; *lo = 8 * 0.05; *hi = 16 * 0.05; break;
+    case QS_SCENARIO_DYNAMIC_FORMATIONS: *nform = 8; *lo = 0.0; *hi = 20 * 0.05; break;
+    case QS_SCENARIO_O_SWAP_GOALS: *nform = 7; *lo = 8 * 0.05; *hi = 16 * 0.05; break;   /* QUADS_FORMATION_LIST_OBSTACLES has 7 entries */
+    default: break;
+    }
+}
+
 /* update_formation_and_relate_param scenarios/base.py:123-135 (+ utils.py:55-70, :131-153) */
 static void update_formation(qso_env *e, int slot) {
     const qs_config *c = &e->c;
-    int nform = (c->scenario == QS_SCENARIO_SWARM_VS_SWARM) ? 8 : 1;
-    double lo = 0.0, hi = 0.0;
-    if (c->scenario == QS_SCENARIO_SWARM_VS_SWARM) { lo = 5 * 0.05; hi = 10 * 0.05; }
+    int nform; double lo, hi;
+    scen_params(e->scen, &nform, &lo, &hi);
     int fi;
     if (e->tape) fi = (int)tape_pop(e);
     else { fi = (int)(rng_uniform1(e, QS_SITE_SCEN, slot + 0, 0, 0, 0.0, 1.0) * nform); if (fi >= nform) fi = nform - 1; }
     e->formation = fi;
     e->per_layer = f_is_circle(fi) ? 8 : (f_is_grid(fi) ? 50 : 8);
-    int n = (c->scenario == QS_SCENARIO_SWARM_VS_SWARM) ? c->num_agents / 2 : c->num_agents;
+    int n = (e->scen == QS_SCENARIO_SWARM_VS_SWARM) ? c->num_agents / 2 : c->num_agents;
     if (f_is_circle(fi)) { /* get_circle_radius utils.py:110-113 */
         double theta = 2 * PI / e->per_layer;
         e->form_lo = (0.5 * lo) / sin(theta / 2); e->form_hi = (0.5 * hi) / sin(theta / 2);
@@ -819,64 +833,175 @@ static void svs_create_formations(qso_env *e, int do_shuffle) {
     e->num_goals = r1 + r2;
 }
 
-/* scenario.reset(): static_same_goal (base.py:140-151), o_static_same_goal
- * (obstacles/o_static_same_goal.py:27-48 + o_base.py:69-81,:124-153), swarm_vs_swarm (swarm_vs_swarm.py:80-94) */
+/* QuadrotorScenario.standard_reset scenarios/base.py:153-167 (== .reset :140-151 with the default centre) */
+static void standard_reset(qso_env *e, const double center[3]) {
+    update_formation(e, 0);
+    memcpy(e->center1, center, sizeof e->center1);
+    e->num_goals = generate_goals(e, e->c.num_agents, e->center1, e->layer_dist, e->goals);
+    shuffle_rows(e, e->goals, e->num_goals, 0);
+}
+
+/* free cells in np.where(obst_map == 0) order (row-major) */
+static int free_space(const qso_env *e, int fs[][2]) {
+    int L = e->c.obst_area[0], W = e->c.obst_area[1], n = 0;
+    for (int r = 0; r < L; ++r) for (int q = 0; q < W; ++q) if (!e->obst_map[r][q]) { fs[n][0] = r; fs[n][1] = q; ++n; }
+    return n;
+}
+static void cell_pos(const qso_env *e, const int cell[2], double out[2]) { /* o_base.py:69-73: index = x + width*y */
+    int index = cell[0] + e->c.obst_area[0] * cell[1];
+    out[0] = e->cell_centers[2 * index]; out[1] = e->cell_centers[2 * index + 1];
+}
+/* Scenario_o_base.generate_pos_obst_map_2 o_base.py:69-81: N distinct free cells + z ~ U(1,3) */
+static void pos_obst_map_2(qso_env *e, double out[][3], int slot_choice, int slot_z) {
+    int N = e->c.num_agents;
+    int (*fs)[2] = (int (*)[2])malloc(sizeof(int[2]) * 64 * 64);
+    int nfree = free_space(e, fs), ids[MAXN];
+    if (e->tape) { for (int k = 0; k < N; ++k) ids[k] = (int)tape_pop(e); }
+    else {
+        int *pool = (int *)malloc(sizeof(int) * 64 * 64);
+        for (int k = 0; k < nfree; ++k) pool[k] = k;
+        for (int k = 0; k < N; ++k) {
+            int j = k + (int)(rng_uniform1(e, QS_SITE_SCEN, slot_choice + k, 0, 0, 0.0, 1.0) * (nfree - k));
+            if (j >= nfree) j = nfree - 1;
+            int t = pool[k]; pool[k] = pool[j]; pool[j] = t; ids[k] = pool[k];
+        }
+        free(pool);
+    }
+    for (int k = 0; k < N; ++k) {
+        cell_pos(e, fs[ids[k]], out[k]);
+        out[k][2] = rng_uniform1(e, QS_SITE_SCEN, slot_z + k, 0, 0, 1.0, 3.0);
+    }
+    free(fs);
+}
+/* Scenario_o_base.generate_pos_obst_map o_base.py:48-67 (check_surroundings=False): one free cell + z ~ U(0.75,3) */
+static void pos_obst_map_1(qso_env *e, double out[3], int slot) {
+    int (*fs)[2] = (int (*)[2])malloc(sizeof(int[2]) * 64 * 64);
+    int nfree = free_space(e, fs), idx;
+    if (e->tape) idx = (int)tape_pop(e);
+    else { idx = (int)(rng_uniform1(e, QS_SITE_SCEN, slot, 0, 0, 0.0, 1.0) * nfree); if (idx >= nfree) idx = nfree - 1; }
+    cell_pos(e, fs[idx], out);
+    out[2] = rng_uniform1(e, QS_SITE_SCEN, slot + 1, 0, 0, 0.75, 3.0);
+    free(fs);
+}
+/* Scenario_o_base.max_square_area_center o_base.py:124-153 */
+static void max_square_center(qso_env *e, double out[3], int slot_z) {
+    int L = e->c.obst_area[0], W = e->c.obst_area[1];
+    static int dp[64][64];
+    memset(dp, 0, sizeof dp);
+    for (int q = 0; q < W; ++q) dp[0][q] = e->obst_map[0][q];
+    for (int r = 0; r < L; ++r) dp[r][0] = e->obst_map[r][0];
+    int max_size = 0, cx = 0, cy = 0;
+    for (int r = 1; r < L; ++r)
+        for (int q = 1; q < W; ++q)
+            if (e->obst_map[r][q] == 0) {
+                int m = dp[r - 1][q] < dp[r][q - 1] ? dp[r - 1][q] : dp[r][q - 1];
+                if (dp[r - 1][q - 1] < m) m = dp[r - 1][q - 1];
+                dp[r][q] = m + 1;
+                if (dp[r][q] > max_size) { max_size = dp[r][q]; cx = r - (max_size - 1) / 2; cy = q - (max_size - 1) / 2; }
+            }
+    int index = cx + W * cy;
+    out[0] = e->cell_centers[2 * index]; out[1] = e->cell_centers[2 * index + 1];
+    out[2] = rng_uniform1(e, QS_SITE_SCEN, slot_z, 0, 0, 1.5, 3.0);
+}
+
+static int mix_pick(qso_env *e) { /* Scenario_mix.reset scenarios/mix.py:84-90 + utils.py:10-25 */
+    static const int LIST_MULTI[9] = {QS_SCENARIO_STATIC_SAME_GOAL, QS_SCENARIO_STATIC_DIFF_GOAL, QS_SCENARIO_EP_LISSAJOUS3D,
+                                      QS_SCENARIO_EP_RAND_BEZIER, QS_SCENARIO_DYNAMIC_SAME_GOAL, QS_SCENARIO_DYNAMIC_DIFF_GOAL,
+                                      QS_SCENARIO_DYNAMIC_FORMATIONS, QS_SCENARIO_SWAP_GOALS, QS_SCENARIO_SWARM_VS_SWARM};
+    static const int LIST_SINGLE[5] = {QS_SCENARIO_STATIC_SAME_GOAL, QS_SCENARIO_STATIC_DIFF_GOAL, QS_SCENARIO_EP_LISSAJOUS3D,
+                                       QS_SCENARIO_EP_RAND_BEZIER, QS_SCENARIO_DYNAMIC_SAME_GOAL};
+    static const int LIST_OBST[2] = {QS_SCENARIO_O_RANDOM, QS_SCENARIO_O_STATIC_SAME_GOAL};
+    const qs_config *c = &e->c;
+    const int *list; int n;
+    if (c->num_agents == 1) { if (c->use_obstacles) { list = LIST_OBST; n = 1; } else { list = LIST_SINGLE; n = 5; } }
+    else if (!c->use_obstacles) { list = LIST_MULTI; n = 9; }
+    else { list = LIST_OBST; n = 2; }
+    int k;
+    if (e->tape) k = (int)tape_pop(e);
+    else { k = (int)(rng_uniform1(e, QS_SITE_SCEN, 288, 0, 0, 0.0, 1.0) * n); if (k >= n) k = n - 1; }
+    return list[k];
+}
+
+/* scenario.reset() of every supported scenario (file:line at each case) */
 static void scenario_reset(qso_env *e) {
     const qs_config *c = &e->c;
     int N = c->num_agents;
+    double control_freq = 1.0 / (c->dt * c->sim_steps);
     e->have_spawn_points = 0;
-    if (c->scenario == QS_SCENARIO_STATIC_SAME_GOAL) {
-        update_formation(e, 0);
-        double center[3] = {0.0, 0.0, 2.0};
-        e->num_goals = generate_goals(e, N, center, e->layer_dist, e->goals);
-        if (e->tape) tape_skip(e, N); /* np.random.shuffle(goals): all rows identical */
-    } else if (c->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL) {
-        int L = c->obst_area[0], W = c->obst_area[1];
-        (void)rng_uniform1(e, QS_SITE_SCEN, 8, 0, 0, 4.0, 6.0); /* duration_time (unused by step) */
-        int fs[64 * 64][2], nfree = 0; /* np.where(obst_map == 0): row-major order */
-        for (int r = 0; r < L; ++r) for (int q = 0; q < W; ++q) if (!e->obst_map[r][q]) { fs[nfree][0] = r; fs[nfree][1] = q; ++nfree; }
-        /* generate_pos_obst_map_2: choice(range(nfree), N, replace=False) */
-        int ids[MAXN];
-        if (e->tape) { for (int k = 0; k < N; ++k) ids[k] = (int)tape_pop(e); }
-        else {
-            int pool[64 * 64];
-            for (int k = 0; k < nfree; ++k) pool[k] = k;
-            for (int k = 0; k < N; ++k) {
-                int j = k + (int)(rng_uniform1(e, QS_SITE_SCEN, 16 + k, 0, 0, 0.0, 1.0) * (nfree - k));
-                if (j >= nfree) j = nfree - 1;
-                int t = pool[k]; pool[k] = pool[j]; pool[j] = t; ids[k] = pool[k];
-            }
-        }
-        for (int k = 0; k < N; ++k) {
-            int x = fs[ids[k]][0], y = fs[ids[k]][1], index = x + L * y; /* width = obstacle_map.shape[0] */
-            e->spawn_points[k][0] = e->cell_centers[2 * index]; e->spawn_points[k][1] = e->cell_centers[2 * index + 1];
-            e->spawn_points[k][2] = rng_uniform1(e, QS_SITE_SCEN, 96 + k, 0, 0, 1.0, 3.0);
-        }
-        e->have_spawn_points = 1;
-        /* max_square_area_center o_base.py:124-153 */
-        int dp[64][64]; memset(dp, 0, sizeof dp);
-        for (int q = 0; q < W; ++q) dp[0][q] = e->obst_map[0][q];
-        for (int r = 0; r < L; ++r) dp[r][0] = e->obst_map[r][0];
-        int max_size = 0, cx = 0, cy = 0;
-        for (int r = 1; r < L; ++r)
-            for (int q = 1; q < W; ++q)
-                if (e->obst_map[r][q] == 0) {
-                    int m = dp[r - 1][q] < dp[r][q - 1] ? dp[r - 1][q] : dp[r][q - 1];
-                    if (dp[r - 1][q - 1] < m) m = dp[r - 1][q - 1];
-                    dp[r][q] = m + 1;
-                    if (dp[r][q] > max_size) { max_size = dp[r][q]; cx = r - (max_size - 1) / 2; cy = q - (max_size - 1) / 2; }
-                }
-        int index = cx + W * cy;
-        double end[3] = {e->cell_centers[2 * index], e->cell_centers[2 * index + 1], 0};
-        end[2] = rng_uniform1(e, QS_SITE_SCEN, 9, 0, 0, 1.5, 3.0);
-        update_formation(e, 0);
-        for (int k = 0; k < N; ++k) memcpy(e->goals[k], end, sizeof end);
-        e->num_goals = N;
-    } else { /* swarm_vs_swarm */
+    e->bez_valid = 0;
+    int constructed = 0;
+    if (c->scenario == QS_SCENARIO_MIX) { e->scen = mix_pick(e); constructed = 1; }   /* a new scenario object per episode */
+    else { e->scen = c->scenario; constructed = !e->scen_constructed; e->scen_constructed = 1; }
+    /* constructors: control_step_for_sec defaults (5 s; o_swap_goals 6 s) and dynamic_formations' speed draw (:13) */
+    if (constructed) {
+        e->control_step_for_sec = (int)((e->scen == QS_SCENARIO_O_SWAP_GOALS ? 6.0 : 5.0) * control_freq);
+        if (e->scen == QS_SCENARIO_DYNAMIC_FORMATIONS) e->speed = rng_uniform1(e, QS_SITE_SCEN, 289, 0, 0, 1.0, 3.0);
+    }
+    const double c002[3] = {0.0, 0.0, 2.0};
+    switch (e->scen) {
+    case QS_SCENARIO_STATIC_SAME_GOAL:       /* scenarios/base.py:140-151 */
+    case QS_SCENARIO_STATIC_DIFF_GOAL:       /* scenarios/static_diff_goal.py (base reset) */
+    case QS_SCENARIO_EP_RAND_BEZIER:         /* scenarios/ep_rand_bezier.py (base reset) */
+        standard_reset(e, c002);
+        break;
+    case QS_SCENARIO_DYNAMIC_SAME_GOAL:      /* scenarios/dynamic_same_goal.py:31-37 */
+    case QS_SCENARIO_DYNAMIC_DIFF_GOAL:      /* scenarios/dynamic_diff_goal.py:36-42 */
+    case QS_SCENARIO_SWAP_GOALS: {           /* scenarios/swap_goals.py:26-32 */
         double dur = rng_uniform1(e, QS_SITE_SCEN, 8, 0, 0, 4.0, 6.0);
-        e->control_step_for_sec = (int)(dur * (1.0 / (c->dt * c->sim_steps)));
+        e->control_step_for_sec = (int)(dur * control_freq);
+        standard_reset(e, c002);
+        break;
+    }
+    case QS_SCENARIO_DYNAMIC_FORMATIONS: {   /* scenarios/dynamic_formations.py:37-42 */
+        e->increase = rng_uniform1(e, QS_SITE_SCEN, 290, 0, 0, 0.0, 1.0) < 0.5;
+        e->speed = rng_uniform1(e, QS_SITE_SCEN, 291, 0, 0, 1.0, 3.0);
+        standard_reset(e, c002);
+        break;
+    }
+    case QS_SCENARIO_EP_LISSAJOUS3D: {       /* scenarios/ep_lissajous3D.py:31-38 */
         update_formation(e, 0);
-        /* formation_centers swarm_vs_swarm.py:17-50 */
+        const double ctr[3] = {-2.0, 0.0, 2.0};
+        memcpy(e->center1, ctr, sizeof ctr);
+        e->num_goals = generate_goals(e, N, e->center1, 0.0, e->goals);
+        break;
+    }
+    case QS_SCENARIO_O_STATIC_SAME_GOAL:     /* scenarios/obstacles/o_static_same_goal.py:27-48 */
+    case QS_SCENARIO_O_DYNAMIC_SAME_GOAL: {  /* scenarios/obstacles/o_dynamic_same_goal.py:30-51 */
+        double dur = rng_uniform1(e, QS_SITE_SCEN, 8, 0, 0, 4.0, 6.0);
+        e->control_step_for_sec = (int)(dur * control_freq);
+        pos_obst_map_2(e, e->spawn_points, 16, 96);
+        e->have_spawn_points = 1;
+        max_square_center(e, e->end_point, 9);
+        update_formation(e, 0);
+        for (int k = 0; k < N; ++k) memcpy(e->goals[k], e->end_point, sizeof e->end_point);
+        e->num_goals = N;
+        break;
+    }
+    case QS_SCENARIO_O_RANDOM: {             /* scenarios/obstacles/o_random.py:27-52 */
+        if (e->tape) tape_skip(e, 4 * N);    /* N x (generate_pos_obst_map() twice): results are overwritten below */
+        pos_obst_map_2(e, e->spawn_points, 16, 96);
+        e->have_spawn_points = 1;
+        pos_obst_map_2(e, e->goals, 160, 224);
+        e->num_goals = N;
+        e->duration_step = (int)(rng_uniform1(e, QS_SITE_SCEN, 8, 0, 0, 2.0, 4.0) * control_freq);
+        update_formation(e, 0);
+        break;
+    }
+    case QS_SCENARIO_O_SWAP_GOALS: {         /* scenarios/obstacles/o_swap_goals.py:27-52 */
+        double dur = rng_uniform1(e, QS_SITE_SCEN, 8, 0, 0, 4.0, 6.0);
+        e->control_step_for_sec = (int)(dur * control_freq);
+        update_formation(e, 0);
+        pos_obst_map_2(e, e->spawn_points, 16, 96);
+        e->have_spawn_points = 1;
+        max_square_center(e, e->center1, 9);
+        e->num_goals = generate_goals(e, N, e->center1, e->layer_dist, e->goals);
+        shuffle_rows(e, e->goals, e->num_goals, 0);
+        break;
+    }
+    default: {                               /* swarm_vs_swarm: scenarios/swarm_vs_swarm.py:80-94, :17-50 */
+        double dur = rng_uniform1(e, QS_SITE_SCEN, 8, 0, 0, 4.0, 6.0);
+        e->control_step_for_sec = (int)(dur * control_freq);
+        update_formation(e, 0);
         double box = c->spawn_box, low = e->form_lo, xy[2];
         rng_uniform(e, QS_SITE_SCEN, 9, 0, 0, 2, -box, box, xy);
         /* get_z_value scenarios/utils.py:170-181 */
@@ -897,19 +1022,135 @@ static void scenario_reset(qso_env *e) {
             if (fabs(df) < low) { double sg = (df > 0) - (df < 0); e->center2[ax] = sg * low + e->center1[ax]; }
         }
         svs_create_formations(e, 0);
+        break;
     }
+    }
+    /* approch_goal_metric: 0.5 (base.py:31, o_random.py:10), 1.0 for the other obstacle scenarios (o_base.py:16) */
+    e->approach_metric = (e->scen == QS_SCENARIO_O_STATIC_SAME_GOAL || e->scen == QS_SCENARIO_O_DYNAMIC_SAME_GOAL ||
+                          e->scen == QS_SCENARIO_O_SWAP_GOALS) ? 1.0 : 0.5;
 }
 
-/* scenario.step(): only swarm_vs_swarm moves goals (swarm_vs_swarm.py:59-79) */
+static void set_all_goals(qso_env *e) { for (int i = 0; i < e->c.num_agents; ++i) memcpy(e->d[i].goal, e->goals[i], sizeof e->d[i].goal); }
+
+/* get_z_value scenarios/utils.py:170-181 */
+static double get_z_value(qso_env *e, int slot) {
+    double box = e->c.spawn_box;
+    double z = rng_uniform1(e, QS_SITE_SCEN, slot, 0, 0, -0.5 * box, 0.5 * box) + 2.0, zlb = 0.25;
+    int f = e->formation;
+    if (f == 3 || f == 1 || f == 2) zlb = e->form_size + 0.25;
+    else if (f == 5 || f == 6) { int rn = e->c.num_agents < e->per_layer ? e->c.num_agents : e->per_layer, d1, d2; grid_dim(rn, &d1, &d2); zlb = d1 * e->form_size + 0.25; }
+    return fmax(zlb, z);
+}
+
+/* scenario.step() (called once per control step after the collision responses, quadrotor_multi.py:590) */
 static void scenario_step(qso_env *e) {
     const qs_config *c = &e->c;
-    if (c->scenario != QS_SCENARIO_SWARM_VS_SWARM) return;
-    int tick = e->tick;
-    if (e->control_step_for_sec > 0 && tick % e->control_step_for_sec == 0 && tick > 0) {
-        double t[3]; memcpy(t, e->center1, sizeof t); memcpy(e->center1, e->center2, sizeof t); memcpy(e->center2, t, sizeof t);
-        update_formation(e, 32);
-        svs_create_formations(e, 1);
-        for (int i = 0; i < c->num_agents; ++i) memcpy(e->d[i].goal, e->goals[i], sizeof e->d[i].goal);
+    int tick = e->tick, N = c->num_agents;
+    double control_freq = 1.0 / (c->dt * c->sim_steps);
+    int at_period = e->control_step_for_sec > 0 && tick % e->control_step_for_sec == 0 && tick > 0;
+    switch (e->scen) {
+    case QS_SCENARIO_SWARM_VS_SWARM:         /* scenarios/swarm_vs_swarm.py:59-79 */
+        if (at_period) {
+            double t[3]; memcpy(t, e->center1, sizeof t); memcpy(e->center1, e->center2, sizeof t); memcpy(e->center2, t, sizeof t);
+            update_formation(e, 32);
+            svs_create_formations(e, 1);
+            set_all_goals(e);
+        }
+        break;
+    case QS_SCENARIO_DYNAMIC_SAME_GOAL:      /* scenarios/dynamic_same_goal.py:16-29 */
+        if (at_period) {
+            double box = c->spawn_box, xy[2];
+            rng_uniform(e, QS_SITE_SCEN, 40, 0, 0, 2, -box, box, xy);
+            double z = fmax(0.25, rng_uniform1(e, QS_SITE_SCEN, 41, 0, 0, -0.5 * box, 0.5 * box) + 2.0);
+            e->center1[0] = xy[0]; e->center1[1] = xy[1]; e->center1[2] = z;
+            e->num_goals = generate_goals(e, N, e->center1, 0.0, e->goals);
+            set_all_goals(e);
+        }
+        break;
+    case QS_SCENARIO_DYNAMIC_DIFF_GOAL:      /* scenarios/dynamic_diff_goal.py:8-34 */
+        if (at_period) {
+            double box = c->spawn_box, xy[2];
+            rng_uniform(e, QS_SITE_SCEN, 40, 0, 0, 2, -box, box, xy);
+            double z = get_z_value(e, 41);
+            e->center1[0] = xy[0]; e->center1[1] = xy[1]; e->center1[2] = z;
+            update_formation(e, 32);
+            e->num_goals = generate_goals(e, N, e->center1, e->layer_dist, e->goals);
+            shuffle_rows(e, e->goals, e->num_goals, 0);
+            set_all_goals(e);
+        }
+        break;
+    case QS_SCENARIO_DYNAMIC_FORMATIONS:     /* scenarios/dynamic_formations.py:16-35 */
+        if (e->form_size <= -e->form_hi) { e->increase = 1; e->speed = rng_uniform1(e, QS_SITE_SCEN, 292, 0, 0, 1.0, 3.0); }
+        else if (e->form_size >= e->form_hi) { e->increase = 0; e->speed = rng_uniform1(e, QS_SITE_SCEN, 292, 0, 0, 1.0, 3.0); }
+        if (e->increase) e->form_size += 0.001 * e->speed; else e->form_size -= 0.001 * e->speed;
+        e->num_goals = generate_goals(e, N, e->center1, e->layer_dist, e->goals);
+        set_all_goals(e);
+        break;
+    case QS_SCENARIO_SWAP_GOALS:             /* scenarios/swap_goals.py:13-24 */
+    case QS_SCENARIO_O_SWAP_GOALS:           /* scenarios/obstacles/o_swap_goals.py:14-25 */
+        if (at_period) { shuffle_rows(e, e->goals, e->num_goals, 0); set_all_goals(e); }
+        break;
+    case QS_SCENARIO_EP_LISSAJOUS3D: {       /* scenarios/ep_lissajous3D.py:8-26 (phi = psi = 90 rad, a .03, b = c = .01, n = m = 2) */
+        double t = tick / control_freq;
+        double x = 0.03 * sin(t), y = 0.01 * sin(2 * t + 90), z = 0.01 * cos(2 * t + 90);
+        double g0[3] = {x + e->goals[0][0], y + e->goals[0][1], z + e->goals[0][2]};
+        for (int i = 0; i < N; ++i) memcpy(e->goals[i], g0, sizeof g0);
+        e->num_goals = N;
+        set_all_goals(e);
+        break;
+    }
+    case QS_SCENARIO_EP_RAND_BEZIER: {       /* scenarios/ep_rand_bezier.py:8-48 */
+        int control_steps = (int)(5 * control_freq), t = tick % control_steps;
+        double room[3] = {c->room_hi[0] - c->room_lo[0] - e->form_size, c->room_hi[1] - c->room_lo[1] - e->form_size, c->room_hi[2] - c->room_lo[2] - e->form_size};
+        double mx = fmax(room[0], fmax(room[1], room[2])), max_dist = fmin(30.0, mx), min_dist = max_dist / 2;
+        if (tick % control_steps == 0 || tick == 1) {
+            double low[3] = {-room[0] / 2, -room[1] / 2, 0}, high[3] = {room[0] / 2, room[1] / 2, room[2]};
+            double np_[3][2];
+            for (int it = 0; it < 100000; ++it) {
+                double u[6];   /* uniform(low=-high, high=high, size=(2,3)).reshape(3,2): flat order u0..u5 -> [[u0,u1],[u2,u3],[u4,u5]] */
+                if (e->tape) { for (int k = 0; k < 6; ++k) u[k] = tape_pop(e); }
+                else { for (int k = 0; k < 6; ++k) { int ax = k % 3; u[k] = rng_uniform1(e, QS_SITE_SCEN, 300 + 8 * it + k, 0, 0, -high[ax], high[ax]); } }
+                int lo_i = (int)ceil(min_dist), hi_i = (int)max_dist + 1, r;   /* np.random.randint(min_dist, max_dist + 1) */
+                if (e->tape) r = (int)tape_pop(e);
+                else { r = lo_i + (int)(rng_uniform1(e, QS_SITE_SCEN, 300 + 8 * it + 6, 0, 0, 0.0, 1.0) * (hi_i - lo_i)); if (r >= hi_i) r = hi_i - 1; }
+                int ok = 1;
+                for (int col = 0; col < 2; ++col) {
+                    double v[3] = {u[0 + col], u[2 + col], u[4 + col]}, n = norm3(v);
+                    for (int row = 0; row < 3; ++row) {
+                        np_[row][col] = e->goals[0][row] + v[row] * r / n;
+                        if (!(np_[row][col] > low[row] + 0.5) || !(np_[row][col] < high[row] - 0.5)) ok = 0;
+                    }
+                }
+                if (ok) break;
+            }
+            for (int row = 0; row < 3; ++row) { e->bez[row] = e->goals[0][row]; e->bez[3 + row] = np_[row][0]; e->bez[6 + row] = np_[row][1]; }
+            e->bez_valid = 1;
+        }
+        if (tick % control_steps != 0 && tick > 1) {
+            /* bezier.Curve(nodes, degree=2).evaluate_multi(linspace(0,1,control_steps))[:, t]: quadratic Bernstein form */
+            double sv = (double)t / (double)(control_steps - 1), om = 1.0 - sv;
+            double g0[3];
+            for (int row = 0; row < 3; ++row) g0[row] = om * om * e->bez[row] + 2.0 * om * sv * e->bez[3 + row] + sv * sv * e->bez[6 + row];
+            for (int i = 0; i < N; ++i) memcpy(e->goals[i], g0, sizeof g0);
+            e->num_goals = N;
+            set_all_goals(e);
+        }
+        break;
+    }
+    case QS_SCENARIO_O_DYNAMIC_SAME_GOAL:    /* scenarios/obstacles/o_dynamic_same_goal.py:17-28 */
+        if ((e->control_step_for_sec > 0 && tick % e->control_step_for_sec == 0) || tick == 1) {
+            double ng[3];
+            for (int it = 0; it < 100000; ++it) {
+                pos_obst_map_1(e, ng, 5000 + 2 * it);
+                double df[3] = {e->end_point[0] - ng[0], e->end_point[1] - ng[1], e->end_point[2] - ng[2]};
+                if (!(norm3(df) > 4.0)) break;
+            }
+            memcpy(e->end_point, ng, sizeof ng);
+            for (int i = 0; i < N; ++i) memcpy(e->goals[i], ng, sizeof ng);
+            set_all_goals(e);
+        }
+        break;
+    default: break;   /* static_same_goal, static_diff_goal, o_static_same_goal, o_random (its step re-assigns the same goals) */
     }
 }
 
@@ -1115,7 +1356,7 @@ void qso_step(qso_env *e, const double *actions, double *obs, double *rew, uint8
         }
         drone_t *d = &e->d[i];
         d->dist_hist[d->dist_len++] = -ri_local[i][QS_RI_RAW_POS];
-        if (d->dist_len >= 5 && mean_tail(d->dist_hist, d->dist_len, 5) / c->dt < c->approach_goal_metric && !(d->flags & F_REACHED))
+        if (d->dist_len >= 5 && mean_tail(d->dist_hist, d->dist_len, 5) / c->dt < e->approach_metric && !(d->flags & F_REACHED))
             d->flags |= F_REACHED;
     }
 
@@ -1160,10 +1401,12 @@ void qso_step(qso_env *e, const double *actions, double *obs, double *rew, uint8
             done[i] = 1;
         }
         memcpy(e->info.ep_counters, e->info.counters, sizeof e->info.counters);
+        e->info.ep_scenario = e->scen;
         env_reset(e, obs);
         for (int i = 0; i < N; ++i) e->info.flags[i] = e->d[i].flags;
     }
     e->info.tick = e->tick;
+    e->info.scenario = e->scen;
 }
 
 void qso_reset(qso_env *e, double *obs_out) {
@@ -1171,6 +1414,7 @@ void qso_reset(qso_env *e, double *obs_out) {
     env_reset(e, tmp);
     e->info.tick = e->tick;
     for (int i = 0; i < e->c.num_agents; ++i) e->info.flags[i] = e->d[i].flags;
+    e->info.scenario = e->scen;
     if (!obs_out) free(tmp);
 }
 

@@ -36,6 +36,7 @@ typedef struct qso_info {
     double acc[QS_MAX_AGENTS][3];
     int32_t nan_reward;
     int32_t tape_underrun;
+    int32_t scenario, ep_scenario;   /* active scenario id (the sub-scenario under `mix`) now / of the last finished episode */
 } qso_info;
 
 size_t qso_sizeof_config(void);

@@ -196,7 +196,7 @@ def snapshot(env):
     )
 
 
-def run_case(name, cfg, steps, seed, action_fn=None, forces=None, with_extra=True):
+def run_case(name, cfg, steps, seed, action_fn=None, forces=None, with_extra=True, slim=False):
     """forces: dict step_index -> callable(env) mutating dynamics before that step; the resulting
     full (pos, vel, rot, omega) of every drone is stored so the oracle can apply the same override."""
     global TAPE
@@ -285,10 +285,16 @@ def run_case(name, cfg, steps, seed, action_fn=None, forces=None, with_extra=Tru
             "pos": (3,), "vel": (3,), "rot": (3, 3), "omega": (3,)}[k])
     for k, v in rec.items():
         out[k] = np.array(v)
+    keep = ("pos", "goal", "tick", "on_floor") if slim else tuple(snaps0)   # slim fixtures: obs/rew/done + a few state rows
     for k, v in snaps0.items():
-        out["s0_" + k] = v
+        if k in keep:
+            out["s0_" + k] = v
     for k, v in snaps.items():
-        out["s_" + k] = np.array(v)
+        if k in keep:
+            out["s_" + k] = np.array(v)
+    if slim:
+        for k in ("rew_info", "curr_pairs", "new_pairs"):
+            out.pop(k)
     if obst_pos:
         out["obst_pos"] = np.array(obst_pos)
     # constants (G1)
@@ -490,6 +496,32 @@ def c4_svs_resets():
     # many resets (short episodes) to sweep the formation types of swarm_vs_swarm
     run_case("c4_svs_resets", default_cfg(num_agents=12, neighbor_visible_num=6, quads_mode="swarm_vs_swarm",
                                           ep_time=0.05), steps=96, seed=43)
+
+
+def _scen_case(name, steps, seed, **over):
+    def fn():
+        run_case(name, default_cfg(**over), steps=steps, seed=seed, action_fn=hover_actions, slim=True)
+    fn.__name__ = name
+    CASES[name] = fn
+
+
+OBST = dict(use_obstacles=True, neighbor_visible_num=2, obs_repr="xyz_vxyz_R_omega_floor",
+            rew_coeff=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0,
+                           quadcol_bin=5.0, quadcol_bin_smooth_max=4.0, quadcol_bin_obst=5.0))
+# remaining scenarios: short episodes so that reset + the per-step goal dynamics are both exercised
+_scen_case("s_static_diff_goal", 110, 51, quads_mode="static_diff_goal", ep_time=0.5, num_agents=10)
+_scen_case("s_dynamic_same_goal", 650, 52, quads_mode="dynamic_same_goal", ep_time=6.2, num_agents=3, neighbor_visible_num=2)
+_scen_case("s_dynamic_diff_goal", 650, 53, quads_mode="dynamic_diff_goal", ep_time=6.2, num_agents=5, neighbor_visible_num=2)
+_scen_case("s_dynamic_formations", 260, 54, quads_mode="dynamic_formations", ep_time=1.2, num_agents=9)
+_scen_case("s_swap_goals", 650, 55, quads_mode="swap_goals", ep_time=6.2, num_agents=4, neighbor_visible_num=2)
+_scen_case("s_ep_lissajous3D", 130, 56, quads_mode="ep_lissajous3D", ep_time=0.6, num_agents=3, neighbor_visible_num=2)
+_scen_case("s_ep_rand_bezier", 650, 57, quads_mode="ep_rand_bezier", ep_time=6.2, num_agents=2, neighbor_visible_num=1)
+_scen_case("s_o_random", 130, 58, quads_mode="o_random", ep_time=0.6, **OBST)
+_scen_case("s_o_dynamic_same_goal", 650, 59, quads_mode="o_dynamic_same_goal", ep_time=6.2, **dict(OBST, num_agents=3))
+_scen_case("s_o_swap_goals", 650, 60, quads_mode="o_swap_goals", ep_time=6.2, **dict(OBST, num_agents=4))
+_scen_case("s_mix", 420, 61, quads_mode="mix", ep_time=0.2, num_agents=6, neighbor_visible_num=3)
+_scen_case("s_mix_obst", 200, 62, quads_mode="mix", ep_time=0.2, **dict(OBST, num_agents=4))
+_scen_case("s_mix_single", 200, 63, quads_mode="mix", ep_time=0.2, num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none")
 
 
 if __name__ == "__main__":

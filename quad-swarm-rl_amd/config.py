@@ -17,8 +17,10 @@ QS_STATE_STRIDE = 35
 
 OBS_REPR = {"xyz_vxyz_R_omega": 0, "xyz_vxyz_R_omega_floor": 1, "xyz_vxyz_R_omega_wall": 2}
 OBS_REPR_DIM = {"xyz_vxyz_R_omega": 18, "xyz_vxyz_R_omega_floor": 19, "xyz_vxyz_R_omega_wall": 24}  # quad_utils.py:30-34
-SCENARIOS = {"static_same_goal": 0, "o_static_same_goal": 1, "swarm_vs_swarm": 2}
-SCENARIO_CLASS_NAMES = {0: "Scenario_static_same_goal", 1: "Scenario_o_static_same_goal", 2: "Scenario_swarm_vs_swarm"}
+SCENARIOS = {"static_same_goal": 0, "o_static_same_goal": 1, "swarm_vs_swarm": 2, "static_diff_goal": 3, "dynamic_same_goal": 4,
+             "dynamic_diff_goal": 5, "dynamic_formations": 6, "swap_goals": 7, "ep_lissajous3D": 8, "ep_rand_bezier": 9,
+             "o_random": 10, "o_dynamic_same_goal": 11, "o_swap_goals": 12, "mix": 13}
+SCENARIO_CLASS_NAMES = {v: "Scenario_" + k for k, v in SCENARIOS.items()}
 REW_COEFF_KEYS = ["pos", "effort", "crash", "orient", "spin", "quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"]
 # quadrotor_multi.py:91-94
 REW_COEFF_DEFAULT = dict(pos=1., effort=0.05, action_change=0., crash=1., orient=1., yaw=0., rot=0., attitude=0., spin=0.1,
@@ -94,7 +96,7 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
         raise ValueError(f"unknown obs_repr {obs_repr}")
     if quads_mode == "swarm_vs_swarm" and num_agents < 2:
         raise ValueError("swarm_vs_swarm needs >= 2 drones (scenarios/utils.py:12)")
-    if use_obstacles != quads_mode.startswith("o_"):
+    if quads_mode != "mix" and use_obstacles != quads_mode.startswith("o_"):
         raise ValueError("obstacle scenarios (o_*) require use_obstacles=True and vice versa")
 
     c = QsConfig()
