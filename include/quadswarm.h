@@ -148,6 +148,8 @@ typedef struct qs_buffers {
     void *ep_stats;           /* real  [QS_EPS_COUNT, E*N], ep_counters int32 [QS_CNT_COUNT, E]: snapshot at last done */
     void *ep_counters;
     void *error_flag;         /* uint32 [1]: nonzero if a reward was NaN/Inf (quadrotor_single.py:87-90) */
+    void *scenario_id;        /* int32 [E]: active scenario (the sub-scenario chosen by `mix` for this episode) */
+    void *ep_scenario;        /* int32 [E]: scenario of the last finished episode (names the per-scenario episode stats) */
     int32_t obs_dim;
     int32_t real_size;        /* 4 or 8 */
 } qs_buffers;

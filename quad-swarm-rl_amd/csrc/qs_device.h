@@ -177,6 +177,7 @@ template <typename real> struct Consts {
     int32_t sim_steps, ep_len, floor_mode, svd_period, sense_noise, obs_repr, self_dim, obs_dim;
     int32_t num_neighbors, use_downwash, use_obstacles, scenario, num_obstacles, obst_area[2];
     int32_t grace_steps, final_steps, control_freq;
+    int32_t cube_fd_all;  // int(N ** (1/3)) for the whole swarm (all scenarios except swarm_vs_swarm)
     int32_t cube_fd[2];   // int(n ** (1/3)) for the two half-swarms, evaluated on the host with libm's pow (scenarios/base.py:98-99)
     uint32_t seed_lo, seed_hi;
     int32_t env_id_offset, num_envs, num_agents;
@@ -642,17 +643,27 @@ __device__ int generate_goals(const Formation<real> &F, int n, int fd, const rea
     return rows;
 }
 
+// QUADS_PARAMS_DICT scenarios/utils.py:33-51: number of candidate formations and [low, high] formation size
+__device__ __forceinline__ void scen_params(int scen, int *nform, float *lo, float *hi) {
+    *nform = 1; *lo = 0.f; *hi = 0.f;
+    if (scen == QS_SCENARIO_STATIC_DIFF_GOAL || scen == QS_SCENARIO_DYNAMIC_DIFF_GOAL || scen == QS_SCENARIO_SWARM_VS_SWARM) { *nform = 8; *lo = 0.25f; *hi = 0.5f; }
+    else if (scen == QS_SCENARIO_SWAP_GOALS) { *nform = 8; *lo = 0.4f; *hi = 0.8f; }
+    else if (scen == QS_SCENARIO_DYNAMIC_FORMATIONS) { *nform = 8; *lo = 0.f; *hi = 1.0f; }
+    else if (scen == QS_SCENARIO_O_SWAP_GOALS) { *nform = 7; *lo = 0.4f; *hi = 0.8f; }
+}
+
 // update_formation_and_relate_param scenarios/base.py:123-135
 template <typename real>
-__device__ void update_formation(const Consts<real> &c, const RngKey &key, int slot, int num_agents, Formation<real> &F) {
-    bool svs = c.scenario == QS_SCENARIO_SWARM_VS_SWARM;
-    int nform = svs ? 8 : 1;
-    real lo = svs ? (real)(5 * 0.05) : (real)0, hi = svs ? (real)(10 * 0.05) : (real)0;
-    int fi = (int)(rng_uniform1<real>(key, QS_SITE_SCEN, slot + 0, 0, 0, (real)0, (real)1) * (real)nform);
-    if (fi >= nform) fi = nform - 1;
+__device__ void update_formation(int scen, const RngKey &key, int slot, int num_agents, Formation<real> &F) {
+    int nform; float lof, hif;
+    scen_params(scen, &nform, &lof, &hif);
+    // 5*0.05 etc. are evaluated in double by the reference; 0.25/0.5/1.0 are exact, 0.4/0.8 need the double literal
+    real lo = (scen == QS_SCENARIO_SWAP_GOALS || scen == QS_SCENARIO_O_SWAP_GOALS) ? (real)(8 * 0.05) : (real)lof;
+    real hi = (scen == QS_SCENARIO_SWAP_GOALS || scen == QS_SCENARIO_O_SWAP_GOALS) ? (real)(16 * 0.05) : (real)hif;
+    int fi = rng_index<real>(key, QS_SITE_SCEN, slot + 0, nform);
     F.f = fi;
     F.per_layer = f_is_circle(fi) ? 8 : (f_is_grid(fi) ? 50 : 8);
-    int n = svs ? num_agents / 2 : num_agents;
+    int n = (scen == QS_SCENARIO_SWARM_VS_SWARM) ? num_agents / 2 : num_agents;
     if (f_is_circle(fi)) {
         real theta = (real)2 * (real)QS_PI_D / (real)F.per_layer, sn = M<real>::sin(theta / (real)2);
         F.lo = ((real)0.5 * lo) / sn; F.hi = ((real)0.5 * hi) / sn;
@@ -665,14 +676,25 @@ __device__ void update_formation(const Consts<real> &c, const RngKey &key, int s
     F.layer_dist = rng_uniform1<real>(key, QS_SITE_SCEN, slot + 2, 0, 0, F.lo, F.hi);
 }
 
+// floor(u * n) and lo + (hi-lo)*u evaluated in double from the exactly-representable uniform: identical to the oracle
+// in both precisions (these decide indices / switching ticks, where an fp32 rounding would flip a discrete outcome)
+template <typename real> __device__ __forceinline__ int rng_index(const RngKey &k, int site, int slot, int n) {
+    double u = (double)rng_uniform1<real>(k, site, slot, 0, 0, (real)0, (real)1);
+    int j = (int)(u * (double)n);
+    return j >= n ? n - 1 : j;
+}
+template <typename real> __device__ __forceinline__ int draw_period(const RngKey &k, int slot, double lo, double hi, int control_freq) {
+    double u = (double)rng_uniform1<real>(k, QS_SITE_SCEN, slot, 0, 0, (real)0, (real)1);
+    return (int)((lo + (hi - lo) * u) * (double)control_freq);
+}
+
 // np.random.shuffle on rows [0,n) of buf (stride ld): Fisher-Yates with the QS_SITE_SCEN_SHUFFLE stream
 template <typename real>
 __device__ void shuffle_rows(const RngKey &key, real *buf, int ld, int n, int slot_base) {
     // the oracle builds perm by swapping from the top, then gathers rows[k] = old[perm[k]]; applying the same
     // swaps directly to the rows is the identical permutation.
     for (int i = n - 1; i >= 1; --i) {
-        int j = (int)(rng_uniform1<real>(key, QS_SITE_SCEN_SHUFFLE, slot_base + i, 0, 0, (real)0, (real)1) * (real)(i + 1));
-        if (j > i) j = i;
+        int j = rng_index<real>(key, QS_SITE_SCEN_SHUFFLE, slot_base + i, i + 1);
         for (int q = 0; q < 3; ++q) { real t = buf[i * ld + q]; buf[i * ld + q] = buf[j * ld + q]; buf[j * ld + q] = t; }
     }
 }

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "qs_device.h"
+#include "qs_scenarios.h"
 
 using namespace qs;
 
@@ -43,6 +44,9 @@ template <typename real> struct Ptrs {
     real *scen_real;
     int32_t *scen_int;
     uint32_t *error_flag;
+    uint64_t *scen_omap;   // [4, E] obstacle map bitsets (scenarios that sample free cells during an episode)
+    int32_t *scenario_id;  // [E] active scenario (the sub-scenario under `mix`)
+    int32_t *ep_scenario;  // [E] scenario of the last finished episode
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
 };
@@ -53,13 +57,17 @@ template <typename real> struct Ptrs {
 #define QS_STAMP(k) do { } while (0)
 #endif
 
-struct LdsLayout { int off_mask, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total; };
+struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total; };
 #define QS_RESET_SCRATCH_INTS 160   // per env: virtual-pool index/value lists (2x64) + two DP rows (2x16)
 
 static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K) {
     LdsLayout L;
     int o = 0;
     L.off_mask = o; o += 8 * B;                       // u64 per lane: new-pair masks for the serial response path
+    L.off_omap = o; o += 8 * 4 * epb;                 // full-scenario kernels: obstacle map bitset, scenario ints / reals per env
+    L.off_si = o; o += 4 * SI_COUNT * epb;
+    L.off_sr = o; o += real_size * SR_COUNT * epb;
+    o = (o + 15) & ~15;
     L.off_envflag = o; o += 4 * ((2 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods
     L.off_scratch = o; o += 4 * QS_RESET_SCRATCH_INTS * epb;
     o = (o + 15) & ~15;
@@ -289,6 +297,26 @@ __device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, cons
     for (int q = 0; q < 3; ++q) { vel[q] = d.vel[q]; omega[q] = d.omega[q]; }
 }
 
+// full-scenario kernels: per-env scenario state HBM <-> LDS (each drone of the env moves a strided part)
+template <typename real>
+__device__ __forceinline__ void scen_lds_load(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
+    real *sr = (real *)(smem + L.off_sr) + le * SR_COUNT;
+    int *si = (int *)(smem + L.off_si) + le * SI_COUNT;
+    uint64_t *om = (uint64_t *)(smem + L.off_omap) + le * 4;
+    for (int k = i; k < SR_COUNT; k += N) sr[k] = p.scen_real[k * E + e];
+    for (int k = i; k < SI_COUNT; k += N) si[k] = p.scen_int[k * E + e];
+    for (int k = i; k < 4; k += N) om[k] = p.scen_omap[k * E + e];
+}
+template <typename real>
+__device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
+    const real *sr = (const real *)(smem + L.off_sr) + le * SR_COUNT;
+    const int *si = (const int *)(smem + L.off_si) + le * SI_COUNT;
+    const uint64_t *om = (const uint64_t *)(smem + L.off_omap) + le * 4;
+    for (int k = i; k < SR_COUNT; k += N) p.scen_real[k * E + e] = sr[k];
+    for (int k = i; k < SI_COUNT; k += N) p.scen_int[k * E + e] = si[k];
+    for (int k = i; k < 4; k += N) p.scen_omap[k * E + e] = om[k];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Episode reset of the envs whose lanes have `do_reset` set: QuadrotorEnvMulti.reset quadrotor_multi.py:339-411
 // (+ QuadrotorSingle._reset quadrotor_single.py:387-447, obst_generation_given_density quadrotor_multi.py:304-325,
@@ -297,7 +325,7 @@ __device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, cons
 // per-env global scratch (obstacle positions, scenario state).  `stale_vel` are the previous episode's final
 // velocities: the first neighbour obs of an episode is computed from them (SURVEY App. A reset quirk).
 // ------------------------------------------------------------------------------------------------
-template <typename real>
+template <typename real, bool FULL>
 __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem, int epb, const RngKey &key,
                                         bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3]) {
     const Consts<real> &c = *cp;
@@ -320,17 +348,18 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         uint32_t have_spawn = 0;
         uint64_t omap[4] = {0, 0, 0, 0};   // obstacle map bitset, cell id = rid*W + cid
         const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W;
+        if (FULL) for (int q = 0; q < 4; ++q) ((uint64_t *)(smem + L.off_omap))[le * 4 + q] = 0;
         if (c.use_obstacles) {
             // np.random.choice(cells, M, replace=False): partial Fisher-Yates on a virtual pool
             int nt = 0;
             for (int k = 0; k < M_; ++k) {
-                int j = k + (int)(rng_uniform1<real>(key, QS_SITE_OBST_MAP, k, 0, 0, (real)0, (real)1) * (real)(cells - k));
-                if (j >= cells) j = cells - 1;
+                int j = k + rng_index<real>(key, QS_SITE_OBST_MAP, k, cells - k);
                 int vk = k, vj = j, pj = -1;
                 for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
                 if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }   // pool[j] = pool[k]; the pick is old pool[j]
                 int id = vj, rid = id / W, cid = id - rid * W;
                 omap[id >> 6] |= 1ull << (id & 63);
+                if (FULL) ((uint64_t *)(smem + L.off_omap))[le * 4 + (id >> 6)] |= 1ull << (id & 63);
                 // cell centre index rid + L*cid (quadrotor_multi.py:321); centres per obstacles/utils.py:47-58
                 int ci = rid + Lr * cid, ii = ci / W, jj = (W - 1) - (ci - ii * W);
                 real ox = (real)ii + (real)0.5 - (real)(Lr / 2), oy = (real)jj + (real)0.5 - (real)(W / 2);
@@ -341,8 +370,15 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             }
         }
         Formation<real> F;
-        if (c.scenario == QS_SCENARIO_STATIC_SAME_GOAL) {
-            update_formation<real>(c, key, 0, N, F);
+        if (FULL) {
+            ScenCtx<real> x = {(real *)(smem + L.off_sr) + le * SR_COUNT, (int *)(smem + L.off_si) + le * SI_COUNT,
+                               (uint64_t *)(smem + L.off_omap) + le * 4, goals, s_spawn, B, base, N};
+            scenario_reset_full<real>(c, key, x, tidx);
+            have_spawn = (uint32_t)x.si[SI_HAVE_SPAWN];
+            s_envflag[epb + le] = (uint32_t)x.si[SI_PERIOD];
+            p.scenario_id[e] = x.si[SI_SCEN];
+        } else if (c.scenario == QS_SCENARIO_STATIC_SAME_GOAL) {
+            update_formation<real>(c.scenario, key, 0, N, F);
             real center[3] = {0, 0, 2};
             generate_goals<real>(F, N, 1, center, goals, 3);
         } else if (c.scenario == QS_SCENARIO_O_STATIC_SAME_GOAL) {
@@ -350,8 +386,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             int nfree = cells - M_;
             int nt = 0;
             for (int k = 0; k < N; ++k) {
-                int j = k + (int)(rng_uniform1<real>(key, QS_SITE_SCEN, 16 + k, 0, 0, (real)0, (real)1) * (real)(nfree - k));
-                if (j >= nfree) j = nfree - 1;
+                int j = k + rng_index<real>(key, QS_SITE_SCEN, 16 + k, nfree - k);
                 int vk = k, vj = j, pj = -1;
                 for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
                 if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }
@@ -387,10 +422,10 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             for (int k = 0; k < N; ++k) for (int q = 0; q < 3; ++q) goals[k * 3 + q] = end[q];
         } else {
             // swarm_vs_swarm.py:80-94 (reset) + :17-50 (formation_centers) + scenarios/utils.py:170-181 (get_z_value)
-            real dur = rng_uniform1<real>(key, QS_SITE_SCEN, 8, 0, 0, (real)4, (real)6);
-            p.scen_int[e] = (int)(dur * (real)c.control_freq);
-            s_envflag[epb + le] = (uint32_t)(int)(dur * (real)c.control_freq);
-            update_formation<real>(c, key, 0, N, F);
+            const int period = draw_period<real>(key, 8, 4.0, 6.0, c.control_freq);
+            p.scen_int[e] = period;
+            s_envflag[epb + le] = (uint32_t)period;
+            update_formation<real>(c.scenario, key, 0, N, F);
             real box = c.spawn_box, xy[2];
             rng_uniform<real, 2>(key, QS_SITE_SCEN, 9, 0, 0, -box, box, xy);
             real z = rng_uniform1<real>(key, QS_SITE_SCEN, 10, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2, zlb = (real)0.25;
@@ -453,17 +488,27 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     }
 }
 
+#define QS_SCEN_FULL 0
 #define QS_MULTI 0
 #include "qs_step_kernel.inc"
 #undef QS_MULTI
 #define QS_MULTI 1
 #include "qs_step_kernel.inc"
 #undef QS_MULTI
+#undef QS_SCEN_FULL
+#define QS_SCEN_FULL 1      // all scenarios incl. `mix` (qs_scenarios.h); scenario state in LDS
+#define QS_MULTI 0
+#include "qs_step_kernel.inc"
+#undef QS_MULTI
+#define QS_MULTI 1
+#include "qs_step_kernel.inc"
+#undef QS_MULTI
+#undef QS_SCEN_FULL
 
 // ------------------------------------------------------------------------------------------------
 // reset kernel (qs_reset): resets the envs flagged in reset_mask
 // ------------------------------------------------------------------------------------------------
-template <typename real>
+template <typename real, bool FULL>
 __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c, Ptrs<real> p, LdsLayout L, int epb) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Consts<real> *cp = &c;
@@ -479,7 +524,10 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c,
 #pragma unroll
     for (int q = 0; q < 3; ++q) stale_vel[q] = p.vel[q * T + g];
     d.flags = p.flags[g];
-    reset_body<real>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);
+    if (FULL && in_range) scen_lds_load<real>(p, L, smem, E, e, le, i, N);
+    if (FULL) __syncthreads();
+    reset_body<real, FULL>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);
+    if (FULL) { __syncthreads(); if (do_reset) scen_lds_store<real>(p, L, smem, E, e, le, i, N); }
     if (do_reset) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = 0; p.omega[q * T + g] = 0; p.goal[q * T + g] = goal[q]; }
@@ -545,6 +593,7 @@ struct qs_handle {
     int real_size = 4;
     int obs_dim = 0, epb = 1, blocks = 0;
     LdsLayout lds;
+    bool full = false;     // scenario outside the fast set => kernels compiled with QS_SCEN_FULL
     Consts<float> kf;    // kernel constants, passed by value in the kernarg segment
     Consts<double> kd;
     Ptrs<float> pf;     // same field layout for float/double: only the pointee type differs
@@ -593,6 +642,7 @@ template <typename real> static void fill_consts(const qs_config &c, Consts<real
     k.control_freq = (int)(control_freq + 0.5);
     k.grace_steps = (int)std::ceil(1.5 * control_freq - 1e-9);    // tick >= 1.5*control_freq (quadrotor_multi.py:146,:451)
     k.final_steps = (int)std::floor(5.0 * control_freq + 1e-9);   // time_remain <= 5*control_freq (:150,:455)
+    k.cube_fd_all = (int)pow((double)c.num_agents, 1.0 / 3);
     k.cube_fd[0] = (int)pow((double)(c.num_agents / 2), 1.0 / 3);
     k.cube_fd[1] = (int)pow((double)(c.num_agents - c.num_agents / 2), 1.0 / 3);
     k.seed_lo = (uint32_t)(c.seed & 0xffffffffu); k.seed_hi = (uint32_t)(c.seed >> 32);
@@ -613,9 +663,13 @@ static int validate(const qs_config *c) {
     if (c->num_agents < 1 || c->num_agents > QS_MAX_AGENTS) return fail(QS_ERR_INVALID, "num_agents must be in [1, 64]");
     if (c->num_neighbors < 0 || c->num_neighbors > c->num_agents - 1) return fail(QS_ERR_INVALID, "Incorrect number of neigbors");
     if (c->precision != QS_PRECISION_F32 && c->precision != QS_PRECISION_F64) return fail(QS_ERR_INVALID, "bad precision");
-    if (c->scenario < 0 || c->scenario > QS_SCENARIO_SWARM_VS_SWARM) return fail(QS_ERR_UNSUPPORTED, "unsupported scenario");
+    if (c->scenario < 0 || c->scenario >= QS_SCENARIO_COUNT) return fail(QS_ERR_UNSUPPORTED, "unsupported scenario");
     if (c->scenario == QS_SCENARIO_SWARM_VS_SWARM && c->num_agents < 2) return fail(QS_ERR_INVALID, "swarm_vs_swarm needs >= 2 drones");
-    if ((c->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL) != (c->use_obstacles != 0)) return fail(QS_ERR_INVALID, "obstacle scenario <=> use_obstacles");
+    {
+        const bool o_scen = c->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_RANDOM ||
+                            c->scenario == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_SWAP_GOALS;
+        if (c->scenario != QS_SCENARIO_MIX && o_scen != (c->use_obstacles != 0)) return fail(QS_ERR_INVALID, "obstacle scenario <=> use_obstacles");
+    }
     if (c->use_obstacles) {
         if (c->obst_area[0] < 1 || c->obst_area[1] < 1 || c->obst_area[0] > 16 || c->obst_area[1] > 16) return fail(QS_ERR_UNSUPPORTED, "obst_area must be within [1,16]x[1,16]");
         if (c->num_obstacles < 1 || c->num_obstacles > QS_MAX_OBSTACLES || c->num_obstacles > c->obst_area[0] * c->obst_area[1]) return fail(QS_ERR_INVALID, "bad num_obstacles");
@@ -652,7 +706,8 @@ template <typename real> static int create_typed(qs_handle *h) {
     DA(obs, T * D); DA(reward, T); DA(rew_info, QS_RI_COUNT * T); DA(done, T); DA(obst_hit_idx, T);
     DA(unique_col, E); DA(obst_new, E); DA(room_new, E); DA(counters, QS_CNT_COUNT * E); DA(tick, E); DA(step_ctr, E);
     DA(obst_pos, 2 * E * (M_ ? M_ : 1)); DA(dist_ring, 4 * T); DA(dist_sums, 3 * T); DA(ep_stats, QS_EPS_COUNT * T); DA(ep_counters, QS_CNT_COUNT * E);
-    DA(scen_real, 6 * E); DA(scen_int, E); DA(error_flag, 1); DA(reset_mask, E); DA(timing, 32);
+    DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
+    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 32);
 #undef DA
     real *act = nullptr;
     if ((rc = dalloc(h, &act, 4 * T)) != QS_OK) return rc;
@@ -668,7 +723,7 @@ template <typename real> static int create_typed(qs_handle *h) {
     b.ou_state = p.ou; b.goal = p.goal; b.flags = p.flags; b.obst_hit_idx = p.obst_hit_idx; b.col_pair_mask = p.pair_mask;
     b.new_pair_mask = p.new_pair_mask; b.unique_col_mask = p.unique_col; b.obst_new_mask = p.obst_new; b.room_new_mask = p.room_new;
     b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters;
-    b.error_flag = p.error_flag; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
+    b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
     return QS_OK;
 }
 
@@ -736,6 +791,8 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
     h->epb = QS_WAVE / cfg->num_agents;
     h->blocks = (cfg->num_envs + h->epb - 1) / h->epb;
     h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors);
+    h->full = !(cfg->scenario == QS_SCENARIO_STATIC_SAME_GOAL || cfg->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL ||
+                cfg->scenario == QS_SCENARIO_SWARM_VS_SWARM);
     rc = (h->real_size == 8) ? create_typed<double>(h) : create_typed<float>(h);
     if (rc == QS_OK) {
         if (hipMalloc((void **)&h->d_state_buf, sizeof(double) * QS_MAX_AGENTS * QS_STATE_STRIDE) != hipSuccess ||
@@ -745,16 +802,16 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
     }
     if (rc != QS_OK) { qs_destroy(h); return rc; }
     if (h->lds.total > 64 * 1024) {
-        hipError_t e1 = (h->real_size == 8)
-            ? hipFuncSetAttribute((const void *)qs_step_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total)
-            : hipFuncSetAttribute((const void *)qs_step_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total);
-        if (e1 == hipSuccess) e1 = (h->real_size == 8)
-            ? hipFuncSetAttribute((const void *)qs_rollout_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total)
-            : hipFuncSetAttribute((const void *)qs_rollout_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total);
-        hipError_t e2 = (h->real_size == 8)
-            ? hipFuncSetAttribute((const void *)qs_reset_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total)
-            : hipFuncSetAttribute((const void *)qs_reset_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total);
-        if (e1 != hipSuccess || e2 != hipSuccess) { qs_destroy(h); return fail(QS_ERR_HIP, "cannot raise dynamic LDS limit"); }
+        const void *fns[] = {(const void *)qs_step_kernel<float>, (const void *)qs_step_kernel<double>, (const void *)qs_rollout_kernel<float>,
+                             (const void *)qs_rollout_kernel<double>, (const void *)qs_step_kernel_full<float>, (const void *)qs_step_kernel_full<double>,
+                             (const void *)qs_rollout_kernel_full<float>, (const void *)qs_rollout_kernel_full<double>,
+                             (const void *)qs_reset_kernel<float, false>, (const void *)qs_reset_kernel<double, false>,
+                             (const void *)qs_reset_kernel<float, true>, (const void *)qs_reset_kernel<double, true>};
+        for (const void *fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds.total) != hipSuccess) {
+                qs_destroy(h);
+                return fail(QS_ERR_HIP, "cannot raise dynamic LDS limit");
+            }
     }
     *out = h;
     return QS_OK;
@@ -778,9 +835,11 @@ int qs_destroy(qs_handle *h) {
 static int launch_reset(qs_handle *h, hipStream_t s) {
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
-        hipLaunchKernelGGL(qs_reset_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
+        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<double, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
+        else hipLaunchKernelGGL((qs_reset_kernel<double, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
     } else {
-        hipLaunchKernelGGL(qs_reset_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, h->lds, h->epb);
+        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<float, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, h->lds, h->epb);
+        else hipLaunchKernelGGL((qs_reset_kernel<float, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, h->lds, h->epb);
     }
     HIP_TRY(hipGetLastError());
     return QS_OK;
@@ -811,14 +870,17 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
         ++h->events_used;
         HIP_TRY(hipEventRecord(e0, s));
     }
+#define QS_LAUNCH(KERNEL, CONSTS, PTRS, TYPE, ...) hipLaunchKernelGGL(KERNEL<TYPE>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, CONSTS, PTRS, \
+                                                                    (const TYPE *)actions, h->lds, h->epb, ##__VA_ARGS__)
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
-        if (ksteps == 1) hipLaunchKernelGGL(qs_step_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, (const double *)actions, h->lds, h->epb);
-        else hipLaunchKernelGGL(qs_rollout_kernel<double>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, (const double *)actions, h->lds, h->epb, ksteps);
+        if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_kernel_full, h->kd, p, double); else QS_LAUNCH(qs_step_kernel, h->kd, p, double); }
+        else { if (h->full) QS_LAUNCH(qs_rollout_kernel_full, h->kd, p, double, ksteps); else QS_LAUNCH(qs_rollout_kernel, h->kd, p, double, ksteps); }
     } else {
-        if (ksteps == 1) hipLaunchKernelGGL(qs_step_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, (const float *)actions, h->lds, h->epb);
-        else hipLaunchKernelGGL(qs_rollout_kernel<float>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, (const float *)actions, h->lds, h->epb, ksteps);
+        if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_kernel_full, h->kf, h->pf, float); else QS_LAUNCH(qs_step_kernel, h->kf, h->pf, float); }
+        else { if (h->full) QS_LAUNCH(qs_rollout_kernel_full, h->kf, h->pf, float, ksteps); else QS_LAUNCH(qs_rollout_kernel, h->kf, h->pf, float, ksteps); }
     }
+#undef QS_LAUNCH
     HIP_TRY(hipGetLastError());
     if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
     return QS_OK;   // the auto-reset is the tail of the step kernel itself

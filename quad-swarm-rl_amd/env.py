@@ -29,12 +29,17 @@ except Exception:  # pragma: no cover - minimal stand-in with the attributes SF 
 class _Scenario:
     """Just enough of scenarios/base.py for the wrappers (`scenario.name()`, `.approch_goal_metric`)."""
 
-    def __init__(self, cfg):
-        self._name = qcfg.SCENARIO_CLASS_NAMES[cfg.scenario]
+    def __init__(self, cfg, stepper=None):
+        self._cfg, self._stepper = cfg, stepper
         self.approch_goal_metric = cfg.approach_goal_metric
 
-    def name(self):
-        return self._name
+    def name(self, finished_episode=False):
+        """Class name of the active scenario; under `mix` that is the sub-scenario of env 0's current episode
+        (scenarios/mix.py:67-71), or of its last finished episode for the episode statistics."""
+        sid = self._cfg.scenario
+        if sid == qcfg.SCENARIOS["mix"] and self._stepper is not None:
+            sid = int(self._stepper.to_host("ep_scenario" if finished_episode else "scenario_id")[0])
+        return qcfg.SCENARIO_CLASS_NAMES[sid]
 
 
 class QuadSwarmVecEnv:
@@ -57,7 +62,7 @@ class QuadSwarmVecEnv:
         self.rew_coeff = dict(qcfg.REW_COEFF_DEFAULT)
         self.rew_coeff.update({k: self.cfg.rew_coeff[i] for i, k in enumerate(qcfg.REW_COEFF_KEYS)})
         self._pushed_coeff = [self.rew_coeff[k] for k in qcfg.REW_COEFF_KEYS]
-        self.scenario = _Scenario(self.cfg)
+        self.scenario = _Scenario(self.cfg, self.stepper)
         self._t = self.stepper.tensor
 
     def _sync_rew_coeff(self):
@@ -166,7 +171,7 @@ class QuadrotorEnvMulti:
         """Per-agent dicts with the keys of quadrotor_multi.py:637-718, from the device-side episode snapshot."""
         st, n = self._vec.stepper, self.num_agents
         eps, cnt = st.to_host("ep_stats").astype(np.float64), st.to_host("ep_counters")[:, 0]
-        name = self.scenario.name()[9:]
+        name = self.scenario.name(finished_episode=True)[9:]
         ok = np.logical_and(eps[4], eps[5])
         succ = float(np.sum(np.logical_and(ok, eps[3])) / n)
         dead = float(np.sum(np.logical_and(ok, 1 - eps[3])) / n)

@@ -15,6 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("QS_LIB", os.path.join(CSRC, "libquadswarm_hip.so"))   # QS_LIB: A/B builds (tools only)
 SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_device.h"),
+           os.path.join(CSRC, "qs_scenarios.h"),
            os.path.join(os.path.dirname(HERE), "include", "quadswarm.h")]
 
 QS_OK = 0
@@ -26,7 +27,7 @@ class QsBuffers(C.Structure):
         "obs", "reward", "done", "rew_info", "actions", "pos", "vel", "omega", "rot", "thrust_rot_damp",
         "thrust_cmds_damp", "ou_state", "goal", "flags", "obst_hit_idx", "col_pair_mask", "new_pair_mask",
         "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_pos", "ep_stats",
-        "ep_counters", "error_flag")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
+        "ep_counters", "error_flag", "scenario_id", "ep_scenario")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
 
 
 def build(force=False, verbose=False):
@@ -128,7 +129,8 @@ class Stepper:
             col_pair_mask=((self.T,), "u8"), new_pair_mask=((self.T,), "u8"), unique_col_mask=((self.E,), "u8"),
             obst_new_mask=((self.E,), "u8"), room_new_mask=((self.E,), "u8"), counters=((11, self.E), "i4"),
             tick=((self.E,), "i4"), obst_pos=((2, self.E * max(cfg.num_obstacles, 1)), "real"),
-            ep_stats=((6, self.T), "real"), ep_counters=((11, self.E), "i4"), error_flag=((1,), "u4"))
+            ep_stats=((6, self.T), "real"), ep_counters=((11, self.E), "i4"), error_flag=((1,), "u4"),
+            scenario_id=((self.E,), "i4"), ep_scenario=((self.E,), "i4"))
         self._torch_cache = {}
 
     # ---- lifecycle -------------------------------------------------------------------------

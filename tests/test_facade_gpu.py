@@ -108,3 +108,25 @@ def test_step_many_rollout_equals_stepwise():
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=5e-5)
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=5e-6)
     np.testing.assert_array_equal(outs[0][2], outs[1][2])
+
+
+def test_mix_scenario_names_follow_the_episode():
+    """Under quads_mode=mix the per-scenario stat keys carry the finished episode's sub-scenario (mix.py:67-71)."""
+    from quad_swarm_rl_amd import config as qcfg
+    from quad_swarm_rl_amd import sf_env
+    cfg = parse(["--quads_num_agents=4", "--quads_neighbor_visible_num=2", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
+                 "--quads_mode=mix", "--quads_episode_duration=0.1", "--quads_seed=5"])
+    env = sf_env.make_quadrotor_env("quadrotor_multi", cfg=cfg)
+    env.reset()
+    quad = env.unwrapped
+    allowed = {"Scenario_" + n for n in qcfg.SCENARIOS if not n.startswith("o_") and n != "mix"}
+    seen = set()
+    for t in range(120):
+        before = quad.scenario.name()
+        assert before in allowed
+        _, _, term, _, infos = env.step([env.action_space.sample() for _ in range(4)])
+        if term.any():
+            assert f"{before[9:]}/agent_col_rate" in infos[0]["episode_extra_stats"]
+            seen.add(before)
+    assert len(seen) >= 3, seen
+    env.close()

@@ -35,6 +35,35 @@ CASES = {
                              obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.5),
     "c4_n32_svs": dict(num_agents=32, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
                        collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swarm_vs_swarm"),
+    # the remaining scenarios (full-scenario kernel variants), short episodes so that resets and goal dynamics both occur
+    "s_static_diff": dict(num_agents=10, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                          rew_coeff=REW, quads_mode="static_diff_goal", ep_time=0.3),
+    "s_dynamic_same": dict(num_agents=3, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                           rew_coeff=REW, quads_mode="dynamic_same_goal", ep_time=15.0),
+    "s_dynamic_diff": dict(num_agents=5, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                           rew_coeff=REW, quads_mode="dynamic_diff_goal", ep_time=15.0),
+    "s_dynamic_formations": dict(num_agents=9, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True,
+                                 collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="dynamic_formations", ep_time=0.4),
+    "s_swap_goals": dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                         rew_coeff=REW, quads_mode="swap_goals", ep_time=15.0),
+    "s_lissajous": dict(num_agents=3, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                        rew_coeff=REW, quads_mode="ep_lissajous3D", ep_time=0.4),
+    "s_bezier": dict(num_agents=2, neighbor_visible_num=1, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                     rew_coeff=REW, quads_mode="ep_rand_bezier", ep_time=15.0),
+    "s_o_random": dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                       rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_random",
+                       obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.3),
+    "s_o_dynamic_same": dict(num_agents=3, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                             rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0),
+                             quads_mode="o_dynamic_same_goal", obs_repr="xyz_vxyz_R_omega_floor", ep_time=15.0),
+    "s_o_swap": dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                     rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_swap_goals",
+                     obs_repr="xyz_vxyz_R_omega_floor", ep_time=15.0),
+    "s_mix": dict(num_agents=6, neighbor_visible_num=3, neighbor_obs_type="pos_vel", use_numba=True, use_downwash=True,
+                  collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="mix", ep_time=0.12),
+    "s_mix_obst": dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                       rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="mix",
+                       obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.12),
     "c4_n12_svs_short": dict(num_agents=12, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True,
                              use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swarm_vs_swarm", ep_time=0.1),
 }
@@ -172,9 +201,12 @@ def check_floats(t, tol, o, h, what):
         assert err <= tol * (1.0 + np.abs(a).max()), f"{what}: {nm} step {t}: max abs err {err}"
 
 
+LONG = {"s_dynamic_same": 640, "s_dynamic_diff": 640, "s_swap_goals": 640, "s_bezier": 560, "s_o_dynamic_same": 640, "s_o_swap": 640}
+
+
 @pytest.mark.parametrize("case", list(CASES))
 def test_rollout_f64_bit_exact_discrete(case):
-    E, steps, tol = 11, 70, 1e-8
+    E, steps, tol = (3, LONG[case], 1e-7) if case in LONG else (11, 70, 1e-8)
     pr = Pair(case, E, "f64")
     rng = np.random.RandomState(5)
     oobs, hobs = pr.reset()
@@ -197,23 +229,38 @@ def test_rollout_f64_bit_exact_discrete(case):
         pr.compare_state(t, tol)
         if o[2].any():
             pr.compare_ep_stats(t, 1e-7)
+        if case.startswith("s_"):
+            sid = pr.hip.to_host("scenario_id")
+            for e, oe in enumerate(pr.oenvs):
+                assert sid[e] == oe.info().scenario, f"scenario id step {t} env {e}"
     pr.hip.check_errors()
     pr.close()
 
 
-@pytest.mark.parametrize("case", ["c1_single", "c2_n8_dw", "c3_n8_obst", "c4_n32_svs", "c2_n8_k2_numpy_wall"])
+@pytest.mark.parametrize("case", ["c1_single", "c2_n8_dw", "c3_n8_obst", "c4_n32_svs", "c2_n8_k2_numpy_wall",
+                                  "s_static_diff", "s_dynamic_formations", "s_lissajous", "s_o_random", "s_mix", "s_mix_obst",
+                                  "s_dynamic_diff", "s_bezier", "s_o_swap"])
 def test_teacher_forced_f32(case):
-    E, steps, tol = 7, 60, 1e-5
+    E, steps, tol = (3, LONG[case], 1e-5) if case in LONG else (7, 60, 1e-5)
     pr = Pair(case, E, "f32")
     rng = np.random.RandomState(9)
     oobs, hobs = pr.reset()
     np.testing.assert_allclose(hobs, oobs, rtol=0, atol=2e-5)
+    thr = pr.cfg.arm if pr.cfg.floor_mode == 0 else 0.05
     worst = 0.0
     for t in range(steps):
         for e, o in enumerate(pr.oenvs):
             s, tick = o.get_state()
             oxy = pr.obst_xy(e).astype(np.float64) if pr.cfg.use_obstacles else None
-            if force_events(t, e, s, pr.N, oxy, pr.cfg.obst_size / 2):
+            changed = force_events(t, e, s, pr.N, oxy, pr.cfg.obst_size / 2)
+            # A drone that lifted off the floor by less than ~1e-6 m sits closer to the `pos_z <= threshold` test
+            # (quadrotor_dynamics.py:577) than fp32 resolves (ulp(0.046) = 3.7e-9): which sub-step it lands in is then
+            # decided by rounding.  Lift such drones to a representable margin in BOTH states instead of skipping them.
+            hover = (s[:, 30] == 0) & (s[:, 2] - thr > 0) & (s[:, 2] - thr < 1e-6)
+            if hover.any():
+                s[hover, 2] = thr + 1e-4
+                changed = True
+            if changed:
                 o.set_state(s, tick)
             pr.hip.set_state(e, s, tick)          # teacher forcing: device state <- oracle state (rounded to f32)
         gentle = (t // 10) % 2 == 1

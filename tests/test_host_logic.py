@@ -66,3 +66,23 @@ def test_flag_semantics():
     assert c.num_obstacles == 12 and c.spawn_box == 0.1 and c.approach_goal_metric == 1.0
     assert qcfg.svd_period(0.005) == 100     # fl(sum of 100 x 0.005) = 0.5000000000000003 > 0.5
     assert qcfg.make_config(ep_time=15.0).ep_len == 1500
+
+
+def test_scenario_table_matches_header():
+    """Every quads_mode of the reference's training configs is accepted, and the ids are the header's enum."""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "quadswarm.h")).read()
+    ids = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"QS_SCENARIO_([A-Z0-9_]+) = (\d+)", hdr)}
+    count = ids.pop("count")
+    assert count == len(qcfg.SCENARIOS) == 14
+    for name, sid in qcfg.SCENARIOS.items():
+        assert ids[name.lower()] == sid
+        obst = name.startswith("o_")
+        c = qcfg.make_config(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", quads_mode=name,
+                             use_obstacles=obst, obst_spawn_area=(8.0, 8.0), obst_density=0.2)
+        assert c.scenario == sid
+        assert qcfg.SCENARIO_CLASS_NAMES[sid] == "Scenario_" + name
+    # obstacle scenarios need obstacles and vice versa (quadrotor_multi.py:118-125, scenarios/mix.py:16-29)
+    with pytest.raises((AssertionError, ValueError, NotImplementedError)):
+        qcfg.make_config(quads_mode="o_random", use_obstacles=False)
