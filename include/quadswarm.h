@@ -220,6 +220,19 @@ int qs_set_profiling(qs_handle *h, int32_t enable);
 int qs_get_kernel_time(qs_handle *h, double *avg_ms, int64_t *launches);
 
 /*
+ * Config-specialised kernels (no counterpart in the reference; the analogue of Numba compiling the env's hot
+ * functions for the argument types it sees, gym_art/quadrotor_multi/quadrotor_dynamics.py:498,:570).  Besides
+ * the generic kernels of the library, qs_create() can run a code object compiled for exactly one
+ * configuration - every constant a literal - which shortens the per-step critical path by ~25-30 %.
+ * Environment: QS_SPEC=jit (default: build on first use with hipcc --genco, ~20 s, cached in
+ * QS_SPEC_CACHE or <library dir>/spec_cache), =cache (use only if cached), =off (generic kernels).
+ * Results are identical either way.  qs_spec_build() creates the cache entry ahead of time, without a GPU
+ * (team: 1 = 4-wave kernels, 0 = single-wave, -1 = what qs_create picks on a 256-CU device).
+ */
+int qs_spec_build(const qs_config *cfg, int team, char *path_out, int cap);
+int qs_is_specialized(qs_handle *h);
+
+/*
  * Random numbers.  Every stochastic term of the reference is drawn from a
  * counter-based Philox4x32-10 generator:   bits = philox(counter={env_global, step_ctr, site|slot<<8,
  * i|j<<16}, key={seed_lo, seed_hi});  u = ((bits>>9)+0.5)*2^-23 (exact in fp32 and fp64);

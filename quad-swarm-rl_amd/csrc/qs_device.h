@@ -596,6 +596,10 @@ template <typename real> __device__ __forceinline__ void goal_by_formation(int f
 // QuadrotorScenario.generate_goals scenarios/base.py:39-113.  out: [rows][3] with stride `ld` reals per row.
 template <typename real>
 __device__ int generate_goals(const Formation<real> &F, int n, int fd, const real center[3], real *out, int ld) {
+    // Opaque n: in a config-specialised build n is a literal and the loops below get fully unrolled + SLP-vectorised; the
+    // fp32 grid branch then came out wrong on gfx950 (rows 0 and 2 of the second half-swarm, ROCm 7.2 clang), and this is
+    // cold per-episode code where unrolling buys nothing.
+    asm volatile("" : "+v"(n));
     int f = F.f, per = F.per_layer, rows = n;
     real size = F.size;
     if (f_is_circle(f)) {

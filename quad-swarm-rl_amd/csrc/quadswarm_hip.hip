@@ -14,569 +14,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <string>
 #include <vector>
 
-#include "qs_device.h"
-#include "qs_scenarios.h"
-
-using namespace qs;
-
-#define QS_WAVE 64
-
-// ------------------------------------------------------------------------------------------------
-// device buffers
-// ------------------------------------------------------------------------------------------------
-template <typename real> struct Ptrs {
-    real *pos, *vel, *rot, *omega, *rot_damp, *cmds_damp, *ou, *goal;
-    uint32_t *flags;
-    uint64_t *pair_mask, *new_pair_mask;
-    real *obs, *reward, *rew_info;
-    uint8_t *done;
-    int32_t *obst_hit_idx;
-    uint64_t *unique_col, *obst_new, *room_new;
-    int32_t *counters, *tick;
-    uint32_t *step_ctr;
-    real *obst_pos;
-    real *dist_ring, *dist_sums;
-    real *ep_stats;
-    int32_t *ep_counters;
-    real *scen_real;
-    int32_t *scen_int;
-    uint32_t *error_flag;
-    uint64_t *scen_omap;   // [4, E] obstacle map bitsets (scenarios that sample free cells during an episode)
-    int32_t *scenario_id;  // [E] active scenario (the sub-scenario under `mix`)
-    int32_t *ep_scenario;  // [E] scenario of the last finished episode
-    uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
-    unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
-};
-
-#ifdef QS_TIMING
-#define QS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.timing[k] = clock64(); } while (0)
-#else
-#define QS_STAMP(k) do { } while (0)
-#endif
-
-struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total; };
-#define QS_RESET_SCRATCH_INTS 160   // per env: virtual-pool index/value lists (2x64) + two DP rows (2x16)
-
-static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K) {
-    LdsLayout L;
-    int o = 0;
-    L.off_mask = o; o += 8 * B;                       // u64 per lane: new-pair masks for the serial response path
-    L.off_omap = o; o += 8 * 4 * epb;                 // full-scenario kernels: obstacle map bitset, scenario ints / reals per env
-    L.off_si = o; o += 4 * SI_COUNT * epb;
-    L.off_sr = o; o += real_size * SR_COUNT * epb;
-    o = (o + 15) & ~15;
-    L.off_envflag = o; o += 4 * ((2 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods
-    L.off_scratch = o; o += 4 * QS_RESET_SCRATCH_INTS * epb;
-    o = (o + 15) & ~15;
-    L.off_pos = o; o += real_size * 3 * B;
-    L.off_vel = o; o += real_size * 3 * B;
-    L.off_zax = o; o += real_size * 3 * B;            // body z axes (downwash); spawn points in the reset tail
-    L.off_om = o; o += real_size * 3 * B;
-    L.goal_rows = 2 * N + 8;
-    L.off_goal = o; o += real_size * 3 * L.goal_rows * epb;
-    L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
-    L.off_metric = o; o += (K > 8 && K < N - 1) ? real_size * N * B : 0;         // neighbour metric rows, [N][B]
-    o = (o + 15) & ~15;
-    L.off_obs = o; o += real_size * obs_dim * B;      // observation staging, row-major, contiguous
-    L.total = (o + 15) & ~15;
-    return L;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K-nearest neighbour observation for one drone (neighborhood_indices quadrotor_multi.py:247-274,
-// extend_obs_space :233-245).  pos/vel of the env's drones are in LDS (component-major, stride B).
-// The N-1 metrics are evaluated once into an LDS row, then K rounds of arg-min (lowest index wins ties,
-// like the stable ordering of argsort on distinct keys).
-// ------------------------------------------------------------------------------------------------
-// neighborhood_indices quadrotor_multi.py:247-274 + extend_obs_space :233-245.
-// pos/vel of the env's drones are in LDS (component-major, stride B).  Measured on MI355X (lone wave per SIMD, every
-// LDS round trip exposed): N <= 8 is fastest with all candidates in registers and rank-by-counting (independent
-// compares); larger N with a streaming sorted top-K list (insertion by compare-exchange).  Both give the first K
-// entries of the stable ascending order of the metric = argsort.
-template <typename real>
-__device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
-                                             real *s_metric, const real mypos[3], const real myvel[3], real *o) {
-    const int K = c.num_neighbors;
-    if (K <= 0) return;
-    if (K == N - 1 || N <= 8) {
-        const bool all_others = (K == N - 1);   // all other drones in index order (:253-254)
-        for (int j0 = 0; j0 < N; j0 += 8) {      // (a single chunk unless all_others with N > 8)
-            real rp[8][3], rv[8][3];
-            int rank[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {        // 48 LDS reads issued before the first use: one round trip
-                const int j = (j0 + u < N) ? j0 + u : N - 1;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
-            }
-            if (all_others) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) rank[u] = (j0 + u < i) ? j0 + u : j0 + u - 1;
-            } else {
-                real mj[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    real rd = M<real>::fmax(norm3<real>(rp[u]), (real)0.01);
-                    real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) * M<real>::rcp(rd);
-                    mj[u] = (u < N && u != i) ? m : (real)3.4e38;
-                    rank[u] = 0;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) rank[u] += (mj[k] < mj[u] || (mj[k] == mj[u] && k < u)) ? 1 : 0;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = j0 + u;
-                if (j < N && j != i && rank[u] < K) {
-                    real *oo = o + rank[u] * 6;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        oo[a] = clipr<real>(rp[u][a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
-                        oo[3 + a] = clipr<real>(rv[u][a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
-                    }
-                }
-            }
-        }
-        return;
-    }
-    if (K <= 8) {
-        // streaming pass over the candidates, 4 per LDS round trip; sorted top-8 (metric, index) list in registers.  A new
-        // candidate is inserted behind entries with an equal metric, i.e. lower index first.
-        real bm[8];
-        int bi[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { bm[k] = (real)3.4e38; bi[k] = 0; }
-        for (int j0 = 0; j0 < N; j0 += 4) {
-            real rp[4][3], rv[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = (j0 + u < N) ? j0 + u : N - 1;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                real rd = M<real>::fmax(norm3<real>(rp[u]), (real)0.01);
-                real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) * M<real>::rcp(rd);
-                m = (j < N && j != i) ? m : (real)3.4e38;
-                int mi = j;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const bool lt = m < bm[k];
-                    const real tm = lt ? bm[k] : m;
-                    const int ti = lt ? bi[k] : mi;
-                    bm[k] = lt ? m : bm[k];
-                    bi[k] = lt ? mi : bi[k];
-                    m = tm; mi = ti;
-                }
-            }
-        }
-        real vals[8][6];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k < K) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { vals[k][a] = s_pos[a * B + base + bi[k]] - mypos[a]; vals[k][3 + a] = s_vel[a * B + base + bi[k]] - myvel[a]; }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k < K) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    o[k * 6 + a] = clipr<real>(vals[k][a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
-                    o[k * 6 + 3 + a] = clipr<real>(vals[k][3 + a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
-                }
-            }
-        }
-        return;
-    }
-    // 8 < K < N-1 (unusual): metrics into this lane's LDS column, then K rounds of arg-min (lowest index wins ties)
-    for (int j = 0; j < N; ++j) {
-        real rp[3] = {s_pos[0 * B + base + j] - mypos[0], s_pos[1 * B + base + j] - mypos[1], s_pos[2 * B + base + j] - mypos[2]};
-        real rv[3] = {s_vel[0 * B + base + j] - myvel[0], s_vel[1 * B + base + j] - myvel[1], s_vel[2 * B + base + j] - myvel[2]};
-        real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
-        real mm = rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) * M<real>::rcp(rd);
-        s_metric[j * B + tid] = (j == i) ? (real)3.4e38 : mm;
-    }
-    uint64_t taken = 1ull << i;
-    for (int k = 0; k < K; ++k) {
-        int best = -1;
-        real bmin = (real)3.4e38;
-        for (int j = 0; j < N; ++j) {
-            real mm = s_metric[j * B + tid];
-            bool better = !(taken >> j & 1) && (best < 0 || mm < bmin);
-            best = better ? j : best;
-            bmin = better ? mm : bmin;
-        }
-        taken |= 1ull << best;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            o[k * 6 + a] = clipr<real>(s_pos[a * B + base + best] - mypos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
-            o[k * 6 + 3 + a] = clipr<real>(s_vel[a * B + base + best] - myvel[a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
-        }
-    }
-}
-
-// get_surround_sdfs obstacles/utils.py:5-27 (obstacle xy of the env in LDS)
-template <typename real>
-__device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o) {
-    const real res = (real)0.1;
-    real gx[3] = {px - res, px, px + res}, gy[3] = {py - res, py, py + res};
-    real mind[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) mind[q] = (real)100;
-    for (int k = 0; k < M_; ++k) {
-        real x = ox[k], y = oy[k];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                real dx = gx[a] - x, dy = gy[b] - y, dist = M<real>::sqrt(dx * dx + dy * dy);
-                mind[a * 3 + b] = dist < mind[a * 3 + b] ? dist : mind[a * 3 + b];
-            }
-    }
-#pragma unroll
-    for (int q = 0; q < 9; ++q) o[q] = mind[q] - c.obst_radius;
-}
-
-// perform_collision_between_drones collisions/quadrotors.py:24-59 on LDS-resident vel/omega (serial per env)
-template <typename real>
-__device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int j, int base, int B, const real *s_pos, real *s_vel, real *s_om) {
-    real p1[3], p2[3], v1[3], v2[3];
-    for (int q = 0; q < 3; ++q) { p1[q] = s_pos[q * B + base + i]; p2[q] = s_pos[q * B + base + j]; v1[q] = s_vel[q * B + base + i]; v2[q] = s_vel[q * B + base + j]; }
-    real n[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    real mag = norm3<real>(n), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
-    for (int q = 0; q < 3; ++q) n[q] /= den;
-    real v1n = dot3<real>(v1, n), v2n = dot3<real>(v2, n);
-    real vc[3] = {(v2n - v1n) * n[0], (v2n - v1n) * n[1], (v2n - v1n) * n[2]};
-    real s1[3] = {vc[0], vc[1], vc[2]}, s2[3] = {-vc[0], -vc[1], -vc[2]};
-    for (int t = 0; t < 3; ++t) {
-        real cons[3], n1[3], n2[3], t1[3], t2[3];
-        rng_normal<real, 3>(key, QS_SITE_DD_N, t * 3 + 0, i, j, cons);
-        rng_normal<real, 3>(key, QS_SITE_DD_N, t * 3 + 1, i, j, n1);
-        rng_normal<real, 3>(key, QS_SITE_DD_N, t * 3 + 2, i, j, n2);
-        for (int q = 0; q < 3; ++q) {
-            real a = (real)0.8 * cons[q] + (real)0.15 * n1[q], b = -((real)0.8 * cons[q]) + (real)0.15 * n2[q];
-            s1[q] = vc[q] + a; s2[q] = -vc[q] + b;
-            t1[q] = v1[q] + s1[q]; t2[q] = v2[q] + s2[q];
-        }
-        if (dot3<real>(t1, n) > (real)0 && (real)0 > dot3<real>(t2, n)) break;
-    }
-    real maxv = M<real>::fmax(norm3<real>(v1), norm3<real>(v2));
-    real dec[2]; rng_uniform<real, 2>(key, QS_SITE_DD_U, 0, i, j, (real)0.2, (real)0.8, dec);
-    compute_new_vel<real>(maxv, v1, s1, dec[0]);
-    compute_new_vel<real>(maxv, v2, s2, dec[1]);
-    uint32_t w[4]; rng_words(key, QS_SITE_DD_W, 0, i, j, w);
-    real u[4] = {(real)-1 + (real)2 * u01<real>(w[0]), (real)-1 + (real)2 * u01<real>(w[1]), (real)-1 + (real)2 * u01<real>(w[2]),
-                 (real)(10.0 * QS_PI_D) + (real)(20.0 * QS_PI_D - 10.0 * QS_PI_D) * u01<real>(w[3])};
-    real dw[3]; compute_new_omega<real>(u, dw);
-    for (int q = 0; q < 3; ++q) {
-        s_vel[q * B + base + i] = v1[q]; s_vel[q * B + base + j] = v2[q];
-        s_om[q * B + base + i] += dw[q]; s_om[q * B + base + j] -= dw[q];
-    }
-}
-
-// rare per-drone responses kept out of line so the hot path stays compact
-template <typename real>
-__device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, const RngKey &key, int i, uint32_t bits, real ox, real oy, real pos[3], real vel[3], real omega[3]) {
-    const Consts<real> &c = *cp;
-    Drone<real> d;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { d.pos[q] = pos[q]; d.vel[q] = vel[q]; d.omega[q] = omega[q]; }
-    if (bits & B_OBST_NEW) collide_obstacle<real>(c, key, i, d, ox, oy);      // collisions/obstacles.py:23-50
-    if (bits & B_WALL_NEW) collide_room<real>(c, key, i, d, true);            // collisions/room.py:6-44
-    if (bits & B_CEIL_NEW) collide_room<real>(c, key, i, d, false);           // collisions/room.py:91-113
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { vel[q] = d.vel[q]; omega[q] = d.omega[q]; }
-}
-
-// full-scenario kernels: per-env scenario state HBM <-> LDS (each drone of the env moves a strided part)
-template <typename real>
-__device__ __forceinline__ void scen_lds_load(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
-    real *sr = (real *)(smem + L.off_sr) + le * SR_COUNT;
-    int *si = (int *)(smem + L.off_si) + le * SI_COUNT;
-    uint64_t *om = (uint64_t *)(smem + L.off_omap) + le * 4;
-    for (int k = i; k < SR_COUNT; k += N) sr[k] = p.scen_real[k * E + e];
-    for (int k = i; k < SI_COUNT; k += N) si[k] = p.scen_int[k * E + e];
-    for (int k = i; k < 4; k += N) om[k] = p.scen_omap[k * E + e];
-}
-template <typename real>
-__device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
-    const real *sr = (const real *)(smem + L.off_sr) + le * SR_COUNT;
-    const int *si = (const int *)(smem + L.off_si) + le * SI_COUNT;
-    const uint64_t *om = (const uint64_t *)(smem + L.off_omap) + le * 4;
-    for (int k = i; k < SR_COUNT; k += N) p.scen_real[k * E + e] = sr[k];
-    for (int k = i; k < SI_COUNT; k += N) p.scen_int[k * E + e] = si[k];
-    for (int k = i; k < 4; k += N) p.scen_omap[k * E + e] = om[k];
-}
-
-// ------------------------------------------------------------------------------------------------
-// Episode reset of the envs whose lanes have `do_reset` set: QuadrotorEnvMulti.reset quadrotor_multi.py:339-411
-// (+ QuadrotorSingle._reset quadrotor_single.py:387-447, obst_generation_given_density quadrotor_multi.py:304-325,
-// scenario.reset()).  Shared by the reset kernel and the tail of the step kernel (auto-reset inside step, :720).
-// Must be entered by the whole workgroup (contains barriers).  Outputs: d / goal (registers), the obs row in LDS,
-// per-env global scratch (obstacle positions, scenario state).  `stale_vel` are the previous episode's final
-// velocities: the first neighbour obs of an episode is computed from them (SURVEY App. A reset quirk).
-// ------------------------------------------------------------------------------------------------
-template <typename real, bool FULL>
-__device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem, int epb, const RngKey &key,
-                                        bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3]) {
-    const Consts<real> &c = *cp;
-    const Ptrs<real> &p = *pp;
-    const LdsLayout &L = *Lp;
-    Drone<real> &d = *dp;
-    const int B = QS_WAVE, N = c.num_agents, E = c.num_envs;
-    real *s_pos = (real *)(smem + L.off_pos), *s_vel = (real *)(smem + L.off_vel), *s_spawn = (real *)(smem + L.off_zax);
-    real *s_goal = (real *)(smem + L.off_goal), *s_obs = (real *)(smem + L.off_obs), *s_obst = (real *)(smem + L.off_obst);
-    real *s_metric = (real *)(smem + L.off_metric);
-    uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
-    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
-    const int M_ = c.num_obstacles;
-    real *myobs = s_obs + tid * c.obs_dim;
-    int *tidx = (int *)(smem + L.off_scratch) + le * QS_RESET_SCRATCH_INTS, *tval = tidx + 64, *prev_row = tidx + 128, *cur_row = tidx + 144;
-
-    // ---- per-env part (one lane): obstacle map + scenario.reset() ----
-    if (do_reset && i == 0) {
-        real *goals = s_goal + le * L.goal_rows * 3;
-        uint32_t have_spawn = 0;
-        uint64_t omap[4] = {0, 0, 0, 0};   // obstacle map bitset, cell id = rid*W + cid
-        const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W;
-        if (FULL) for (int q = 0; q < 4; ++q) ((uint64_t *)(smem + L.off_omap))[le * 4 + q] = 0;
-        if (c.use_obstacles) {
-            // np.random.choice(cells, M, replace=False): partial Fisher-Yates on a virtual pool
-            int nt = 0;
-            for (int k = 0; k < M_; ++k) {
-                int j = k + rng_index<real>(key, QS_SITE_OBST_MAP, k, cells - k);
-                int vk = k, vj = j, pj = -1;
-                for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
-                if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }   // pool[j] = pool[k]; the pick is old pool[j]
-                int id = vj, rid = id / W, cid = id - rid * W;
-                omap[id >> 6] |= 1ull << (id & 63);
-                if (FULL) ((uint64_t *)(smem + L.off_omap))[le * 4 + (id >> 6)] |= 1ull << (id & 63);
-                // cell centre index rid + L*cid (quadrotor_multi.py:321); centres per obstacles/utils.py:47-58
-                int ci = rid + Lr * cid, ii = ci / W, jj = (W - 1) - (ci - ii * W);
-                real ox = (real)ii + (real)0.5 - (real)(Lr / 2), oy = (real)jj + (real)0.5 - (real)(W / 2);
-                p.obst_pos[(size_t)e * M_ + k] = ox;
-                p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + k] = oy;
-                s_obst[(le * 2 + 0) * M_ + k] = ox;
-                s_obst[(le * 2 + 1) * M_ + k] = oy;
-            }
-        }
-        Formation<real> F;
-        if (FULL) {
-            ScenCtx<real> x = {(real *)(smem + L.off_sr) + le * SR_COUNT, (int *)(smem + L.off_si) + le * SI_COUNT,
-                               (uint64_t *)(smem + L.off_omap) + le * 4, goals, s_spawn, B, base, N};
-            scenario_reset_full<real>(c, key, x, tidx);
-            have_spawn = (uint32_t)x.si[SI_HAVE_SPAWN];
-            s_envflag[epb + le] = (uint32_t)x.si[SI_PERIOD];
-            p.scenario_id[e] = x.si[SI_SCEN];
-        } else if (c.scenario == QS_SCENARIO_STATIC_SAME_GOAL) {
-            update_formation<real>(c.scenario, key, 0, N, F);
-            real center[3] = {0, 0, 2};
-            generate_goals<real>(F, N, 1, center, goals, 3);
-        } else if (c.scenario == QS_SCENARIO_O_STATIC_SAME_GOAL) {
-            // obstacles/o_static_same_goal.py:27-48 + o_base.py:69-81,:124-153
-            int nfree = cells - M_;
-            int nt = 0;
-            for (int k = 0; k < N; ++k) {
-                int j = k + rng_index<real>(key, QS_SITE_SCEN, 16 + k, nfree - k);
-                int vk = k, vj = j, pj = -1;
-                for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
-                if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }
-                int seen = 0, cell = 0;   // vj-th free cell in row-major order (np.where(obst_map == 0))
-                for (int id = 0; id < cells; ++id) if (!(omap[id >> 6] >> (id & 63) & 1)) { if (seen == vj) { cell = id; break; } ++seen; }
-                int x = cell / W, y = cell - x * W, index = x + Lr * y, ii = index / W, jj = (W - 1) - (index - ii * W);
-                s_spawn[0 * B + base + k] = (real)ii + (real)0.5 - (real)(Lr / 2);
-                s_spawn[1 * B + base + k] = (real)jj + (real)0.5 - (real)(W / 2);
-                s_spawn[2 * B + base + k] = rng_uniform1<real>(key, QS_SITE_SCEN, 96 + k, 0, 0, (real)1, (real)3);
-            }
-            have_spawn = 1;
-            // max_square_area_center o_base.py:124-153 (two-row dynamic programme)
-            int max_size = 0, cx = 0, cy = 0;
-            for (int q = 0; q < W; ++q) prev_row[q] = (int)(omap[q >> 6] >> (q & 63) & 1);
-            for (int r = 1; r < Lr; ++r) {
-                int id0 = r * W;
-                cur_row[0] = (int)(omap[id0 >> 6] >> (id0 & 63) & 1);
-                for (int q = 1; q < W; ++q) {
-                    int id = r * W + q;
-                    cur_row[q] = 0;
-                    if (!(omap[id >> 6] >> (id & 63) & 1)) {
-                        int m = prev_row[q] < cur_row[q - 1] ? prev_row[q] : cur_row[q - 1];
-                        if (prev_row[q - 1] < m) m = prev_row[q - 1];
-                        cur_row[q] = m + 1;
-                        if (cur_row[q] > max_size) { max_size = cur_row[q]; cx = r - (max_size - 1) / 2; cy = q - (max_size - 1) / 2; }
-                    }
-                }
-                for (int q = 0; q < W; ++q) prev_row[q] = cur_row[q];
-            }
-            int index = cx + W * cy, ii = index / W, jj = (W - 1) - (index - ii * W);
-            real end[3] = {(real)ii + (real)0.5 - (real)(Lr / 2), (real)jj + (real)0.5 - (real)(W / 2), 0};
-            end[2] = rng_uniform1<real>(key, QS_SITE_SCEN, 9, 0, 0, (real)1.5, (real)3);
-            for (int k = 0; k < N; ++k) for (int q = 0; q < 3; ++q) goals[k * 3 + q] = end[q];
-        } else {
-            // swarm_vs_swarm.py:80-94 (reset) + :17-50 (formation_centers) + scenarios/utils.py:170-181 (get_z_value)
-            const int period = draw_period<real>(key, 8, 4.0, 6.0, c.control_freq);
-            p.scen_int[e] = period;
-            s_envflag[epb + le] = (uint32_t)period;
-            update_formation<real>(c.scenario, key, 0, N, F);
-            real box = c.spawn_box, xy[2];
-            rng_uniform<real, 2>(key, QS_SITE_SCEN, 9, 0, 0, -box, box, xy);
-            real z = rng_uniform1<real>(key, QS_SITE_SCEN, 10, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2, zlb = (real)0.25;
-            const int f = F.f;
-            if (f == 3 || f == 1 || f == 2) zlb = F.size + (real)0.25;
-            else if (f == 5 || f == 6) { int rn = N < F.per_layer ? N : F.per_layer, d1, d2; grid_dim(rn, &d1, &d2); zlb = (real)d1 * F.size + (real)0.25; }
-            z = M<real>::fmax(zlb, z);
-            real c1[3] = {xy[0], xy[1], z}, c2[3];
-            real dist = rng_uniform1<real>(key, QS_SITE_SCEN, 11, 0, 0, box / (real)4, box);
-            real phi = rng_uniform1<real>(key, QS_SITE_SCEN, 12, 0, 0, (real)-QS_PI_D, (real)QS_PI_D);
-            real theta = rng_uniform1<real>(key, QS_SITE_SCEN, 13, 0, 0, (real)(-0.5 * QS_PI_D), (real)(0.5 * QS_PI_D));
-            real st, ct, sp, cph; M<real>::sincos(theta, &st, &ct); M<real>::sincos(phi, &sp, &cph);
-            c2[0] = c1[0] + dist * (st * cph); c2[1] = c1[1] + dist * (st * sp); c2[2] = c1[2] + dist * ct;
-            int s = f_suffix(f), ax = (s == 0) ? 2 : ((s == 1) ? 1 : ((s == 2) ? 0 : -1));
-            if (ax >= 0) {
-                real df = c2[ax] - c1[ax];
-                if (M<real>::fabs(df) < F.lo) { real sg = (real)((df > 0) - (df < 0)); c2[ax] = sg * F.lo + c1[ax]; }
-            }
-            for (int q = 0; q < 3; ++q) { p.scen_real[q * E + e] = c1[q]; p.scen_real[(3 + q) * E + e] = c2[q]; }
-            svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, false, goals);
-        }
-        s_envflag[le] = have_spawn;
-    }
-    __syncthreads();
-
-    if (do_reset) {
-        // ---- per-drone part: QuadrotorSingle._reset quadrotor_single.py:387-447 ----
-        real spawn[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            goal[q] = s_goal[(le * L.goal_rows + i) * 3 + q];
-            spawn[q] = s_envflag[le] ? s_spawn[q * B + tid] : goal[q];
-        }
-        real u[3];
-        rng_uniform<real, 3>(key, QS_SITE_SPAWN, 0, i, 0, -c.spawn_box, c.spawn_box, u);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) d.pos[q] = u[q] + spawn[q];
-        if (d.pos[2] < (real)0.75) d.pos[2] = (real)0.75;
-        real xy[3] = {-d.pos[0], -d.pos[1], 0}, n = norm3<real>(xy);
-        if (n >= (real)0.00001) { xy[0] /= n; xy[1] /= n; }
-        for (int t = 0; t < 256; ++t) {   // yaw rejection (:431-434)
-            real th = rng_uniform1<real>(key, QS_SITE_SPAWN_YAW, t, i, 0, (real)-QS_PI_D, (real)QS_PI_D);
-            yaw_rot<real>(th, d.rot);
-            if (!(d.rot[0] * xy[0] + d.rot[3] * xy[1] < (real)0.5)) break;
-        }
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { s_vel[q * B + tid] = stale_vel[q]; s_pos[q * B + tid] = d.pos[q]; d.vel[q] = 0; d.omega[q] = 0; }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { d.rot_damp[q] = 0; d.cmds_damp[q] = 0; }
-        d.flags = F_COL_AGENT_OK | F_COL_OBST_OK | (d.flags & F_SVD_MASK);   // since_last_svd persists (App. A)
-        SensNoise<real> sn;
-        if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 0, sn);
-        self_obs<real>(c, sn, d, goal, myobs);
-    }
-    __syncthreads();
-    if (do_reset) {
-        neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, stale_vel, myobs + c.self_dim);
-        if (c.use_obstacles)
-            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors);
-    }
-}
-
-#define QS_SCEN_FULL 0
-#define QS_MULTI 0
-#include "qs_step_kernel.inc"
-#undef QS_MULTI
-#define QS_MULTI 1
-#include "qs_step_kernel.inc"
-#undef QS_MULTI
-#undef QS_SCEN_FULL
-#define QS_SCEN_FULL 1      // all scenarios incl. `mix` (qs_scenarios.h); scenario state in LDS
-#define QS_MULTI 0
-#include "qs_step_kernel.inc"
-#undef QS_MULTI
-#define QS_MULTI 1
-#include "qs_step_kernel.inc"
-#undef QS_MULTI
-#undef QS_SCEN_FULL
-
-// ------------------------------------------------------------------------------------------------
-// reset kernel (qs_reset): resets the envs flagged in reset_mask
-// ------------------------------------------------------------------------------------------------
-template <typename real, bool FULL>
-__global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c, Ptrs<real> p, LdsLayout L, int epb) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const Consts<real> *cp = &c;
-    const int N = c.num_agents, E = c.num_envs, T = E * N;
-    real *s_obs = (real *)(smem + L.off_obs);
-    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le;
-    const bool in_range = (le < epb) && (e < E);
-    const bool do_reset = in_range && p.reset_mask[e] != 0;
-    const int g = in_range ? e * N + i : 0;
-    RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + (in_range ? e : 0)), in_range ? p.step_ctr[e] : 0u};
-    Drone<real> d;
-    real goal[3] = {0, 0, 0}, stale_vel[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) stale_vel[q] = p.vel[q * T + g];
-    d.flags = p.flags[g];
-    if (FULL && in_range) scen_lds_load<real>(p, L, smem, E, e, le, i, N);
-    if (FULL) __syncthreads();
-    reset_body<real, FULL>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);
-    if (FULL) { __syncthreads(); if (do_reset) scen_lds_store<real>(p, L, smem, E, e, le, i, N); }
-    if (do_reset) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = 0; p.omega[q * T + g] = 0; p.goal[q * T + g] = goal[q]; }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) p.rot[q * T + g] = d.rot[q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { p.rot_damp[q * T + g] = 0; p.cmds_damp[q * T + g] = 0; p.dist_ring[q * T + g] = 0; }
-        p.flags[g] = d.flags;
-        p.pair_mask[g] = 0;
-        p.new_pair_mask[g] = 0;
-        p.obst_hit_idx[g] = -1;
-        const real *myobs = s_obs + tid * c.obs_dim;
-        real *dst = p.obs + (size_t)g * c.obs_dim;
-        for (int q = 0; q < c.obs_dim; ++q) dst[q] = myobs[q];
-        if (i == 0) {
-            for (int q = 0; q < QS_CNT_COUNT; ++q) p.counters[q * E + e] = 0;
-            p.tick[e] = 0;
-            p.unique_col[e] = 0; p.obst_new[e] = 0; p.room_new[e] = 0;
-            p.reset_mask[e] = 0;
-        }
-    }
-}
-
-// state get/set for one env (qs_get_state / qs_set_state)
-template <typename real>
-__global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf, int32_t *tick_io, int set) {
-    const int i = threadIdx.x, T = E * N;
-    if (i >= N) return;
-    const int g = env * N + i;
-    double *s = buf + (size_t)i * QS_STATE_STRIDE;
-    if (!set) {
-        for (int q = 0; q < 3; ++q) { s[q] = p.pos[q * T + g]; s[3 + q] = p.vel[q * T + g]; s[15 + q] = p.omega[q * T + g]; s[32 + q] = p.goal[q * T + g]; }
-        for (int q = 0; q < 9; ++q) s[6 + q] = p.rot[q * T + g];
-        for (int q = 0; q < 4; ++q) { s[18 + q] = p.rot_damp[q * T + g]; s[22 + q] = p.cmds_damp[q * T + g]; s[26 + q] = p.ou[q * T + g]; }
-        uint32_t f = p.flags[g];
-        s[30] = (f & F_ON_FLOOR) ? 1.0 : 0.0;
-        s[31] = (double)((f & F_SVD_MASK) >> F_SVD_SHIFT);
-        if (i == 0) *tick_io = p.tick[env];
-    } else {
-        for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = (real)s[q]; p.vel[q * T + g] = (real)s[3 + q]; p.omega[q * T + g] = (real)s[15 + q]; p.goal[q * T + g] = (real)s[32 + q]; }
-        for (int q = 0; q < 9; ++q) p.rot[q * T + g] = (real)s[6 + q];
-        for (int q = 0; q < 4; ++q) { p.rot_damp[q * T + g] = (real)s[18 + q]; p.cmds_damp[q * T + g] = (real)s[22 + q]; p.ou[q * T + g] = (real)s[26 + q]; }
-        uint32_t f = p.flags[g] & ~(F_ON_FLOOR | F_SVD_MASK);
-        if (s[30] != 0.0) f |= F_ON_FLOOR;
-        f |= ((uint32_t)s[31] & 0xffu) << F_SVD_SHIFT;
-        p.flags[g] = f;
-        if (i == 0 && *tick_io >= 0) p.tick[env] = *tick_io;
-    }
-}
+#include "qs_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -594,6 +39,10 @@ struct qs_handle {
     int obs_dim = 0, epb = 1, blocks = 0;
     LdsLayout lds;
     bool full = false;     // scenario outside the fast set => kernels compiled with QS_SCEN_FULL
+    bool team = false;     // 4 waves per workgroup (qs_step_team.inc) instead of 1 (qs_step_kernel.inc)
+    // config-specialised code object (qs_spec_kernels.hip), when one is cached / could be built
+    hipModule_t spec_mod = nullptr;
+    hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr;
     Consts<float> kf;    // kernel constants, passed by value in the kernarg segment
     Consts<double> kd;
     Ptrs<float> pf;     // same field layout for float/double: only the pointee type differs
@@ -657,6 +106,129 @@ template <typename real> static void fill_consts(const qs_config &c, Consts<real
 }
 
 extern "C" int qs_obs_dim(const qs_config *c);
+static int validate(const qs_config *c);
+
+// ------------------------------------------------------------------------------------------------
+// Config-specialised code objects: header text -> key -> <cache>/qs_<key>.hsaco (built with hipcc --genco)
+// ------------------------------------------------------------------------------------------------
+static bool scenario_is_full(int scenario) {
+    return !(scenario == QS_SCENARIO_STATIC_SAME_GOAL || scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || scenario == QS_SCENARIO_SWARM_VS_SWARM);
+}
+static bool team_default(int blocks, int cus) { return blocks <= 4 * cus; }
+
+static std::string spec_header_text(const qs_config *cfg, int team) {
+    const int rs = cfg->precision == QS_PRECISION_F64 ? 8 : 4, epb = QS_WAVE / cfg->num_agents;
+    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team != 0);
+    std::vector<uint32_t> w;
+    if (rs == 8) { Consts<double> k; fill_consts<double>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0; k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
+                   w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
+    else { Consts<float> k; fill_consts<float>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0; k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
+           w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
+    std::string o = "// generated by quadswarm_hip (spec_header_text): configuration constants as literals\n";
+    char t[256];
+    snprintf(t, sizeof t, "#define QS_SPEC_PRECISION %d\n#define QS_SPEC_TEAM %d\n#define QS_SPEC_FULL %d\n#define QS_SPEC_EPB %d\n", rs, team ? 1 : 0,
+             scenario_is_full(cfg->scenario) ? 1 : 0, epb);
+    o += t;
+    snprintf(t, sizeof t, "struct QsSpecCW { uint32_t w[%zu]; };\n", w.size()); o += t;
+    o += "static constexpr QsSpecCW qs_spec_cw = {{";
+    for (size_t k = 0; k < w.size(); ++k) { snprintf(t, sizeof t, "%s0x%08xu", k ? "," : "", w[k]); o += t; }
+    o += "}};\n";
+    const int *li = (const int *)&L;
+    snprintf(t, sizeof t, "struct QsSpecLW { int w[%zu]; };\n", sizeof L / 4); o += t;
+    o += "static constexpr QsSpecLW qs_spec_lw = {{";
+    for (size_t k = 0; k < sizeof L / 4; ++k) { snprintf(t, sizeof t, "%s%d", k ? "," : "", li[k]); o += t; }
+    o += "}};\n";
+    return o;
+}
+
+static std::string lib_dir() {
+    Dl_info info;
+    if (dladdr((const void *)&qs_obs_dim, &info) && info.dli_fname) {
+        std::string f = info.dli_fname;
+        size_t k = f.rfind('/');
+        return k == std::string::npos ? std::string(".") : f.substr(0, k);
+    }
+    return ".";
+}
+static uint64_t fnv1a(uint64_t h, const std::string &s) { for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ull; } return h; }
+static bool read_file(const std::string &path, std::string &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[65536]; size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+}
+static const char *const kSpecSources[] = {"qs_spec_kernels.hip", "qs_kernels.h", "qs_device.h", "qs_scenarios.h", "qs_step_kernel.inc", "qs_step_team.inc"};
+static const char *const kSpecFlags = "--genco --offload-arch=gfx950 -O3 -std=c++17";
+
+// key = hash(header text, kernel sources, flags); false if the sources are not next to the library
+static bool spec_key(const std::string &header, std::string &key) {
+    uint64_t h = fnv1a(14695981039346656037ull, header);
+    h = fnv1a(h, kSpecFlags);
+    const std::string dir = lib_dir();
+    for (const char *src : kSpecSources) {
+        std::string text;
+        if (!read_file(dir + "/" + src, text)) return false;
+        h = fnv1a(h, text);
+    }
+    std::string pub;
+    if (!read_file(dir + "/../../include/quadswarm.h", pub)) return false;
+    h = fnv1a(h, pub);
+    char t[32];
+    snprintf(t, sizeof t, "%016llx", (unsigned long long)h);
+    key = t;
+    return true;
+}
+static std::string spec_cache_dir() {
+    const char *ev = getenv("QS_SPEC_CACHE");
+    return (ev && ev[0]) ? std::string(ev) : lib_dir() + "/spec_cache";
+}
+static bool file_exists(const std::string &path) { struct stat st; return stat(path.c_str(), &st) == 0 && st.st_size > 0; }
+
+// build <cache>/qs_<key>.hsaco if it is missing; returns its path or "" (reason in g_last_error)
+static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
+    const std::string header = spec_header_text(cfg, team);
+    std::string key;
+    if (!spec_key(header, key)) { g_last_error = "kernel sources not found next to the library"; return ""; }
+    const std::string dir = spec_cache_dir(), out = dir + "/qs_" + key + ".hsaco";
+    if (file_exists(out)) return out;
+    if (!build) { g_last_error = "no cached code object for this configuration"; return ""; }
+    mkdir(dir.c_str(), 0755);
+    char tag[64];
+    snprintf(tag, sizeof tag, ".%ld.tmp", (long)getpid());
+    const std::string hdr = dir + "/qs_" + key + ".h", tmp = out + tag, log = dir + "/qs_" + key + ".log";
+    {
+        FILE *f = fopen((hdr + tag).c_str(), "wb");
+        if (!f) { g_last_error = "cannot write " + hdr; return ""; }
+        fwrite(header.data(), 1, header.size(), f);
+        fclose(f);
+        rename((hdr + tag).c_str(), hdr.c_str());
+    }
+    const char *cc = getenv("HIPCC");
+    const std::string src = lib_dir();
+    std::string cmd = std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src +
+                      "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
+    int rc = system(cmd.c_str());
+    if (rc != 0 || !file_exists(tmp)) { unlink(tmp.c_str()); g_last_error = "specialised kernel build failed, see " + log; return ""; }
+    if (rename(tmp.c_str(), out.c_str()) != 0) { unlink(tmp.c_str()); g_last_error = "cannot move code object into the cache"; return ""; }
+    return out;
+}
+
+// Ahead-of-time build of the code object qs_create() would look for (no GPU needed).  team: 0 / 1, or -1 = the default
+// rule for a 256-CU device.  Writes the path to path_out; returns 0, or < 0 with qs_last_error() set.
+extern "C" int qs_spec_build(const qs_config *cfg, int team, char *path_out, int cap) {
+    if (!cfg) return fail(QS_ERR_INVALID, "null argument");
+    int rc = validate(cfg);
+    if (rc != QS_OK) return rc;
+    const int epb = QS_WAVE / cfg->num_agents, blocks = (cfg->num_envs + epb - 1) / epb;
+    if (team < 0) team = team_default(blocks, 256) ? 1 : 0;
+    std::string path = spec_ensure(cfg, team, true);
+    if (path.empty()) return QS_ERR_UNSUPPORTED;
+    if (path_out) { if ((int)path.size() + 1 > cap) return fail(QS_ERR_INVALID, "buffer too small"); memcpy(path_out, path.c_str(), path.size() + 1); }
+    return QS_OK;
+}
 
 static int validate(const qs_config *c) {
     if (c->num_envs < 1) return fail(QS_ERR_INVALID, "num_envs must be >= 1");
@@ -676,7 +248,7 @@ static int validate(const qs_config *c) {
         if (c->obst_area[0] * c->obst_area[1] - c->num_obstacles < c->num_agents) return fail(QS_ERR_INVALID, "not enough free cells to spawn the drones");
     }
     {
-        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents, qs_obs_dim(c), c->num_obstacles, c->num_neighbors);
+        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents, qs_obs_dim(c), c->num_obstacles, c->num_neighbors, true);
         if (L.total > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "observation staging does not fit the 160 KiB LDS of a CU");
     }
     if (c->sim_steps < 1 || c->ep_len < 1 || c->svd_period < 1 || c->svd_period > 255) return fail(QS_ERR_INVALID, "bad sim_steps/ep_len/svd_period");
@@ -790,9 +362,19 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
     h->obs_dim = qs_obs_dim(cfg);
     h->epb = QS_WAVE / cfg->num_agents;
     h->blocks = (cfg->num_envs + h->epb - 1) / h->epb;
-    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors);
-    h->full = !(cfg->scenario == QS_SCENARIO_STATIC_SAME_GOAL || cfg->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL ||
-                cfg->scenario == QS_SCENARIO_SWARM_VS_SWARM);
+    // Kernel flavour: a team of 4 waves per workgroup shortens the per-step critical path when the batch cannot fill the
+    // chip anyway (<= 4 workgroups per CU); the single-wave kernels do less total work per drone and win on throughput.
+    // QS_TEAM=0/1 in the environment overrides the choice (both flavours produce the same results).
+    {
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        h->team = team_default(h->blocks, cus);
+        const char *ev = getenv("QS_TEAM");
+        if (ev && (ev[0] == '0' || ev[0] == '1')) h->team = ev[0] == '1';
+    }
+    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team);
+    h->full = scenario_is_full(cfg->scenario);
     rc = (h->real_size == 8) ? create_typed<double>(h) : create_typed<float>(h);
     if (rc == QS_OK) {
         if (hipMalloc((void **)&h->d_state_buf, sizeof(double) * QS_MAX_AGENTS * QS_STATE_STRIDE) != hipSuccess ||
@@ -805,6 +387,9 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         const void *fns[] = {(const void *)qs_step_kernel<float>, (const void *)qs_step_kernel<double>, (const void *)qs_rollout_kernel<float>,
                              (const void *)qs_rollout_kernel<double>, (const void *)qs_step_kernel_full<float>, (const void *)qs_step_kernel_full<double>,
                              (const void *)qs_rollout_kernel_full<float>, (const void *)qs_rollout_kernel_full<double>,
+                             (const void *)qs_step_team<float>, (const void *)qs_step_team<double>, (const void *)qs_rollout_team<float>,
+                             (const void *)qs_rollout_team<double>, (const void *)qs_step_team_full<float>, (const void *)qs_step_team_full<double>,
+                             (const void *)qs_rollout_team_full<float>, (const void *)qs_rollout_team_full<double>,
                              (const void *)qs_reset_kernel<float, false>, (const void *)qs_reset_kernel<double, false>,
                              (const void *)qs_reset_kernel<float, true>, (const void *)qs_reset_kernel<double, true>};
         for (const void *fn : fns)
@@ -813,14 +398,43 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
                 return fail(QS_ERR_HIP, "cannot raise dynamic LDS limit");
             }
     }
+    // Config-specialised kernels.  QS_SPEC = "jit" (default): use the cached code object of this configuration, building it
+    // first if needed (one hipcc run, ~20 s, cached next to the library); "cache": use it only if it is already there;
+    // "off": always the generic kernels.  Any failure falls back to the generic kernels (same results, slower).
+    {
+        const char *ev = getenv("QS_SPEC");
+        const std::string mode = (ev && ev[0]) ? ev : "jit";
+        if (mode != "off" && mode != "0" && h->lds.total <= 64 * 1024) {
+            const std::string path = spec_ensure(cfg, h->team ? 1 : 0, mode == "jit");
+            if (!path.empty()) {
+                if (hipModuleLoad(&h->spec_mod, path.c_str()) == hipSuccess &&
+                    hipModuleGetFunction(&h->spec_step, h->spec_mod, "qs_spec_step") == hipSuccess &&
+                    hipModuleGetFunction(&h->spec_rollout, h->spec_mod, "qs_spec_rollout") == hipSuccess &&
+                    hipModuleGetFunction(&h->spec_reset, h->spec_mod, "qs_spec_reset") == hipSuccess) {
+                    // specialised kernels in use
+                } else {
+                    (void)hipGetLastError();
+                    if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
+                    h->spec_step = h->spec_rollout = h->spec_reset = nullptr;
+                    fprintf(stderr, "quadswarm_hip: cannot load %s, using the generic kernels\n", path.c_str());
+                }
+            } else if (mode == "jit") {
+                fprintf(stderr, "quadswarm_hip: %s; using the generic kernels\n", g_last_error.c_str());
+            }
+        }
+    }
     *out = h;
     return QS_OK;
 }
+
+// 1 if the handle runs config-specialised kernels, 0 if the generic ones
+int qs_is_specialized(qs_handle *h) { return (h && h->spec_step) ? 1 : 0; }
 
 int qs_destroy(qs_handle *h) {
     if (!h) return QS_OK;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
+    if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
     for (void *q : h->allocs) (void)hipFree(q);
     if (h->d_state_buf) (void)hipFree(h->d_state_buf);
     if (h->d_tick_io) (void)hipFree(h->d_tick_io);
@@ -833,6 +447,12 @@ int qs_destroy(qs_handle *h) {
 }
 
 static int launch_reset(qs_handle *h, hipStream_t s) {
+    if (h->spec_reset) {
+        Ptrs<double> pd; memcpy(&pd, &h->pf, sizeof pd);
+        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&h->pf, &h->lds, &h->epb};
+        HIP_TRY(hipModuleLaunchKernel(h->spec_reset, h->blocks, 1, 1, QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
+        return QS_OK;
+    }
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
         if (h->full) hipLaunchKernelGGL((qs_reset_kernel<double, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
@@ -870,16 +490,30 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
         ++h->events_used;
         HIP_TRY(hipEventRecord(e0, s));
     }
-#define QS_LAUNCH(KERNEL, CONSTS, PTRS, TYPE, ...) hipLaunchKernelGGL(KERNEL<TYPE>, dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, CONSTS, PTRS, \
-                                                                    (const TYPE *)actions, h->lds, h->epb, ##__VA_ARGS__)
+    if (h->spec_step) {
+        Ptrs<double> pd; memcpy(&pd, &h->pf, sizeof pd);
+        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&h->pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
+        HIP_TRY(hipModuleLaunchKernel(ksteps == 1 ? h->spec_step : h->spec_rollout, h->blocks, 1, 1, h->team ? QS_TEAM_THREADS : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
+        if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
+        return QS_OK;
+    }
+#define QS_LAUNCH(KERNEL, THREADS, CONSTS, PTRS, TYPE, ...) hipLaunchKernelGGL(KERNEL<TYPE>, dim3(h->blocks), dim3(THREADS), h->lds.total, s, CONSTS, PTRS, \
+                                                                             (const TYPE *)actions, h->lds, h->epb, ##__VA_ARGS__)
+#define QS_LAUNCH_ALL(CONSTS, PTRS, TYPE) do { \
+        if (h->team) { \
+            if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); } \
+            else { if (h->full) QS_LAUNCH(qs_rollout_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); else QS_LAUNCH(qs_rollout_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); } \
+        } else { \
+            if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_kernel_full, QS_WAVE, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_kernel, QS_WAVE, CONSTS, PTRS, TYPE); } \
+            else { if (h->full) QS_LAUNCH(qs_rollout_kernel_full, QS_WAVE, CONSTS, PTRS, TYPE, ksteps); else QS_LAUNCH(qs_rollout_kernel, QS_WAVE, CONSTS, PTRS, TYPE, ksteps); } \
+        } } while (0)
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
-        if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_kernel_full, h->kd, p, double); else QS_LAUNCH(qs_step_kernel, h->kd, p, double); }
-        else { if (h->full) QS_LAUNCH(qs_rollout_kernel_full, h->kd, p, double, ksteps); else QS_LAUNCH(qs_rollout_kernel, h->kd, p, double, ksteps); }
+        QS_LAUNCH_ALL(h->kd, p, double);
     } else {
-        if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_kernel_full, h->kf, h->pf, float); else QS_LAUNCH(qs_step_kernel, h->kf, h->pf, float); }
-        else { if (h->full) QS_LAUNCH(qs_rollout_kernel_full, h->kf, h->pf, float, ksteps); else QS_LAUNCH(qs_rollout_kernel, h->kf, h->pf, float, ksteps); }
+        QS_LAUNCH_ALL(h->kf, h->pf, float);
     }
+#undef QS_LAUNCH_ALL
 #undef QS_LAUNCH
     HIP_TRY(hipGetLastError());
     if (h->profiling) HIP_TRY(hipEventRecord(e1, s));

@@ -14,7 +14,8 @@ from . import config as qcfg
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("QS_LIB", os.path.join(CSRC, "libquadswarm_hip.so"))   # QS_LIB: A/B builds (tools only)
-SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_device.h"),
+SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_kernels.h"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_step_team.inc"),
+           os.path.join(CSRC, "qs_device.h"),
            os.path.join(CSRC, "qs_scenarios.h"),
            os.path.join(os.path.dirname(HERE), "include", "quadswarm.h")]
 
@@ -73,6 +74,8 @@ def lib():
         L.qs_check_errors.argtypes = [vp]
         L.qs_set_profiling.argtypes = [vp, C.c_int32]
         L.qs_get_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.qs_spec_build.argtypes = [C.POINTER(qcfg.QsConfig), C.c_int, C.c_char_p, C.c_int]
+        L.qs_is_specialized.argtypes = [vp]
         if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
             raise RuntimeError("qs_config layout mismatch between config.py and libquadswarm_hip.so")
         _lib = L
@@ -82,11 +85,21 @@ def lib():
 EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
                     "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_check_errors", "qs_set_profiling",
-                    "qs_get_kernel_time"]
+                    "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized"]
 
 
 class QsError(RuntimeError):
     pass
+
+
+def spec_build(cfg, team=-1):
+    """Ahead-of-time build of the config-specialised code object of `cfg` (hipcc --genco; no GPU needed).
+    Returns the path of the cached .hsaco.  team: 1 = 4-wave kernels, 0 = single-wave, -1 = qs_create's default."""
+    buf = C.create_string_buffer(4096)
+    rc = lib().qs_spec_build(C.byref(cfg), team, buf, len(buf))
+    if rc != QS_OK:
+        raise QsError(f"qs_spec_build failed ({rc}): {lib().qs_last_error().decode()}")
+    return buf.value.decode()
 
 
 def _check(rc):
@@ -179,6 +192,11 @@ class Stepper:
 
     def set_profiling(self, enable):
         _check(lib().qs_set_profiling(self._h, int(enable)))
+
+    @property
+    def specialized(self):
+        """True when the handle runs a config-specialised code object (QS_SPEC, include/quadswarm.h)."""
+        return bool(lib().qs_is_specialized(self._h))
 
     def kernel_time(self):
         ms, n = C.c_double(0), C.c_int64(0)

@@ -10,8 +10,9 @@ import numpy as np
 from quad_swarm_rl_amd import config as qcfg, native
 
 lib_t = os.path.join(native.CSRC, "libquadswarm_hip_timing.so")
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DQS_TIMING",
-                       "-o", lib_t, native.SOURCES[0]])
+if not os.path.exists(lib_t) or any(os.path.getmtime(f) > os.path.getmtime(lib_t) for f in native.SOURCES):
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DQS_TIMING",
+                           "-o", lib_t, native.SOURCES[0]])
 native.LIB_PATH = lib_t
 import bench
 args = sys.argv[1:]
@@ -28,9 +29,17 @@ L = native.lib()
 L.qs_debug_timing.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 st.reset()
 rng = np.random.RandomState(0)
-names = ["loads-issue", "ou-rng", "2 substeps", "reward", "self-obs", "publish+pairscan", "ballots/reward2", "downwash", "responses/scen",
-         "final obs+nbr", "reset-check", "barrier", "obs copy-out", "state stores"]
-acc = np.zeros(13)
+team = os.environ.get("QS_TEAM", "1") != "0" and st.T // cfg.num_agents <= 1024 * (64 // cfg.num_agents)
+if team:
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14, 15, 10, 11, 12, 13]
+    names = ["loads+ou-rng", "ou update", "2 substeps", "publish+reward", "wait barrier 1", "pair share (+wait barrier 2)", "combine/ballots/reward2",
+             "downwash", "responses/scen", "publish vel + barrier 3", "metrics + barrier 4", "ranks/nbr rows + barrier 5", "reset-check",
+             "barrier 6 + obs copy-out", "outputs + state stores"]
+else:
+    order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14, 15, 16, 10, 11, 12, 13]
+    names = ["loads+rng", "ou update", "2 substeps", "reward", "self-obs", "publish+pairscan", "ballots/reward2", "downwash", "responses/scen",
+             "publish vel", "refresh self-obs", "barrier", "neighbour+sdf obs", "reset-check", "barrier + obs copy-out", "outputs + state stores"]
+acc = np.zeros(len(order) - 1)
 n = 0
 for t in range(60):
     st.from_host("actions", rng.uniform(-1, 1, size=(st.T, 4)))
@@ -38,14 +47,11 @@ for t in range(60):
     st.sync()
     buf = (C.c_ulonglong * 32)()
     L.qs_debug_timing(st._h, buf)
-    ts = np.array(buf[:14], dtype=np.float64)
-    extra = np.array(buf[14:17], dtype=np.float64)
+    ts = np.array([buf[k] for k in order], dtype=np.float64)
     if t >= 10:
         acc += np.diff(ts)
-        ex = ex + np.array([extra[0] - ts[9], extra[1] - extra[0], extra[2] - extra[1], ts[10] - extra[2]]) if t > 10 else np.array([extra[0] - ts[9], extra[1] - extra[0], extra[2] - extra[1], ts[10] - extra[2]])
         n += 1
 acc /= n
-print(f"workload {wl} {args[1:]}: per-phase shader cycles (workgroup 0, lane 0), total {acc.sum():.0f}")
+print(f"workload {wl} {args[1:]} team={team}: per-phase s_memtime ticks (workgroup 0, wave 0 lane 0), total {acc.sum():.0f}")
 for nm, v in zip(names, acc):
-    print(f"  {nm:22s} {v:9.0f}")
-print("  final-obs split: publish vel %.0f | refresh self-obs %.0f | barrier %.0f | neighbour+sdf obs %.0f" % tuple(ex / n))
+    print(f"  {nm:32s} {v:9.0f}")
