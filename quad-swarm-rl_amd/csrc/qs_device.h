@@ -30,7 +30,9 @@ enum : uint32_t { B_OBST_HIT = 1, B_OBST_NEW = 2, B_FLOOR = 4, B_WALL_NEW = 8, B
 // ------------------------------------------------------------------------------------------------
 template <typename real> struct M;
 template <> struct M<float> {
-    static __device__ __forceinline__ float sqrt(float x) { return __fsqrt_rn(x); }
+    // v_sqrt_f32: 1 ulp, one instruction (the correctly rounded sqrtf expands to ~12 with its denormal scaling); the fp32
+    // path is specified to 1e-5 and takes ~40 square roots per drone-step (norms, distances)
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float sin(float x) { return sinf(x); }
     static __device__ __forceinline__ float cos(float x) { return cosf(x); }
     static __device__ __forceinline__ void sincos(float x, float *s, float *c) { sincosf(x, s, c); }
@@ -79,6 +81,8 @@ template <> struct M<double> {
 };
 
 template <typename real> __device__ __forceinline__ real clipr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// fp32: one v_med3_f32 instead of two compare + select pairs (identical for every non-NaN x when lo <= hi)
+template <> __device__ __forceinline__ float clipr<float>(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 template <typename real> __device__ __forceinline__ real norm3(const real v[3]) { return M<real>::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 template <typename real> __device__ __forceinline__ real dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 

@@ -167,6 +167,7 @@ static const char *const kSpecFlags = "--genco --offload-arch=gfx950 -O3 -std=c+
 static bool spec_key(const std::string &header, std::string &key) {
     uint64_t h = fnv1a(14695981039346656037ull, header);
     h = fnv1a(h, kSpecFlags);
+    if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools_phase_timing.py
     const std::string dir = lib_dir();
     for (const char *src : kSpecSources) {
         std::string text;
@@ -208,7 +209,7 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     }
     const char *cc = getenv("HIPCC");
     const std::string src = lib_dir();
-    std::string cmd = std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src +
+    std::string cmd = std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src +
                       "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
     int rc = system(cmd.c_str());
     if (rc != 0 || !file_exists(tmp)) { unlink(tmp.c_str()); g_last_error = "specialised kernel build failed, see " + log; return ""; }

@@ -9,11 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from quad_swarm_rl_amd import config as qcfg, native
 
-lib_t = os.path.join(native.CSRC, "libquadswarm_hip_timing.so")
-if not os.path.exists(lib_t) or any(os.path.getmtime(f) > os.path.getmtime(lib_t) for f in native.SOURCES):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DQS_TIMING",
-                           "-o", lib_t, native.SOURCES[0]])
-native.LIB_PATH = lib_t
+# the phase stamps are compiled into the config-specialised code object (QS_SPEC=jit is the default)
+os.environ["QS_SPEC_EXTRA_FLAGS"] = "-DQS_TIMING"
+os.environ.setdefault("QS_SPEC", "jit")
 import bench
 args = sys.argv[1:]
 wl = args[0] if args else "c2"
@@ -30,6 +28,7 @@ L.qs_debug_timing.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 st.reset()
 rng = np.random.RandomState(0)
 team = os.environ.get("QS_TEAM", "1") != "0" and st.T // cfg.num_agents <= 1024 * (64 // cfg.num_agents)
+assert st.specialized
 if team:
     order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14, 15, 10, 11, 12, 13]
     names = ["loads+ou-rng", "ou update", "2 substeps", "publish+reward", "wait barrier 1", "pair share (+wait barrier 2)", "combine/ballots/reward2",
