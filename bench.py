@@ -74,6 +74,19 @@ def cpu_baseline(workload, seconds):
                        f"{threads} threads")
 
 
+def pmc_traffic(workload, num_envs, kernel):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC pass (profiles/r01_pmc_traffic.json, produced by
+    tools_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units and gfx950 corrections of MI355X_MICROARCH.md);
+    None when no measurement of this workload / batch / kernel is on file."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(f"{workload}:{num_envs}:{kernel}")
+        return rec["fetch_bytes"] + rec["write_bytes"] if rec else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,12 +169,18 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    # HIP events on the launch stream (= torch's current stream) bracket the timed region: device-side duration of the K
+    # back-to-back step-kernel launches, i.e. the average launch-to-launch duration rocprofv3 --kernel-trace also reports
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(stream)
     run(args.steps, args.warmup)
+    ev1.record(stream)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    region_kernel_ms = ev0.elapsed_time(ev1) / args.steps
     if dist is not None:
         tmax = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -182,7 +201,7 @@ def main():
         dt = time.perf_counter() - t0
         rollout = {"steps_per_launch": kk, "value": T * 2 * reps * kk / dt, "unit": "env-steps/s", "us_per_step": 1e6 * dt / (reps * kk)}
 
-    # dominant-kernel duration: HIP events recorded on the launch stream around every step-kernel launch
+    # second view of the same kernel: a HIP event pair around every single launch (includes the event packets themselves)
     st.set_profiling(True)
     for t in range(args.profile_steps):
         st.step(aptr + (t % ring) * astride, stream=stream)
@@ -192,7 +211,7 @@ def main():
     if rank == 0:
         value = world * T * 2 * args.steps / elapsed
         algo = ALGO_BYTES_PER_DRONE_STEP[args.workload]
-        achieved = algo * T / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        achieved = algo * T / (region_kernel_ms * 1e-3) / 1e9 if region_kernel_ms > 0 else 0.0
         out = {
             "metric": "env-steps/s (drones x envs x sim_steps)", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -205,7 +224,9 @@ def main():
                        "open_loop_rollout": rollout, "rew_info": bool(args.rew_info),
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "qs_step_kernel<float>", "kernel_avg_us": kernel_ms * 1e3, "kernel_launches": launches,
+                         "traffic": pmc_traffic(args.workload, E, st.kernel_name), "kernel": st.kernel_name,
+                         "kernel_flavor": ("config-specialised, " if st.specialized else "generic, ") + ("4 waves per workgroup" if st.team else "1 wave per workgroup"), "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": args.steps,
+                         "kernel_avg_us_event_pair_per_launch": kernel_ms * 1e3, "event_pair_launches": launches,
                          "algorithmic_bytes_per_launch": algo * T},
         }
         if world == 1 and args.cpu_seconds > 0:

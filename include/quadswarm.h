@@ -231,6 +231,8 @@ int qs_get_kernel_time(qs_handle *h, double *avg_ms, int64_t *launches);
  */
 int qs_spec_build(const qs_config *cfg, int team, char *path_out, int cap);
 int qs_is_specialized(qs_handle *h);
+/* which step kernel the handle launches: bit 0 = config-specialised, bit 1 = 4-wave team kernels, bit 2 = full scenario set */
+int qs_kernel_flavor(qs_handle *h);
 
 /*
  * Random numbers.  Every stochastic term of the reference is drawn from a

@@ -285,7 +285,7 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
     }
     // rare re-orthogonalisation (:546-551); counter in flags bits 16..23
     uint32_t svd = ((d.flags & F_SVD_MASK) >> F_SVD_SHIFT) + 1;
-    if ((int)svd >= c.svd_period) { polar_rotation<real>(R); svd = 0; }
+    if (__builtin_expect((int)svd >= c.svd_period, 0)) { polar_rotation<real>(R); svd = 0; }   // once in svd_period sub-steps
     d.flags = (d.flags & ~F_SVD_MASK) | (svd << F_SVD_SHIFT);
     // omega update (:555-560)
     real Iw[3] = {c.inertia[0] * om[0], c.inertia[1] * om[1], c.inertia[2] * om[2]};
@@ -332,7 +332,7 @@ __device__ __forceinline__ void substep(const Consts<real> &c, const RngKey &key
 #pragma unroll
             for (int q = 0; q < 3; ++q) { d.vel[q] = 0; om[q] = 0; }
             real theta;
-            if (R[8] < (real)0) {
+            if (__builtin_expect(R[8] < (real)0, 0)) {
                 if (c.floor_mode != QS_FLOOR_NUMPY) {
                     theta = rng_uniform1<real>(key, QS_SITE_FLOOR_YAW, sub * 64, drone, 0, (real)-QS_PI_D, (real)QS_PI_D);
                     yaw_rot<real>(theta, R);

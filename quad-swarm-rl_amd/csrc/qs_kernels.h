@@ -75,7 +75,8 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     L.goal_rows = 2 * N + 8;
     L.off_goal = o; o += real_size * 3 * L.goal_rows * epb;
     L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
-    L.off_metric = o; o += ((team ? K > 0 : K > 8) && K < N - 1) ? real_size * N * B : 0;   // neighbour metric rows, [N][B]
+    // neighbour metric rows [N][B]; team kernels with N > 8: four sorted top-8 lists, metrics [32][B] + indices [32][B]
+    L.off_metric = o; o += ((team ? K > 0 : K > 8) && K < N - 1) ? ((team && N > 8) ? ((real_size + 4) * 32 > real_size * N ? (real_size + 4) * 32 : real_size * N) * B : real_size * N * B) : 0;
     o = (o + 15) & ~15;
     if (team) {   // exchange rows of the 4-wave kernels
         L.off_t_col = o; o += 8 * B;

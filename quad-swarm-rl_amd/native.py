@@ -76,6 +76,7 @@ def lib():
         L.qs_get_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.qs_spec_build.argtypes = [C.POINTER(qcfg.QsConfig), C.c_int, C.c_char_p, C.c_int]
         L.qs_is_specialized.argtypes = [vp]
+        L.qs_kernel_flavor.argtypes = [vp]
         if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
             raise RuntimeError("qs_config layout mismatch between config.py and libquadswarm_hip.so")
         _lib = L
@@ -85,7 +86,7 @@ def lib():
 EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
                     "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_check_errors", "qs_set_profiling",
-                    "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized"]
+                    "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor"]
 
 
 class QsError(RuntimeError):
@@ -197,6 +198,20 @@ class Stepper:
     def specialized(self):
         """True when the handle runs a config-specialised code object (QS_SPEC, include/quadswarm.h)."""
         return bool(lib().qs_is_specialized(self._h))
+
+    @property
+    def team(self):
+        """True when the handle launches the 4-wave team kernels (small batches), False for the single-wave ones."""
+        return bool(lib().qs_kernel_flavor(self._h) & 2)
+
+    @property
+    def kernel_name(self):
+        """Name of the step kernel this handle launches (as it appears in a rocprofv3 kernel trace)."""
+        fl = lib().qs_kernel_flavor(self._h)
+        if fl & 1:
+            return "qs_spec_step"
+        real = "float" if self.real_size == 4 else "double"
+        return ("qs_step_team" if fl & 2 else "qs_step_kernel") + ("_full" if fl & 4 else "") + f"<{real}>"
 
     def kernel_time(self):
         ms, n = C.c_double(0), C.c_int64(0)

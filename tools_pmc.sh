@@ -1,24 +1,32 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> [bench args...]   (run on the GPU box through gpurun); PMC passes are separate runs with
-# --kernel-trace only, as the node pool requires.
-tag=$1; shift
+# usage: tools_pmc.sh <tag> <workload> [bench args...]   (run on the GPU box through gpurun)
+# rocprofv3 PMC passes of the step kernel, each in its own run with --kernel-trace only (the node pool refuses PMC together
+# with other trace domains).  Writes gpurun_out/pmc_<tag>_summary.txt and gpurun_out/pmc_<tag>_traffic.json
+# (per-launch means; FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3).
+tag=$1; wl=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for pmc in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
+for pmc in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   n=$(echo $pmc | cut -c1-14 | tr " " "_")
-  rocprofv3 --kernel-trace --pmc $pmc -d $R/gpurun_out/pmc_${tag}_$n -o p --output-format csv -- python $R/bench.py --steps 200 --warmup 20 --profile-steps 10 --cpu-seconds 0 "$@" > /dev/null 2> $R/gpurun_out/pmc_${tag}_$n.err
+  rocprofv3 --kernel-trace --pmc $pmc -d $R/gpurun_out/pmc_${tag}_$n -o p --output-format csv -- python $R/bench.py --workload $wl --steps 200 --warmup 20 --profile-steps 10 --rollout-steps 0 --cpu-seconds 0 "$@" > $R/gpurun_out/pmc_${tag}_$n.out 2> $R/gpurun_out/pmc_${tag}_$n.err
 done
 python - <<PY
-import csv, collections, glob
-out=["# PMC summary of qs_step_kernel, tag ${tag}, args: $@ (per launch means)"]
+import csv, collections, glob, json
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sorted(glob.glob("$R/gpurun_out/pmc_${tag}_*/p_counter_collection.csv")):
-    rows=list(csv.DictReader(open(d)))
-    acc=collections.defaultdict(list)
-    for r in rows:
-        if 'qs_step_kernel' in r['Kernel_Name']:
-            acc[r['Counter_Name']].append(float(r['Counter_Value']))
-    for k,v in sorted(acc.items()):
-        out.append(f'{k:28s} launches={len(v):4d} mean={sum(v)/len(v):16.1f}')
-open("$R/gpurun_out/pmc_${tag}_summary.txt","w").write("\n".join(out)+"\n")
-print("\n".join(out))
+    for r in csv.DictReader(open(d)):
+        k = r['Kernel_Name']
+        if k.startswith('qs_spec_step') or k.startswith('void qs_step') or k.startswith('qs_step'):
+            acc[k.split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+out = ["# rocprofv3 PMC summary, tag ${tag}: bench.py --workload $wl $@ (per-launch means of the step kernel)"]
+traffic = {}
+for k, cs in acc.items():
+    out.append(f"kernel {k}")
+    for c, v in sorted(cs.items()):
+        out.append(f"  {c:24s} launches={len(v):4d} mean={sum(v)/len(v):16.1f}")
+    if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
+        traffic[k] = {"fetch_bytes": 1024 * sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE']), "write_bytes": 1024 * sum(cs['WRITE_SIZE']) / len(cs['WRITE_SIZE'])}
+open("$R/gpurun_out/pmc_${tag}_summary.txt", "w").write("\n".join(out) + "\n")
+json.dump(traffic, open("$R/gpurun_out/pmc_${tag}_traffic.json", "w"), indent=1)
+print("\n".join(out)); print(json.dumps(traffic))
 PY
