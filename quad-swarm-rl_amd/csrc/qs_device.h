@@ -80,6 +80,16 @@ template <> struct M<double> {
     }
 };
 
+// NaN / overflow test of the reward (quadrotor_single.py:87-90) on the bit pattern: fp32 config-specialised objects are
+// built with -ffast-math, under which `x != x` may be folded away
+__device__ __forceinline__ bool not_finite(float x) {
+    uint32_t b = __float_as_uint(x);
+    asm volatile("" : "+v"(b));   // opaque: otherwise the no-NaN assumption travels through the bitcast and folds the test to false
+    return (b & 0x7fffffffu) > 0x7f61b1e6u;   // |x| > 3.0e38 (0x7f61b1e6), which includes Inf and every NaN pattern
+}
+__device__ __forceinline__ bool not_finite(double x) {
+    return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull || fabs(x) > 3.0e38;
+}
 template <typename real> __device__ __forceinline__ real clipr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 // fp32: one v_med3_f32 instead of two compare + select pairs (identical for every non-NaN x when lo <= hi)
 template <> __device__ __forceinline__ float clipr<float>(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }

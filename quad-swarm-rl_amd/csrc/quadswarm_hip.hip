@@ -162,11 +162,16 @@ static bool read_file(const std::string &path, std::string &out) {
 }
 static const char *const kSpecSources[] = {"qs_spec_kernels.hip", "qs_kernels.h", "qs_device.h", "qs_scenarios.h", "qs_step_kernel.inc", "qs_step_team.inc"};
 static const char *const kSpecFlags = "--genco --offload-arch=gfx950 -O3 -std=c++17";
+// fp32 objects only (the production precision, specified to 1e-5): reassociation / finite-math simplifications are worth ~8 %
+// of the step; the SLP vectoriser's v_pk_* pairs cost more register shuffling than they save on this code.  The f64 parity
+// instantiation and the generic library keep strict IEEE semantics.
+static const char *const kSpecFlagsF32 = "-ffast-math -fno-slp-vectorize";
 
 // key = hash(header text, kernel sources, flags); false if the sources are not next to the library
 static bool spec_key(const std::string &header, std::string &key) {
     uint64_t h = fnv1a(14695981039346656037ull, header);
     h = fnv1a(h, kSpecFlags);
+    h = fnv1a(h, kSpecFlagsF32);
     if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools_phase_timing.py
     const std::string dir = lib_dir();
     for (const char *src : kSpecSources) {
@@ -209,7 +214,7 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     }
     const char *cc = getenv("HIPCC");
     const std::string src = lib_dir();
-    std::string cmd = std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src +
+    std::string cmd = std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src +
                       "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
     int rc = system(cmd.c_str());
     if (rc != 0 || !file_exists(tmp)) { unlink(tmp.c_str()); g_last_error = "specialised kernel build failed, see " + log; return ""; }

@@ -83,3 +83,21 @@ def test_invalid_arguments_rejected_before_touching_the_gpu():
     cfg.scenario = 14            # QS_SCENARIO_COUNT: run_away / o_ep_rand_bezier and anything unknown are unsupported
     assert L.qs_create(C.byref(cfg), 0, C.byref(h)) == -4
     assert L.qs_step(None, None, None) == -1
+
+
+def test_spec_build_without_gpu(tmp_path, monkeypatch):
+    """qs_spec_build compiles the config-specialised code object on a machine without a GPU; the cache key follows the
+    configuration constants, not the run-time arguments (reward coefficients, seed, env offset, env count)."""
+    monkeypatch.setenv("QS_SPEC_CACHE", str(tmp_path))
+    kw = dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True)
+    p1 = native.spec_build(qcfg.make_config(num_envs=16, seed=1, **kw))
+    assert p1.startswith(str(tmp_path)) and p1.endswith(".hsaco") and os.path.getsize(p1) > 10000
+    t1 = os.path.getmtime(p1)
+    p2 = native.spec_build(qcfg.make_config(num_envs=64, seed=99, env_id_offset=5, rew_coeff=dict(quadcol_bin=3.0), **kw))
+    assert p2 == p1 and os.path.getmtime(p2) == t1                    # cache hit: nothing rebuilt
+    p3 = native.spec_build(qcfg.make_config(num_envs=16, seed=1, **dict(kw, neighbor_visible_num=3)))
+    assert p3 != p1                                                   # another configuration, another object
+    assert native.spec_build(qcfg.make_config(num_envs=16, seed=1, **kw), team=0) != p1   # kernel flavour is part of the key
+    blob = open(p1, "rb").read()
+    for sym in (b"qs_spec_step", b"qs_spec_rollout", b"qs_spec_reset"):
+        assert sym in blob

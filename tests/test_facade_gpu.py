@@ -130,3 +130,34 @@ def test_mix_scenario_names_follow_the_episode():
             seen.add(before)
     assert len(seen) >= 3, seen
     env.close()
+
+
+def test_specialised_and_generic_kernels_agree(monkeypatch):
+    """QS_SPEC=jit (default) runs the config-specialised code object, QS_SPEC=off the generic kernels, QS_TEAM picks the
+    1-wave / 4-wave flavour: all four combinations give the same f64 trajectory (to reassociation-level rounding)."""
+    from quad_swarm_rl_amd import config as qcfg, native
+    kw = dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+              collision_falloff_radius=4.0, rew_coeff=dict(quadcol_bin=5.0, quadcol_bin_smooth_max=10.0), ep_time=0.2)
+    rng = np.random.RandomState(5)
+    acts = rng.uniform(-1, 1, size=(30, 6 * 8, 4))
+    runs = {}
+    for spec in ("jit", "off"):
+        for team in ("1", "0"):
+            monkeypatch.setenv("QS_SPEC", spec)
+            monkeypatch.setenv("QS_TEAM", team)
+            st = native.Stepper(qcfg.make_config(num_envs=6, seed=3, precision="f64", **kw))
+            assert st.specialized == (spec == "jit") and st.team == (team == "1")
+            assert st.kernel_name == ("qs_spec_step" if spec == "jit" else ("qs_step_team<double>" if team == "1" else "qs_step_kernel<double>"))
+            st.reset()
+            out = [st.to_host("obs").copy()]
+            for a in acts:
+                st.from_host("actions", a)
+                st.step()
+                out += [st.to_host("obs").copy(), st.to_host("reward").copy(), st.to_host("done").copy()]
+            st.check_errors()
+            st.close()
+            runs[(spec, team)] = out
+    ref = runs[("off", "0")]
+    for key, out in runs.items():
+        for a, b in zip(ref, out):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-9, err_msg=str(key))
