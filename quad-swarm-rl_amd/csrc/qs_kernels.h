@@ -48,15 +48,18 @@ template <typename real> struct Ptrs {
 
 #ifdef QS_TIMING
 #define QS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.timing[k] = clock64(); } while (0)
+// helper waves of the team kernels: stamp k of wave w (1..3) lands in timing[32*w + k]
+#define QS_STAMPW(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x >= 64) p.timing[32 * (threadIdx.x >> 6) + (k)] = clock64(); } while (0)
 #else
 #define QS_STAMP(k) do { } while (0)
+#define QS_STAMPW(k) do { } while (0)
 #endif
 
 struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
                    int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit; };
 #define QS_RESET_SCRATCH_INTS 160   // per env: virtual-pool index/value lists (2x64) + two DP rows (2x16)
 
-static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K, bool team) {
+static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K, int team /* waves per workgroup of the team kernels, 0 = single-wave */) {
     LdsLayout L;
     memset(&L, 0, sizeof L);
     int o = 0;
@@ -75,15 +78,15 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     L.goal_rows = 2 * N + 8;
     L.off_goal = o; o += real_size * 3 * L.goal_rows * epb;
     L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
-    // neighbour metric rows [N][B]; team kernels with N > 8: four sorted top-8 lists, metrics [32][B] + indices [32][B]
-    L.off_metric = o; o += ((team ? K > 0 : K > 8) && K < N - 1) ? ((team && N > 8) ? ((real_size + 4) * 32 > real_size * N ? (real_size + 4) * 32 : real_size * N) * B : real_size * N * B) : 0;
+    // neighbour metric rows [N][B]; team kernels with N > 8: one sorted top-8 list per wave, metrics [8W][B] + indices [8W][B]
+    L.off_metric = o; o += ((team ? K > 0 : K > 8) && K < N - 1) ? ((team && N > 8) ? ((real_size + 4) * 8 * team > real_size * N ? (real_size + 4) * 8 * team : real_size * N) * B : real_size * N * B) : 0;
     o = (o + 15) & ~15;
     if (team) {   // exchange rows of the 4-wave kernels
         L.off_t_col = o; o += 8 * B;
         L.off_t_dw = o; o += 8 * B;
         L.off_t_rot = o; o += real_size * 6 * B;
         L.off_t_goal = o; o += real_size * 3 * B;
-        L.off_t_prox = o; o += real_size * 3 * B;
+        L.off_t_prox = o; o += real_size * (team - 1) * B;
         L.off_t_ohit = o; o += 4 * B;
         o = (o + 15) & ~15;
     }
@@ -566,6 +569,7 @@ __device__ __forceinline__ Consts<real> qs_spec_consts(const Consts<real> &rt) {
 #define QS_SPEC_PROLOGUE const Consts<real> c = qs_spec_consts(c_rt); const LdsLayout L = __builtin_bit_cast(LdsLayout, qs_spec_lw); const int epb = QS_SPEC_EPB; (void)L_rt; (void)epb_rt;
 #define QS_SCEN_FULL QS_SPEC_FULL
 #if QS_SPEC_TEAM
+#define QS_TW QS_SPEC_TEAM
 #define QS_MULTI 0
 #include "qs_step_team.inc"
 #undef QS_MULTI
@@ -608,6 +612,7 @@ extern "C" __global__ void __launch_bounds__(QS_WAVE) qs_spec_reset(const Consts
 #undef QS_MULTI
 #undef QS_SCEN_FULL
 // the same four kernels as a team of 4 waves per workgroup (latency variant for small batches)
+#define QS_TW QS_TEAM_WAVES
 #define QS_SCEN_FULL 0
 #define QS_MULTI 0
 #include "qs_step_team.inc"

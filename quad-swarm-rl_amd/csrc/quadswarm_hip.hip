@@ -39,7 +39,7 @@ struct qs_handle {
     int obs_dim = 0, epb = 1, blocks = 0;
     LdsLayout lds;
     bool full = false;     // scenario outside the fast set => kernels compiled with QS_SCEN_FULL
-    bool team = false;     // 4 waves per workgroup (qs_step_team.inc) instead of 1 (qs_step_kernel.inc)
+    int team = 0;          // waves per workgroup of the team kernels (qs_step_team.inc): 4 generic, 8 (or 4) specialised; 0 = single-wave kernels
     // config-specialised code object (qs_spec_kernels.hip), when one is cached / could be built
     hipModule_t spec_mod = nullptr;
     hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr;
@@ -115,10 +115,13 @@ static bool scenario_is_full(int scenario) {
     return !(scenario == QS_SCENARIO_STATIC_SAME_GOAL || scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || scenario == QS_SCENARIO_SWARM_VS_SWARM);
 }
 static bool team_default(int blocks, int cus) { return blocks <= 4 * cus; }
+// Specialised team kernels: 8 waves (2 per SIMD) halve the striped phases once more for N <= 8 (C2 8.65 -> 8.15 us); with
+// N > 8 the merge of 8 sorted lists outweighs that (C4 24.6 -> 28.3 us), so those keep 4 waves.
+static int spec_team_waves(int num_agents) { return num_agents <= 8 ? 8 : 4; }
 
 static std::string spec_header_text(const qs_config *cfg, int team) {
     const int rs = cfg->precision == QS_PRECISION_F64 ? 8 : 4, epb = QS_WAVE / cfg->num_agents;
-    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team != 0);
+    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team);
     std::vector<uint32_t> w;
     if (rs == 8) { Consts<double> k; fill_consts<double>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0; k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
                    w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
@@ -126,7 +129,7 @@ static std::string spec_header_text(const qs_config *cfg, int team) {
            w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
     std::string o = "// generated by quadswarm_hip (spec_header_text): configuration constants as literals\n";
     char t[256];
-    snprintf(t, sizeof t, "#define QS_SPEC_PRECISION %d\n#define QS_SPEC_TEAM %d\n#define QS_SPEC_FULL %d\n#define QS_SPEC_EPB %d\n", rs, team ? 1 : 0,
+    snprintf(t, sizeof t, "#define QS_SPEC_PRECISION %d\n#define QS_SPEC_TEAM %d\n#define QS_SPEC_FULL %d\n#define QS_SPEC_EPB %d\n", rs, team,
              scenario_is_full(cfg->scenario) ? 1 : 0, epb);
     o += t;
     snprintf(t, sizeof t, "struct QsSpecCW { uint32_t w[%zu]; };\n", w.size()); o += t;
@@ -230,6 +233,8 @@ extern "C" int qs_spec_build(const qs_config *cfg, int team, char *path_out, int
     if (rc != QS_OK) return rc;
     const int epb = QS_WAVE / cfg->num_agents, blocks = (cfg->num_envs + epb - 1) / epb;
     if (team < 0) team = team_default(blocks, 256) ? 1 : 0;
+    if (team == 1) team = spec_team_waves(cfg->num_agents);
+    if (team != 0 && team != 4 && team != 8) return fail(QS_ERR_INVALID, "team must be -1, 0, 1, 4 or 8");
     std::string path = spec_ensure(cfg, team, true);
     if (path.empty()) return QS_ERR_UNSUPPORTED;
     if (path_out) { if ((int)path.size() + 1 > cap) return fail(QS_ERR_INVALID, "buffer too small"); memcpy(path_out, path.c_str(), path.size() + 1); }
@@ -285,7 +290,7 @@ template <typename real> static int create_typed(qs_handle *h) {
     DA(unique_col, E); DA(obst_new, E); DA(room_new, E); DA(counters, QS_CNT_COUNT * E); DA(tick, E); DA(step_ctr, E);
     DA(obst_pos, 2 * E * (M_ ? M_ : 1)); DA(dist_ring, 4 * T); DA(dist_sums, 3 * T); DA(ep_stats, QS_EPS_COUNT * T); DA(ep_counters, QS_CNT_COUNT * E);
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
-    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 32);
+    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128);
 #undef DA
     real *act = nullptr;
     if ((rc = dalloc(h, &act, 4 * T)) != QS_OK) return rc;
@@ -375,9 +380,37 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         hipDeviceProp_t prop;
         int cus = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        h->team = team_default(h->blocks, cus);
+        h->team = team_default(h->blocks, cus) ? QS_TEAM_WAVES : 0;
         const char *ev = getenv("QS_TEAM");
-        if (ev && (ev[0] == '0' || ev[0] == '1')) h->team = ev[0] == '1';
+        if (ev && ev[0] == '0') h->team = 0;
+        else if (ev && (ev[0] == '1' || ev[0] == '4' || ev[0] == '8')) h->team = QS_TEAM_WAVES;
+    }
+    // Config-specialised kernels.  QS_SPEC = "jit" (default): use the cached code object of this configuration, building it
+    // first if needed (one hipcc run, ~5 s, cached next to the library); "cache": use it only if it is already there;
+    // "off": always the generic kernels.  Any failure falls back to the generic kernels (same results, slower).
+    {
+        const char *ev = getenv("QS_SPEC"), *tv = getenv("QS_TEAM");
+        const std::string mode = (ev && ev[0]) ? ev : "jit";
+        const int spec_team = h->team ? ((tv && tv[0] == '4') ? 4 : ((tv && tv[0] == '8') ? 8 : spec_team_waves(cfg->num_agents))) : 0;
+        const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, spec_team);
+        if (mode != "off" && mode != "0" && sl.total <= 64 * 1024) {
+            const std::string path = spec_ensure(cfg, spec_team, mode == "jit");
+            if (!path.empty()) {
+                if (hipModuleLoad(&h->spec_mod, path.c_str()) == hipSuccess &&
+                    hipModuleGetFunction(&h->spec_step, h->spec_mod, "qs_spec_step") == hipSuccess &&
+                    hipModuleGetFunction(&h->spec_rollout, h->spec_mod, "qs_spec_rollout") == hipSuccess &&
+                    hipModuleGetFunction(&h->spec_reset, h->spec_mod, "qs_spec_reset") == hipSuccess) {
+                    h->team = spec_team;   // specialised kernels in use
+                } else {
+                    (void)hipGetLastError();
+                    if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
+                    h->spec_step = h->spec_rollout = h->spec_reset = nullptr;
+                    fprintf(stderr, "quadswarm_hip: cannot load %s, using the generic kernels\n", path.c_str());
+                }
+            } else if (mode == "jit") {
+                fprintf(stderr, "quadswarm_hip: %s; using the generic kernels\n", g_last_error.c_str());
+            }
+        }
     }
     h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team);
     h->full = scenario_is_full(cfg->scenario);
@@ -403,31 +436,6 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
                 qs_destroy(h);
                 return fail(QS_ERR_HIP, "cannot raise dynamic LDS limit");
             }
-    }
-    // Config-specialised kernels.  QS_SPEC = "jit" (default): use the cached code object of this configuration, building it
-    // first if needed (one hipcc run, ~20 s, cached next to the library); "cache": use it only if it is already there;
-    // "off": always the generic kernels.  Any failure falls back to the generic kernels (same results, slower).
-    {
-        const char *ev = getenv("QS_SPEC");
-        const std::string mode = (ev && ev[0]) ? ev : "jit";
-        if (mode != "off" && mode != "0" && h->lds.total <= 64 * 1024) {
-            const std::string path = spec_ensure(cfg, h->team ? 1 : 0, mode == "jit");
-            if (!path.empty()) {
-                if (hipModuleLoad(&h->spec_mod, path.c_str()) == hipSuccess &&
-                    hipModuleGetFunction(&h->spec_step, h->spec_mod, "qs_spec_step") == hipSuccess &&
-                    hipModuleGetFunction(&h->spec_rollout, h->spec_mod, "qs_spec_rollout") == hipSuccess &&
-                    hipModuleGetFunction(&h->spec_reset, h->spec_mod, "qs_spec_reset") == hipSuccess) {
-                    // specialised kernels in use
-                } else {
-                    (void)hipGetLastError();
-                    if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
-                    h->spec_step = h->spec_rollout = h->spec_reset = nullptr;
-                    fprintf(stderr, "quadswarm_hip: cannot load %s, using the generic kernels\n", path.c_str());
-                }
-            } else if (mode == "jit") {
-                fprintf(stderr, "quadswarm_hip: %s; using the generic kernels\n", g_last_error.c_str());
-            }
-        }
     }
     *out = h;
     return QS_OK;
@@ -501,7 +509,7 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &h->pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&h->pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
-        HIP_TRY(hipModuleLaunchKernel(ksteps == 1 ? h->spec_step : h->spec_rollout, h->blocks, 1, 1, h->team ? QS_TEAM_THREADS : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
+        HIP_TRY(hipModuleLaunchKernel(ksteps == 1 ? h->spec_step : h->spec_rollout, h->blocks, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
     }
@@ -623,11 +631,11 @@ int qs_memcpy_h2d(qs_handle *h, void *dev_dst, const void *host_src, size_t byte
 }
 
 /* debug: phase time stamps (shader clock) of workgroup 0; all zero unless built with -DQS_TIMING */
-int qs_debug_timing(qs_handle *h, unsigned long long *out32) {
-    if (!h || !out32) return fail(QS_ERR_INVALID, "null argument");
+int qs_debug_timing(qs_handle *h, unsigned long long *out128) {   // [4 waves][32 stamps] of workgroup 0 (QS_TIMING builds)
+    if (!h || !out128) return fail(QS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out32, h->pf.timing, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out128, h->pf.timing, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return QS_OK;
 }
 

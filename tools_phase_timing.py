@@ -10,7 +10,7 @@ import numpy as np
 from quad_swarm_rl_amd import config as qcfg, native
 
 # the phase stamps are compiled into the config-specialised code object (QS_SPEC=jit is the default)
-os.environ["QS_SPEC_EXTRA_FLAGS"] = "-DQS_TIMING"
+os.environ["QS_SPEC_EXTRA_FLAGS"] = "-DQS_TIMING " + os.environ.get("QS_TIMING_EXTRA", "")
 os.environ.setdefault("QS_SPEC", "jit")
 import bench
 args = sys.argv[1:]
@@ -44,13 +44,23 @@ for t in range(60):
     st.from_host("actions", rng.uniform(-1, 1, size=(st.T, 4)))
     st.step()
     st.sync()
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 128)()
     L.qs_debug_timing(st._h, buf)
     ts = np.array([buf[k] for k in order], dtype=np.float64)
     if t >= 10:
         acc += np.diff(ts)
         n += 1
+        if team:   # helper waves: arrival at / release from each barrier relative to wave 0's kernel entry
+            hw = np.array([[buf[32 * w + k] for k in range(18)] for w in (1, 2, 3)], dtype=np.float64) - float(buf[0])
+            w0 = np.array([buf[k] for k in (0, 4, 5, 6, 9, 14, 14, 15, 15, 10, 10, 11, 12, 12)], dtype=np.float64) - float(buf[0])
+            hacc = hw if t == 10 else hacc + hw
+            w0acc = w0 if t == 10 else w0acc + w0
 acc /= n
 print(f"workload {wl} {args[1:]} team={team}: per-phase s_memtime ticks (workgroup 0, wave 0 lane 0), total {acc.sum():.0f}")
 for nm, v in zip(names, acc):
     print(f"  {nm:32s} {v:9.0f}")
+if team:
+    print("helper waves (ticks since wave 0 entered the kernel): stamp = entry, [arrive, leave] x barriers 1..6, copy-out done")
+    print("  wave 0 (nearest stamps)", np.round(w0acc / n).astype(int).tolist())
+    for w in range(3):
+        print(f"  wave {w + 1}", np.round(hacc[w] / n).astype(int).tolist())
