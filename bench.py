@@ -7,8 +7,11 @@
 A "step" is one control step (= 2 physics sub-steps) of all environments of the workload on synthetic
 U(-1,1)^4 actions that are already resident in HBM.  Workload at N=1 (BASELINE.json configs[1], "C2"):
 8 drones x 1024 envs, static_same_goal, 6 visible neighbours (obs 54), downwash on, Numba-path semantics,
-sensor + thrust noise on, auto-resets included.  Each extra GPU gets its own 1024-env shard (weak scaling)
-and every rollout step ends with ONE RCCL all-gather of the observations.
+sensor + thrust noise on, auto-resets included.  Each extra GPU gets its own 1024-env shard (weak scaling); the shards
+are independent (no cross-env term on this path), so the timed region has no data-path collective.  The optional
+variant of north_star / SURVEY.md 8e - ONE RCCL all-gather of the observations after every step - is timed right after
+and reported as config.with_obs_allgather (or becomes the headline with --gather): it moves 12.4 MB per GPU per step and
+is xGMI-link-bound at >= ~28 us per step whatever the implementation.
 
 metric:  env-steps/s = drones x envs x sim_steps(2) x control-steps/s   (BASELINE.md "Metric")
 roofline: HBM-bound; algorithmic bytes per drone-control-step = 500 B (read state 120 + flags 4 +
@@ -96,7 +99,10 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's env count per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=400, help="steps of the HIP-event kernel-duration pass")
-    ap.add_argument("--no-gather", action="store_true", help="skip the per-step obs all-gather at N>1")
+    ap.add_argument("--gather", action="store_true", help="N>1: put ONE RCCL all-gather of the observations after every step inside the timed region "
+                                                          "(default: shards step independently; the gather variant is measured separately and reported in config)")
+    ap.add_argument("--force-gather", action="store_true", help="run the RCCL obs all-gather path even at N=1 (exercises the multi-GPU code on a 1-GPU box)")
+    ap.add_argument("--no-gather", action="store_true", help="skip the separate all-gather measurement at N>1")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a workload keyword (python literal)")
@@ -117,9 +123,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP stepper has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import ast
@@ -141,12 +150,14 @@ def main():
     actions = (torch.rand((ring, T, 4), device=f"cuda:{local_rank}", generator=gen, dtype=torch.float32) * 2.0 - 1.0).contiguous()
     aptr, astride = actions.data_ptr(), T * 4 * 4
     obs = st.tensor("obs")
-    gather = None
-    if world > 1 and not args.no_gather:
+    gather = gather_variant = None
+    if (world > 1 or args.force_gather) and not args.no_gather:
         from quad_swarm_rl_amd import parallel
-        gather = parallel.ObsGather(obs, overlap=not args.no_overlap)   # ONE RCCL all-gather of the obs per rollout step
+        gather_variant = parallel.ObsGather(obs, overlap=not args.no_overlap)   # ONE RCCL all-gather of the obs per rollout step
+        if args.gather or args.force_gather:
+            gather = gather_variant
 
-    def run(k, offset=0):
+    def run(k, offset=0, gather=gather):
         if args.graph > 0 and gather is None:
             # open-loop rollout over the action ring: qs_step_many keeps the state in registers across the steps of a launch
             g = min(args.graph, ring)
@@ -187,6 +198,23 @@ def main():
         elapsed = float(tmax.item())
     st.check_errors()
 
+    # N>1: the optional collective variant (north_star: one RCCL all-gather of the observations per rollout step), timed
+    # separately with the same bracketing; `value` above is the independent-shard rate unless --gather was given
+    with_gather = None
+    if gather_variant is not None and gather is None:
+        gk = min(args.steps, 1000)
+        run(50, 0, gather_variant)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(gk, 50, gather_variant)
+        dist.barrier()
+        torch.cuda.synchronize()
+        gdt = torch.tensor([time.perf_counter() - t0], device=f"cuda:{local_rank}", dtype=torch.float64)
+        dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
+        with_gather = {"value": world * T * 2 * gk / float(gdt.item()), "unit": "env-steps/s", "ms_per_step": 1e3 * float(gdt.item()) / gk, "steps": gk,
+                       "collective": "rccl all_gather_into_tensor of the obs per step" + ("" if args.no_overlap else ", overlapped with the next step")}
+
     # extra: the same workload as open-loop rollouts (pre-generated actions, K control steps per launch)
     rollout = None
     if world == 1 and args.rollout_steps > 0 and args.graph == 0:
@@ -219,7 +247,9 @@ def main():
             "config": {"workload": f"{args.workload}: {N} drones x {E} envs per GPU, {WORKLOADS[args.workload]['kw'].get('quads_mode', 'static_same_goal')}, "
                                    f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
                        "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N,
-                       "obs_gather": ("rccl all_gather_into_tensor per step" + ("" if args.no_overlap else ", overlapped with the next step")) if gather is not None else "none",
+                       "obs_gather": ("rccl all_gather_into_tensor per step" + ("" if args.no_overlap else ", overlapped with the next step")) if gather is not None
+                                     else ("none: env shards are independent, no data-path collective (DESIGN.md 7)" if world > 1 else "none"),
+                       "with_obs_allgather": with_gather,
                        "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and world == 1 else "one launch per control step",
                        "open_loop_rollout": rollout, "rew_info": bool(args.rew_info),
                        "overrides": args.set},
