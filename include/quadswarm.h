@@ -63,6 +63,11 @@ enum { QS_CNT_COLLISIONS = 0, QS_CNT_COLLISIONS_AFTER_SETTLE, QS_CNT_COLLISIONS_
        QS_CNT_OBST, QS_CNT_OBST_AFTER_SETTLE, QS_CNT_OBST_DIST_3_5, QS_CNT_OBST_DIST_5, QS_CNT_COUNT };
 
 /* per-drone episode statistics written when an episode ends (quadrotor_multi.py:626-718) */
+/* rows of qs_buffers.run_sums / ep_sums: [0, QS_RI_COUNT) = sum of each reward term over the episode,
+ * then sum a_k (k = 0..3) and sum a_k^2 of the raw policy actions */
+#define QS_SUM_ACT (QS_RI_COUNT)
+#define QS_SUM_ACT2 (QS_RI_COUNT + 4)
+#define QS_SUM_COUNT (QS_RI_COUNT + 8)
 enum { QS_EPS_DIST_1S = 0, QS_EPS_DIST_3S, QS_EPS_DIST_5S, QS_EPS_REACHED_GOAL, QS_EPS_COL_AGENT_OK,
        QS_EPS_COL_OBST_OK, QS_EPS_COUNT };
 
@@ -118,6 +123,9 @@ typedef struct qs_config {
     /* ---- outputs ---- */
     int32_t write_rew_info;    /* 1: fill qs_buffers.rew_info every step (the infos[i]['rewards'] terms the SF
                                   reward-shaping wrapper logs); 0: skip those 17 stores per drone */
+    int32_t episode_sums;      /* 1: accumulate, per drone and episode, the sums the SF reward-shaping wrapper keeps on the
+                                  host (swarm_rl/env_wrappers/reward_shaping.py:78-110): the 17 reward terms and the
+                                  first / second moments of the 4 actions; snapshot into qs_buffers.ep_sums at done */
 } qs_config;
 
 /* Device pointers (element type = float for QS_PRECISION_F32, double for QS_PRECISION_F64 where
@@ -150,6 +158,8 @@ typedef struct qs_buffers {
     void *error_flag;         /* uint32 [1]: nonzero if a reward was NaN/Inf (quadrotor_single.py:87-90) */
     void *scenario_id;        /* int32 [E]: active scenario (the sub-scenario chosen by `mix` for this episode) */
     void *ep_scenario;        /* int32 [E]: scenario of the last finished episode (names the per-scenario episode stats) */
+    void *run_sums;           /* real [QS_SUM_COUNT, E*N]: running sums of the current episode (episode_sums = 1) */
+    void *ep_sums;            /* real [QS_SUM_COUNT, E*N]: the sums of the last finished episode */
     int32_t obs_dim;
     int32_t real_size;        /* 4 or 8 */
 } qs_buffers;

@@ -61,6 +61,7 @@ class QsConfig(C.Structure):
         ("obst_size", C.c_double), ("obst_density", C.c_double),
         ("obst_area", C.c_int32 * 2), ("num_obstacles", C.c_int32),
         ("write_rew_info", C.c_int32),
+        ("episode_sums", C.c_int32),
     ]
 
 
@@ -85,7 +86,7 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
                 use_obstacles=False, obst_density=0.2, obst_size=1.0, obst_spawn_area=(6.0, 6.0),
                 use_downwash=False, use_numba=False, quads_mode="static_same_goal", room_dims=(10.0, 10.0, 10.0),
                 sense_noise="default", thrust_noise_ratio=0.05, sim_freq=200.0, sim_steps=2,
-                seed=0, env_id_offset=0, precision="f32", write_rew_info=True):
+                seed=0, env_id_offset=0, precision="f32", write_rew_info=True, episode_sums=False):
     """Build a QsConfig.  Argument names/defaults follow the reference's `--quads_*` flags
     (swarm_rl/env_wrappers/quadrotor_params.py:15-120) and QuadrotorEnvMulti.__init__."""
     if num_agents < 1 or num_agents > QS_MAX_AGENTS:
@@ -154,6 +155,7 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
     c.obst_area[:] = [int(obst_spawn_area[0]), int(obst_spawn_area[1])]
     c.num_obstacles = int(obst_density * obst_spawn_area[0] * obst_spawn_area[1]) if use_obstacles else 0
     c.write_rew_info = int(bool(write_rew_info))
+    c.episode_sums = int(bool(episode_sums))
     if c.num_obstacles > QS_MAX_OBSTACLES:
         raise ValueError(f"more than {QS_MAX_OBSTACLES} obstacles")
     return c

@@ -198,6 +198,7 @@ template <typename real> struct Consts {
     real inv_dt, prox_ratio;   // 1/dt; -quadcol_smooth_max / collision_falloff_threshold (collisions/quadrotors.py:97)
     real inv_win[3];           // 1/min(ep_len+1, {1,3,5} s of control steps): episode-stat window sizes
     int32_t write_rew_info;   // 0: skip the 17-term reward-info matrix (it is logging, not part of obs/reward/done)
+    int32_t episode_sums;     // 1: per-episode sums of the reward terms and action moments (reward_shaping.py:78-110)
 };
 
 // per-drone dynamic state held in registers

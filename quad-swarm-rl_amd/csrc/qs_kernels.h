@@ -42,6 +42,7 @@ template <typename real> struct Ptrs {
     uint64_t *scen_omap;   // [4, E] obstacle map bitsets (scenarios that sample free cells during an episode)
     int32_t *scenario_id;  // [E] active scenario (the sub-scenario under `mix`)
     int32_t *ep_scenario;  // [E] scenario of the last finished episode
+    real *run_sums, *ep_sums;   // [QS_SUM_COUNT, T] per-episode sums (running / last finished episode)
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
 };
@@ -539,6 +540,9 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
         p.pair_mask[g] = 0;
         p.new_pair_mask[g] = 0;
         p.obst_hit_idx[g] = -1;
+        if (c.episode_sums) {
+            for (int q = 0; q < QS_SUM_COUNT; ++q) p.run_sums[q * T + g] = 0;
+        }
         const real *myobs = s_obs + tid * c.obs_dim;
         real *dst = p.obs + (size_t)g * c.obs_dim;
         for (int q = 0; q < c.obs_dim; ++q) dst[q] = myobs[q];

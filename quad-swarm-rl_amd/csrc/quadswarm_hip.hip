@@ -97,6 +97,7 @@ template <typename real> static void fill_consts(const qs_config &c, Consts<real
     k.seed_lo = (uint32_t)(c.seed & 0xffffffffu); k.seed_hi = (uint32_t)(c.seed >> 32);
     k.env_id_offset = c.env_id_offset; k.num_envs = c.num_envs; k.num_agents = c.num_agents;
     k.write_rew_info = c.write_rew_info;
+    k.episode_sums = c.episode_sums;
     k.inv_dt = (real)(1.0 / c.dt);
     k.prox_ratio = (real)(-c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX] / c.collision_falloff_threshold);
     for (int w = 0; w < 3; ++w) {
@@ -289,6 +290,7 @@ template <typename real> static int create_typed(qs_handle *h) {
     DA(obs, T * D); DA(reward, T); DA(rew_info, QS_RI_COUNT * T); DA(done, T); DA(obst_hit_idx, T);
     DA(unique_col, E); DA(obst_new, E); DA(room_new, E); DA(counters, QS_CNT_COUNT * E); DA(tick, E); DA(step_ctr, E);
     DA(obst_pos, 2 * E * (M_ ? M_ : 1)); DA(dist_ring, 4 * T); DA(dist_sums, 3 * T); DA(ep_stats, QS_EPS_COUNT * T); DA(ep_counters, QS_CNT_COUNT * E);
+    DA(run_sums, QS_SUM_COUNT * T); DA(ep_sums, QS_SUM_COUNT * T);
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
     DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128);
 #undef DA
@@ -305,7 +307,7 @@ template <typename real> static int create_typed(qs_handle *h) {
     b.pos = p.pos; b.vel = p.vel; b.omega = p.omega; b.rot = p.rot; b.thrust_rot_damp = p.rot_damp; b.thrust_cmds_damp = p.cmds_damp;
     b.ou_state = p.ou; b.goal = p.goal; b.flags = p.flags; b.obst_hit_idx = p.obst_hit_idx; b.col_pair_mask = p.pair_mask;
     b.new_pair_mask = p.new_pair_mask; b.unique_col_mask = p.unique_col; b.obst_new_mask = p.obst_new; b.room_new_mask = p.room_new;
-    b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters;
+    b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters; b.run_sums = p.run_sums; b.ep_sums = p.ep_sums;
     b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
     return QS_OK;
 }
@@ -355,6 +357,7 @@ int qs_default_config(qs_config *c, int32_t num_envs, int32_t num_agents) {
     for (int q = 0; q < 3; ++q) { c->nbr_clip_pos[q] = 10.0; c->nbr_clip_vel[q] = 6.0; }
     c->obst_size = 1.0; c->obst_density = 0.2; c->obst_area[0] = 6; c->obst_area[1] = 6; c->num_obstacles = 0;
     c->write_rew_info = 1;
+    c->episode_sums = 0;
     return QS_OK;
 }
 

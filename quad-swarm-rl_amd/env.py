@@ -88,6 +88,15 @@ class QuadSwarmVecEnv:
         """[17, E*N] device tensor of the `infos[i]['rewards']` terms (row order: config.REW_INFO_KEYS)."""
         return self._t("rew_info")
 
+    def episode_sums(self):
+        """[25, E*N] device tensor, valid after a done: per-agent sums over the finished episode of the 17 reward terms
+        (rows 0-16, config.REW_INFO_KEYS order), of the 4 raw actions (17-20) and of their squares (21-24).  Needs
+        `episode_sums=True`; the device-side counterpart of the reward-shaping wrapper's bookkeeping
+        (swarm_rl/env_wrappers/reward_shaping.py:78-110)."""
+        if not self.cfg.episode_sums:
+            raise RuntimeError("create the env with episode_sums=True")
+        return self._t("ep_sums")
+
     def close(self):
         self.stepper.close()
 

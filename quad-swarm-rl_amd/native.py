@@ -5,6 +5,7 @@ GPU is visible, the constructor raises.
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -28,7 +29,7 @@ class QsBuffers(C.Structure):
         "obs", "reward", "done", "rew_info", "actions", "pos", "vel", "omega", "rot", "thrust_rot_damp",
         "thrust_cmds_damp", "ou_state", "goal", "flags", "obst_hit_idx", "col_pair_mask", "new_pair_mask",
         "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_pos", "ep_stats",
-        "ep_counters", "error_flag", "scenario_id", "ep_scenario")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
+        "ep_counters", "error_flag", "scenario_id", "ep_scenario", "run_sums", "ep_sums")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
 
 
 def build(force=False, verbose=False):
@@ -47,11 +48,36 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).  One process
+    must run ONE HIP runtime: if this library pulled in the system copy first, a later `import torch` would come up with
+    "No HIP GPUs are available".  So, when torch is installed, its copy is loaded first (without importing torch) and
+    libquadswarm_hip.so binds to it - the same arrangement as when the caller imported torch before us."""
+    import importlib.util
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
+        _preload_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.qs_version.restype = C.c_int
@@ -144,7 +170,8 @@ class Stepper:
             obst_new_mask=((self.E,), "u8"), room_new_mask=((self.E,), "u8"), counters=((11, self.E), "i4"),
             tick=((self.E,), "i4"), obst_pos=((2, self.E * max(cfg.num_obstacles, 1)), "real"),
             ep_stats=((6, self.T), "real"), ep_counters=((11, self.E), "i4"), error_flag=((1,), "u4"),
-            scenario_id=((self.E,), "i4"), ep_scenario=((self.E,), "i4"))
+            scenario_id=((self.E,), "i4"), ep_scenario=((self.E,), "i4"),
+            run_sums=((25, self.T), "real"), ep_sums=((25, self.T), "real"))
         self._torch_cache = {}
 
     # ---- lifecycle -------------------------------------------------------------------------

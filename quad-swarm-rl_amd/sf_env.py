@@ -73,6 +73,8 @@ def add_quadrotors_env_args(env, parser):
     p.add_argument("--quads_sim2real", default=False, type=str2bool)
     # the stepper's own flags
     p.add_argument("--quads_seed", default=0, type=int, help="seed of the counter-based noise stream")
+    p.add_argument("--quads_num_envs", default=1, type=int, help="> 1: one device-resident batched env of this many environments "
+                                                                 "(num_agents = envs x quads) instead of the single-env facade")
     p.add_argument("--quads_device", default=0, type=int, help="HIP device index")
     p.add_argument("--quads_precision", default="f32", type=str, choices=["f32", "f64"])
 
@@ -160,6 +162,104 @@ class RewardShapingWrapper(_Wrapper):
         return obs, rewards, dones, infos
 
 
+class BatchedQuadSwarm:
+    """E environments x N drones behind one object with the batched-sampling shape of Sample Factory (num_agents = E*N,
+    device tensors in and out) and the semantics of QuadsRewardShapingWrapper + the compatibility wrapper
+    (reward_shaping.py:22-123, compatibility.py:21-50), with the per-step bookkeeping moved onto the GPU:
+    the step kernel keeps the per-episode sums of the reward terms and action moments (`episode_sums`), so a control step
+    costs one kernel launch and no device->host traffic; only the step on which episodes end reads the sums back and
+    builds the `infos` dicts.  SURVEY.md 8f rank 1.  (Sample Factory is not in this image: the call protocol follows its
+    documentation for vectorised GPU envs, i.e. `reset() -> (obs_dict, info)`, `step(actions) -> (obs_dict, rewards,
+    terminated, truncated, infos)` with torch tensors of leading dimension num_agents.)"""
+
+    def __init__(self, num_envs, reward_shaping_scheme=None, annealing=None, device=0, seed=0, **env_kwargs):
+        import torch
+        from . import config as qcfg
+        from .env import QuadSwarmVecEnv
+        self._torch = torch
+        self.vec = QuadSwarmVecEnv(num_envs, device=device, seed=seed, episode_sums=True, write_rew_info=False, **env_kwargs)
+        self.num_envs, self.agents_per_env = num_envs, self.vec.num_agents_per_env
+        self.num_agents = self.vec.num_agents
+        self.is_multiagent = True
+        self.observation_space, self.action_space = self.vec.observation_space, self.vec.action_space
+        self.rew_coeff = self.vec.rew_coeff
+        self.scenario = self.vec.scenario
+        self.reward_shaping_scheme = reward_shaping_scheme or copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
+        self.reward_shaping_updated = True
+        self.annealing = annealing
+        self.training_info = {}
+        self._keys = qcfg.REW_INFO_KEYS
+        self._ep_steps = self.vec.cfg.ep_len + 1          # every episode ends by time: tick > ep_len (quadrotor_single.py:353)
+        self._ticks = np.zeros(num_envs, dtype=np.int64)  # host mirror of the per-env tick: tells when a done is due without a sync
+        self._truncated = None
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def set_training_info(self, training_info):
+        self.training_info = training_info
+
+    def reset(self, seed=None, options=None):
+        obs = self.vec.reset()
+        self._ticks[:] = 0
+        return {"obs": obs}, {}
+
+    def step(self, actions):
+        torch = self._torch
+        if self.reward_shaping_updated:   # reward_shaping.py:55-61
+            for key, weight in self.reward_shaping_scheme["quad_rewards"].items():
+                if key in self.rew_coeff:
+                    self.rew_coeff[key] = weight
+            self.reward_shaping_updated = False
+        obs, rew, done, _ = self.vec.step(actions)
+        if self._truncated is None:
+            self._truncated = torch.zeros_like(done, dtype=torch.bool)
+        self._ticks += 1
+        finished = np.nonzero(self._ticks >= self._ep_steps)[0]
+        infos = [{} for _ in range(self.num_agents)] if len(finished) else []
+        if len(finished):
+            self._ticks[finished] = 0
+            self._episode_infos(finished, infos)
+        return {"obs": obs}, rew, done.bool(), self._truncated, infos
+
+    def _episode_infos(self, finished, infos):
+        """The dicts QuadsRewardShapingWrapper attaches at episode end (reward_shaping.py:85-118) + the env's own
+        episode_extra_stats, for the agents of the finished envs, from the device-side sums."""
+        st, n = self.vec.stepper, self.agents_per_env
+        sums = st.to_host("ep_sums").astype(np.float64)
+        approx = self.training_info.get("approx_total_training_steps", 0)
+        scen_ids = st.to_host("ep_scenario")
+        from . import config as qcfg
+        count = float(self._ep_steps * n)
+        for e in finished:
+            sl = slice(e * n, (e + 1) * n)
+            a1, a2 = sums[17:21, sl].sum(axis=1) / count, sums[21:25, sl].sum(axis=1) / count
+            a_std = np.sqrt(np.maximum(a2 - a1 * a1, 0.0))    # np.std over agents x steps (:103-108)
+            scenario_name = qcfg.SCENARIO_CLASS_NAMES[int(scen_ids[e])]
+            for i in range(e * n, (e + 1) * n):
+                cum = {k: float(sums[j, i]) for j, k in enumerate(self._keys) if self.vec.cfg.use_obstacles or j < 15}
+                true_reward = cum["rewraw_main"] + 1000 * cum.get("rewraw_quadcol", 0)
+                cum["rewraw_main"] = true_reward
+                extra = dict(cum)
+                extra["z_approx_total_training_steps"] = approx
+                for rew_key in ("rew_pos", "rew_crash"):
+                    extra[f"{scenario_name}/{rew_key}"] = cum[rew_key]
+                for k in range(4):
+                    extra[f"z_action{k}_mean"], extra[f"z_action{k}_std"] = float(a1[k]), float(a_std[k])
+                infos[i]["true_reward"] = true_reward
+                infos[i]["episode_extra_stats"] = extra
+        if self.annealing:   # :111-118, once per step on which episodes ended (same values for every agent)
+            for sched in self.annealing:
+                self.rew_coeff[sched.coeff_name] = min(sched.final_value * approx / sched.anneal_env_steps, sched.final_value)
+                for e in finished:
+                    for i in range(e * n, (e + 1) * n):
+                        infos[i]["episode_extra_stats"][f"z_anneal_{sched.coeff_name}"] = self.rew_coeff[sched.coeff_name]
+
+    def close(self):
+        self.vec.close()
+
+
 class Compatibility(_Wrapper):
     """compatibility.py:21-50: old 4-tuple step -> gymnasium 5-tuple; reset(seed, options) ignores the seed."""
 
@@ -206,8 +306,34 @@ def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
     return Compatibility(env)
 
 
+def make_quadrotor_env_batched(cfg, **kwargs):
+    """`--quads_num_envs E` > 1: the device-resident batched env (E*N agents) with the same flags and shaping schedule."""
+    reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
+    reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
+    reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty
+    reward_shaping["quad_rewards"]["quadcol_bin_obst"] = cfg.quads_obst_collision_reward
+    annealing = None
+    if cfg.anneal_collision_steps > 0:
+        for k in ("quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"):
+            reward_shaping["quad_rewards"][k] = 0.0
+        annealing = [AnnealSchedule("quadcol_bin", cfg.quads_collision_reward, cfg.anneal_collision_steps),
+                     AnnealSchedule("quadcol_bin_smooth_max", cfg.quads_collision_smooth_max_penalty, cfg.anneal_collision_steps),
+                     AnnealSchedule("quadcol_bin_obst", cfg.quads_obst_collision_reward, cfg.anneal_collision_steps)]
+    return BatchedQuadSwarm(
+        cfg.quads_num_envs, reward_shaping_scheme=reward_shaping, annealing=annealing,
+        device=getattr(cfg, "quads_device", 0), seed=getattr(cfg, "quads_seed", 0), precision=getattr(cfg, "quads_precision", "f32"),
+        num_agents=cfg.quads_num_agents, ep_time=cfg.quads_episode_duration, rew_coeff=dict(DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]),
+        obs_repr=cfg.quads_obs_repr, neighbor_visible_num=cfg.quads_neighbor_visible_num, neighbor_obs_type=cfg.quads_neighbor_obs_type,
+        collision_hitbox_radius=cfg.quads_collision_hitbox_radius, collision_falloff_radius=cfg.quads_collision_falloff_radius,
+        use_obstacles=cfg.quads_use_obstacles, obst_density=cfg.quads_obst_density, obst_size=cfg.quads_obst_size,
+        obst_spawn_area=cfg.quads_obst_spawn_area, use_downwash=cfg.quads_use_downwash, use_numba=cfg.quads_use_numba,
+        quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims)
+
+
 def make_quadrotor_env(env_name, cfg=None, _env_config=None, render_mode=None, **kwargs):
     if env_name == "quadrotor_multi":
+        if getattr(cfg, "quads_num_envs", 1) > 1:
+            return make_quadrotor_env_batched(cfg, **kwargs)
         return make_quadrotor_env_multi(cfg, render_mode, **kwargs)
     raise NotImplementedError
 

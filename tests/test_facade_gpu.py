@@ -161,3 +161,73 @@ def test_specialised_and_generic_kernels_agree(monkeypatch):
     for key, out in runs.items():
         for a, b in zip(ref, out):
             np.testing.assert_allclose(a, b, rtol=0, atol=1e-9, err_msg=str(key))
+
+
+def test_episode_sums_on_device_match_host_accumulation():
+    """episode_sums=1: the kernel's per-episode sums of the 17 reward terms / action moments equal what a host loop
+    accumulates from the per-step rew_info (reward_shaping.py:78-83), including the step on which the episode ends."""
+    from quad_swarm_rl_amd import config as qcfg, native
+    kw = dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, use_downwash=True,
+              collision_falloff_radius=4.0, rew_coeff=dict(quadcol_bin=5.0, quadcol_bin_smooth_max=10.0), ep_time=0.25)
+    for precision, tol in (("f64", 1e-10), ("f32", 2e-5)):
+        st = native.Stepper(qcfg.make_config(num_envs=5, seed=21, precision=precision, episode_sums=True, write_rew_info=True, **kw))
+        st.reset()
+        rng = np.random.RandomState(2)
+        acc = np.zeros((25, st.T))
+        episodes = 0
+        for t in range(60):
+            a = rng.uniform(-1.2, 1.2, size=(st.T, 4)).astype(st.np_real)
+            st.from_host("actions", a)
+            st.step()
+            st.sync()
+            acc[:17] += st.to_host("rew_info")
+            acc[17:21] += a.T.astype(np.float64)
+            acc[21:25] += (a.T.astype(np.float64)) ** 2
+            if st.to_host("done").any():
+                assert st.to_host("done").all()
+                np.testing.assert_allclose(st.to_host("ep_sums"), acc, rtol=0, atol=tol * (1 + np.abs(acc).max()))
+                np.testing.assert_array_equal(st.to_host("run_sums"), 0)
+                acc[:] = 0
+                episodes += 1
+        assert episodes == 2
+        st.close()
+
+
+def test_batched_env_matches_the_single_env_wrapper_stack():
+    """BatchedQuadSwarm (E envs, device tensors, on-device sums) reports at episode end what the reference-shaped stack
+    QuadrotorEnvMulti -> RewardShapingWrapper -> Compatibility reports for the same env, seed and actions."""
+    import torch
+    from quad_swarm_rl_amd import sf_env
+    argv = ["--quads_num_agents=4", "--quads_neighbor_visible_num=2", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
+            "--quads_collision_reward=5.0", "--quads_collision_falloff_radius=4.0", "--quads_episode_duration=0.2",
+            "--anneal_collision_steps=1000", "--quads_seed=9", "--quads_precision=f64"]
+    single = sf_env.make_quadrotor_env("quadrotor_multi", cfg=parse(argv))
+    batched = sf_env.make_quadrotor_env("quadrotor_multi", cfg=parse(argv + ["--quads_num_envs=3"]))
+    assert batched.num_agents == 12 and isinstance(batched, sf_env.BatchedQuadSwarm)
+    for env in (single, batched):
+        env.set_training_info({"approx_total_training_steps": 400})
+    obs_s, _ = single.reset()
+    obs_b, _ = batched.reset()
+    np.testing.assert_allclose(obs_b["obs"][:4].cpu().numpy(), obs_s, atol=1e-12)
+    rng = np.random.RandomState(4)
+    saw = 0
+    for t in range(45):
+        a = rng.uniform(-1, 1, size=(12, 4))
+        o_s, r_s, term_s, _, inf_s = single.step([a[i] for i in range(4)])
+        o_b, r_b, term_b, trunc_b, inf_b = batched.step(torch.as_tensor(a, device="cuda:0", dtype=torch.float64))
+        np.testing.assert_allclose(o_b["obs"][:4].cpu().numpy(), o_s, atol=1e-10)
+        np.testing.assert_allclose(r_b[:4].cpu().numpy(), r_s, atol=1e-12)
+        assert term_b[:4].cpu().numpy().tolist() == list(term_s) and not trunc_b.any()
+        if term_s.any():
+            saw += 1
+            assert len(inf_b) == 12
+            for i in range(4):
+                assert inf_b[i]["true_reward"] == pytest.approx(inf_s[i]["true_reward"], abs=1e-9)
+                es, eb = inf_s[i]["episode_extra_stats"], inf_b[i]["episode_extra_stats"]
+                for k, v in eb.items():
+                    assert k in es, k
+                    assert v == pytest.approx(es[k], abs=1e-9), k
+        else:
+            assert inf_b == []
+    assert saw == 2
+    single.close(); batched.close()
