@@ -230,6 +230,19 @@ int qs_set_profiling(qs_handle *h, int32_t enable);
 int qs_get_kernel_time(qs_handle *h, double *avg_ms, int64_t *launches);
 
 /*
+ * Environment snapshots: device-side deep copies of single environments, replacing `deepcopy(self.env)` of the
+ * replay wrapper (gym_art/quadrotor_multi/quad_experience_replay.py:99-104, :176-187).  A snapshot holds every
+ * per-drone and per-env array of one environment (state, flags, pair masks, counters, tick, goals, scenario state,
+ * obstacle map, running episode sums, and the observation that goes with them) except the position in the noise
+ * stream: a restored environment draws fresh noise, as the reference's does.  qs_snapshot_pool() (re)allocates
+ * `slots` snapshot slots; save / load / copy are asynchronous on `stream`.
+ */
+int qs_snapshot_pool(qs_handle *h, int32_t slots);
+int qs_snapshot_save(qs_handle *h, int32_t env, int32_t slot, void *stream);
+int qs_snapshot_load(qs_handle *h, int32_t slot, int32_t env, void *stream);
+int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *stream);
+
+/*
  * Config-specialised kernels (no counterpart in the reference; the analogue of Numba compiling the env's hot
  * functions for the argument types it sees, gym_art/quadrotor_multi/quadrotor_dynamics.py:498,:570).  Besides
  * the generic kernels of the library, qs_create() can run a code object compiled for exactly one

@@ -41,6 +41,12 @@ struct qs_handle {
     bool full = false;     // scenario outside the fast set => kernels compiled with QS_SCEN_FULL
     int team = 0;          // waves per workgroup of the team kernels (qs_step_team.inc): 4 generic, 8 (or 4) specialised; 0 = single-wave kernels
     // config-specialised code object (qs_spec_kernels.hip), when one is cached / could be built
+    // environment snapshots (qs_snapshot_*): `snap_slots` packed copies of one environment's complete state
+    struct SnapArray { char *base; size_t elem, comps, comp_stride, per_env; };   // strides / counts in elements
+    std::vector<SnapArray> snap_arrays;
+    size_t snap_bytes = 0;
+    char *snap_pool = nullptr;
+    int32_t snap_slots = 0;
     hipModule_t spec_mod = nullptr;
     hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr;
     Consts<float> kf;    // kernel constants, passed by value in the kernarg segment
@@ -309,6 +315,24 @@ template <typename real> static int create_typed(qs_handle *h) {
     b.new_pair_mask = p.new_pair_mask; b.unique_col_mask = p.unique_col; b.obst_new_mask = p.obst_new; b.room_new_mask = p.room_new;
     b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters; b.run_sums = p.run_sums; b.ep_sums = p.ep_sums;
     b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
+    // what a deep copy of one reference env carries (quad_experience_replay.py:99-104 deep-copies the whole env): every
+    // per-drone and per-env array except the noise-stream position (step_ctr: a restored env draws fresh noise, as the
+    // reference's does from the global numpy stream) and the per-step outputs
+    auto &sa = h->snap_arrays;
+    sa.clear();
+#define SNAP_T(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), T, N})
+#define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1})
+    SNAP_T(pos, 3); SNAP_T(vel, 3); SNAP_T(rot, 9); SNAP_T(omega, 3); SNAP_T(rot_damp, 4); SNAP_T(cmds_damp, 4); SNAP_T(ou, 4); SNAP_T(goal, 3);
+    SNAP_T(flags, 1); SNAP_T(pair_mask, 1); SNAP_T(new_pair_mask, 1); SNAP_T(obst_hit_idx, 1); SNAP_T(dist_ring, 4); SNAP_T(dist_sums, 3);
+    SNAP_T(run_sums, QS_SUM_COUNT);
+    sa.push_back({(char *)p.obs, sizeof(real), 1, T * D, N * D});                        // the observation that goes with the state
+    SNAP_E(unique_col, 1); SNAP_E(obst_new, 1); SNAP_E(room_new, 1); SNAP_E(counters, QS_CNT_COUNT); SNAP_E(tick, 1);
+    SNAP_E(scen_real, SR_COUNT); SNAP_E(scen_int, SI_COUNT); SNAP_E(scen_omap, 4); SNAP_E(scenario_id, 1);
+    sa.push_back({(char *)p.obst_pos, sizeof(real), 2, E * (M_ ? M_ : 1), (M_ ? M_ : 1)});
+#undef SNAP_T
+#undef SNAP_E
+    h->snap_bytes = 0;
+    for (const auto &a : sa) h->snap_bytes += (a.elem * a.comps * a.per_env + 15) & ~(size_t)15;
     return QS_OK;
 }
 
@@ -454,6 +478,7 @@ int qs_destroy(qs_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
+    if (h->snap_pool) (void)hipFree(h->snap_pool);
     for (void *q : h->allocs) (void)hipFree(q);
     if (h->d_state_buf) (void)hipFree(h->d_state_buf);
     if (h->d_tick_io) (void)hipFree(h->d_tick_io);
@@ -634,6 +659,43 @@ int qs_memcpy_h2d(qs_handle *h, void *dev_dst, const void *host_src, size_t byte
 }
 
 /* debug: phase time stamps (shader clock) of workgroup 0; all zero unless built with -DQS_TIMING */
+// ---- environment snapshots: device-side deep copies of single environments (replay wrapper) ----
+int qs_snapshot_pool(qs_handle *h, int32_t slots) {
+    if (!h || slots < 0) return fail(QS_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->snap_pool) { (void)hipFree(h->snap_pool); h->snap_pool = nullptr; h->snap_slots = 0; }
+    if (slots == 0) return QS_OK;
+    HIP_TRY(hipMalloc((void **)&h->snap_pool, h->snap_bytes * (size_t)slots));
+    h->snap_slots = slots;
+    return QS_OK;
+}
+
+static int snapshot_io(qs_handle *h, int32_t env, int32_t slot, bool save, hipStream_t s) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    if (env < 0 || env >= h->cfg.num_envs) return fail(QS_ERR_INVALID, "env out of range");
+    if (slot < 0 || slot >= h->snap_slots) return fail(QS_ERR_INVALID, "snapshot slot out of range (qs_snapshot_pool first)");
+    HIP_TRY(hipSetDevice(h->device));
+    char *dst = h->snap_pool + h->snap_bytes * (size_t)slot;
+    for (const auto &a : h->snap_arrays) {
+        char *src = a.base + a.elem * a.per_env * (size_t)env;
+        const size_t width = a.elem * a.per_env, spitch = a.elem * a.comp_stride;
+        if (save) HIP_TRY(hipMemcpy2DAsync(dst, width, src, spitch, width, a.comps, hipMemcpyDeviceToDevice, s));
+        else HIP_TRY(hipMemcpy2DAsync(src, spitch, dst, width, width, a.comps, hipMemcpyDeviceToDevice, s));
+        dst += (a.elem * a.comps * a.per_env + 15) & ~(size_t)15;
+    }
+    return QS_OK;
+}
+int qs_snapshot_save(qs_handle *h, int32_t env, int32_t slot, void *stream) { return snapshot_io(h, env, slot, true, (hipStream_t)stream); }
+int qs_snapshot_load(qs_handle *h, int32_t slot, int32_t env, void *stream) { return snapshot_io(h, env, slot, false, (hipStream_t)stream); }
+int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *stream) {
+    if (!h || src_slot < 0 || dst_slot < 0 || src_slot >= h->snap_slots || dst_slot >= h->snap_slots) return fail(QS_ERR_INVALID, "snapshot slot out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMemcpyAsync(h->snap_pool + h->snap_bytes * (size_t)dst_slot, h->snap_pool + h->snap_bytes * (size_t)src_slot, h->snap_bytes,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return QS_OK;
+}
+
 int qs_debug_timing(qs_handle *h, unsigned long long *out128) {   // [4 waves][32 stamps] of workgroup 0 (QS_TIMING builds)
     if (!h || !out128) return fail(QS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));

@@ -42,6 +42,21 @@ class _Scenario:
         return qcfg.SCENARIO_CLASS_NAMES[sid]
 
 
+class _SingleView:
+    """`env.envs[0]` of the reference, as far as the wrappers look at it: `.tick`, `.control_freq`."""
+
+    def __init__(self, multi):
+        self._multi = multi
+
+    @property
+    def tick(self):
+        return int(self._multi._vec.stepper.to_host("tick")[0])
+
+    @property
+    def control_freq(self):
+        return self._multi.control_freq
+
+
 class QuadSwarmVecEnv:
     """Batched env: all E*N agents stepped by one kernel launch; observations are born in HBM.
 
@@ -142,14 +157,70 @@ class QuadrotorEnvMulti:
         self.last_step_unique_collisions = np.array([], dtype=np.int64)
         self.curr_quad_col = np.array([], dtype=np.int64)
         self._real = v.stepper.np_real
+        # replay-buffer bookkeeping of the reference env (quadrotor_multi.py:166-175, :280-287)
+        from collections import deque
+        self.activate_replay_buffer = False
+        self.saved_in_replay_buffer = False
+        self.crashes_in_recent_episodes = deque([], maxlen=100)
+        self.crashes_last_episode = 0
+        self.collisions_grace_period_seconds = 1.5
+        self.obst_density, self.obst_size = obst_density, obst_size
+        self.envs = [_SingleView(self)]
 
     @property
     def unwrapped(self):
         return self
 
+    def can_drones_fly(self):   # quadrotor_multi.py:280-287
+        c = self.crashes_in_recent_episodes
+        return len(c) >= 10 and abs(np.mean(c)) < 1
+
+    def _on_reset(self):   # quadrotor_multi.py:355-359, run by every reset incl. the one inside step
+        if self.use_replay_buffer and not self.activate_replay_buffer:
+            self.crashes_in_recent_episodes.append(self.crashes_last_episode)
+            self.activate_replay_buffer = self.can_drones_fly()
+            self.crashes_last_episode = 0
+
     def reset(self, obst_density=None, obst_size=None):
+        if (obst_density is not None and obst_density != self.obst_density) or (obst_size is not None and obst_size != self.obst_size):
+            raise NotImplementedError("per-episode obstacle density / size randomisation is not part of the stepper (fixed at creation)")
         self._vec.stepper.reset()
+        self._on_reset()
         return self._vec.stepper.to_host("obs").astype(np.float64)
+
+    # ---- device-side deep copies for the replay wrapper (quad_experience_replay.py) ----
+    _HOST_STATE = ("activate_replay_buffer", "saved_in_replay_buffer", "crashes_last_episode", "obst_density", "obst_size")
+
+    def save_checkpoint(self, slot):
+        """`deepcopy(env)`: device state into snapshot slot `slot`, host-side attributes returned to the caller."""
+        self._vec.stepper.snapshot_save(0, slot)
+        host = {k: getattr(self, k) for k in self._HOST_STATE}
+        host["crashes_in_recent_episodes"] = list(self.crashes_in_recent_episodes)
+        return host
+
+    def load_checkpoint(self, slot, host):
+        st = self._vec.stepper
+        st.snapshot_load(slot, 0)
+        st.sync()
+        for k in self._HOST_STATE:
+            setattr(self, k, host[k])
+        self.crashes_in_recent_episodes.clear()
+        self.crashes_in_recent_episodes.extend(host["crashes_in_recent_episodes"])
+        self._read_masks(st)
+
+    def zero_collision_counters(self):
+        """collisions_per_episode = collisions_after_settle = obst_quad_... = 0 (quad_experience_replay.py:183-185)."""
+        st = self._vec.stepper
+        cnt = st.to_host("counters")
+        cnt[[0, 1, 7, 8], 0] = 0
+        st.from_host("counters", cnt)
+
+    def _read_masks(self, st):
+        ids = int(st.to_host("unique_col_mask")[0])
+        self.last_step_unique_collisions = np.array([i for i in range(self.num_agents) if ids >> i & 1], dtype=np.int64)
+        if self.use_obstacles:
+            ids = int(st.to_host("obst_new_mask")[0])
+            self.curr_quad_col = np.array([i for i in range(self.num_agents) if ids >> i & 1], dtype=np.int64)
 
     def step(self, actions):
         st = self._vec.stepper
@@ -165,15 +236,18 @@ class QuadrotorEnvMulti:
         ri = st.to_host("rew_info")
         keys = qcfg.REW_INFO_KEYS if self.use_obstacles else qcfg.REW_INFO_KEYS[:15]
         infos = [{"rewards": {k: float(ri[j, i]) for j, k in enumerate(keys)}} for i in range(self.num_agents)]
-        ids = int(st.to_host("unique_col_mask")[0])
-        self.last_step_unique_collisions = np.array([i for i in range(self.num_agents) if ids >> i & 1], dtype=np.int64)
-        if self.use_obstacles:
-            ids = int(st.to_host("obst_new_mask")[0])
-            self.curr_quad_col = np.array([i for i in range(self.num_agents) if ids >> i & 1], dtype=np.int64)
+        self._read_masks(st)
+        if self.use_replay_buffer and not self.activate_replay_buffer:   # quadrotor_multi.py:610-612
+            self.crashes_last_episode += infos[0]["rewards"]["rew_crash"]
         if any(dones):
-            stats = self.episode_extra_stats()
+            if self.saved_in_replay_buffer:   # quadrotor_multi.py:629-633
+                cnt = st.to_host("ep_counters")[:, 0]
+                stats = [{"num_collisions_replay": int(cnt[0]), "num_collisions_obst_replay": int(cnt[7])} for _ in range(self.num_agents)]
+            else:
+                stats = self.episode_extra_stats()
             for i in range(self.num_agents):
                 infos[i]["episode_extra_stats"] = stats[i]
+            self._on_reset()   # the auto-reset inside step (:720-722)
         return obs, rewards, dones, infos
 
     def episode_extra_stats(self):

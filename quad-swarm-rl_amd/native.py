@@ -103,6 +103,10 @@ def lib():
         L.qs_spec_build.argtypes = [C.POINTER(qcfg.QsConfig), C.c_int, C.c_char_p, C.c_int]
         L.qs_is_specialized.argtypes = [vp]
         L.qs_kernel_flavor.argtypes = [vp]
+        L.qs_snapshot_pool.argtypes = [vp, C.c_int32]
+        L.qs_snapshot_save.argtypes = [vp, C.c_int32, C.c_int32, vp]
+        L.qs_snapshot_load.argtypes = [vp, C.c_int32, C.c_int32, vp]
+        L.qs_snapshot_copy.argtypes = [vp, C.c_int32, C.c_int32, vp]
         if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
             raise RuntimeError("qs_config layout mismatch between config.py and libquadswarm_hip.so")
         _lib = L
@@ -112,7 +116,8 @@ def lib():
 EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
                     "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_check_errors", "qs_set_profiling",
-                    "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor"]
+                    "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor",
+                    "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy"]
 
 
 class QsError(RuntimeError):
@@ -220,6 +225,19 @@ class Stepper:
 
     def set_profiling(self, enable):
         _check(lib().qs_set_profiling(self._h, int(enable)))
+
+    # ---- environment snapshots (include/quadswarm.h) ------------------------------------------------
+    def snapshot_pool(self, slots):
+        _check(lib().qs_snapshot_pool(self._h, slots))
+
+    def snapshot_save(self, env, slot, stream=None):
+        _check(lib().qs_snapshot_save(self._h, env, slot, self._stream_ptr(stream)))
+
+    def snapshot_load(self, slot, env, stream=None):
+        _check(lib().qs_snapshot_load(self._h, slot, env, self._stream_ptr(stream)))
+
+    def snapshot_copy(self, src_slot, dst_slot, stream=None):
+        _check(lib().qs_snapshot_copy(self._h, src_slot, dst_slot, self._stream_ptr(stream)))
 
     @property
     def specialized(self):

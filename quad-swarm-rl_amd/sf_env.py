@@ -274,8 +274,7 @@ class Compatibility(_Wrapper):
 
 def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
     """quad_utils.py:20-110 on the HIP stepper (replay wrapper / V-value wrapper: SURVEY 8f 'next')."""
-    if getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0:
-        raise NotImplementedError("ExperienceReplayWrapper is not part of the stepper yet (SURVEY.md 8f)")
+    use_replay_buffer = getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0
     rew_coeff = DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]
     env = QuadrotorEnvMulti(
         num_agents=cfg.quads_num_agents, ep_time=cfg.quads_episode_duration,
@@ -285,12 +284,16 @@ def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
         collision_hitbox_radius=cfg.quads_collision_hitbox_radius, collision_falloff_radius=cfg.quads_collision_falloff_radius,
         use_obstacles=cfg.quads_use_obstacles, obst_density=cfg.quads_obst_density, obst_size=cfg.quads_obst_size,
         obst_spawn_area=cfg.quads_obst_spawn_area, use_downwash=cfg.quads_use_downwash, use_numba=cfg.quads_use_numba,
-        quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims, use_replay_buffer=False,
+        quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims, use_replay_buffer=use_replay_buffer,
         quads_view_mode=getattr(cfg, "quads_view_mode", None), quads_render=getattr(cfg, "quads_render", False),
         dynamics_params="Crazyflie", raw_control=True, raw_control_zero_middle=True, dynamics_randomize_every=None,
         dynamics_change=dict(noise=dict(thrust_noise_ratio=0.05), damp=dict(vel=0, omega_quadratic=0)), dyn_sampler_1=None,
         sense_noise="default", init_random_state=False, render_mode=render_mode,
         seed=getattr(cfg, "quads_seed", 0), device=getattr(cfg, "quads_device", 0), precision=getattr(cfg, "quads_precision", "f32"))
+    if use_replay_buffer:   # quad_utils.py:67-70
+        from .replay import ExperienceReplayWrapper
+        env = ExperienceReplayWrapper(env, cfg.replay_buffer_sample_prob, cfg.quads_obst_density, cfg.quads_obst_size,
+                                      getattr(cfg, "quads_domain_random", False), seed=getattr(cfg, "quads_seed", 0))
     reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
     reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
     reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty

@@ -231,3 +231,101 @@ def test_batched_env_matches_the_single_env_wrapper_stack():
             assert inf_b == []
     assert saw == 2
     single.close(); batched.close()
+
+
+STATE_ARRAYS = ("pos", "vel", "rot", "omega", "thrust_rot_damp", "thrust_cmds_damp", "ou_state", "goal", "flags", "col_pair_mask",
+                "new_pair_mask", "obst_hit_idx", "run_sums", "obs", "unique_col_mask", "counters", "tick", "scenario_id", "obst_pos")
+
+
+def _env_slice(st, name, e):
+    a = st.to_host(name)
+    N, E, T = st.N, st.E, st.T
+    if name == "obs":
+        return a[e * N:(e + 1) * N].copy()
+    if name == "obst_pos":
+        M = a.shape[1] // E
+        return a[:, e * M:(e + 1) * M].copy()
+    if a.shape[-1] == T:
+        return a[..., e * N:(e + 1) * N].copy()
+    return a[..., e:e + 1].copy()
+
+
+def test_snapshot_save_load_is_a_deep_copy_of_one_env():
+    """qs_snapshot_save / load replace deepcopy(env) of the replay wrapper: every state array of the env comes back bit for bit,
+    other envs are untouched, and a snapshot can be loaded into another env index."""
+    from quad_swarm_rl_amd import config as qcfg, native
+    st = native.Stepper(qcfg.make_config(num_envs=3, num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True,
+                                         use_obstacles=True, quads_mode="o_random", obst_spawn_area=(8.0, 8.0), obst_density=0.2,
+                                         obs_repr="xyz_vxyz_R_omega_floor", episode_sums=True, ep_time=0.6))
+    st.snapshot_pool(2)
+    st.reset()
+    rng = np.random.RandomState(0)
+
+    def run(k):
+        for _ in range(k):
+            st.from_host("actions", rng.uniform(-1, 1, size=(st.T, 4)).astype(np.float32))
+            st.step()
+        st.sync()
+
+    run(25)
+    saved = {n: _env_slice(st, n, 1) for n in STATE_ARRAYS}
+    st.snapshot_save(1, 0)
+    run(50)                                       # crosses an episode boundary (61 steps per episode)
+    others = {n: (_env_slice(st, n, 0), _env_slice(st, n, 2)) for n in STATE_ARRAYS}
+    assert any((saved[n] != _env_slice(st, n, 1)).any() for n in ("pos", "tick", "goal"))
+    st.snapshot_load(0, 1)
+    st.sync()
+    for n in STATE_ARRAYS:
+        np.testing.assert_array_equal(_env_slice(st, n, 1), saved[n], err_msg=n)
+        np.testing.assert_array_equal(_env_slice(st, n, 0), others[n][0], err_msg=n)
+        np.testing.assert_array_equal(_env_slice(st, n, 2), others[n][1], err_msg=n)
+    st.snapshot_copy(0, 1)
+    st.snapshot_load(1, 2)                        # same state into another env index
+    st.sync()
+    for n in STATE_ARRAYS:
+        np.testing.assert_array_equal(_env_slice(st, n, 2), saved[n], err_msg=n)
+    run(5)                                        # and the restored envs keep stepping
+    st.check_errors()
+    with pytest.raises(native.QsError):
+        st.snapshot_save(0, 5)
+    st.close()
+
+
+def test_experience_replay_wrapper_replays_a_collision_event():
+    """quad_experience_replay.py on device snapshots: checkpoints every 0.5 s, a collision after the grace period files the
+    checkpoint from 1.5 s earlier, and the next episode starts from that checkpoint."""
+    from quad_swarm_rl_amd import sf_env
+    from quad_swarm_rl_amd.replay import ExperienceReplayWrapper
+    cfg = parse(["--quads_num_agents=4", "--quads_neighbor_visible_num=2", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
+                 "--quads_episode_duration=3.0", "--replay_buffer_sample_prob=1.0", "--quads_precision=f64", "--quads_seed=2"])
+    env = sf_env.make_quadrotor_env("quadrotor_multi", cfg=cfg)
+    replay, quad = env.env.env, env.unwrapped          # Compatibility -> RewardShaping -> ExperienceReplay -> QuadrotorEnvMulti
+    assert isinstance(replay, ExperienceReplayWrapper) and quad.use_replay_buffer and not quad.activate_replay_buffer
+    env.reset()
+    quad.activate_replay_buffer = True                 # (the reference switches it on after 10 episodes without crashes, :280-287)
+    st = quad._vec.stepper
+    hover = [np.full(4, 0.06) for _ in range(4)]
+    cp_obs = {}
+    for t in range(1, 302):
+        if t == 211:                                   # two drones on top of each other: a new collision pair at tick 211
+            s, tick = st.get_state(0)
+            s[1, 0:3] = s[0, 0:3] + np.array([0.03, 0.0, 0.0])
+            st.set_state(0, s, tick)
+        obs, rew, term, trunc, infos = env.step(hover)
+        if t in (50, 100, 150, 200) and not term.any():
+            cp_obs[t] = np.array(obs, copy=True)
+        if t == 211:
+            assert len(replay.replay_buffer) == 1 and replay.last_tick_added_to_buffer == 211
+            assert len(replay.episode_checkpoints) == 4
+        if t < 301:
+            assert not term.any()
+    assert term.all()                                  # tick 301 > ep_len 300
+    st_info = infos[0]["episode_extra_stats"]
+    assert st_info["replay/replay_rate"] == 1.0 and st_info["replay/replay_buffer_size"] == 1 and st_info["replay/avg_replayed"] == 1.0
+    # steps_ago = 1.5 / 0.5 = 3 checkpoints before the collision: the one taken at tick 100
+    assert quad.envs[0].tick == 100 and quad.saved_in_replay_buffer
+    np.testing.assert_array_equal(obs, cp_obs[100])
+    for t in range(101, 302):                          # the replayed episode runs to its own end
+        obs, rew, term, trunc, infos = env.step(hover)
+    assert term.all() and "num_collisions_replay" in infos[0]["episode_extra_stats"]
+    env.close()
