@@ -255,7 +255,7 @@ def main():
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, E, st.kernel_name), "kernel": st.kernel_name,
-                         "kernel_flavor": ("config-specialised, " if st.specialized else "generic, ") + ("4 waves per workgroup" if st.team else "1 wave per workgroup"), "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": args.steps,
+                         "kernel_flavor": ("config-specialised, " if st.specialized else "generic, ") + f"{st.waves_per_workgroup} wave{'s' if st.waves_per_workgroup > 1 else ''} per workgroup", "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": args.steps,
                          "kernel_avg_us_event_pair_per_launch": kernel_ms * 1e3, "event_pair_launches": launches,
                          "algorithmic_bytes_per_launch": algo * T},
         }

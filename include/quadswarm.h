@@ -254,7 +254,8 @@ int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *str
  */
 int qs_spec_build(const qs_config *cfg, int team, char *path_out, int cap);
 int qs_is_specialized(qs_handle *h);
-/* which step kernel the handle launches: bit 0 = config-specialised, bit 1 = 4-wave team kernels, bit 2 = full scenario set */
+/* which step kernel the handle launches: bit 0 = config-specialised, bit 1 = team kernels, bit 2 = full scenario set,
+ * bits 8..15 = waves per workgroup (1, 4 or 8) */
 int qs_kernel_flavor(qs_handle *h);
 
 /*

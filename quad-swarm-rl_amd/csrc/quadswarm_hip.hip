@@ -470,8 +470,8 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
 
 // 1 if the handle runs config-specialised kernels, 0 if the generic ones
 int qs_is_specialized(qs_handle *h) { return (h && h->spec_step) ? 1 : 0; }
-// bit 0: config-specialised code object, bit 1: team (4-wave) kernels, bit 2: full scenario set
-int qs_kernel_flavor(qs_handle *h) { return h ? ((h->spec_step ? 1 : 0) | (h->team ? 2 : 0) | (h->full ? 4 : 0)) : 0; }
+// bit 0: config-specialised code object, bit 1: team kernels, bit 2: full scenario set, bits 8..15: waves per workgroup
+int qs_kernel_flavor(qs_handle *h) { return h ? ((h->spec_step ? 1 : 0) | (h->team ? 2 : 0) | (h->full ? 4 : 0) | ((h->team ? h->team : 1) << 8)) : 0; }
 
 int qs_destroy(qs_handle *h) {
     if (!h) return QS_OK;

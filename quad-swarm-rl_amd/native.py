@@ -250,6 +250,10 @@ class Stepper:
         return bool(lib().qs_kernel_flavor(self._h) & 2)
 
     @property
+    def waves_per_workgroup(self):
+        return (lib().qs_kernel_flavor(self._h) >> 8) & 0xff
+
+    @property
     def kernel_name(self):
         """Name of the step kernel this handle launches (as it appears in a rocprofv3 kernel trace)."""
         fl = lib().qs_kernel_flavor(self._h)
