@@ -314,3 +314,47 @@ def test_determinism_and_sharding_invariance():
     lo, hi = run(E // 2, 0, slice(0, E // 2)), run(E // 2, E // 2, slice(E // 2, E))
     for a, b, c in zip(full1, lo, hi):
         np.testing.assert_array_equal(a, np.concatenate([b, c], axis=0))
+
+
+def test_full_size_properties_c2():
+    """BASELINE configs[1] at full size (8 drones x 1024 envs, fp32 production kernels): properties that do not need the
+    oracle - sharding invariance (two 512-env handles == one 1024-env handle, bit for bit), finite outputs, mask / counter
+    consistency, auto-reset cadence."""
+    from quad_swarm_rl_amd import native
+    kw = dict(CASES["c2_n8_dw"], ep_time=0.3)
+    E, N, steps = 1024, 8, 40
+    rng = np.random.RandomState(11)
+    acts = rng.uniform(-1, 1, size=(steps, E * N, 4)).astype(np.float32)
+
+    def run(num_envs, offset):
+        st = native.Stepper(qcfg.make_config(num_envs=num_envs, seed=5, env_id_offset=offset, **kw))
+        assert st.specialized
+        st.reset()
+        lo, hi = offset * N, (offset + num_envs) * N
+        out = []
+        for t in range(steps):
+            st.from_host("actions", acts[t, lo:hi])
+            st.step()
+            out.append((st.to_host("obs").copy(), st.to_host("reward").copy(), st.to_host("done").copy(),
+                        st.to_host("unique_col_mask").copy(), st.to_host("counters").copy(), st.to_host("col_pair_mask").copy()))
+        st.check_errors()
+        st.close()
+        return out
+
+    full, a, b = run(E, 0), run(E // 2, 0), run(E // 2, E // 2)
+    for t in range(steps):
+        obs, rew, done, uniq, cnt, pairs = full[t]
+        for k in range(6):
+            axis = 1 if k == 4 else 0
+            np.testing.assert_array_equal(full[t][k], np.concatenate([a[t][k], b[t][k]], axis=axis), err_msg=f"step {t} output {k}")
+        assert np.isfinite(obs).all() and np.isfinite(rew).all()
+        assert done.all() == ((t + 1) % 31 == 0) and done.any() == done.all()          # ep_len 30: done on every 31st step, all envs
+        assert (uniq >> N == 0).all()                                                    # ids are drone indices < N
+        pm = pairs.reshape(E, N)
+        for d in range(N):                                                              # pair bits only above the own index
+            assert ((pm[:, d] & ((1 << (d + 1)) - 1)) == 0).all()
+        if t > 0 and not full[t - 1][2].any() and not done.any():
+            assert (cnt >= full[t - 1][4]).all()                                         # counters only grow inside an episode
+            grew = cnt[0] - full[t - 1][4][0]
+            pop = np.array([bin(int(u)).count("1") // 2 for u in uniq])
+            np.testing.assert_array_equal(grew, pop)                                     # collisions += len(unique ids) // 2
