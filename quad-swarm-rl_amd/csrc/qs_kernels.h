@@ -47,6 +47,13 @@ template <typename real> struct Ptrs {
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
 };
 
+// (neighbour metric, drone index) as one unsigned key whose order is "smaller metric first, lower index first": the IEEE bit
+// pattern of a float is monotone after flipping the sign bit of non-negatives and all bits of negatives
+__device__ __forceinline__ unsigned long long nbr_key(float m, int idx) {
+    const uint32_t b = __float_as_uint(m), o = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+    return ((unsigned long long)o << 32) | (uint32_t)idx;
+}
+
 #ifdef QS_TIMING
 #define QS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.timing[k] = clock64(); } while (0)
 // helper waves of the team kernels: stamp k of wave w (1..3) lands in timing[32*w + k]
