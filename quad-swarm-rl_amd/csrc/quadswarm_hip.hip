@@ -121,7 +121,10 @@ static int validate(const qs_config *c);
 static bool scenario_is_full(int scenario) {
     return !(scenario == QS_SCENARIO_STATIC_SAME_GOAL || scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || scenario == QS_SCENARIO_SWARM_VS_SWARM);
 }
-static bool team_default(int blocks, int cus) { return blocks <= 4 * cus; }
+static int spec_team_waves(int num_agents);
+// Team kernels pay off while the whole batch still fits at <= 8 waves per CU (measured on MI355X, specialised fp32 kernels, us per
+// step team / single-wave: C2 shape 1024 envs 8.3 / 9.1, 2048 envs 9.1 / 9.8, 3072 envs 13.8 / 10.8; C4 shape 1024 envs 23.1 / 26.4)
+static bool team_default(int blocks, int cus, int num_agents) { return (long)blocks * spec_team_waves(num_agents) <= 8L * cus; }
 // Specialised team kernels: 8 waves (2 per SIMD) halve the striped phases once more for N <= 8 (C2 8.65 -> 8.15 us); with
 // N > 8 the merge of 8 sorted lists outweighs that (C4 24.6 -> 28.3 us), so those keep 4 waves.
 static int spec_team_waves(int num_agents) { return num_agents <= 8 ? 8 : 4; }
@@ -239,7 +242,7 @@ extern "C" int qs_spec_build(const qs_config *cfg, int team, char *path_out, int
     int rc = validate(cfg);
     if (rc != QS_OK) return rc;
     const int epb = QS_WAVE / cfg->num_agents, blocks = (cfg->num_envs + epb - 1) / epb;
-    if (team < 0) team = team_default(blocks, 256) ? 1 : 0;
+    if (team < 0) team = team_default(blocks, 256, cfg->num_agents) ? 1 : 0;
     if (team == 1) team = spec_team_waves(cfg->num_agents);
     if (team != 0 && team != 4 && team != 8) return fail(QS_ERR_INVALID, "team must be -1, 0, 1, 4 or 8");
     std::string path = spec_ensure(cfg, team, true);
@@ -401,13 +404,13 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
     h->epb = QS_WAVE / cfg->num_agents;
     h->blocks = (cfg->num_envs + h->epb - 1) / h->epb;
     // Kernel flavour: a team of 4 waves per workgroup shortens the per-step critical path when the batch cannot fill the
-    // chip anyway (<= 4 workgroups per CU); the single-wave kernels do less total work per drone and win on throughput.
+    // chip anyway (<= 8 waves per CU, team_default); the single-wave kernels do less total work per drone and win on throughput.
     // QS_TEAM=0/1 in the environment overrides the choice (both flavours produce the same results).
     {
         hipDeviceProp_t prop;
         int cus = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        h->team = team_default(h->blocks, cus) ? QS_TEAM_WAVES : 0;
+        h->team = team_default(h->blocks, cus, cfg->num_agents) ? QS_TEAM_WAVES : 0;
         const char *ev = getenv("QS_TEAM");
         if (ev && ev[0] == '0') h->team = 0;
         else if (ev && (ev[0] == '1' || ev[0] == '4' || ev[0] == '8')) h->team = QS_TEAM_WAVES;
