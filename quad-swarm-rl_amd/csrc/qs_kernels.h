@@ -145,7 +145,7 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) rank[u] += (mj[k] < mj[u] || (mj[k] == mj[u] && k < u)) ? 1 : 0;
+                    for (int u = 0; u < 8; ++u) rank[u] += (int)((mj[k] < mj[u]) | ((mj[k] == mj[u]) & (k < u)));
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {

@@ -7,6 +7,8 @@ Both sides draw every stochastic term from the same counter-based Philox stream 
     overwritten with the oracle's, one control step is taken, outputs must agree to 1e-5 (the tolerance
     north_star states for fp32 dynamics state) and the discrete outputs exactly.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -328,7 +330,7 @@ def test_full_size_properties_c2():
 
     def run(num_envs, offset):
         st = native.Stepper(qcfg.make_config(num_envs=num_envs, seed=5, env_id_offset=offset, **kw))
-        assert st.specialized
+        assert st.specialized or os.environ.get("QS_SPEC", "jit") in ("off", "0", "cache")
         st.reset()
         lo, hi = offset * N, (offset + num_envs) * N
         out = []
