@@ -977,6 +977,33 @@ static void scenario_reset(qso_env *e) {
         e->num_goals = N;
         break;
     }
+    case QS_SCENARIO_O_EP_RAND_BEZIER: {     /* scenarios/obstacles/o_ep_rand_bezier.py:57-97 */
+        pos_obst_map_2(e, e->spawn_points, 16, 96);
+        e->have_spawn_points = 1;
+        pos_obst_map_1(e, e->end_point, 9);
+        if (e->tape) {
+            /* :72-90 ten "trajectory points" from the free cells, never used afterwards (step() has the line commented out): the
+             * loop only consumes draws.  Replayed against the tape; with the counter-based stream there is nothing to skip. */
+            int (*fs)[2] = (int (*)[2])malloc(sizeof(int[2]) * 64 * 64);
+            int nfree = free_space(e, fs), sampled[10], ns = 0;
+            free(fs);
+            while (ns < 10) {
+                int idx = (int)tape_pop(e), reject = 0;   /* np.random.choice(len(self.free_space)) */
+                for (int q = 0; q < ns; ++q) {            /* cell_centers[] is indexed with free-space indices in the reference */
+                    double dx = e->cell_centers[2 * sampled[q]] - e->cell_centers[2 * idx], dy = e->cell_centers[2 * sampled[q] + 1] - e->cell_centers[2 * idx + 1];
+                    if (sqrt(dx * dx + dy * dy) > 4.0) reject = 1;
+                }
+                if (reject) continue;
+                sampled[ns++] = idx;
+                --nfree;                                   /* self.free_space.pop(point_idx) */
+            }
+            (void)nfree;
+        }
+        update_formation(e, 0);
+        for (int k = 0; k < N; ++k) memcpy(e->goals[k], e->end_point, sizeof e->end_point);
+        e->num_goals = N;
+        break;
+    }
     case QS_SCENARIO_O_RANDOM: {             /* scenarios/obstacles/o_random.py:27-52 */
         if (e->tape) tape_skip(e, 4 * N);    /* N x (generate_pos_obst_map() twice): results are overwritten below */
         pos_obst_map_2(e, e->spawn_points, 16, 96);
@@ -1027,7 +1054,7 @@ static void scenario_reset(qso_env *e) {
     }
     /* approch_goal_metric: 0.5 (base.py:31, o_random.py:10), 1.0 for the other obstacle scenarios (o_base.py:16) */
     e->approach_metric = (e->scen == QS_SCENARIO_O_STATIC_SAME_GOAL || e->scen == QS_SCENARIO_O_DYNAMIC_SAME_GOAL ||
-                          e->scen == QS_SCENARIO_O_SWAP_GOALS) ? 1.0 : 0.5;
+                          e->scen == QS_SCENARIO_O_SWAP_GOALS || e->scen == QS_SCENARIO_O_EP_RAND_BEZIER) ? 1.0 : 0.5;
 }
 
 static void set_all_goals(qso_env *e) { for (int i = 0; i < e->c.num_agents; ++i) memcpy(e->d[i].goal, e->goals[i], sizeof e->d[i].goal); }
@@ -1099,18 +1126,20 @@ static void scenario_step(qso_env *e) {
         set_all_goals(e);
         break;
     }
-    case QS_SCENARIO_EP_RAND_BEZIER: {       /* scenarios/ep_rand_bezier.py:8-48 */
-        int control_steps = (int)(5 * control_freq), t = tick % control_steps;
+    case QS_SCENARIO_EP_RAND_BEZIER:         /* scenarios/ep_rand_bezier.py:8-48 */
+    case QS_SCENARIO_O_EP_RAND_BEZIER: {     /* scenarios/obstacles/o_ep_rand_bezier.py:16-55: 6 s legs, <= 5 m, goal height in [1.5, 3] */
+        const int obst = e->scen == QS_SCENARIO_O_EP_RAND_BEZIER;
+        int control_steps = (int)((obst ? 6 : 5) * control_freq), t = tick % control_steps;
         double room[3] = {c->room_hi[0] - c->room_lo[0] - e->form_size, c->room_hi[1] - c->room_lo[1] - e->form_size, c->room_hi[2] - c->room_lo[2] - e->form_size};
-        double mx = fmax(room[0], fmax(room[1], room[2])), max_dist = fmin(30.0, mx), min_dist = max_dist / 2;
+        double mx = fmax(room[0], fmax(room[1], room[2])), max_dist = fmin(obst ? 5.0 : 30.0, mx), min_dist = max_dist / 2;
         if (tick % control_steps == 0 || tick == 1) {
-            double low[3] = {-room[0] / 2, -room[1] / 2, 0}, high[3] = {room[0] / 2, room[1] / 2, room[2]};
+            double low[3] = {-room[0] / 2, -room[1] / 2, obst ? 1.5 : 0}, high[3] = {room[0] / 2, room[1] / 2, obst ? 3.0 : room[2]};
             double np_[3][2];
             for (int it = 0; it < 100000; ++it) {
                 double u[6];   /* uniform(low=-high, high=high, size=(2,3)).reshape(3,2): flat order u0..u5 -> [[u0,u1],[u2,u3],[u4,u5]] */
                 if (e->tape) { for (int k = 0; k < 6; ++k) u[k] = tape_pop(e); }
                 else { for (int k = 0; k < 6; ++k) { int ax = k % 3; u[k] = rng_uniform1(e, QS_SITE_SCEN, 300 + 8 * it + k, 0, 0, -high[ax], high[ax]); } }
-                int lo_i = (int)ceil(min_dist), hi_i = (int)max_dist + 1, r;   /* np.random.randint(min_dist, max_dist + 1) */
+                int lo_i = (int)floor(min_dist), hi_i = (int)max_dist + 1, r;   /* np.random.randint(min_dist, max_dist + 1): a float low is truncated */
                 if (e->tape) r = (int)tape_pop(e);
                 else { r = lo_i + (int)(rng_uniform1(e, QS_SITE_SCEN, 300 + 8 * it + 6, 0, 0, 0.0, 1.0) * (hi_i - lo_i)); if (r >= hi_i) r = hi_i - 1; }
                 int ok = 1;

@@ -19,7 +19,7 @@ OBS_REPR = {"xyz_vxyz_R_omega": 0, "xyz_vxyz_R_omega_floor": 1, "xyz_vxyz_R_omeg
 OBS_REPR_DIM = {"xyz_vxyz_R_omega": 18, "xyz_vxyz_R_omega_floor": 19, "xyz_vxyz_R_omega_wall": 24}  # quad_utils.py:30-34
 SCENARIOS = {"static_same_goal": 0, "o_static_same_goal": 1, "swarm_vs_swarm": 2, "static_diff_goal": 3, "dynamic_same_goal": 4,
              "dynamic_diff_goal": 5, "dynamic_formations": 6, "swap_goals": 7, "ep_lissajous3D": 8, "ep_rand_bezier": 9,
-             "o_random": 10, "o_dynamic_same_goal": 11, "o_swap_goals": 12, "mix": 13}
+             "o_random": 10, "o_dynamic_same_goal": 11, "o_swap_goals": 12, "mix": 13, "o_ep_rand_bezier": 14}
 SCENARIO_CLASS_NAMES = {v: "Scenario_" + k for k, v in SCENARIOS.items()}
 REW_COEFF_KEYS = ["pos", "effort", "crash", "orient", "spin", "quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"]
 # quadrotor_multi.py:91-94

@@ -186,6 +186,17 @@ __device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, co
         store_formation<real>(x, F);
         for (int q = 0; q < 3; ++q) x.sr[SR_END + q] = end[q];
         for (int k = 0; k < N; ++k) for (int q = 0; q < 3; ++q) x.goals[k * 3 + q] = end[q];
+    } else if (sc == QS_SCENARIO_O_EP_RAND_BEZIER) {     // obstacles/o_ep_rand_bezier.py:57-97
+        pos_obst_map_2<real>(c, key, x, tidx, tval, 16, 96, true);
+        x.si[SI_HAVE_SPAWN] = 1;
+        real end[3];
+        pos_obst_map_1<real>(c, key, x.omap, 9, end);
+        // (:72-90 sample ten "trajectory points" that step() never uses: with the counter-based stream there is nothing to skip)
+        Formation<real> F;
+        update_formation<real>(sc, key, 0, N, F);
+        store_formation<real>(x, F);
+        for (int q = 0; q < 3; ++q) x.sr[SR_END + q] = end[q];
+        for (int k = 0; k < N; ++k) for (int q = 0; q < 3; ++q) x.goals[k * 3 + q] = end[q];
     } else if (sc == QS_SCENARIO_O_RANDOM) {
         pos_obst_map_2<real>(c, key, x, tidx, tval, 16, 96, true);
         x.si[SI_HAVE_SPAWN] = 1;
@@ -228,7 +239,8 @@ __device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, co
         for (int q = 0; q < 3; ++q) { x.sr[SR_C1 + q] = c1[q]; x.sr[SR_C2 + q] = c2[q]; }
         svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, false, x.goals);
     }
-    x.sr[SR_METRIC] = (sc == QS_SCENARIO_O_STATIC_SAME_GOAL || sc == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || sc == QS_SCENARIO_O_SWAP_GOALS) ? (real)1 : (real)0.5;
+    x.sr[SR_METRIC] = (sc == QS_SCENARIO_O_STATIC_SAME_GOAL || sc == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || sc == QS_SCENARIO_O_SWAP_GOALS ||
+                       sc == QS_SCENARIO_O_EP_RAND_BEZIER) ? (real)1 : (real)0.5;
 }
 
 // Does scenario `sc` need the serial (one lane per env, all goals) part of step() at this tick?
@@ -294,20 +306,22 @@ __device__ void scenario_step_local(const Consts<real> &c, const RngKey &key, co
         goal[0] = (real)0.03 * M<real>::sin(t) + goal[0];
         goal[1] = (real)0.01 * M<real>::sin((real)2 * t + (real)90) + goal[1];
         goal[2] = (real)0.01 * M<real>::cos((real)2 * t + (real)90) + goal[2];
-    } else if (sc == QS_SCENARIO_EP_RAND_BEZIER) {       // ep_rand_bezier.py:8-48
-        const int control_steps = 5 * c.control_freq, t = tick % control_steps;
+    } else if (sc == QS_SCENARIO_EP_RAND_BEZIER || sc == QS_SCENARIO_O_EP_RAND_BEZIER) {
+        // ep_rand_bezier.py:8-48 / obstacles/o_ep_rand_bezier.py:16-55 (6 s legs, <= 5 m, goal height in [1.5, 3])
+        const bool obst = sc == QS_SCENARIO_O_EP_RAND_BEZIER;
+        const int control_steps = (obst ? 6 : 5) * c.control_freq, t = tick % control_steps;
         real fsz = x.sr[SR_SIZE];
         real room[3] = {c.room_hi[0] - c.room_lo[0] - fsz, c.room_hi[1] - c.room_lo[1] - fsz, c.room_hi[2] - c.room_lo[2] - fsz};
-        real mx = M<real>::fmax(room[0], M<real>::fmax(room[1], room[2])), max_dist = M<real>::fmin((real)30, mx), min_dist = max_dist / (real)2;
+        real mx = M<real>::fmax(room[0], M<real>::fmax(room[1], room[2])), max_dist = M<real>::fmin(obst ? (real)5 : (real)30, mx), min_dist = max_dist / (real)2;
         real bez[9];
         for (int q = 0; q < 9; ++q) bez[q] = x.sr[SR_BEZ + q];
         if (tick % control_steps == 0 || tick == 1) {
-            real low[3] = {-room[0] / (real)2, -room[1] / (real)2, 0}, high[3] = {room[0] / (real)2, room[1] / (real)2, room[2]};
+            real low[3] = {-room[0] / (real)2, -room[1] / (real)2, obst ? (real)1.5 : (real)0}, high[3] = {room[0] / (real)2, room[1] / (real)2, obst ? (real)3 : room[2]};
             real np_[3][2];
             for (int it = 0; it < 100000; ++it) {
                 real u[6];
                 for (int k = 0; k < 6; ++k) { int ax = k % 3; u[k] = rng_uniform1<real>(key, QS_SITE_SCEN, 300 + 8 * it + k, 0, 0, -high[ax], high[ax]); }
-                int lo_i = (int)ceilf((float)min_dist), hi_i = (int)max_dist + 1;
+                int lo_i = (int)floorf((float)min_dist), hi_i = (int)max_dist + 1;   // np.random.randint truncates a float low
                 int r = lo_i + rng_index<real>(key, QS_SITE_SCEN, 300 + 8 * it + 6, hi_i - lo_i);
                 bool ok = true;
                 for (int col = 0; col < 2; ++col) {

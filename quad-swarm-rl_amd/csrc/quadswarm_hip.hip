@@ -260,7 +260,8 @@ static int validate(const qs_config *c) {
     if (c->scenario == QS_SCENARIO_SWARM_VS_SWARM && c->num_agents < 2) return fail(QS_ERR_INVALID, "swarm_vs_swarm needs >= 2 drones");
     {
         const bool o_scen = c->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_RANDOM ||
-                            c->scenario == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_SWAP_GOALS;
+                            c->scenario == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_SWAP_GOALS ||
+                            c->scenario == QS_SCENARIO_O_EP_RAND_BEZIER;
         if (c->scenario != QS_SCENARIO_MIX && o_scen != (c->use_obstacles != 0)) return fail(QS_ERR_INVALID, "obstacle scenario <=> use_obstacles");
     }
     if (c->use_obstacles) {
