@@ -39,7 +39,8 @@ enum { QS_SCENARIO_STATIC_SAME_GOAL = 0, QS_SCENARIO_O_STATIC_SAME_GOAL = 1, QS_
        QS_SCENARIO_STATIC_DIFF_GOAL = 3, QS_SCENARIO_DYNAMIC_SAME_GOAL = 4, QS_SCENARIO_DYNAMIC_DIFF_GOAL = 5,
        QS_SCENARIO_DYNAMIC_FORMATIONS = 6, QS_SCENARIO_SWAP_GOALS = 7, QS_SCENARIO_EP_LISSAJOUS3D = 8,
        QS_SCENARIO_EP_RAND_BEZIER = 9, QS_SCENARIO_O_RANDOM = 10, QS_SCENARIO_O_DYNAMIC_SAME_GOAL = 11,
-       QS_SCENARIO_O_SWAP_GOALS = 12, QS_SCENARIO_MIX = 13, QS_SCENARIO_O_EP_RAND_BEZIER = 14, QS_SCENARIO_COUNT = 15 };
+       QS_SCENARIO_O_SWAP_GOALS = 12, QS_SCENARIO_MIX = 13, QS_SCENARIO_O_EP_RAND_BEZIER = 14,
+       QS_SCENARIO_RUN_AWAY = 15, QS_SCENARIO_COUNT = 16 };
 /* floor_mode: which of the two reference semantics */
 enum { QS_FLOOR_NUMBA = 0, QS_FLOOR_NUMPY = 1 };
 /* precision of the device state / arithmetic */

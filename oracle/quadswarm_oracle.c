@@ -788,7 +788,7 @@ static void shuffle_rows(qso_env *e, double rows[][3], int n, int slot_base) {
 static void scen_params(int scen, int *nform, double *lo, double *hi) {
     *nform = 1; *lo = 0.0; *hi = 0.0;
     switch (scen) {
-    case QS_SCENARIO_STATIC_DIFF_GOAL: case QS_SCENARIO_DYNAMIC_DIFF_GOAL: case QS_SCENARIO_SWARM_VS_SWARM:
+    case QS_SCENARIO_STATIC_DIFF_GOAL: case QS_SCENARIO_DYNAMIC_DIFF_GOAL: case QS_SCENARIO_SWARM_VS_SWARM: case QS_SCENARIO_RUN_AWAY:
         *nform = 8; *lo = 5 * 0.05; *hi = 10 * 0.05; break;
     case QS_SCENARIO_SWAP_GOALS: *nform = 8; *lo = 8 * 0.05; *hi = 16 * 0.05; break;
     case QS_SCENARIO_DYNAMIC_FORMATIONS: *nform = 8; *lo = 0.0; *hi = 20 * 0.05; break;
@@ -944,6 +944,10 @@ static void scenario_reset(qso_env *e) {
     case QS_SCENARIO_EP_RAND_BEZIER:         /* scenarios/ep_rand_bezier.py (base reset) */
         standard_reset(e, c002);
         break;
+    case QS_SCENARIO_RUN_AWAY:               /* scenarios/run_away.py:29-40 (= the base reset); step() acts once per second */
+        e->control_step_for_sec = (int)(1.0 * control_freq);
+        standard_reset(e, c002);
+        break;
     case QS_SCENARIO_DYNAMIC_SAME_GOAL:      /* scenarios/dynamic_same_goal.py:31-37 */
     case QS_SCENARIO_DYNAMIC_DIFF_GOAL:      /* scenarios/dynamic_diff_goal.py:36-42 */
     case QS_SCENARIO_SWAP_GOALS: {           /* scenarios/swap_goals.py:26-32 */
@@ -1082,6 +1086,19 @@ static void scenario_step(qso_env *e) {
             update_formation(e, 32);
             svs_create_formations(e, 1);
             set_all_goals(e);
+        }
+        break;
+    case QS_SCENARIO_RUN_AWAY:               /* scenarios/run_away.py:15-27: drones 0 and 1 get the goals of two random others */
+        if (at_period) {
+            int gi[2];
+            for (int k = 0; k < 2; ++k) {            /* np.random.randint(low=1, high=N, size=2) */
+                if (e->tape) gi[k] = (int)tape_pop(e);
+                else { gi[k] = 1 + (int)(rng_uniform1(e, QS_SITE_SCEN, 44 + k, 0, 0, 0.0, 1.0) * (N - 1)); if (gi[k] > N - 1) gi[k] = N - 1; }
+            }
+            memcpy(e->goals[0], e->goals[gi[0]], sizeof e->goals[0]);
+            memcpy(e->goals[1], e->goals[gi[1]], sizeof e->goals[1]);
+            memcpy(e->d[0].goal, e->goals[0], sizeof e->d[0].goal);
+            memcpy(e->d[1].goal, e->goals[1], sizeof e->d[1].goal);
         }
         break;
     case QS_SCENARIO_DYNAMIC_SAME_GOAL:      /* scenarios/dynamic_same_goal.py:16-29 */

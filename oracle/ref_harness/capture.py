@@ -520,6 +520,7 @@ _scen_case("s_o_random", 130, 58, quads_mode="o_random", ep_time=0.6, **OBST)
 _scen_case("s_o_dynamic_same_goal", 650, 59, quads_mode="o_dynamic_same_goal", ep_time=6.2, **dict(OBST, num_agents=3))
 _scen_case("s_o_swap_goals", 650, 60, quads_mode="o_swap_goals", ep_time=6.2, **dict(OBST, num_agents=4))
 _scen_case("s_o_ep_rand_bezier", 700, 64, quads_mode="o_ep_rand_bezier", ep_time=6.5, **dict(OBST, num_agents=2, neighbor_visible_num=1))
+_scen_case("s_run_away", 330, 65, quads_mode="run_away", ep_time=2.5, num_agents=5, neighbor_visible_num=2)
 _scen_case("s_mix", 420, 61, quads_mode="mix", ep_time=0.2, num_agents=6, neighbor_visible_num=3)
 _scen_case("s_mix_obst", 200, 62, quads_mode="mix", ep_time=0.2, **dict(OBST, num_agents=4))
 _scen_case("s_mix_single", 200, 63, quads_mode="mix", ep_time=0.2, num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none")

@@ -19,7 +19,7 @@ OBS_REPR = {"xyz_vxyz_R_omega": 0, "xyz_vxyz_R_omega_floor": 1, "xyz_vxyz_R_omeg
 OBS_REPR_DIM = {"xyz_vxyz_R_omega": 18, "xyz_vxyz_R_omega_floor": 19, "xyz_vxyz_R_omega_wall": 24}  # quad_utils.py:30-34
 SCENARIOS = {"static_same_goal": 0, "o_static_same_goal": 1, "swarm_vs_swarm": 2, "static_diff_goal": 3, "dynamic_same_goal": 4,
              "dynamic_diff_goal": 5, "dynamic_formations": 6, "swap_goals": 7, "ep_lissajous3D": 8, "ep_rand_bezier": 9,
-             "o_random": 10, "o_dynamic_same_goal": 11, "o_swap_goals": 12, "mix": 13, "o_ep_rand_bezier": 14}
+             "o_random": 10, "o_dynamic_same_goal": 11, "o_swap_goals": 12, "mix": 13, "o_ep_rand_bezier": 14, "run_away": 15}
 SCENARIO_CLASS_NAMES = {v: "Scenario_" + k for k, v in SCENARIOS.items()}
 REW_COEFF_KEYS = ["pos", "effort", "crash", "orient", "spin", "quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"]
 # quadrotor_multi.py:91-94
@@ -97,6 +97,8 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
         raise ValueError(f"unknown obs_repr {obs_repr}")
     if quads_mode == "swarm_vs_swarm" and num_agents < 2:
         raise ValueError("swarm_vs_swarm needs >= 2 drones (scenarios/utils.py:12)")
+    if quads_mode == "run_away" and num_agents < 2:
+        raise ValueError("run_away re-targets drones 0 and 1 (scenarios/run_away.py:21-25): needs >= 2 drones")
     if quads_mode != "mix" and use_obstacles != quads_mode.startswith("o_"):
         raise ValueError("obstacle scenarios (o_*) require use_obstacles=True and vice versa")
 

@@ -665,7 +665,7 @@ __device__ int generate_goals(const Formation<real> &F, int n, int fd, const rea
 // QUADS_PARAMS_DICT scenarios/utils.py:33-51: number of candidate formations and [low, high] formation size
 __device__ __forceinline__ void scen_params(int scen, int *nform, float *lo, float *hi) {
     *nform = 1; *lo = 0.f; *hi = 0.f;
-    if (scen == QS_SCENARIO_STATIC_DIFF_GOAL || scen == QS_SCENARIO_DYNAMIC_DIFF_GOAL || scen == QS_SCENARIO_SWARM_VS_SWARM) { *nform = 8; *lo = 0.25f; *hi = 0.5f; }
+    if (scen == QS_SCENARIO_STATIC_DIFF_GOAL || scen == QS_SCENARIO_DYNAMIC_DIFF_GOAL || scen == QS_SCENARIO_SWARM_VS_SWARM || scen == QS_SCENARIO_RUN_AWAY) { *nform = 8; *lo = 0.25f; *hi = 0.5f; }
     else if (scen == QS_SCENARIO_SWAP_GOALS) { *nform = 8; *lo = 0.4f; *hi = 0.8f; }
     else if (scen == QS_SCENARIO_DYNAMIC_FORMATIONS) { *nform = 8; *lo = 0.f; *hi = 1.0f; }
     else if (scen == QS_SCENARIO_O_SWAP_GOALS) { *nform = 7; *lo = 0.4f; *hi = 0.8f; }

@@ -160,6 +160,9 @@ __device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, co
     const real c002[3] = {0, 0, 2};
     if (sc == QS_SCENARIO_STATIC_SAME_GOAL || sc == QS_SCENARIO_STATIC_DIFF_GOAL || sc == QS_SCENARIO_EP_RAND_BEZIER) {
         standard_reset<real>(c, key, x, sc, c002);
+    } else if (sc == QS_SCENARIO_RUN_AWAY) {             // run_away.py:29-40 (= the base reset); step() acts once per second
+        x.si[SI_PERIOD] = c.control_freq;
+        standard_reset<real>(c, key, x, sc, c002);
     } else if (sc == QS_SCENARIO_DYNAMIC_SAME_GOAL || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS) {
         x.si[SI_PERIOD] = draw_period<real>(key, 8, 4.0, 6.0, c.control_freq);
         standard_reset<real>(c, key, x, sc, c002);
@@ -247,7 +250,8 @@ __device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, co
 __device__ __forceinline__ bool scen_step_serial_needed(int sc, int period, int tick) {
     const bool at_period = period > 0 && tick % period == 0 && tick > 0;
     return sc == QS_SCENARIO_DYNAMIC_FORMATIONS ||
-           (at_period && (sc == QS_SCENARIO_SWARM_VS_SWARM || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS || sc == QS_SCENARIO_O_SWAP_GOALS));
+           (at_period && (sc == QS_SCENARIO_SWARM_VS_SWARM || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS || sc == QS_SCENARIO_O_SWAP_GOALS ||
+                          sc == QS_SCENARIO_RUN_AWAY));
 }
 
 // serial part of scenario.step(): rewrites the env's goal rows in LDS (current goals were published there first)
@@ -282,6 +286,10 @@ __device__ void scenario_step_serial(const Consts<real> &c, const RngKey &key, c
         x.si[SI_INCREASE] = inc; x.sr[SR_SPEED] = speed; x.sr[SR_SIZE] = F.size;
         real ctr[3] = {x.sr[SR_C1], x.sr[SR_C1 + 1], x.sr[SR_C1 + 2]};
         generate_goals<real>(F, N, c.cube_fd_all, ctr, x.goals, 3);
+    } else if (sc == QS_SCENARIO_RUN_AWAY) {            // run_away.py:15-27: drones 0 and 1 get the goals of two random others
+        const int g0 = 1 + rng_index<real>(key, QS_SITE_SCEN, 44, N - 1), g1 = 1 + rng_index<real>(key, QS_SITE_SCEN, 45, N - 1);
+        for (int q = 0; q < 3; ++q) x.goals[0 * 3 + q] = x.goals[g0 * 3 + q];
+        for (int q = 0; q < 3; ++q) x.goals[1 * 3 + q] = x.goals[g1 * 3 + q];
     } else {                                            // swap_goals.py:13-24 / o_swap_goals.py:14-25
         shuffle_rows<real>(key, x.goals, 3, N, 0);
     }

@@ -258,6 +258,7 @@ static int validate(const qs_config *c) {
     if (c->precision != QS_PRECISION_F32 && c->precision != QS_PRECISION_F64) return fail(QS_ERR_INVALID, "bad precision");
     if (c->scenario < 0 || c->scenario >= QS_SCENARIO_COUNT) return fail(QS_ERR_UNSUPPORTED, "unsupported scenario");
     if (c->scenario == QS_SCENARIO_SWARM_VS_SWARM && c->num_agents < 2) return fail(QS_ERR_INVALID, "swarm_vs_swarm needs >= 2 drones");
+    if (c->scenario == QS_SCENARIO_RUN_AWAY && c->num_agents < 2) return fail(QS_ERR_INVALID, "run_away needs >= 2 drones");
     {
         const bool o_scen = c->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_RANDOM ||
                             c->scenario == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_SWAP_GOALS ||

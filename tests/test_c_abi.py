@@ -80,7 +80,7 @@ def test_invalid_arguments_rejected_before_touching_the_gpu():
     assert L.qs_create(C.byref(cfg), 0, C.byref(h)) == -1
     assert b"neigbors" in L.qs_last_error()      # the reference's RuntimeError text (quadrotor_multi.py:274)
     cfg = qcfg.make_config(num_envs=2, num_agents=4)
-    cfg.scenario = 15            # QS_SCENARIO_COUNT: run_away and anything unknown are unsupported
+    cfg.scenario = 16            # QS_SCENARIO_COUNT: anything unknown is unsupported
     assert L.qs_create(C.byref(cfg), 0, C.byref(h)) == -4
     assert L.qs_step(None, None, None) == -1
 

@@ -67,6 +67,8 @@ CASES = {
     "s_o_ep_bezier_short": dict(num_agents=3, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
                                 rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0),
                                 quads_mode="o_ep_rand_bezier", obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.2),
+    "s_run_away": dict(num_agents=5, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                       rew_coeff=REW, quads_mode="run_away", ep_time=2.3),
     "s_mix": dict(num_agents=6, neighbor_visible_num=3, neighbor_obs_type="pos_vel", use_numba=True, use_downwash=True,
                   collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="mix", ep_time=0.12),
     "s_mix_obst": dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
@@ -209,7 +211,7 @@ def check_floats(t, tol, o, h, what):
         assert err <= tol * (1.0 + np.abs(a).max()), f"{what}: {nm} step {t}: max abs err {err}"
 
 
-LONG = {"s_o_ep_bezier": 640, "s_dynamic_same": 640, "s_dynamic_diff": 640, "s_swap_goals": 640, "s_bezier": 560, "s_o_dynamic_same": 640, "s_o_swap": 640}
+LONG = {"s_run_away": 320, "s_o_ep_bezier": 640, "s_dynamic_same": 640, "s_dynamic_diff": 640, "s_swap_goals": 640, "s_bezier": 560, "s_o_dynamic_same": 640, "s_o_swap": 640}
 
 
 @pytest.mark.parametrize("case", list(CASES))
@@ -247,7 +249,7 @@ def test_rollout_f64_bit_exact_discrete(case):
 
 @pytest.mark.parametrize("case", ["c1_single", "c2_n8_dw", "c3_n8_obst", "c4_n32_svs", "c2_n8_k2_numpy_wall",
                                   "s_static_diff", "s_dynamic_formations", "s_lissajous", "s_o_random", "s_mix", "s_mix_obst",
-                                  "s_dynamic_diff", "s_bezier", "s_o_swap", "s_o_ep_bezier", "s_o_ep_bezier_short"])
+                                  "s_dynamic_diff", "s_bezier", "s_o_swap", "s_o_ep_bezier", "s_o_ep_bezier_short", "s_run_away"])
 def test_teacher_forced_f32(case):
     E, steps, tol = (3, LONG[case], 1e-5) if case in LONG else (7, 60, 1e-5)
     pr = Pair(case, E, "f32")

@@ -75,7 +75,7 @@ def test_scenario_table_matches_header():
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "quadswarm.h")).read()
     ids = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"QS_SCENARIO_([A-Z0-9_]+) = (\d+)", hdr)}
     count = ids.pop("count")
-    assert count == len(qcfg.SCENARIOS) == 15
+    assert count == len(qcfg.SCENARIOS) == 16
     for name, sid in qcfg.SCENARIOS.items():
         assert ids[name.lower()] == sid
         obst = name.startswith("o_")

@@ -15,7 +15,7 @@ from quad_swarm_rl_amd import config as qcfg
 from tests import golden_util as gu
 
 SCEN_CASES = ["s_static_diff_goal", "s_dynamic_same_goal", "s_dynamic_diff_goal", "s_dynamic_formations", "s_swap_goals",
-              "s_ep_lissajous3D", "s_ep_rand_bezier", "s_o_random", "s_o_dynamic_same_goal", "s_o_swap_goals", "s_o_ep_rand_bezier", "s_mix", "s_mix_obst",
+              "s_ep_lissajous3D", "s_ep_rand_bezier", "s_o_random", "s_o_dynamic_same_goal", "s_o_swap_goals", "s_o_ep_rand_bezier", "s_run_away", "s_mix", "s_mix_obst",
               "s_mix_single"]
 CASES = ["c1_single_numpy", "c1_single_numba", "c2_n8_random", "c2_n8_hover_svd", "c2_n8_events", "c2_n8_episode",
          "c2_n8_k2_numpy", "c2_n8_kall", "c3_n8_obst", "c3_n8_obst_episode", "c4_n32_svs", "c4_n6_svs_switch",
