@@ -77,7 +77,7 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     L.off_sr = o; o += real_size * SR_COUNT * epb;
     o = (o + 15) & ~15;
     L.off_envflag = o; o += 4 * ((2 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods
-    L.off_scratch = o; o += 4 * QS_RESET_SCRATCH_INTS * epb;
+    L.off_scratch = o; o += num_obst > 0 ? 4 * QS_RESET_SCRATCH_INTS * epb : 0;   // only the obstacle-map / free-cell code uses it
     o = (o + 15) & ~15;
     L.off_pos = o; o += real_size * 3 * B;
     L.off_vel = o; o += real_size * 3 * B;
