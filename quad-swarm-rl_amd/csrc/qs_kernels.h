@@ -22,7 +22,14 @@ using namespace qs;
 // ------------------------------------------------------------------------------------------------
 // device buffers
 // ------------------------------------------------------------------------------------------------
+// The per-drone arrays the step kernels touch every launch live in ONE allocation, so that the kernels address them through a
+// single buffer resource: `buffer_load/store vdata, voffset(lane), srsrc, soffset(array + component)` needs one SALU add per
+// access where a flat 64-bit address needs three VALU instructions (about 90 accesses per drone-step; the throughput
+// regime of the single-wave kernels is VALU-bound).  The typed pointers below still point into the block.
+struct StateBlk { char *base; uint32_t bytes, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit; };
+
 template <typename real> struct Ptrs {
+    StateBlk blk;
     real *pos, *vel, *rot, *omega, *rot_damp, *cmds_damp, *ou, *goal;
     uint32_t *flags;
     uint64_t *pair_mask, *new_pair_mask;
@@ -46,6 +53,25 @@ template <typename real> struct Ptrs {
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
 };
+
+// One component-major array inside the state block, seen from one lane: element type T, `row_bytes` between components, this
+// lane's element `lane_off` bytes into a row.
+typedef unsigned int qs_u32x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct BufRow {
+    __amdgpu_buffer_rsrc_t r;
+    uint32_t off, row_bytes, lane_off;
+    __device__ __forceinline__ T ld(int q = 0) const {
+        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + (uint32_t)q * row_bytes, 0));
+        else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, off + (uint32_t)q * row_bytes, 0));
+    }
+    __device__ __forceinline__ void st(T v, int q = 0) const {
+        if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qs_u32x2, v), r, lane_off, off + (uint32_t)q * row_bytes, 0);
+        else if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, lane_off, off + (uint32_t)q * row_bytes, 0);
+        else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, r, lane_off, off + (uint32_t)q * row_bytes, 0);
+    }
+};
+#define QS_BUF_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void *)(p).blk.base, 0, (p).blk.bytes, 0x00020000)
+#define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (p).blk.name, (uint32_t)((T) * sizeof(TYPE)), (uint32_t)((g) * sizeof(TYPE))}
 
 // (neighbour metric, drone index) as one unsigned key whose order is "smaller metric first, lower index first": the IEEE bit
 // pattern of a float is monotone after flipping the sign bit of non-negatives and all bits of negatives

@@ -296,11 +296,28 @@ template <typename real> static int create_typed(qs_handle *h) {
     memset(&p, 0, sizeof p);
     int rc;
 #define DA(field, count) if ((rc = dalloc(h, &p.field, (count))) != QS_OK) return rc
-    DA(pos, 3 * T); DA(vel, 3 * T); DA(rot, 9 * T); DA(omega, 3 * T); DA(rot_damp, 4 * T); DA(cmds_damp, 4 * T); DA(ou, 4 * T); DA(goal, 3 * T);
-    DA(flags, T); DA(pair_mask, T); DA(new_pair_mask, T);
-    DA(obs, T * D); DA(reward, T); DA(rew_info, QS_RI_COUNT * T); DA(done, T); DA(obst_hit_idx, T);
+    {   // the state block (StateBlk, qs_kernels.h): one allocation, 256-byte aligned sub-arrays, 32-bit offsets
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t R = sizeof(real);
+        const size_t o_pos = carve(3 * T * R), o_vel = carve(3 * T * R), o_rot = carve(9 * T * R), o_omega = carve(3 * T * R), o_rd = carve(4 * T * R),
+                     o_cd = carve(4 * T * R), o_ou = carve(4 * T * R), o_goal = carve(3 * T * R), o_ring = carve(4 * T * R), o_sums = carve(3 * T * R),
+                     o_flags = carve(T * 4), o_pair = carve(T * 8), o_newpair = carve(T * 8), o_reward = carve(T * R), o_done = carve(T), o_ohit = carve(T * 4);
+        if (off >= ((size_t)1 << 32)) return fail(QS_ERR_UNSUPPORTED, "per-drone state exceeds the 4 GiB a buffer resource addresses: use fewer envs per handle");
+        char *blk = nullptr;
+        if ((rc = dalloc(h, &blk, off)) != QS_OK) return rc;
+        p.blk = {blk, (uint32_t)off, (uint32_t)o_pos, (uint32_t)o_vel, (uint32_t)o_rot, (uint32_t)o_omega, (uint32_t)o_rd, (uint32_t)o_cd, (uint32_t)o_ou,
+                 (uint32_t)o_goal, (uint32_t)o_ring, (uint32_t)o_sums, (uint32_t)o_flags, (uint32_t)o_pair, (uint32_t)o_newpair, (uint32_t)o_reward,
+                 (uint32_t)o_done, (uint32_t)o_ohit};
+        p.pos = (real *)(blk + o_pos); p.vel = (real *)(blk + o_vel); p.rot = (real *)(blk + o_rot); p.omega = (real *)(blk + o_omega);
+        p.rot_damp = (real *)(blk + o_rd); p.cmds_damp = (real *)(blk + o_cd); p.ou = (real *)(blk + o_ou); p.goal = (real *)(blk + o_goal);
+        p.dist_ring = (real *)(blk + o_ring); p.dist_sums = (real *)(blk + o_sums); p.flags = (uint32_t *)(blk + o_flags);
+        p.pair_mask = (uint64_t *)(blk + o_pair); p.new_pair_mask = (uint64_t *)(blk + o_newpair); p.reward = (real *)(blk + o_reward);
+        p.done = (uint8_t *)(blk + o_done); p.obst_hit_idx = (int32_t *)(blk + o_ohit);
+    }
+    DA(obs, T * D); DA(rew_info, QS_RI_COUNT * T);
     DA(unique_col, E); DA(obst_new, E); DA(room_new, E); DA(counters, QS_CNT_COUNT * E); DA(tick, E); DA(step_ctr, E);
-    DA(obst_pos, 2 * E * (M_ ? M_ : 1)); DA(dist_ring, 4 * T); DA(dist_sums, 3 * T); DA(ep_stats, QS_EPS_COUNT * T); DA(ep_counters, QS_CNT_COUNT * E);
+    DA(obst_pos, 2 * E * (M_ ? M_ : 1)); DA(ep_stats, QS_EPS_COUNT * T); DA(ep_counters, QS_CNT_COUNT * E);
     DA(run_sums, QS_SUM_COUNT * T); DA(ep_sums, QS_SUM_COUNT * T);
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
     DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128);
