@@ -1,0 +1,43 @@
+/*
+ * quadswarm_encoder.h - C ABI of the fused policy-encoder forward pass (MI355X / gfx950 matrix cores).
+ *
+ * Replaces, for inference during rollouts, the forward() of the reference's QuadMultiEncoder
+ * (swarm_rl/models/quad_multi_model.py:250-350) with the `mean_embed` neighbour encoder (:22-43): self MLP,
+ * per-neighbour MLP + mean, optional obstacle MLP, feed-forward; tanh; hidden size 256; output [B, 512] fp32.
+ * bf16 weights / activations, fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Weights are handed over pre-packed:
+ *   layer with torch weight W[M_real, K_real], bias b[M_real]  ->  M = ceil16(M_real), K = ceil32(K_real), zero padded,
+ *   w[((mt * (K/32) + ks) * 64 + lane) * 8 + j] = bf16(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),  b as fp32[M].
+ * (quad-swarm-rl_amd/policy.py does the packing from a torch module.)  All pointers are device pointers.
+ */
+#ifndef QUADSWARM_ENCODER_H
+#define QUADSWARM_ENCODER_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qs_enc_layer { const uint16_t *w; const float *b; int32_t M, K; } qs_enc_layer;
+
+typedef struct qs_enc_params {
+    int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;   /* obs row = [self | num_nbr x nbr_dim | obst] */
+    qs_enc_layer s1, s2;   /* self encoder      (quad_multi_model.py:303-309) */
+    qs_enc_layer n1, n2;   /* neighbour MLP     (:29-34), mean over neighbours (:41-42) */
+    qs_enc_layer o1, o2;   /* obstacle encoder  (:315-322), unused when obst_dim == 0 */
+    qs_enc_layer f;        /* feed forward      (:329-332): K = 256 * (1 + (num_nbr > 0) + (obst_dim > 0)), M = 512 */
+} qs_enc_params;
+
+size_t qs_enc_sizeof_params(void);
+size_t qs_enc_lds_bytes(void);
+const char *qs_enc_last_error(void);
+
+/* out[B, 512] = encoder(obs[B, obs_dim]) on `stream`.  0 on success, < 0 on error (qs_enc_last_error()). */
+int qs_enc_forward(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream);
+
+/* `iters` back-to-back forward passes timed with HIP events on `stream` (no host work in between): average ms per pass. */
+int qs_enc_benchmark(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream, int32_t iters, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,334 @@
+// qs_policy_encoder.hip - fused forward pass of the quad-swarm policy encoder on gfx950 matrix cores.
+//
+// Reference: swarm_rl/models/quad_multi_model.py:250-350 (QuadMultiEncoder: self encoder, neighbour encoder, optional obstacle
+// encoder, feed-forward) with the `mean_embed` neighbour encoder (:22-43, QuadNeighborhoodEncoderDeepsets); tanh non-linearity,
+// hidden size 256.  It reads the observation rows straight from the stepper's buffer.
+// Not covered: the `attention` neighbour encoder (:46-101).  Its `self_obs.repeat(K, 1)` (:84) and `mean.repeat(K, 1)` (:92)
+// tile the WHOLE batch, so row (agent a, neighbour k) is paired with the self observation and the mean embedding of agent
+// (a*K + k) mod batch: an inter-agent dependence on an intermediate result, i.e. a two-kernel job with a grid-wide hand-over.
+//
+// One workgroup = 8 waves = 16 agents.  Every layer is a transposed GEMM on v_mfma_f32_16x16x32_bf16:
+//     C[feature][row] = sum_k W[feature][k] * X[row][k]
+//   A operand = weights, packed on the host in fragment order ([M/16][K/32][64 lanes][8 bf16]) and streamed from L2 with one
+//               16-byte load per lane;
+//   B operand = activations, row-major bf16 in LDS with K contiguous (one ds_read_b128 per lane);
+//   C         = 4 consecutive features of one row per lane  ->  bias, tanh, bf16, one 8-byte LDS store.
+// Wave w owns features [32w, 32w+32) of a 256-wide layer.  Neighbour rows are ordered neighbour-major (row = k*16 + agent), so
+// the row tile index IS the neighbour index and the mean over neighbours is a lane-local sum across accumulator tiles.
+// Operand layout verified on hardware by tools/mfma_layout_probe.hip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define ENC_H 256            // hidden size of every MLP (rnn_size = neighbor_hidden_size = obst_hidden_size = 256)
+#define ENC_TA 16            // agents per workgroup = one 16-row tile
+#define ENC_MAX_NBR 8        // neighbours per agent handled in registers (6 or 2 in the reference's configurations)
+#ifndef ENC_WAVES
+#define ENC_WAVES 8   // 2 waves per SIMD: the layer chain of one workgroup is latency-bound, a second wave hides part of it (49 -> 40 us at 8192 agents)
+#endif
+#define ENC_MT (16 / ENC_WAVES)       // 16-feature tiles of a 256-wide layer per wave
+#define ENC_MTF (32 / ENC_WAVES)      // ... of the 512-wide feed-forward layer
+#define ENC_XS 40            // row stride (bf16) of the 32-wide input staging rows  (+8 pad: spreads the LDS banks)
+#define ENC_YS (ENC_H + 8)   // row stride of a 256-wide activation buffer
+#define ENC_CS (3 * ENC_H + 8)
+
+struct EncLayer { const uint16_t *w; const float *b; int32_t M, K; };   // K padded to a multiple of 32, M to a multiple of 16
+struct EncParams {
+    int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;
+    EncLayer s1, s2;            // self encoder        :303-309
+    EncLayer n1, n2;            // neighbour embedding :29-34 (QuadNeighborhoodEncoderDeepsets)
+    EncLayer o1, o2;            // obstacle encoder    :315-322
+    EncLayer f;                 // feed forward        :329-332
+};
+
+#ifdef ENC_TIMING   // phase stamps of workgroup 0, wave 0 (tools/enc_quick.py prints them)
+__device__ unsigned long long enc_stamps[16];
+#define ENC_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) enc_stamps[k] = clock64(); } while (0)
+#else
+#define ENC_STAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1); v_exp_f32 + v_rcp_f32
+#ifdef ENC_EXP_NO_TANH   // timing experiment
+    return x;
+#endif
+    const float e = __expf(2.0f * x);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// acc[mt][nt] (+)= W[features of (wave, mt)] x X[rows of tile nt], K-loop over the whole layer.
+// One wave per SIMD means nothing else hides the L2 latency of the weight fragments, so they are software-pipelined ENC_PD
+// K-steps ahead through a ring of register sets: the slot an MFMA group has just consumed is refilled with the fragment of
+// K-step ks + ENC_PD.
+#define ENC_PD 4
+#ifdef ENC_EXP_NO_WLOAD   // timing experiment: no weight traffic
+#define ENC_WLOAD(x) (bf16x8){}
+#else
+#define ENC_WLOAD(x) (x)
+#endif
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_tiles(const EncLayer &L, int mtile0, const uint16_t *X, int xstride, int ntiles, f32x4 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63, ksteps = L.K >> 5;
+    const uint16_t *xrow = X + (lane & 15) * xstride + 8 * (lane >> 4);
+    const bf16x8 *wbase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wbase[mt] = (const bf16x8 *)(L.w + ((size_t)(mtile0 + mt) * ksteps * 64 + lane) * 8);   // + ks * 64 fragments
+    bf16x8 a[ENC_PD][MT];
+#pragma unroll
+    for (int s = 0; s < ENC_PD; ++s)
+        if (s < ksteps) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[s][mt] = ENC_WLOAD(wbase[mt][s * 64]);
+        }
+    for (int ks0 = 0; ks0 < ksteps; ks0 += ENC_PD) {
+#pragma unroll
+        for (int s = 0; s < ENC_PD; ++s) {
+            const int ks = ks0 + s;
+            if (ks < ksteps) {
+                bf16x8 b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (nt < ntiles) b[nt] = *(const bf16x8 *)(xrow + nt * 16 * xstride + ks * 32);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#ifndef ENC_EXP_NO_MFMA   // timing experiment
+                        if (nt < ntiles) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][mt], b[nt], acc[mt][nt], 0, 0, 0);
+#else
+                        if (nt < ntiles) acc[mt][nt][0] += (float)a[s][mt][0] * (float)b[nt][0];
+#endif
+                if (ks + ENC_PD < ksteps) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) a[s][mt] = ENC_WLOAD(wbase[mt][(ks + ENC_PD) * 64]);
+                }
+            }
+        }
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void init_bias(const EncLayer &L, int mtile0, f32x4 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 bias = *(const f32x4 *)(L.b + (mtile0 + mt) * 16 + (lane >> 4) * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bias;
+    }
+}
+
+// tanh, bf16, store: lane holds features f0..f0+3 of row (nt*16 + lane&15)
+template <int MT, int NT>
+__device__ __forceinline__ void store_tanh(const f32x4 (&acc)[MT][NT], int mtile0, int ntiles, uint16_t *Y, int ystride, int col0 = 0) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if (nt < ntiles) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (__bf16)fast_tanh(acc[mt][nt][r]);
+                *(bf16x4 *)(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4) = v;
+            }
+}
+
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
+    uint16_t *x_nbr = x_self + ENC_TA * ENC_XS;                       // [NBR*16][XS]
+    uint16_t *x_obst = x_nbr + ENC_MAX_NBR * ENC_TA * ENC_XS;         // [16][XS]
+    uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [NBR*16][YS] hidden layer of the neighbour MLP
+    uint16_t *buf_b = buf_a + ENC_MAX_NBR * ENC_TA * ENC_YS;          // [16][YS]     hidden layer of the self / obstacle MLPs
+    uint16_t *cat = buf_b + ENC_TA * ENC_YS;                          // [16][CS]: self | neighbourhood | obstacles
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, a0 = blockIdx.x * ENC_TA;
+    const int NB = P.num_nbr, D = P.obs_dim;
+    const int col_nbr = ENC_H, col_obst = ENC_H * (NB > 0 ? 2 : 1);   // column blocks of `cat` in the order of the reference's torch.cat
+    const int mt0 = wave * ENC_MT;   // first of this wave's 16-feature tiles of a 256-wide layer
+
+    ENC_STAMP(0);
+    // ---- stage the observation rows as bf16, zero padded to K = 32 ----
+    // The 16 rows of the workgroup are one contiguous block of obs: read it coalesced (every load issued before the first use),
+    // then scatter each element to its slot of the self / neighbour / obstacle staging rows.
+    {
+        uint32_t *z = (uint32_t *)x_self;   // x_self, x_nbr, x_obst are contiguous: clear the padding first
+        for (int idx = tid; idx < (2 + ENC_MAX_NBR) * ENC_TA * ENC_XS / 2; idx += 64 * ENC_WAVES) z[idx] = 0;
+        constexpr int PER = (ENC_TA * (32 + 32 * ENC_MAX_NBR + 32) + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);   // upper bound on elements per thread
+        const int total = ENC_TA * D;
+        const size_t first = (size_t)a0 * D, limit = (size_t)B * D;
+        float v[PER];
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int idx = tid + it * 64 * ENC_WAVES;
+            v[it] = (idx < total && first + idx < limit) ? obs[first + idx] : 0.0f;
+        }
+        __syncthreads();   // zeros are in place
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int idx = tid + it * 64 * ENC_WAVES;
+            if (idx < total) {
+                const int a = idx / D, cidx = idx - a * D;
+                const uint16_t h = __builtin_bit_cast(uint16_t, (__bf16)v[it]);
+                if (cidx < P.self_dim) x_self[a * ENC_XS + cidx] = h;
+                else if (cidx < P.self_dim + P.nbr_dim * NB) {
+                    const int q = cidx - P.self_dim, nb = q / P.nbr_dim, j = q - nb * P.nbr_dim;
+                    x_nbr[(nb * ENC_TA + a) * ENC_XS + j] = h;
+                } else x_obst[a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB)] = h;
+            }
+        }
+    }
+    __syncthreads();
+
+    ENC_STAMP(1);
+    // ---- self encoder -> cat[:, 0:256] ----
+    {
+        f32x4 acc[ENC_MT][1];
+        init_bias<ENC_MT, 1>(P.s1, mt0, acc);
+        gemm_tiles<ENC_MT, 1>(P.s1, mt0, x_self, ENC_XS, 1, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_b, ENC_YS);
+        __syncthreads();
+        init_bias<ENC_MT, 1>(P.s2, mt0, acc);
+        gemm_tiles<ENC_MT, 1>(P.s2, mt0, buf_b, ENC_YS, 1, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, 1, cat, ENC_CS, 0);
+    }
+    ENC_STAMP(2);
+    // ---- obstacle encoder -> cat[:, 512:768] ----
+    if (P.obst_dim > 0) {
+        __syncthreads();
+        f32x4 acc[ENC_MT][1];
+        init_bias<ENC_MT, 1>(P.o1, mt0, acc);
+        gemm_tiles<ENC_MT, 1>(P.o1, mt0, x_obst, ENC_XS, 1, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_b, ENC_YS);
+        __syncthreads();
+        init_bias<ENC_MT, 1>(P.o2, mt0, acc);
+        gemm_tiles<ENC_MT, 1>(P.o2, mt0, buf_b, ENC_YS, 1, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, 1, cat, ENC_CS, col_obst);
+    }
+    __syncthreads();
+
+    ENC_STAMP(3);
+    // ---- neighbour encoder -> cat[:, 256:512] ----
+    if (NB > 0) {
+        f32x4 acc[ENC_MT][ENC_MAX_NBR];
+        init_bias<ENC_MT, ENC_MAX_NBR>(P.n1, mt0, acc);
+        gemm_tiles<ENC_MT, ENC_MAX_NBR>(P.n1, mt0, x_nbr, ENC_XS, NB, acc);
+        ENC_STAMP(4);
+        store_tanh<ENC_MT, ENC_MAX_NBR>(acc, mt0, NB, buf_a, ENC_YS);
+        __syncthreads();
+        ENC_STAMP(5);
+        init_bias<ENC_MT, ENC_MAX_NBR>(P.n2, mt0, acc);
+        gemm_tiles<ENC_MT, ENC_MAX_NBR>(P.n2, mt0, buf_a, ENC_YS, NB, acc);
+        ENC_STAMP(6);
+        // e_i = tanh(.) in registers; the mean over neighbours is a sum over the row tiles (same lane, same register)
+        f32x4 mean[ENC_MT];
+        const float inv = 1.0f / (float)NB;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            mean[mt] = (f32x4){0, 0, 0, 0};
+#pragma unroll
+            for (int nt = 0; nt < ENC_MAX_NBR; ++nt)
+                if (nt < NB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc[mt][nt][r] = fast_tanh(acc[mt][nt][r]); mean[mt][r] += acc[mt][nt][r]; }
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mean[mt][r] *= inv;
+        }
+        // mean_embed: torch.mean(neighbor_embeds, dim=1) (:41-42)
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)mean[mt][r];
+            *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+    }
+    __syncthreads();
+
+    ENC_STAMP(7);
+    // ---- feed forward: tanh(F [self | neighbourhood | obstacles]) -> out[a][0:512] (fp32) ----
+    {
+        f32x4 acc[ENC_MTF][1];
+        const int mf0 = wave * ENC_MTF;   // 512 features = 32 tiles
+        init_bias<ENC_MTF, 1>(P.f, mf0, acc);
+        gemm_tiles<ENC_MTF, 1>(P.f, mf0, cat, ENC_CS, 1, acc);
+        ENC_STAMP(8);
+        const int ga = a0 + (lane & 15);
+        if (ga < B) {
+#pragma unroll
+            for (int mt = 0; mt < ENC_MTF; ++mt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fast_tanh(acc[mt][0][r]);
+                *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4) = v;
+            }
+        }
+    }
+    ENC_STAMP(9);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (include/quadswarm_encoder.h)
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_enc_error;
+extern "C" {
+
+const char *qs_enc_last_error(void) { return g_enc_error.c_str(); }
+size_t qs_enc_sizeof_params(void) { return sizeof(EncParams); }
+
+size_t qs_enc_lds_bytes(void) {
+    return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_MAX_NBR * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
+}
+
+// out[B, 512] = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
+int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
+    if (!obs || !params || !out || B < 0) { g_enc_error = "bad argument"; return -1; }
+    const EncParams &P = *params;
+    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32) {
+        g_enc_error = "unsupported encoder shape (inputs wider than 32 or more than 8 neighbours)";
+        return -4;
+    }
+    if (B == 0) return 0;
+    static bool attr_set = false;
+    const size_t lds = qs_enc_lds_bytes();
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            g_enc_error = "cannot raise the dynamic LDS limit";
+            return -2;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(qs_encoder_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_enc_error = hipGetErrorString(e); return -2; }
+    return 0;
+}
+
+#ifdef ENC_TIMING
+int qs_enc_stamps(unsigned long long *out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(enc_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2; }
+#endif
+// `iters` back-to-back forward passes timed with HIP events on `stream` (no host work in between): average ms per pass
+int qs_enc_benchmark(const float *obs, int32_t B, const EncParams *params, float *out, void *stream, int32_t iters, double *avg_ms) {
+    if (iters < 1 || !avg_ms) { g_enc_error = "bad argument"; return -1; }
+    int rc = qs_enc_forward(obs, B, params, out, stream);   // warm-up (+ sets the LDS attribute)
+    if (rc != 0) return rc;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_enc_error = "hipEventCreate failed"; return -2; }
+    hipEventRecord(e0, (hipStream_t)stream);
+    for (int i = 0; i < iters && rc == 0; ++i) rc = qs_enc_forward(obs, B, params, out, stream);
+    hipEventRecord(e1, (hipStream_t)stream);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *avg_ms = (double)ms / iters;
+    return rc;
+}
+}

@@ -1,0 +1,164 @@
+"""Policy-encoder inference next to the stepper.
+
+`QuadMultiEncoderRef` is a plain-PyTorch restatement of the reference's QuadMultiEncoder with the `mean_embed` neighbour
+encoder (swarm_rl/models/quad_multi_model.py:22-43, :250-350; Sample Factory's `fc_layer` is `nn.Linear`, `nonlinearity` is
+tanh in the reference's runs) - it is the fp32 reference the fused kernel is tested against and the source of its weights.
+`FusedQuadEncoder` packs those weights for `csrc/qs_policy_encoder.hip` (include/quadswarm_encoder.h) and runs the forward
+pass as ONE kernel that reads the stepper's observation buffer.  No CPU fallback: without the extension or a GPU it raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import native
+
+ENC_LIB_PATH = os.environ.get("QS_ENC_LIB", os.path.join(native.CSRC, "libquadswarm_encoder.so"))
+ENC_SOURCE = os.path.join(native.CSRC, "qs_policy_encoder.hip")
+HIDDEN = 256
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(ENC_LIB_PATH) and os.path.getmtime(ENC_LIB_PATH) >= os.path.getmtime(ENC_SOURCE):
+        return ENC_LIB_PATH
+    cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", ENC_LIB_PATH, ENC_SOURCE]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return ENC_LIB_PATH
+
+
+class EncLayer(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("M", C.c_int32), ("K", C.c_int32)]
+
+
+class EncParams(C.Structure):
+    _fields_ = [("self_dim", C.c_int32), ("nbr_dim", C.c_int32), ("num_nbr", C.c_int32), ("obst_dim", C.c_int32), ("obs_dim", C.c_int32),
+                ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("o1", EncLayer), ("o2", EncLayer), ("f", EncLayer)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ENC_LIB_PATH):
+            build()
+        native._preload_torch_hip_runtime()
+        L = C.CDLL(ENC_LIB_PATH)
+        L.qs_enc_last_error.restype = C.c_char_p
+        L.qs_enc_sizeof_params.restype = C.c_size_t
+        L.qs_enc_lds_bytes.restype = C.c_size_t
+        L.qs_enc_forward.argtypes = [C.c_void_p, C.c_int32, C.POINTER(EncParams), C.c_void_p, C.c_void_p]
+        L.qs_enc_benchmark.argtypes = [C.c_void_p, C.c_int32, C.POINTER(EncParams), C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]
+        if L.qs_enc_sizeof_params() != C.sizeof(EncParams):
+            raise RuntimeError("qs_enc_params layout mismatch between policy.py and libquadswarm_encoder.so")
+        _lib = L
+    return _lib
+
+
+def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden=HIDDEN, seed=0):
+    """QuadMultiEncoder (mean_embed) as a torch module; random init (there are no checkpoints in this image)."""
+    import torch
+    from torch import nn
+
+    class QuadMultiEncoderRef(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_dim, self.nbr_dim, self.num_nbr, self.obst_dim = self_dim, nbr_dim, num_nbr, obst_dim
+            mlp = lambda i: nn.Sequential(nn.Linear(i, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
+            self.self_encoder = mlp(self_dim)                                   # :303-309
+            self.neighbor_encoder = mlp(nbr_dim) if num_nbr > 0 else None       # :29-34
+            self.obstacle_encoder = mlp(obst_dim) if obst_dim > 0 else None     # :315-322
+            total = hidden * (1 + (num_nbr > 0) + (obst_dim > 0))
+            self.feed_forward = nn.Sequential(nn.Linear(total, 2 * hidden), nn.Tanh())   # :329-332
+
+        def forward(self, obs):
+            B = obs.shape[0]
+            emb = [self.self_encoder(obs[:, :self.self_dim])]
+            nb = self.nbr_dim * self.num_nbr
+            if self.neighbor_encoder is not None:                               # :36-43
+                e = self.neighbor_encoder(obs[:, self.self_dim:self.self_dim + nb].reshape(-1, self.nbr_dim))
+                emb.append(e.reshape(B, -1, e.shape[-1]).mean(dim=1))
+            if self.obstacle_encoder is not None:
+                emb.append(self.obstacle_encoder(obs[:, self.self_dim + nb:]))
+            return self.feed_forward(torch.cat(emb, dim=1))                     # :334-350
+
+    torch.manual_seed(seed)
+    return QuadMultiEncoderRef()
+
+
+def pack_linear(linear, device):
+    """nn.Linear -> (packed bf16 weights in MFMA A-fragment order, padded fp32 bias, M, K); see include/quadswarm_encoder.h."""
+    import torch
+    W = linear.weight.detach().float().cpu().numpy()
+    b = linear.bias.detach().float().cpu().numpy()
+    m_real, k_real = W.shape
+    M, K = -(-m_real // 16) * 16, -(-k_real // 32) * 32
+    Wp = np.zeros((M, K), dtype=np.float32)
+    Wp[:m_real, :k_real] = W
+    bp = np.zeros(M, dtype=np.float32)
+    bp[:m_real] = b
+    lane = np.arange(64)
+    rows = (lane & 15)[None, None, :, None] + 16 * np.arange(M // 16)[:, None, None, None]
+    cols = (8 * (lane >> 4))[None, None, :, None] + np.arange(8)[None, None, None, :] + 32 * np.arange(K // 32)[None, :, None, None]
+    packed = Wp[rows, cols]                                                     # [M/16, K/32, 64, 8]
+    w = torch.from_numpy(np.ascontiguousarray(packed)).to(device).to(torch.bfloat16).contiguous()
+    return w, torch.from_numpy(bp).to(device), M, K
+
+
+class FusedQuadEncoder:
+    """forward(obs[B, D] float32 on the GPU) -> [B, 512] float32, one kernel launch."""
+
+    def __init__(self, module, device=0):
+        import torch
+        self._torch = torch
+        self.device = torch.device("cuda", device)
+        if not torch.cuda.is_available():
+            raise native.QsError("FusedQuadEncoder needs a GPU: there is no CPU fallback")
+        self._keep = []
+        P = EncParams()
+        P.self_dim, P.nbr_dim, P.num_nbr, P.obst_dim = module.self_dim, module.nbr_dim, module.num_nbr, module.obst_dim
+        P.obs_dim = module.self_dim + module.nbr_dim * module.num_nbr + module.obst_dim
+
+        def layer(linear):
+            w, b, M, K = pack_linear(linear, self.device)
+            self._keep += [w, b]
+            return EncLayer(w.data_ptr(), b.data_ptr(), M, K)
+
+        P.s1, P.s2 = layer(module.self_encoder[0]), layer(module.self_encoder[2])
+        if module.neighbor_encoder is not None:
+            P.n1, P.n2 = layer(module.neighbor_encoder[0]), layer(module.neighbor_encoder[2])
+        if module.obstacle_encoder is not None:
+            P.o1, P.o2 = layer(module.obstacle_encoder[0]), layer(module.obstacle_encoder[2])
+        P.f = layer(module.feed_forward[0])
+        if P.f.M != 2 * HIDDEN or P.s1.M != HIDDEN:
+            raise ValueError("the fused encoder is built for hidden size 256")
+        self.params = P
+        self.out_dim = 2 * HIDDEN
+        lib()
+
+    def forward(self, obs, out=None):
+        torch = self._torch
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.params.obs_dim
+        B = obs.shape[0]
+        if out is None:
+            out = torch.empty((B, self.out_dim), device=obs.device, dtype=torch.float32)
+        rc = lib().qs_enc_forward(obs.data_ptr(), B, C.byref(self.params), out.data_ptr(), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        if rc != 0:
+            raise native.QsError(f"qs_enc_forward failed ({rc}): {lib().qs_enc_last_error().decode()}")
+        return out
+
+    __call__ = forward
+
+    def benchmark(self, obs, out, iters=200):
+        """Average seconds per forward pass over `iters` back-to-back launches (HIP events, no host work in between)."""
+        torch = self._torch
+        ms = C.c_double(0)
+        rc = lib().qs_enc_benchmark(obs.data_ptr(), obs.shape[0], C.byref(self.params), out.data_ptr(),
+                                    C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream), iters, C.byref(ms))
+        if rc != 0:
+            raise native.QsError(f"qs_enc_benchmark failed ({rc}): {lib().qs_enc_last_error().decode()}")
+        return ms.value * 1e-3

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Fused policy encoder (qs_policy_encoder.hip) vs PyTorch on the observations of BASELINE config 2 (8192 agents, obs 54).
+Prints one JSON line: us per forward, TFLOP/s (algorithmic FLOPs of the network) and the fraction of the dense bf16 MFMA peak."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from quad_swarm_rl_amd import policy
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+shape = dict(num_nbr=6, obst_dim=0)
+ref = policy.make_reference_encoder(seed=0, **shape).cuda()
+fused = policy.FusedQuadEncoder(ref)
+D = fused.params.obs_dim
+obs = torch.rand((B, D), device="cuda") * 2 - 1
+out = torch.empty((B, 512), device="cuda")
+H = 256
+macs = 18 * H + H * H + shape["num_nbr"] * (6 * H + H * H) + (2 * H) * (2 * H)      # per agent, unpadded
+flops = 2.0 * macs * B
+
+
+def timeit(fn, iters=300):
+    for _ in range(20):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+with torch.no_grad():
+    t_fused_host = timeit(lambda: fused(obs, out=out))   # one python call per pass: includes the host-side call overhead
+    t_fused = fused.benchmark(obs, out, 300)             # device-side rate: back-to-back launches, HIP events
+    t_fp32 = timeit(lambda: ref(obs), 100)
+    ref16 = policy.make_reference_encoder(seed=0, **shape).cuda().to(torch.bfloat16)
+    obs16 = obs.to(torch.bfloat16)
+    t_bf16 = timeit(lambda: ref16(obs16), 100)
+PEAK = 2500.0   # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+print(json.dumps({"kernel": "qs_encoder_kernel", "agents": B, "obs_dim": D, "algorithmic_gflop": flops / 1e9,
+                  "fused_us": t_fused * 1e6, "fused_us_one_python_call_per_pass": t_fused_host * 1e6, "fused_tflops": flops / t_fused / 1e12, "frac_of_bf16_mfma_peak": flops / t_fused / 1e12 / PEAK,
+                  "torch_fp32_eager_us": t_fp32 * 1e6, "torch_bf16_eager_us": t_bf16 * 1e6,
+                  "speedup_vs_torch_fp32": t_fp32 / t_fused, "speedup_vs_torch_bf16": t_bf16 / t_fused}))
