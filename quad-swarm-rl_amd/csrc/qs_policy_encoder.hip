@@ -27,7 +27,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define ENC_H 256            // hidden size of every MLP (rnn_size = neighbor_hidden_size = obst_hidden_size = 256)
 #define ENC_TA 16            // agents per workgroup = one 16-row tile
-#define ENC_MAX_NBR 8        // neighbours per agent handled in registers (6 or 2 in the reference's configurations)
+#define ENC_MAX_NBR 8        // neighbours per agent (6 or 2 in the reference's configurations)
+#define ENC_NH (ENC_MAX_NBR / 2)   // neighbour row tiles per pass of the neighbour MLP
 #ifndef ENC_WAVES
 #define ENC_WAVES 8   // 2 waves per SIMD: the layer chain of one workgroup is latency-bound, a second wave hides part of it (49 -> 40 us at 8192 agents)
 #endif
@@ -139,13 +140,13 @@ __device__ __forceinline__ void store_tanh(const f32x4 (&acc)[MT][NT], int mtile
             }
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_nbr = x_self + ENC_TA * ENC_XS;                       // [NBR*16][XS]
     uint16_t *x_obst = x_nbr + ENC_MAX_NBR * ENC_TA * ENC_XS;         // [16][XS]
-    uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [NBR*16][YS] hidden layer of the neighbour MLP
-    uint16_t *buf_b = buf_a + ENC_MAX_NBR * ENC_TA * ENC_YS;          // [16][YS]     hidden layer of the self / obstacle MLPs
+    uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [NH*16][YS]  hidden layer of the neighbour MLP (one half at a time)
+    uint16_t *buf_b = buf_a + ENC_NH * ENC_TA * ENC_YS;               // [16][YS]     hidden layer of the self / obstacle MLPs
     uint16_t *cat = buf_b + ENC_TA * ENC_YS;                          // [16][CS]: self | neighbourhood | obstacles
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, a0 = blockIdx.x * ENC_TA;
@@ -215,38 +216,43 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES) qs_encoder_kernel(c
 
     ENC_STAMP(3);
     // ---- neighbour encoder -> cat[:, 256:512] ----
+    // In two halves of up to ENC_NH neighbour tiles: the hidden layer of the neighbour MLP is the largest LDS buffer, and at half
+    // its size two workgroups fit one CU (the layer chain of a single workgroup is latency-bound, a second one overlaps it).
     if (NB > 0) {
-        f32x4 acc[ENC_MT][ENC_MAX_NBR];
-        init_bias<ENC_MT, ENC_MAX_NBR>(P.n1, mt0, acc);
-        gemm_tiles<ENC_MT, ENC_MAX_NBR>(P.n1, mt0, x_nbr, ENC_XS, NB, acc);
-        ENC_STAMP(4);
-        store_tanh<ENC_MT, ENC_MAX_NBR>(acc, mt0, NB, buf_a, ENC_YS);
-        __syncthreads();
-        ENC_STAMP(5);
-        init_bias<ENC_MT, ENC_MAX_NBR>(P.n2, mt0, acc);
-        gemm_tiles<ENC_MT, ENC_MAX_NBR>(P.n2, mt0, buf_a, ENC_YS, NB, acc);
-        ENC_STAMP(6);
-        // e_i = tanh(.) in registers; the mean over neighbours is a sum over the row tiles (same lane, same register)
         f32x4 mean[ENC_MT];
-        const float inv = 1.0f / (float)NB;
 #pragma unroll
-        for (int mt = 0; mt < ENC_MT; ++mt) {
-            mean[mt] = (f32x4){0, 0, 0, 0};
+        for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
+        for (int half = 0; half < 2; ++half) {
+            const int t0 = half * ENC_NH, nth = (NB - t0) < ENC_NH ? (NB - t0) : ENC_NH;
+            if (nth <= 0) break;
+            f32x4 acc[ENC_MT][ENC_NH];
+            init_bias<ENC_MT, ENC_NH>(P.n1, mt0, acc);
+            gemm_tiles<ENC_MT, ENC_NH>(P.n1, mt0, x_nbr + t0 * ENC_TA * ENC_XS, ENC_XS, nth, acc);
+            ENC_STAMP(4);
+            if (half) __syncthreads();   // the previous half's second layer is done reading buf_a
+            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_a, ENC_YS);
+            __syncthreads();
+            ENC_STAMP(5);
+            init_bias<ENC_MT, ENC_NH>(P.n2, mt0, acc);
+            gemm_tiles<ENC_MT, ENC_NH>(P.n2, mt0, buf_a, ENC_YS, nth, acc);
+            ENC_STAMP(6);
+            // e_i = tanh(.); the mean over neighbours is a sum over the row tiles (same lane, same register)
 #pragma unroll
-            for (int nt = 0; nt < ENC_MAX_NBR; ++nt)
-                if (nt < NB) {
+            for (int mt = 0; mt < ENC_MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { acc[mt][nt][r] = fast_tanh(acc[mt][nt][r]); mean[mt][r] += acc[mt][nt][r]; }
-                }
+                for (int nt = 0; nt < ENC_NH; ++nt)
+                    if (nt < nth) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mean[mt][r] *= inv;
+                        for (int r = 0; r < 4; ++r) mean[mt][r] += fast_tanh(acc[mt][nt][r]);
+                    }
         }
         // mean_embed: torch.mean(neighbor_embeds, dim=1) (:41-42)
+        const float inv = 1.0f / (float)NB;
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) {
             bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)mean[mt][r];
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(mean[mt][r] * inv);
             *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
         }
     }
@@ -284,7 +290,7 @@ const char *qs_enc_last_error(void) { return g_enc_error.c_str(); }
 size_t qs_enc_sizeof_params(void) { return sizeof(EncParams); }
 
 size_t qs_enc_lds_bytes(void) {
-    return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_MAX_NBR * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
+    return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
 }
 
 // out[B, 512] = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
