@@ -2,8 +2,9 @@
  * quadswarm_encoder.h - C ABI of the fused policy-encoder forward pass (MI355X / gfx950 matrix cores).
  *
  * Replaces, for inference during rollouts, the forward() of the reference's QuadMultiEncoder
- * (swarm_rl/models/quad_multi_model.py:250-350) with the `mean_embed` neighbour encoder (:22-43): self MLP,
- * per-neighbour MLP + mean, optional obstacle MLP, feed-forward; tanh; hidden size 256; output [B, 512] fp32.
+ * (swarm_rl/models/quad_multi_model.py:250-350) with the `mean_embed` neighbour encoder (:22-43) - self MLP,
+ * per-neighbour MLP + mean, optional obstacle MLP, feed-forward - or the `attention` neighbour encoder (:46-101; two
+ * launches, needs the two scratch buffers below); tanh; hidden size 256; output [B, 512] fp32.
  * bf16 weights / activations, fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Weights are handed over pre-packed:
  *   layer with torch weight W[M_real, K_real], bias b[M_real]  ->  M = ceil16(M_real), K = ceil32(K_real), zero padded,
  *   w[((mt * (K/32) + ks) * 64 + lane) * 8 + j] = bf16(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),  b as fp32[M].
@@ -21,9 +22,17 @@ typedef struct qs_enc_layer { const uint16_t *w; const float *b; int32_t M, K; }
 
 typedef struct qs_enc_params {
     int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;   /* obs row = [self | num_nbr x nbr_dim | obst] */
+    int32_t attention;     /* 0: mean_embed neighbour encoder, 1: attention neighbour encoder (self_dim + nbr_dim <= 32) */
     qs_enc_layer s1, s2;   /* self encoder      (quad_multi_model.py:303-309) */
-    qs_enc_layer n1, n2;   /* neighbour MLP     (:29-34), mean over neighbours (:41-42) */
+    qs_enc_layer n1, n2;   /* neighbour MLP     (:29-34), mean over neighbours (:41-42);
+                              attention: embedding_mlp (:52-57), input [self obs | neighbour obs] */
     qs_enc_layer o1, o2;   /* obstacle encoder  (:315-322), unused when obst_dim == 0 */
+    qs_enc_layer v1, v2;   /* attention: neighbor_value_mlp (:60-65) */
+    qs_enc_layer a1e, a1m; /* attention: attention_mlp[0] (:69) split by input columns: W[:, 0:256] with the bias (e_i half),
+                              W[:, 256:512] (e_mean half; its bias pointer is not read) */
+    qs_enc_layer a2, a3;   /* attention: attention_mlp[2], attention_mlp[4] (256 -> 1, padded to M = 16) */
+    uint16_t *ebuf;        /* attention scratch, device, bf16 [B * num_nbr, 256] */
+    float *gbuf;           /* attention scratch, device, fp32 [B, 256] */
     qs_enc_layer f;        /* feed forward      (:329-332): K = 256 * (1 + (num_nbr > 0) + (obst_dim > 0)), M = 512 */
 } qs_enc_params;
 

@@ -1,0 +1,51 @@
+#!/usr/bin/env python
+"""One-off check, run in the build container only (needs /root/reference): the `attention` neighbour encoder restated in
+quad-swarm-rl_amd/policy.py (QuadMultiEncoderRef, attention=True) against the reference class
+swarm_rl/models/quad_multi_model.py:46-101 with the same weights.  Sample Factory is not installed, so its four imports are
+stubbed (fc_layer = nn.Linear, nonlinearity = tanh, as in the reference's runs); numba/gymnasium come from ./stubs.
+Prints the max abs difference (expected 0.0: same ops in the same order)."""
+import os
+import sys
+import types
+
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "stubs"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def mod(name, **kw):
+    m = types.ModuleType(name)
+    m.__dict__.update(kw)
+    sys.modules[name] = m
+
+
+for name in ("sample_factory", "sample_factory.algo", "sample_factory.algo.utils", "sample_factory.model"):
+    mod(name)
+mod("sample_factory.algo.utils.context", global_model_factory=lambda: None)
+mod("sample_factory.algo.utils.torch_utils", calc_num_elements=lambda *a: 0)
+mod("sample_factory.model.encoder", Encoder=nn.Module)
+mod("sample_factory.model.model_utils", fc_layer=lambda i, o, **k: nn.Linear(i, o), nonlinearity=lambda cfg: nn.Tanh())
+
+from swarm_rl.models import quad_multi_model as ref_model   # noqa: E402
+from quad_swarm_rl_amd import policy                          # noqa: E402
+
+worst = 0.0
+for K, B in ((6, 37), (2, 8), (8, 1), (5, 64)):
+    mine = policy.make_reference_encoder(seed=K, attention=True, num_nbr=K)
+    theirs = ref_model.QuadNeighborhoodEncoderAttention(types.SimpleNamespace(), 6, 256, 18, K)
+    theirs.embedding_mlp.load_state_dict(mine.neighbor_encoder.state_dict())
+    theirs.neighbor_value_mlp.load_state_dict(mine.neighbor_value_mlp.state_dict())
+    theirs.attention_mlp.load_state_dict(mine.attention_mlp.state_dict())
+    obs = torch.rand(B, 18 + 6 * K) * 2 - 1
+    with torch.no_grad():
+        want = theirs(obs[:, :18], obs, 6 * K, B)
+        # the neighbourhood block of QuadMultiEncoderRef.forward, isolated by zeroing what surrounds it
+        mine.feed_forward = nn.Identity()
+        got = mine(obs)[:, 256:512]
+    worst = max(worst, (want - got).abs().max().item())
+print("max abs diff vs the reference class:", worst)
+sys.exit(0 if worst == 0.0 else 1)

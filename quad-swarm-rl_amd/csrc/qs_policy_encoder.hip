@@ -3,9 +3,11 @@
 // Reference: swarm_rl/models/quad_multi_model.py:250-350 (QuadMultiEncoder: self encoder, neighbour encoder, optional obstacle
 // encoder, feed-forward) with the `mean_embed` neighbour encoder (:22-43, QuadNeighborhoodEncoderDeepsets); tanh non-linearity,
 // hidden size 256.  It reads the observation rows straight from the stepper's buffer.
-// Not covered: the `attention` neighbour encoder (:46-101).  Its `self_obs.repeat(K, 1)` (:84) and `mean.repeat(K, 1)` (:92)
+// The `attention` neighbour encoder (:46-101) takes two kernels: its `self_obs.repeat(K, 1)` (:84) and `mean.repeat(K, 1)` (:92)
 // tile the WHOLE batch, so row (agent a, neighbour k) is paired with the self observation and the mean embedding of agent
-// (a*K + k) mod batch: an inter-agent dependence on an intermediate result, i.e. a two-kernel job with a grid-wide hand-over.
+// (a*K + k) mod batch - an inter-agent dependence on an intermediate result.  qs_encoder_embed_kernel computes e_i for every row
+// (with that self observation) and g = W_m e_mean per agent; qs_encoder_kernel then runs value MLP, score MLP (W_e e_i + g[(a*K+k)
+// mod B] + b), softmax over the neighbours and the weighted sum, all lane-local across accumulator tiles.
 //
 // One workgroup = 8 waves = 16 agents.  Every layer is a transposed GEMM on v_mfma_f32_16x16x32_bf16:
 //     C[feature][row] = sum_k W[feature][k] * X[row][k]
@@ -41,9 +43,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 struct EncLayer { const uint16_t *w; const float *b; int32_t M, K; };   // K padded to a multiple of 32, M to a multiple of 16
 struct EncParams {
     int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;
+    int32_t attention;          // 0: mean_embed neighbour encoder (:22-43), 1: attention neighbour encoder (:46-101)
     EncLayer s1, s2;            // self encoder        :303-309
-    EncLayer n1, n2;            // neighbour embedding :29-34 (QuadNeighborhoodEncoderDeepsets)
+    EncLayer n1, n2;            // neighbour embedding :29-34 (input = neighbour obs) / :52-57 (attention: input = [self obs | neighbour obs])
     EncLayer o1, o2;            // obstacle encoder    :315-322
+    EncLayer v1, v2;            // attention: value MLP :60-65
+    EncLayer a1e, a1m, a2, a3;  // attention: score MLP :68-75; its first layer split into the e_i half (with the bias) and the e_mean half
+    uint16_t *ebuf;             // attention scratch: e_i of every (agent, neighbour) row, bf16 [B*num_nbr, 256]
+    float *gbuf;                // attention scratch: W_m e_mean of every agent, fp32 [B, 256]
     EncLayer f;                 // feed forward        :329-332
 };
 
@@ -140,7 +147,72 @@ __device__ __forceinline__ void store_tanh(const f32x4 (&acc)[MT][NT], int mtile
             }
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+// attention, pass 1: e_i = embedding_mlp([self_obs[(a*K+k) mod B] | neighbour obs (a,k)]) -> ebuf;  g_a = W_m mean_k e_(a,k) -> gbuf
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_embed_kernel(const float *__restrict__ obs, int B, EncParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_in = (uint16_t *)smem;                                // [NBR*16][XS]
+    uint16_t *buf_a = x_in + ENC_MAX_NBR * ENC_TA * ENC_XS;           // [NH*16][YS]
+    uint16_t *emean = buf_a + ENC_NH * ENC_TA * ENC_YS;               // [16][YS]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, a0 = blockIdx.x * ENC_TA;
+    const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
+    for (int idx = tid; idx < NB * ENC_TA * 32; idx += 64 * ENC_WAVES) {
+        const int row = idx >> 5, c = idx & 31, k = row >> 4, a = row & 15, ga = a0 + a;
+        float v = 0.0f;
+        if (ga < B) {
+            if (c < P.self_dim) v = obs[(size_t)(((size_t)ga * NB + k) % (size_t)B) * D + c];        // self_obs.repeat(K, 1)  (:84)
+            else if (c < P.self_dim + P.nbr_dim) v = obs[(size_t)ga * D + P.self_dim + k * P.nbr_dim + (c - P.self_dim)];
+        }
+        x_in[row * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+    __syncthreads();
+    f32x4 mean[ENC_MT];
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
+    for (int half = 0; half < 2; ++half) {
+        const int t0 = half * ENC_NH, nth = (NB - t0) < ENC_NH ? (NB - t0) : ENC_NH;
+        if (nth <= 0) break;
+        f32x4 acc[ENC_MT][ENC_NH];
+        init_bias<ENC_MT, ENC_NH>(P.n1, mt0, acc);
+        gemm_tiles<ENC_MT, ENC_NH>(P.n1, mt0, x_in + t0 * ENC_TA * ENC_XS, ENC_XS, nth, acc);
+        if (half) __syncthreads();
+        store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_a, ENC_YS);
+        __syncthreads();
+        init_bias<ENC_MT, ENC_NH>(P.n2, mt0, acc);
+        gemm_tiles<ENC_MT, ENC_NH>(P.n2, mt0, buf_a, ENC_YS, nth, acc);
+        const int ga = a0 + (lane & 15);
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < ENC_NH; ++nt)
+                if (nt < nth) {
+                    bf16x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = fast_tanh(acc[mt][nt][r]); mean[mt][r] += e; v[r] = (__bf16)e; }
+                    if (ga < B) *(bf16x4 *)(P.ebuf + ((size_t)ga * NB + (t0 + nt)) * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+                }
+    }
+    const float inv = 1.0f / (float)NB;   // e_mean (:90-91), then its half of the score MLP's first layer once per agent
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(mean[mt][r] * inv);
+        *(bf16x4 *)(emean + (lane & 15) * ENC_YS + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+    }
+    __syncthreads();
+    f32x4 g[ENC_MT][1];
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) g[mt][0] = (f32x4){0, 0, 0, 0};
+    gemm_tiles<ENC_MT, 1>(P.a1m, mt0, emean, ENC_YS, 1, g);
+    const int ga = a0 + (lane & 15);
+    if (ga < B) {
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) *(f32x4 *)(P.gbuf + (size_t)ga * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = g[mt][0];
+    }
+}
+
+template <bool ATT>
+__device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_nbr = x_self + ENC_TA * ENC_XS;                       // [NBR*16][XS]
@@ -148,6 +220,8 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_kerne
     uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [NH*16][YS]  hidden layer of the neighbour MLP (one half at a time)
     uint16_t *buf_b = buf_a + ENC_NH * ENC_TA * ENC_YS;               // [16][YS]     hidden layer of the self / obstacle MLPs
     uint16_t *cat = buf_b + ENC_TA * ENC_YS;                          // [16][CS]: self | neighbourhood | obstacles
+    uint16_t *att_h = cat + ENC_TA * ENC_CS;                          // attention only: [NH*16][YS] hidden layers of the value / score MLPs
+    float *att_w = (float *)(att_h + ENC_NH * ENC_TA * ENC_YS);       // attention only: [NBR][16] softmax weights
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim;
@@ -218,6 +292,102 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_kerne
     // ---- neighbour encoder -> cat[:, 256:512] ----
     // In two halves of up to ENC_NH neighbour tiles: the hidden layer of the neighbour MLP is the largest LDS buffer, and at half
     // its size two workgroups fit one CU (the layer chain of a single workgroup is latency-bound, a second one overlaps it).
+    if (ATT && NB > 0) {
+        // attention, pass 2 (:88-101).  buf_a holds e_i of one half of the neighbour tiles, buf_h the hidden layers.
+        uint16_t *buf_h = att_h;
+        float *s_w = att_w;
+        f32x4 hval[ENC_MT][ENC_MAX_NBR];   // h_i = value MLP output, kept until the softmax weights exist
+        float alpha[ENC_MAX_NBR];          // scores of agent (lane & 15): valid in lanes 0..15 of wave 0
+#pragma unroll
+        for (int k = 0; k < ENC_MAX_NBR; ++k) alpha[k] = -3.0e38f;
+        for (int half = 0; half < 2; ++half) {
+            const int t0 = half * ENC_NH, nth = (NB - t0) < ENC_NH ? (NB - t0) : ENC_NH;
+            if (nth <= 0) break;
+            if (half) __syncthreads();   // wave 0 is done with the last score layer of the previous half (reads buf_a)
+            for (int idx = tid; idx < nth * ENC_TA * (ENC_H / 8); idx += 64 * ENC_WAVES) {   // e_i rows: 16-byte chunks, coalesced
+                const int row = idx / (ENC_H / 8), ch = idx - row * (ENC_H / 8), k = t0 + (row >> 4), ga = a0 + (row & 15);
+                bf16x8 v = {};
+                if (ga < B) v = *(const bf16x8 *)(P.ebuf + ((size_t)ga * NB + k) * ENC_H + ch * 8);
+                *(bf16x8 *)(buf_a + row * ENC_YS + ch * 8) = v;
+            }
+            __syncthreads();
+            f32x4 acc[ENC_MT][ENC_NH];
+            init_bias<ENC_MT, ENC_NH>(P.v1, mt0, acc);
+            gemm_tiles<ENC_MT, ENC_NH>(P.v1, mt0, buf_a, ENC_YS, nth, acc);
+            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_h, ENC_YS);
+            __syncthreads();
+            init_bias<ENC_MT, ENC_NH>(P.v2, mt0, acc);
+            gemm_tiles<ENC_MT, ENC_NH>(P.v2, mt0, buf_h, ENC_YS, nth, acc);
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < ENC_NH; ++nt) {
+                    if (nt < nth) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[mt][nt][r] = fast_tanh(acc[mt][nt][r]);
+                    }
+                    if (half == 0) hval[mt][nt] = acc[mt][nt]; else hval[mt][ENC_NH + nt] = acc[mt][nt];
+                }
+            // score MLP, first layer on [e_i | e_mean.repeat]: W_e e_i + b + g[(a*K + k) mod B]   (:92-94)
+            init_bias<ENC_MT, ENC_NH>(P.a1e, mt0, acc);
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < ENC_NH; ++nt)
+                    if (nt < nth) {
+                        const int ga = a0 + (lane & 15);
+                        if (ga < B) {
+                            const size_t j = ((size_t)ga * NB + (t0 + nt)) % (size_t)B;
+                            const f32x4 gv = *(const f32x4 *)(P.gbuf + j * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[mt][nt][r] += gv[r];
+                        }
+                    }
+            gemm_tiles<ENC_MT, ENC_NH>(P.a1e, mt0, buf_a, ENC_YS, nth, acc);
+            __syncthreads();   // every wave is done reading buf_h (v2) and buf_a (a1e)
+            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_h, ENC_YS);
+            __syncthreads();
+            init_bias<ENC_MT, ENC_NH>(P.a2, mt0, acc);
+            gemm_tiles<ENC_MT, ENC_NH>(P.a2, mt0, buf_h, ENC_YS, nth, acc);
+            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_a, ENC_YS);
+            __syncthreads();
+            if (wave == 0) {   // last score layer 256 -> 1 (padded to one 16-feature tile): feature 0 = row 0 of D = lanes 0..15, register 0
+                f32x4 sc[1][ENC_NH];
+                init_bias<1, ENC_NH>(P.a3, 0, sc);
+                gemm_tiles<1, ENC_NH>(P.a3, 0, buf_a, ENC_YS, nth, sc);
+#pragma unroll
+                for (int nt = 0; nt < ENC_NH; ++nt)
+                    if (nt < nth) { if (half == 0) alpha[nt] = sc[0][nt][0]; else alpha[ENC_NH + nt] = sc[0][nt][0]; }
+            }
+        }
+        if (wave == 0 && lane < 16) {   // softmax over the neighbours of agent `lane` (:95-96)
+            float mx = -3.0e38f, den = 0.0f, ex[ENC_MAX_NBR];
+#pragma unroll
+            for (int k = 0; k < ENC_MAX_NBR; ++k) if (k < NB) mx = fmaxf(mx, alpha[k]);
+#pragma unroll
+            for (int k = 0; k < ENC_MAX_NBR; ++k) { ex[k] = (k < NB) ? __expf(alpha[k] - mx) : 0.0f; den += ex[k]; }
+            const float rden = 1.0f / den;
+#pragma unroll
+            for (int k = 0; k < ENC_MAX_NBR; ++k) s_w[k * 16 + lane] = ex[k] * rden;
+        }
+        __syncthreads();
+        // sum_i softmax_i * h_i (:98-100): the weight of (neighbour k, agent lane & 15) is the same for all features
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < ENC_MAX_NBR; ++k)
+                if (k < NB) {
+                    const float wgt = s_w[k * 16 + (lane & 15)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += wgt * hval[mt][k][r];
+                }
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)o[r];
+            *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+    } else
     if (NB > 0) {
         f32x4 mean[ENC_MT];
 #pragma unroll
@@ -283,35 +453,52 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_kerne
 // ------------------------------------------------------------------------------------------------
 // C ABI (include/quadswarm_encoder.h)
 // ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+    encoder_body<false>(obs, B, P, out);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_attn_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+    encoder_body<true>(obs, B, P, out);
+}
+
 static thread_local std::string g_enc_error;
 extern "C" {
 
 const char *qs_enc_last_error(void) { return g_enc_error.c_str(); }
 size_t qs_enc_sizeof_params(void) { return sizeof(EncParams); }
 
-size_t qs_enc_lds_bytes(void) {
-    return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
+static size_t lds_main(int attention) {
+    size_t b = sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
+    if (attention) b += sizeof(uint16_t) * ENC_NH * ENC_TA * ENC_YS + sizeof(float) * ENC_MAX_NBR * 16;
+    return b;
 }
+static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
+size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 
 // out[B, 512] = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
     if (!obs || !params || !out || B < 0) { g_enc_error = "bad argument"; return -1; }
     const EncParams &P = *params;
-    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32) {
+    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || (P.attention && (P.self_dim + P.nbr_dim > 32 || !P.ebuf || !P.gbuf))) {
         g_enc_error = "unsupported encoder shape (inputs wider than 32 or more than 8 neighbours)";
         return -4;
     }
     if (B == 0) return 0;
     static bool attr_set = false;
-    const size_t lds = qs_enc_lds_bytes();
+    const size_t lds = lds_main(P.attention && P.num_nbr > 0);
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(0)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed()) != hipSuccess) {
             g_enc_error = "cannot raise the dynamic LDS limit";
             return -2;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(qs_encoder_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
+    if (P.attention && P.num_nbr > 0) {
+        hipLaunchKernelGGL(qs_encoder_embed_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_embed(), (hipStream_t)stream, obs, B, P);
+        hipLaunchKernelGGL(qs_encoder_attn_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
+    } else
+        hipLaunchKernelGGL(qs_encoder_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_enc_error = hipGetErrorString(e); return -2; }
     return 0;

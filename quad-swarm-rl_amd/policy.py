@@ -1,10 +1,10 @@
 """Policy-encoder inference next to the stepper.
 
-`QuadMultiEncoderRef` is a plain-PyTorch restatement of the reference's QuadMultiEncoder with the `mean_embed` neighbour
-encoder (swarm_rl/models/quad_multi_model.py:22-43, :250-350; Sample Factory's `fc_layer` is `nn.Linear`, `nonlinearity` is
+`QuadMultiEncoderRef` is a plain-PyTorch restatement of the reference's QuadMultiEncoder with the `mean_embed` or the
+`attention` neighbour encoder (swarm_rl/models/quad_multi_model.py:22-43, :46-101, :250-350; Sample Factory's `fc_layer` is `nn.Linear`, `nonlinearity` is
 tanh in the reference's runs) - it is the fp32 reference the fused kernel is tested against and the source of its weights.
 `FusedQuadEncoder` packs those weights for `csrc/qs_policy_encoder.hip` (include/quadswarm_encoder.h) and runs the forward
-pass as ONE kernel that reads the stepper's observation buffer.  No CPU fallback: without the extension or a GPU it raises.
+pass as ONE kernel (two for `attention`) that reads the stepper's observation buffer.  No CPU fallback: without the extension or a GPU it raises.
 """
 import ctypes as C
 import os
@@ -35,7 +35,10 @@ class EncLayer(C.Structure):
 
 class EncParams(C.Structure):
     _fields_ = [("self_dim", C.c_int32), ("nbr_dim", C.c_int32), ("num_nbr", C.c_int32), ("obst_dim", C.c_int32), ("obs_dim", C.c_int32),
-                ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("o1", EncLayer), ("o2", EncLayer), ("f", EncLayer)]
+                ("attention", C.c_int32),
+                ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("o1", EncLayer), ("o2", EncLayer),
+                ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3", EncLayer),
+                ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer)]
 
 
 _lib = None
@@ -59,8 +62,8 @@ def lib():
     return _lib
 
 
-def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden=HIDDEN, seed=0):
-    """QuadMultiEncoder (mean_embed) as a torch module; random init (there are no checkpoints in this image)."""
+def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden=HIDDEN, seed=0, attention=False):
+    """QuadMultiEncoder (mean_embed, or attention) as a torch module; random init (there are no checkpoints in this image)."""
     import torch
     from torch import nn
 
@@ -70,7 +73,12 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
             self.self_dim, self.nbr_dim, self.num_nbr, self.obst_dim = self_dim, nbr_dim, num_nbr, obst_dim
             mlp = lambda i: nn.Sequential(nn.Linear(i, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
             self.self_encoder = mlp(self_dim)                                   # :303-309
-            self.neighbor_encoder = mlp(nbr_dim) if num_nbr > 0 else None       # :29-34
+            self.attention = bool(attention) and num_nbr > 0
+            self.neighbor_encoder = mlp(self_dim + nbr_dim if self.attention else nbr_dim) if num_nbr > 0 else None   # :29-34 / :52-57
+            if self.attention:
+                self.neighbor_value_mlp = mlp(hidden)                           # :60-65
+                self.attention_mlp = nn.Sequential(nn.Linear(2 * hidden, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                                   nn.Linear(hidden, 1))        # :68-75
             self.obstacle_encoder = mlp(obst_dim) if obst_dim > 0 else None     # :315-322
             total = hidden * (1 + (num_nbr > 0) + (obst_dim > 0))
             self.feed_forward = nn.Sequential(nn.Linear(total, 2 * hidden), nn.Tanh())   # :329-332
@@ -79,7 +87,16 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
             B = obs.shape[0]
             emb = [self.self_encoder(obs[:, :self.self_dim])]
             nb = self.nbr_dim * self.num_nbr
-            if self.neighbor_encoder is not None:                               # :36-43
+            if self.attention:                                                  # :77-101, including what .repeat() pairs up
+                K = self.num_nbr
+                nbrs = obs[:, self.self_dim:self.self_dim + nb].reshape(-1, self.nbr_dim)
+                e = self.neighbor_encoder(torch.cat((obs[:, :self.self_dim].repeat(K, 1), nbrs), dim=1))
+                h = self.neighbor_value_mlp(e)
+                e_mean = e.reshape(B, -1, e.shape[-1]).mean(dim=1)
+                alpha = self.attention_mlp(torch.cat((e, e_mean.repeat(K, 1)), dim=1)).view(B, -1)
+                w = torch.softmax(alpha, dim=1).view(-1, 1)
+                emb.append((w * h).view(B, -1, h.shape[-1]).sum(dim=1))
+            elif self.neighbor_encoder is not None:                             # :36-43
                 e = self.neighbor_encoder(obs[:, self.self_dim:self.self_dim + nb].reshape(-1, self.nbr_dim))
                 emb.append(e.reshape(B, -1, e.shape[-1]).mean(dim=1))
             if self.obstacle_encoder is not None:
@@ -90,10 +107,13 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
     return QuadMultiEncoderRef()
 
 
-def pack_linear(linear, device):
-    """nn.Linear -> (packed bf16 weights in MFMA A-fragment order, padded fp32 bias, M, K); see include/quadswarm_encoder.h."""
+def pack_linear(linear, device, cols=None):
+    """nn.Linear (or its input columns cols[0]:cols[1]) -> (packed bf16 weights in MFMA A-fragment order, padded fp32 bias, M, K);
+    see include/quadswarm_encoder.h."""
     import torch
     W = linear.weight.detach().float().cpu().numpy()
+    if cols is not None:
+        W = W[:, cols[0]:cols[1]]
     b = linear.bias.detach().float().cpu().numpy()
     m_real, k_real = W.shape
     M, K = -(-m_real // 16) * 16, -(-k_real // 32) * 32
@@ -123,8 +143,8 @@ class FusedQuadEncoder:
         P.self_dim, P.nbr_dim, P.num_nbr, P.obst_dim = module.self_dim, module.nbr_dim, module.num_nbr, module.obst_dim
         P.obs_dim = module.self_dim + module.nbr_dim * module.num_nbr + module.obst_dim
 
-        def layer(linear):
-            w, b, M, K = pack_linear(linear, self.device)
+        def layer(linear, cols=None):
+            w, b, M, K = pack_linear(linear, self.device, cols)
             self._keep += [w, b]
             return EncLayer(w.data_ptr(), b.data_ptr(), M, K)
 
@@ -133,6 +153,14 @@ class FusedQuadEncoder:
             P.n1, P.n2 = layer(module.neighbor_encoder[0]), layer(module.neighbor_encoder[2])
         if module.obstacle_encoder is not None:
             P.o1, P.o2 = layer(module.obstacle_encoder[0]), layer(module.obstacle_encoder[2])
+        P.attention = int(getattr(module, "attention", False))
+        if P.attention:
+            if module.self_dim + module.nbr_dim > 32:
+                raise ValueError("attention encoder: self_dim + nbr_dim must fit one 32-wide K step")
+            P.v1, P.v2 = layer(module.neighbor_value_mlp[0]), layer(module.neighbor_value_mlp[2])
+            P.a1e, P.a1m = layer(module.attention_mlp[0], (0, HIDDEN)), layer(module.attention_mlp[0], (HIDDEN, 2 * HIDDEN))
+            P.a2, P.a3 = layer(module.attention_mlp[2]), layer(module.attention_mlp[4])
+        self._scratch_rows = 0
         P.f = layer(module.feed_forward[0])
         if P.f.M != 2 * HIDDEN or P.s1.M != HIDDEN:
             raise ValueError("the fused encoder is built for hidden size 256")
@@ -146,6 +174,7 @@ class FusedQuadEncoder:
         B = obs.shape[0]
         if out is None:
             out = torch.empty((B, self.out_dim), device=obs.device, dtype=torch.float32)
+        self._scratch(B)
         rc = lib().qs_enc_forward(obs.data_ptr(), B, C.byref(self.params), out.data_ptr(), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
         if rc != 0:
             raise native.QsError(f"qs_enc_forward failed ({rc}): {lib().qs_enc_last_error().decode()}")
@@ -153,10 +182,20 @@ class FusedQuadEncoder:
 
     __call__ = forward
 
+    def _scratch(self, B):
+        """attention only: e_i [B*K, 256] bf16 and W_m e_mean [B, 256] fp32, handed from the first launch to the second"""
+        if self.params.attention and B > self._scratch_rows:
+            torch = self._torch
+            self._ebuf = torch.empty((B * self.params.num_nbr, HIDDEN), device=self.device, dtype=torch.bfloat16)
+            self._gbuf = torch.empty((B, HIDDEN), device=self.device, dtype=torch.float32)
+            self.params.ebuf, self.params.gbuf = self._ebuf.data_ptr(), self._gbuf.data_ptr()
+            self._scratch_rows = B
+
     def benchmark(self, obs, out, iters=200):
         """Average seconds per forward pass over `iters` back-to-back launches (HIP events, no host work in between)."""
         torch = self._torch
         ms = C.c_double(0)
+        self._scratch(obs.shape[0])
         rc = lib().qs_enc_benchmark(obs.data_ptr(), obs.shape[0], C.byref(self.params), out.data_ptr(),
                                     C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream), iters, C.byref(ms))
         if rc != 0:
