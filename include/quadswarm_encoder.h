@@ -2,9 +2,10 @@
  * quadswarm_encoder.h - C ABI of the fused policy-encoder forward pass (MI355X / gfx950 matrix cores).
  *
  * Replaces, for inference during rollouts, the forward() of the reference's QuadMultiEncoder
- * (swarm_rl/models/quad_multi_model.py:250-350) with the `mean_embed` neighbour encoder (:22-43) - self MLP,
- * per-neighbour MLP + mean, optional obstacle MLP, feed-forward - or the `attention` neighbour encoder (:46-101; two
- * launches, needs the two scratch buffers below); tanh; hidden size 256; output [B, 512] fp32.
+ * (swarm_rl/models/quad_multi_model.py:250-350): self MLP, neighbour encoder, optional obstacle MLP, feed-forward; tanh;
+ * hidden size 256; output [B, 512] fp32.  All four --quads_neighbor_encoder_type choices: `mean_embed` (:22-43, per-neighbour
+ * MLP + mean), `attention` (:46-101; two launches, needs the two scratch buffers below), `mlp` (:104-122) and `no_encoder`
+ * (:289-291: the neighbour columns are part of the row but are not read).
  * bf16 weights / activations, fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Weights are handed over pre-packed:
  *   layer with torch weight W[M_real, K_real], bias b[M_real]  ->  M = ceil16(M_real), K = ceil32(K_real), zero padded,
  *   w[((mt * (K/32) + ks) * 64 + lane) * 8 + j] = bf16(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),  b as fp32[M].
@@ -18,14 +19,17 @@
 extern "C" {
 #endif
 
+enum { QS_ENC_NBR_MEAN_EMBED = 0, QS_ENC_NBR_ATTENTION = 1, QS_ENC_NBR_MLP = 2, QS_ENC_NBR_NONE = 3 };
+
 typedef struct qs_enc_layer { const uint16_t *w; const float *b; int32_t M, K; } qs_enc_layer;
 
 typedef struct qs_enc_params {
     int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;   /* obs row = [self | num_nbr x nbr_dim | obst] */
-    int32_t attention;     /* 0: mean_embed neighbour encoder, 1: attention neighbour encoder (self_dim + nbr_dim <= 32) */
+    int32_t nbr_encoder;   /* QS_ENC_NBR_*; attention needs self_dim + nbr_dim <= 32, mlp needs num_nbr * nbr_dim <= 64 */
     qs_enc_layer s1, s2;   /* self encoder      (quad_multi_model.py:303-309) */
-    qs_enc_layer n1, n2;   /* neighbour MLP     (:29-34), mean over neighbours (:41-42);
-                              attention: embedding_mlp (:52-57), input [self obs | neighbour obs] */
+    qs_enc_layer n1, n2, n3; /* mean_embed: neighbour MLP (:29-34) n1, n2, then the mean over neighbours (:41-42);
+                              attention: embedding_mlp (:52-57) n1, n2, input [self obs | neighbour obs];
+                              mlp: neighbor_mlp (:110-117) n1, n2, n3, input = all num_nbr x nbr_dim neighbour columns */
     qs_enc_layer o1, o2;   /* obstacle encoder  (:315-322), unused when obst_dim == 0 */
     qs_enc_layer v1, v2;   /* attention: neighbor_value_mlp (:60-65) */
     qs_enc_layer a1e, a1m; /* attention: attention_mlp[0] (:69) split by input columns: W[:, 0:256] with the bias (e_i half),
@@ -33,7 +37,7 @@ typedef struct qs_enc_params {
     qs_enc_layer a2, a3;   /* attention: attention_mlp[2], attention_mlp[4] (256 -> 1, padded to M = 16) */
     uint16_t *ebuf;        /* attention scratch, device, bf16 [B * num_nbr, 256] */
     float *gbuf;           /* attention scratch, device, fp32 [B, 256] */
-    qs_enc_layer f;        /* feed forward      (:329-332): K = 256 * (1 + (num_nbr > 0) + (obst_dim > 0)), M = 512 */
+    qs_enc_layer f;        /* feed forward      (:329-332): K = 256 * (1 + (neighbour encoder present) + (obst_dim > 0)), M = 512 */
 } qs_enc_params;
 
 size_t qs_enc_sizeof_params(void);

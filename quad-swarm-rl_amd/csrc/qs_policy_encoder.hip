@@ -40,12 +40,15 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define ENC_YS (ENC_H + 8)   // row stride of a 256-wide activation buffer
 #define ENC_CS (3 * ENC_H + 8)
 
+enum { ENC_NBR_MEAN_EMBED = 0, ENC_NBR_ATTENTION = 1, ENC_NBR_MLP = 2, ENC_NBR_NONE = 3 };
+#define ENC_XW 72   // row stride of the mlp neighbour encoder's input rows (all neighbours of one agent, K padded to 64)
 struct EncLayer { const uint16_t *w; const float *b; int32_t M, K; };   // K padded to a multiple of 32, M to a multiple of 16
 struct EncParams {
     int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;
-    int32_t attention;          // 0: mean_embed neighbour encoder (:22-43), 1: attention neighbour encoder (:46-101)
+    int32_t nbr_encoder;        // ENC_NBR_*: mean_embed (:22-43), attention (:46-101), mlp (:104-122), no_encoder (:289-291)
     EncLayer s1, s2;            // self encoder        :303-309
-    EncLayer n1, n2;            // neighbour embedding :29-34 (input = neighbour obs) / :52-57 (attention: input = [self obs | neighbour obs])
+    EncLayer n1, n2, n3;        // neighbour embedding :29-34 (input = neighbour obs) / :52-57 (attention: input = [self obs | neighbour obs])
+                                // / :110-117 (mlp: input = all neighbour obs of the agent, three layers)
     EncLayer o1, o2;            // obstacle encoder    :315-322
     EncLayer v1, v2;            // attention: value MLP :60-65
     EncLayer a1e, a1m, a2, a3;  // attention: score MLP :68-75; its first layer split into the e_i half (with the bias) and the e_mean half
@@ -225,7 +228,9 @@ __device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int 
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim;
-    const int col_nbr = ENC_H, col_obst = ENC_H * (NB > 0 ? 2 : 1);   // column blocks of `cat` in the order of the reference's torch.cat
+    const int mode = P.nbr_encoder;
+    const bool nbr_enc = NB > 0 && mode != ENC_NBR_NONE;   // no_encoder: the neighbour columns are in the row but nothing reads them (:289-291)
+    const int col_nbr = ENC_H, col_obst = ENC_H * (nbr_enc ? 2 : 1);   // column blocks of `cat` in the order of the reference's torch.cat
     const int mt0 = wave * ENC_MT;   // first of this wave's 16-feature tiles of a 256-wide layer
 
     ENC_STAMP(0);
@@ -254,7 +259,8 @@ __device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int 
                 if (cidx < P.self_dim) x_self[a * ENC_XS + cidx] = h;
                 else if (cidx < P.self_dim + P.nbr_dim * NB) {
                     const int q = cidx - P.self_dim, nb = q / P.nbr_dim, j = q - nb * P.nbr_dim;
-                    x_nbr[(nb * ENC_TA + a) * ENC_XS + j] = h;
+                    if (!ATT && mode == ENC_NBR_MLP) x_nbr[a * ENC_XW + q] = h;
+                    else x_nbr[(nb * ENC_TA + a) * ENC_XS + j] = h;
                 } else x_obst[a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB)] = h;
             }
         }
@@ -387,8 +393,21 @@ __device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int 
             for (int r = 0; r < 4; ++r) v[r] = (__bf16)o[r];
             *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
         }
-    } else
-    if (NB > 0) {
+    } else if (!ATT && nbr_enc && mode == ENC_NBR_MLP) {
+        // mlp neighbour encoder (:104-122): three layers on the concatenated neighbour observations of the agent
+        f32x4 acc[ENC_MT][1];
+        init_bias<ENC_MT, 1>(P.n1, mt0, acc);
+        gemm_tiles<ENC_MT, 1>(P.n1, mt0, x_nbr, ENC_XW, 1, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_a, ENC_YS);
+        __syncthreads();
+        init_bias<ENC_MT, 1>(P.n2, mt0, acc);
+        gemm_tiles<ENC_MT, 1>(P.n2, mt0, buf_a, ENC_YS, 1, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_a + ENC_TA * ENC_YS, ENC_YS);
+        __syncthreads();
+        init_bias<ENC_MT, 1>(P.n3, mt0, acc);
+        gemm_tiles<ENC_MT, 1>(P.n3, mt0, buf_a + ENC_TA * ENC_YS, ENC_YS, 1, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, 1, cat, ENC_CS, col_nbr);
+    } else if (!ATT && nbr_enc) {
         f32x4 mean[ENC_MT];
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
@@ -478,13 +497,16 @@ size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
     if (!obs || !params || !out || B < 0) { g_enc_error = "bad argument"; return -1; }
     const EncParams &P = *params;
-    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || (P.attention && (P.self_dim + P.nbr_dim > 32 || !P.ebuf || !P.gbuf))) {
-        g_enc_error = "unsupported encoder shape (inputs wider than 32 or more than 8 neighbours)";
+    const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0;
+    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0 || P.nbr_encoder > ENC_NBR_NONE ||
+        (att && P.self_dim + P.nbr_dim > 32) || (P.nbr_encoder == ENC_NBR_MLP && P.nbr_dim * P.num_nbr > 64)) {
+        g_enc_error = "unsupported encoder shape (inputs wider than 32 - 64 for the mlp neighbour encoder - or more than 8 neighbours)";
         return -4;
     }
+    if (att && (!P.ebuf || !P.gbuf)) { g_enc_error = "the attention neighbour encoder needs the ebuf / gbuf scratch buffers"; return -1; }
     if (B == 0) return 0;
     static bool attr_set = false;
-    const size_t lds = lds_main(P.attention && P.num_nbr > 0);
+    const size_t lds = lds_main(att);
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(0)) != hipSuccess ||
             hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
@@ -494,7 +516,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         }
         attr_set = true;
     }
-    if (P.attention && P.num_nbr > 0) {
+    if (att) {
         hipLaunchKernelGGL(qs_encoder_embed_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_embed(), (hipStream_t)stream, obs, B, P);
         hipLaunchKernelGGL(qs_encoder_attn_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
     } else

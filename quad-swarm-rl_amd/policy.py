@@ -35,8 +35,8 @@ class EncLayer(C.Structure):
 
 class EncParams(C.Structure):
     _fields_ = [("self_dim", C.c_int32), ("nbr_dim", C.c_int32), ("num_nbr", C.c_int32), ("obst_dim", C.c_int32), ("obs_dim", C.c_int32),
-                ("attention", C.c_int32),
-                ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("o1", EncLayer), ("o2", EncLayer),
+                ("nbr_encoder", C.c_int32),
+                ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("n3", EncLayer), ("o1", EncLayer), ("o2", EncLayer),
                 ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3", EncLayer),
                 ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer)]
 
@@ -62,8 +62,15 @@ def lib():
     return _lib
 
 
-def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden=HIDDEN, seed=0, attention=False):
-    """QuadMultiEncoder (mean_embed, or attention) as a torch module; random init (there are no checkpoints in this image)."""
+NBR_ENCODERS = ("mean_embed", "attention", "mlp", "no_encoder")   # --quads_neighbor_encoder_type (quadrotor_params.py:38-40); index = QS_ENC_NBR_*
+
+
+def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden=HIDDEN, seed=0, attention=False, nbr_encoder=None):
+    """QuadMultiEncoder as a torch module; random init (there are no checkpoints in this image).
+    nbr_encoder: one of NBR_ENCODERS (default mean_embed; attention=True is shorthand for "attention")."""
+    nbr_encoder = nbr_encoder or ("attention" if attention else "mean_embed")
+    if nbr_encoder not in NBR_ENCODERS:
+        raise NotImplementedError(nbr_encoder)                                  # :292-293
     import torch
     from torch import nn
 
@@ -73,14 +80,21 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
             self.self_dim, self.nbr_dim, self.num_nbr, self.obst_dim = self_dim, nbr_dim, num_nbr, obst_dim
             mlp = lambda i: nn.Sequential(nn.Linear(i, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
             self.self_encoder = mlp(self_dim)                                   # :303-309
-            self.attention = bool(attention) and num_nbr > 0
-            self.neighbor_encoder = mlp(self_dim + nbr_dim if self.attention else nbr_dim) if num_nbr > 0 else None   # :29-34 / :52-57
+            self.nbr_encoder = nbr_encoder if num_nbr > 0 else "no_encoder"
+            self.attention = self.nbr_encoder == "attention"
+            if self.nbr_encoder == "mlp":                                       # :110-117
+                self.neighbor_encoder = nn.Sequential(nn.Linear(nbr_dim * num_nbr, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
+                                                      nn.Linear(hidden, hidden), nn.Tanh())
+            elif self.nbr_encoder == "no_encoder":                              # :289-291 "blind agent"
+                self.neighbor_encoder = None
+            else:                                                               # :29-34 / :52-57
+                self.neighbor_encoder = mlp(self_dim + nbr_dim if self.attention else nbr_dim)
             if self.attention:
                 self.neighbor_value_mlp = mlp(hidden)                           # :60-65
                 self.attention_mlp = nn.Sequential(nn.Linear(2 * hidden, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
                                                    nn.Linear(hidden, 1))        # :68-75
             self.obstacle_encoder = mlp(obst_dim) if obst_dim > 0 else None     # :315-322
-            total = hidden * (1 + (num_nbr > 0) + (obst_dim > 0))
+            total = hidden * (1 + (self.neighbor_encoder is not None) + (obst_dim > 0))
             self.feed_forward = nn.Sequential(nn.Linear(total, 2 * hidden), nn.Tanh())   # :329-332
 
         def forward(self, obs):
@@ -96,6 +110,8 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
                 alpha = self.attention_mlp(torch.cat((e, e_mean.repeat(K, 1)), dim=1)).view(B, -1)
                 w = torch.softmax(alpha, dim=1).view(-1, 1)
                 emb.append((w * h).view(B, -1, h.shape[-1]).sum(dim=1))
+            elif self.nbr_encoder == "mlp":                                     # :119-122
+                emb.append(self.neighbor_encoder(obs[:, self.self_dim:self.self_dim + nb]))
             elif self.neighbor_encoder is not None:                             # :36-43
                 e = self.neighbor_encoder(obs[:, self.self_dim:self.self_dim + nb].reshape(-1, self.nbr_dim))
                 emb.append(e.reshape(B, -1, e.shape[-1]).mean(dim=1))
@@ -153,8 +169,13 @@ class FusedQuadEncoder:
             P.n1, P.n2 = layer(module.neighbor_encoder[0]), layer(module.neighbor_encoder[2])
         if module.obstacle_encoder is not None:
             P.o1, P.o2 = layer(module.obstacle_encoder[0]), layer(module.obstacle_encoder[2])
-        P.attention = int(getattr(module, "attention", False))
-        if P.attention:
+        P.nbr_encoder = NBR_ENCODERS.index(getattr(module, "nbr_encoder", "mean_embed"))
+        self.attention = P.nbr_encoder == 1
+        if P.nbr_encoder == 2:
+            if module.nbr_dim * module.num_nbr > 64:
+                raise ValueError("mlp neighbour encoder: num_nbr * nbr_dim must fit two 32-wide K steps")
+            P.n3 = layer(module.neighbor_encoder[4])
+        if self.attention:
             if module.self_dim + module.nbr_dim > 32:
                 raise ValueError("attention encoder: self_dim + nbr_dim must fit one 32-wide K step")
             P.v1, P.v2 = layer(module.neighbor_value_mlp[0]), layer(module.neighbor_value_mlp[2])
@@ -184,7 +205,7 @@ class FusedQuadEncoder:
 
     def _scratch(self, B):
         """attention only: e_i [B*K, 256] bf16 and W_m e_mean [B, 256] fp32, handed from the first launch to the second"""
-        if self.params.attention and B > self._scratch_rows:
+        if self.attention and B > self._scratch_rows:
             torch = self._torch
             self._ebuf = torch.empty((B * self.params.num_nbr, HIDDEN), device=self.device, dtype=torch.bfloat16)
             self._gbuf = torch.empty((B, HIDDEN), device=self.device, dtype=torch.float32)
