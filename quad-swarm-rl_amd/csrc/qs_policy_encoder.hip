@@ -34,6 +34,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #ifndef ENC_WAVES
 #define ENC_WAVES 8   // 2 waves per SIMD: the layer chain of one workgroup is latency-bound, a second wave hides part of it (49 -> 40 us at 8192 agents)
 #endif
+#ifndef ENC_OCC
+#define ENC_OCC 4     // waves per SIMD the register budget is set for: two workgroups per CU (<= 128 VGPRs)
+#endif
 #define ENC_MT (16 / ENC_WAVES)       // 16-feature tiles of a 256-wide layer per wave
 #define ENC_MTF (32 / ENC_WAVES)      // ... of the 512-wide feed-forward layer
 #define ENC_XS 40            // row stride (bf16) of the 32-wide input staging rows  (+8 pad: spreads the LDS banks)
@@ -64,6 +67,8 @@ __device__ unsigned long long enc_stamps[16];
 #define ENC_STAMP(k) do { } while (0)
 #endif
 
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }   // in a scalar register
+
 __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1); v_exp_f32 + v_rcp_f32
 #ifdef ENC_EXP_NO_TANH   // timing experiment
     return x;
@@ -72,10 +77,12 @@ __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
-// acc[mt][nt] (+)= W[features of (wave, mt)] x X[rows of tile nt], K-loop over the whole layer.
-// One wave per SIMD means nothing else hides the L2 latency of the weight fragments, so they are software-pipelined ENC_PD
-// K-steps ahead through a ring of register sets: the slot an MFMA group has just consumed is refilled with the fragment of
-// K-step ks + ENC_PD.
+// acc[mt][nt] (+)= W[features of (wave, mt)] x X[rows of tile nt], K-loop over the whole layer.  NT is a compile-time tile count
+// and the steady-state loop has no conditional loads: a run-time bound puts a branch in front of every MFMA and LDS read (a lone
+// pair of waves per SIMD pays for each of them) and makes the compiler drain the load counters every iteration.
+// Weight fragments come from L2 and are software-pipelined ENC_PD K-steps ahead through a ring of register sets (the slot an
+// MFMA group has just consumed is refilled with the fragment of K-step ks + ENC_PD); the activation fragment of a row tile is
+// re-read from LDS for K-step ks + 1 as soon as its MFMAs of K-step ks are issued.
 #define ENC_PD 4
 #ifdef ENC_EXP_NO_WLOAD   // timing experiment: no weight traffic
 #define ENC_WLOAD(x) (bf16x8){}
@@ -83,44 +90,63 @@ __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1)
 #define ENC_WLOAD(x) (x)
 #endif
 template <int MT, int NT>
-__device__ __forceinline__ void gemm_tiles(const EncLayer &L, int mtile0, const uint16_t *X, int xstride, int ntiles, f32x4 (&acc)[MT][NT]) {
+__device__ __forceinline__ void mfma_tile(const bf16x8 (&a)[MT], const bf16x8 &b, f32x4 (&acc)[MT][NT], int nt) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#ifndef ENC_EXP_NO_MFMA   // timing experiment
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
+#else
+        acc[mt][nt][0] += (float)a[mt][0] * (float)b[0];
+#endif
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_tiles(const EncLayer &L, int mtile0, const uint16_t *X, int xstride, f32x4 (&acc)[MT][NT]) {
     const int lane = threadIdx.x & 63, ksteps = L.K >> 5;
     const uint16_t *xrow = X + (lane & 15) * xstride + 8 * (lane >> 4);
-    const bf16x8 *wbase[MT];
+    // fragment address = buffer resource of the layer (scalar registers) + wave-uniform scalar offset (mtile0 is uniform) + one
+    // per-lane byte offset shared by every layer: no per-layer 64-bit address pairs in vector registers
+    const uint32_t voff = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, L.M * L.K * 2, 0x00020000);
+#define ENC_WFRAG(mt, ks) ENC_WLOAD(__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, ((mtile0 + (mt)) * ksteps + (ks)) * 1024, 0)))
+#define ENC_XFRAG(nt, ks) (*(const bf16x8 *)(xrow + (nt) * 16 * xstride + (ks) * 32))
+    if (ksteps & (ENC_PD - 1)) {   // the 32- and 64-wide input layers: one or two K-steps, nothing to pipeline
+        for (int ks = 0; ks < ksteps; ++ks) {
+            bf16x8 a[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) wbase[mt] = (const bf16x8 *)(L.w + ((size_t)(mtile0 + mt) * ksteps * 64 + lane) * 8);   // + ks * 64 fragments
-    bf16x8 a[ENC_PD][MT];
+            for (int mt = 0; mt < MT; ++mt) a[mt] = ENC_WFRAG(mt, ks);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) mfma_tile<MT, NT>(a, ENC_XFRAG(nt, ks), acc, nt);
+        }
+        return;
+    }
+    bf16x8 a[ENC_PD][MT], b[NT];
 #pragma unroll
     for (int s = 0; s < ENC_PD; ++s)
-        if (s < ksteps) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[s][mt] = ENC_WLOAD(wbase[mt][s * 64]);
-        }
-    for (int ks0 = 0; ks0 < ksteps; ks0 += ENC_PD) {
+        for (int mt = 0; mt < MT; ++mt) a[s][mt] = ENC_WFRAG(mt, s);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = ENC_XFRAG(nt, 0);
+    int ks0 = 0;
+    for (; ks0 + ENC_PD < ksteps; ks0 += ENC_PD) {   // steady state: every load unconditional, so the wait counters stay exact
 #pragma unroll
         for (int s = 0; s < ENC_PD; ++s) {
-            const int ks = ks0 + s;
-            if (ks < ksteps) {
-                bf16x8 b[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    if (nt < ntiles) b[nt] = *(const bf16x8 *)(xrow + nt * 16 * xstride + ks * 32);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#ifndef ENC_EXP_NO_MFMA   // timing experiment
-                        if (nt < ntiles) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][mt], b[nt], acc[mt][nt], 0, 0, 0);
-#else
-                        if (nt < ntiles) acc[mt][nt][0] += (float)a[s][mt][0] * (float)b[nt][0];
-#endif
-                if (ks + ENC_PD < ksteps) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) a[s][mt] = ENC_WLOAD(wbase[mt][(ks + ENC_PD) * 64]);
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                mfma_tile<MT, NT>(a[s], b[nt], acc, nt);
+                b[nt] = ENC_XFRAG(nt, ks0 + s + 1);   // this row tile's fragment is consumed: refill it while the other tiles' MFMAs run
             }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[s][mt] = ENC_WFRAG(mt, ks0 + s + ENC_PD);
         }
     }
+#pragma unroll
+    for (int s = 0; s < ENC_PD; ++s)   // the last ENC_PD K-steps: their weights are already in flight
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            mfma_tile<MT, NT>(a[s], b[nt], acc, nt);
+            if (s + 1 < ENC_PD) b[nt] = ENC_XFRAG(nt, ks0 + s + 1);
+        }
 }
 
 template <int MT, int NT>
@@ -136,27 +162,92 @@ __device__ __forceinline__ void init_bias(const EncLayer &L, int mtile0, f32x4 (
 
 // tanh, bf16, store: lane holds features f0..f0+3 of row (nt*16 + lane&15)
 template <int MT, int NT>
-__device__ __forceinline__ void store_tanh(const f32x4 (&acc)[MT][NT], int mtile0, int ntiles, uint16_t *Y, int ystride, int col0 = 0) {
+__device__ __forceinline__ void store_tanh(const f32x4 (&acc)[MT][NT], int mtile0, uint16_t *Y, int ystride, int col0 = 0) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            if (nt < ntiles) {
-                bf16x4 v;
+        for (int nt = 0; nt < NT; ++nt) {
+            bf16x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (__bf16)fast_tanh(acc[mt][nt][r]);
-                *(bf16x4 *)(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4) = v;
-            }
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)fast_tanh(acc[mt][nt][r]);
+            *(bf16x4 *)(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
 }
 
-// attention, pass 1: e_i = embedding_mlp([self_obs[(a*K+k) mod B] | neighbour obs (a,k)]) -> ebuf;  g_a = W_m mean_k e_(a,k) -> gbuf
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_embed_kernel(const float *__restrict__ obs, int B, EncParams P) {
+// one 16-row MLP: Y[:, col0:col0+256] = tanh(L2 tanh(L1 X)), hidden layer through `hid` (one barrier inside)
+__device__ __forceinline__ void mlp2_one_tile(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride, uint16_t *hid,
+                                              uint16_t *Y, int ystride, int col0) {
+    f32x4 acc[ENC_MT][1];
+    init_bias<ENC_MT, 1>(L1, mt0, acc);
+    gemm_tiles<ENC_MT, 1>(L1, mt0, X, xstride, acc);
+    store_tanh<ENC_MT, 1>(acc, mt0, hid, ENC_YS);
+    __syncthreads();
+    init_bias<ENC_MT, 1>(L2, mt0, acc);
+    gemm_tiles<ENC_MT, 1>(L2, mt0, hid, ENC_YS, acc);
+    store_tanh<ENC_MT, 1>(acc, mt0, Y, ystride, col0);
+}
+
+// feed forward: tanh(F [self | neighbourhood | obstacles]) -> out[a][0:512] (fp32)   (:329-332, :349)
+__device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t *cat, int a0, int B, float *__restrict__ out) {
+    const int wave = wave_id(), lane = threadIdx.x & 63;
+    f32x4 acc[ENC_MTF][1];
+    const int mf0 = wave * ENC_MTF;   // 512 features = 32 tiles
+    init_bias<ENC_MTF, 1>(P.f, mf0, acc);
+    gemm_tiles<ENC_MTF, 1>(P.f, mf0, cat, ENC_CS, acc);
+    ENC_STAMP(8);
+    const int ga = a0 + (lane & 15);
+    if (ga < B) {
+#pragma unroll
+        for (int mt = 0; mt < ENC_MTF; ++mt) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fast_tanh(acc[mt][0][r]);
+            *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+    }
+}
+
+#define ENC_DISPATCH_NT(n, CALL) \
+    switch (n) {                 \
+    case 1: CALL(1); break;      \
+    case 2: CALL(2); break;      \
+    case 3: CALL(3); break;      \
+    default: CALL(4); break;     \
+    }
+
+// ------------------------------------------------------------------------------------------------
+// attention, launch 1: e_i = embedding_mlp([self_obs[(a*K+k) mod B] | neighbour obs (a,k)]) -> ebuf;  g_a = W_m mean_k e_(a,k) -> gbuf
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__device__ __forceinline__ void embed_pass(const EncParams &P, int B, int a0, int t0, bool first, const uint16_t *x_in, uint16_t *buf_a, f32x4 (&mean)[ENC_MT]) {
+    const int wave = wave_id(), lane = threadIdx.x & 63, mt0 = wave * ENC_MT, NB = P.num_nbr;
+    f32x4 acc[ENC_MT][NTH];
+    init_bias<ENC_MT, NTH>(P.n1, mt0, acc);
+    gemm_tiles<ENC_MT, NTH>(P.n1, mt0, x_in + t0 * ENC_TA * ENC_XS, ENC_XS, acc);
+    if (!first) __syncthreads();   // the previous pass is done reading buf_a
+    store_tanh<ENC_MT, NTH>(acc, mt0, buf_a, ENC_YS);
+    __syncthreads();
+    init_bias<ENC_MT, NTH>(P.n2, mt0, acc);
+    gemm_tiles<ENC_MT, NTH>(P.n2, mt0, buf_a, ENC_YS, acc);
+    const int ga = a0 + (lane & 15);
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTH; ++nt) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = fast_tanh(acc[mt][nt][r]); mean[mt][r] += e; v[r] = (__bf16)e; }
+            if (ga < B) *(bf16x4 *)(P.ebuf + ((size_t)ga * NB + (t0 + nt)) * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+}
+
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_embed_kernel(const float *__restrict__ obs, int B, EncParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_in = (uint16_t *)smem;                                // [NBR*16][XS]
     uint16_t *buf_a = x_in + ENC_MAX_NBR * ENC_TA * ENC_XS;           // [NH*16][YS]
     uint16_t *emean = buf_a + ENC_NH * ENC_TA * ENC_YS;               // [16][YS]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, a0 = blockIdx.x * ENC_TA;
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
     for (int idx = tid; idx < NB * ENC_TA * 32; idx += 64 * ENC_WAVES) {
         const int row = idx >> 5, c = idx & 31, k = row >> 4, a = row & 15, ga = a0 + a;
@@ -171,28 +262,10 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_embed
     f32x4 mean[ENC_MT];
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
-    for (int half = 0; half < 2; ++half) {
-        const int t0 = half * ENC_NH, nth = (NB - t0) < ENC_NH ? (NB - t0) : ENC_NH;
-        if (nth <= 0) break;
-        f32x4 acc[ENC_MT][ENC_NH];
-        init_bias<ENC_MT, ENC_NH>(P.n1, mt0, acc);
-        gemm_tiles<ENC_MT, ENC_NH>(P.n1, mt0, x_in + t0 * ENC_TA * ENC_XS, ENC_XS, nth, acc);
-        if (half) __syncthreads();
-        store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_a, ENC_YS);
-        __syncthreads();
-        init_bias<ENC_MT, ENC_NH>(P.n2, mt0, acc);
-        gemm_tiles<ENC_MT, ENC_NH>(P.n2, mt0, buf_a, ENC_YS, nth, acc);
-        const int ga = a0 + (lane & 15);
-#pragma unroll
-        for (int mt = 0; mt < ENC_MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < ENC_NH; ++nt)
-                if (nt < nth) {
-                    bf16x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const float e = fast_tanh(acc[mt][nt][r]); mean[mt][r] += e; v[r] = (__bf16)e; }
-                    if (ga < B) *(bf16x4 *)(P.ebuf + ((size_t)ga * NB + (t0 + nt)) * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
-                }
+    for (int t0 = 0; t0 < NB; t0 += ENC_NH) {
+#define ENC_CALL(n) embed_pass<n>(P, B, a0, t0, t0 == 0, x_in, buf_a, mean)
+        ENC_DISPATCH_NT(NB - t0, ENC_CALL)
+#undef ENC_CALL
     }
     const float inv = 1.0f / (float)NB;   // e_mean (:90-91), then its half of the score MLP's first layer once per agent
 #pragma unroll
@@ -206,7 +279,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_embed
     f32x4 g[ENC_MT][1];
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) g[mt][0] = (f32x4){0, 0, 0, 0};
-    gemm_tiles<ENC_MT, 1>(P.a1m, mt0, emean, ENC_YS, 1, g);
+    gemm_tiles<ENC_MT, 1>(P.a1m, mt0, emean, ENC_YS, g);
     const int ga = a0 + (lane & 15);
     if (ga < B) {
 #pragma unroll
@@ -214,19 +287,181 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_embed
     }
 }
 
-template <bool ATT>
-__device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
+// ------------------------------------------------------------------------------------------------
+// attention, launch 2 (:88-101): value MLP, score MLP, softmax over the neighbours, weighted sum; then self / obstacle encoders
+// and the feed-forward layer.  One sweep over the neighbour row tiles in groups of ENC_ANH with an online softmax (running
+// maximum and denominator per agent, the partial sum rescaled when the maximum moves), so that the h_i of earlier groups do not
+// have to be kept: 78 KB of LDS and <= 128 VGPRs, two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+#define ENC_ANH 3
+struct AttnState { f32x4 o[ENC_MT]; float mx, den; };
+
+template <int NTH>
+__device__ __forceinline__ void attn_load_e(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a) {
+    // e_i rows in 16-byte chunks, coalesced; 32-bit offsets into a buffer resource (rows past the batch read as zero: out of range)
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)P.ebuf, 0, (uint32_t)B * (uint32_t)P.num_nbr * (ENC_H * 2), 0x00020000);
+    for (int idx = threadIdx.x; idx < NTH * ENC_TA * (ENC_H / 8); idx += 64 * ENC_WAVES) {
+        const int row = idx >> 5, ch = idx & 31, k = t0 + (row >> 4), ra = a0 + (row & 15);
+        const uint32_t off = ra < B ? ((uint32_t)ra * (uint32_t)P.num_nbr + (uint32_t)k) * (ENC_H * 2) + ch * 16 : 0xffffffffu;
+        *(bf16x8 *)(buf_a + row * ENC_YS + ch * 8) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ers, off, 0, 0));
+    }
+}
+
+// One group of NTH neighbour row tiles: scores first (their second layer overwrites the e_i tile), then e_i again (an L2 hit) for
+// the values, which go straight into the running sum - the h_i are never live together with another layer's accumulators.
+template <int NTH>
+__device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a, uint16_t *buf_h, float *s_alpha, AttnState &st) {
+    const int wave = wave_id(), lane = threadIdx.x & 63, mt0 = wave * ENC_MT;
+    const int ga = a0 + (lane & 15);
+    attn_load_e<NTH>(P, B, a0, t0, buf_a);
+    f32x4 acc[ENC_MT][NTH];
+    // score MLP, first layer on [e_i | e_mean.repeat(K, 1)]: W_e e_i + b + g[(a*K + k) mod B]   (:92-94)
+    init_bias<ENC_MT, NTH>(P.a1e, mt0, acc);
+    {
+        const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)P.gbuf, 0, (uint32_t)B * (ENC_H * 4), 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < NTH; ++nt) {
+            const uint32_t j = ((uint32_t)ga * (uint32_t)P.num_nbr + (uint32_t)(t0 + nt)) % (uint32_t)B;
+            const uint32_t off = ga < B ? j * (ENC_H * 4) + (lane >> 4) * 16 : 0xffffffffu;   // padding rows: out of range, reads zero
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt) {
+                const f32x4 gv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, (mt0 + mt) * 64, 0));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mt][nt][r] += gv[r];
+            }
+        }
+    }
+    __syncthreads();   // e_i is in buf_a; the previous group's value layers are done with buf_h
+    gemm_tiles<ENC_MT, NTH>(P.a1e, mt0, buf_a, ENC_YS, acc);
+    store_tanh<ENC_MT, NTH>(acc, mt0, buf_h, ENC_YS);
+    __syncthreads();
+    init_bias<ENC_MT, NTH>(P.a2, mt0, acc);
+    gemm_tiles<ENC_MT, NTH>(P.a2, mt0, buf_h, ENC_YS, acc);
+    store_tanh<ENC_MT, NTH>(acc, mt0, buf_a, ENC_YS);
+    __syncthreads();
+    if (wave < NTH) {   // last score layer 256 -> 1 (padded to one 16-feature tile), wave w takes row tile w: feature 0 = lanes 0..15, register 0
+        f32x4 sc[1][1];
+        init_bias<1, 1>(P.a3, 0, sc);
+        gemm_tiles<1, 1>(P.a3, 0, buf_a + wave * ENC_TA * ENC_YS, ENC_YS, sc);
+        if (lane < 16) s_alpha[wave * 16 + lane] = sc[0][0][0];
+    }
+    __syncthreads();
+    // h_i = neighbor_value_mlp(e_i)   (:88)
+    attn_load_e<NTH>(P, B, a0, t0, buf_a);
+    __syncthreads();
+    init_bias<ENC_MT, NTH>(P.v1, mt0, acc);
+    gemm_tiles<ENC_MT, NTH>(P.v1, mt0, buf_a, ENC_YS, acc);
+    store_tanh<ENC_MT, NTH>(acc, mt0, buf_h, ENC_YS);
+    __syncthreads();
+    init_bias<ENC_MT, NTH>(P.v2, mt0, acc);
+    gemm_tiles<ENC_MT, NTH>(P.v2, mt0, buf_h, ENC_YS, acc);
+    // online softmax over the neighbours of agent (lane & 15)   (:95-100)
+    float al[NTH], mx = st.mx;
+#pragma unroll
+    for (int nt = 0; nt < NTH; ++nt) { al[nt] = s_alpha[nt * 16 + (lane & 15)]; mx = fmaxf(mx, al[nt]); }
+    const float scale = __expf(st.mx - mx);
+    st.den *= scale;
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st.o[mt][r] *= scale;
+#pragma unroll
+    for (int nt = 0; nt < NTH; ++nt) {
+        const float e = __expf(al[nt] - mx);
+        st.den += e;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st.o[mt][r] += e * fast_tanh(acc[mt][nt][r]);
+    }
+    st.mx = mx;
+}
+
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_attn_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
+    uint16_t *x_obst = x_self + ENC_TA * ENC_XS;                      // [16][XS]
+    uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [ANH*16][YS]  e_i of the group, later the second score layer
+    uint16_t *buf_h = buf_a + ENC_ANH * ENC_TA * ENC_YS;              // [ANH*16][YS]  hidden layers; first the self / obstacle MLPs' (one tile)
+    uint16_t *cat = buf_h + ENC_ANH * ENC_TA * ENC_YS;                // [16][CS]: self | neighbourhood | obstacles
+    float *s_alpha = (float *)(cat + ENC_TA * ENC_CS);                // [ANH][16] scores of the group
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
+    const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
+    const int col_nbr = ENC_H, col_obst = 2 * ENC_H;
+
+    for (int idx = tid; idx < 2 * ENC_TA * 32; idx += 64 * ENC_WAVES) {   // self and obstacle columns as bf16, zero padded to K = 32
+        const int which = idx >> 9, a = (idx >> 5) & 15, c = idx & 31, ga = a0 + a;
+        const int dim = which ? P.obst_dim : P.self_dim, col = which ? P.self_dim + P.nbr_dim * NB : 0;
+        const float v = (ga < B && c < dim) ? obs[(size_t)ga * D + col + c] : 0.0f;
+        (which ? x_obst : x_self)[a * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+    __syncthreads();
+    mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, buf_h, cat, ENC_CS, 0);
+    if (P.obst_dim > 0) {
+        __syncthreads();
+        mlp2_one_tile(P.o1, P.o2, mt0, x_obst, ENC_XS, buf_h, cat, ENC_CS, col_obst);
+    }
+    __syncthreads();
+
+    AttnState st;
+    st.mx = -3.0e38f; st.den = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) st.o[mt] = (f32x4){0, 0, 0, 0};
+    for (int t0 = 0; t0 < NB; t0 += ENC_ANH) {
+        switch (NB - t0) {
+        case 1: attn_pass<1>(P, B, a0, t0, buf_a, buf_h, s_alpha, st); break;
+        case 2: attn_pass<2>(P, B, a0, t0, buf_a, buf_h, s_alpha, st); break;
+        default: attn_pass<3>(P, B, a0, t0, buf_a, buf_h, s_alpha, st); break;
+        }
+    }
+    const float rden = 1.0f / st.den;
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(st.o[mt][r] * rden);
+        *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+    }
+    __syncthreads();
+    feed_forward(P, cat, a0, B, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mean_embed / mlp / no_encoder: one launch
+// ------------------------------------------------------------------------------------------------
+template <int NTH>
+__device__ __forceinline__ void mean_pass(const EncParams &P, int t0, const uint16_t *x_nbr, uint16_t *buf_a, f32x4 (&mean)[ENC_MT]) {
+    const int wave = wave_id(), mt0 = wave * ENC_MT;
+    f32x4 acc[ENC_MT][NTH];
+    init_bias<ENC_MT, NTH>(P.n1, mt0, acc);
+    gemm_tiles<ENC_MT, NTH>(P.n1, mt0, x_nbr + t0 * ENC_TA * ENC_XS, ENC_XS, acc);
+    ENC_STAMP(4);
+    if (t0) __syncthreads();   // the previous pass's second layer is done reading buf_a
+    store_tanh<ENC_MT, NTH>(acc, mt0, buf_a, ENC_YS);
+    __syncthreads();
+    ENC_STAMP(5);
+    init_bias<ENC_MT, NTH>(P.n2, mt0, acc);
+    gemm_tiles<ENC_MT, NTH>(P.n2, mt0, buf_a, ENC_YS, acc);
+    ENC_STAMP(6);
+    // e_i = tanh(.); the mean over neighbours is a sum over the row tiles (same lane, same register)
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTH; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mean[mt][r] += fast_tanh(acc[mt][nt][r]);
+}
+
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_nbr = x_self + ENC_TA * ENC_XS;                       // [NBR*16][XS]
     uint16_t *x_obst = x_nbr + ENC_MAX_NBR * ENC_TA * ENC_XS;         // [16][XS]
-    uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [NH*16][YS]  hidden layer of the neighbour MLP (one half at a time)
+    uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [NH*16][YS]  hidden layer of the neighbour MLP (one pass at a time)
     uint16_t *buf_b = buf_a + ENC_NH * ENC_TA * ENC_YS;               // [16][YS]     hidden layer of the self / obstacle MLPs
     uint16_t *cat = buf_b + ENC_TA * ENC_YS;                          // [16][CS]: self | neighbourhood | obstacles
-    uint16_t *att_h = cat + ENC_TA * ENC_CS;                          // attention only: [NH*16][YS] hidden layers of the value / score MLPs
-    float *att_w = (float *)(att_h + ENC_NH * ENC_TA * ENC_YS);       // attention only: [NBR][16] softmax weights
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, a0 = blockIdx.x * ENC_TA;
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim;
     const int mode = P.nbr_encoder;
     const bool nbr_enc = NB > 0 && mode != ENC_NBR_NONE;   // no_encoder: the neighbour columns are in the row but nothing reads them (:289-291)
@@ -259,7 +494,7 @@ __device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int 
                 if (cidx < P.self_dim) x_self[a * ENC_XS + cidx] = h;
                 else if (cidx < P.self_dim + P.nbr_dim * NB) {
                     const int q = cidx - P.self_dim, nb = q / P.nbr_dim, j = q - nb * P.nbr_dim;
-                    if (!ATT && mode == ENC_NBR_MLP) x_nbr[a * ENC_XW + q] = h;
+                    if (mode == ENC_NBR_MLP) x_nbr[a * ENC_XW + q] = h;
                     else x_nbr[(nb * ENC_TA + a) * ENC_XS + j] = h;
                 } else x_obst[a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB)] = h;
             }
@@ -268,175 +503,36 @@ __device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int 
     __syncthreads();
 
     ENC_STAMP(1);
-    // ---- self encoder -> cat[:, 0:256] ----
-    {
-        f32x4 acc[ENC_MT][1];
-        init_bias<ENC_MT, 1>(P.s1, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.s1, mt0, x_self, ENC_XS, 1, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_b, ENC_YS);
-        __syncthreads();
-        init_bias<ENC_MT, 1>(P.s2, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.s2, mt0, buf_b, ENC_YS, 1, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, 1, cat, ENC_CS, 0);
-    }
+    mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, buf_b, cat, ENC_CS, 0);                      // self encoder -> cat[:, 0:256]
     ENC_STAMP(2);
-    // ---- obstacle encoder -> cat[:, 512:768] ----
     if (P.obst_dim > 0) {
         __syncthreads();
-        f32x4 acc[ENC_MT][1];
-        init_bias<ENC_MT, 1>(P.o1, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.o1, mt0, x_obst, ENC_XS, 1, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_b, ENC_YS);
-        __syncthreads();
-        init_bias<ENC_MT, 1>(P.o2, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.o2, mt0, buf_b, ENC_YS, 1, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, 1, cat, ENC_CS, col_obst);
+        mlp2_one_tile(P.o1, P.o2, mt0, x_obst, ENC_XS, buf_b, cat, ENC_CS, col_obst);           // obstacle encoder -> cat[:, 512:768]
     }
     __syncthreads();
 
     ENC_STAMP(3);
     // ---- neighbour encoder -> cat[:, 256:512] ----
-    // In two halves of up to ENC_NH neighbour tiles: the hidden layer of the neighbour MLP is the largest LDS buffer, and at half
-    // its size two workgroups fit one CU (the layer chain of a single workgroup is latency-bound, a second one overlaps it).
-    if (ATT && NB > 0) {
-        // attention, pass 2 (:88-101).  buf_a holds e_i of one half of the neighbour tiles, buf_h the hidden layers.
-        uint16_t *buf_h = att_h;
-        float *s_w = att_w;
-        f32x4 hval[ENC_MT][ENC_MAX_NBR];   // h_i = value MLP output, kept until the softmax weights exist
-        float alpha[ENC_MAX_NBR];          // scores of agent (lane & 15): valid in lanes 0..15 of wave 0
-#pragma unroll
-        for (int k = 0; k < ENC_MAX_NBR; ++k) alpha[k] = -3.0e38f;
-        for (int half = 0; half < 2; ++half) {
-            const int t0 = half * ENC_NH, nth = (NB - t0) < ENC_NH ? (NB - t0) : ENC_NH;
-            if (nth <= 0) break;
-            if (half) __syncthreads();   // wave 0 is done with the last score layer of the previous half (reads buf_a)
-            for (int idx = tid; idx < nth * ENC_TA * (ENC_H / 8); idx += 64 * ENC_WAVES) {   // e_i rows: 16-byte chunks, coalesced
-                const int row = idx / (ENC_H / 8), ch = idx - row * (ENC_H / 8), k = t0 + (row >> 4), ga = a0 + (row & 15);
-                bf16x8 v = {};
-                if (ga < B) v = *(const bf16x8 *)(P.ebuf + ((size_t)ga * NB + k) * ENC_H + ch * 8);
-                *(bf16x8 *)(buf_a + row * ENC_YS + ch * 8) = v;
-            }
-            __syncthreads();
-            f32x4 acc[ENC_MT][ENC_NH];
-            init_bias<ENC_MT, ENC_NH>(P.v1, mt0, acc);
-            gemm_tiles<ENC_MT, ENC_NH>(P.v1, mt0, buf_a, ENC_YS, nth, acc);
-            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_h, ENC_YS);
-            __syncthreads();
-            init_bias<ENC_MT, ENC_NH>(P.v2, mt0, acc);
-            gemm_tiles<ENC_MT, ENC_NH>(P.v2, mt0, buf_h, ENC_YS, nth, acc);
-#pragma unroll
-            for (int mt = 0; mt < ENC_MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < ENC_NH; ++nt) {
-                    if (nt < nth) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[mt][nt][r] = fast_tanh(acc[mt][nt][r]);
-                    }
-                    if (half == 0) hval[mt][nt] = acc[mt][nt]; else hval[mt][ENC_NH + nt] = acc[mt][nt];
-                }
-            // score MLP, first layer on [e_i | e_mean.repeat]: W_e e_i + b + g[(a*K + k) mod B]   (:92-94)
-            init_bias<ENC_MT, ENC_NH>(P.a1e, mt0, acc);
-#pragma unroll
-            for (int mt = 0; mt < ENC_MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < ENC_NH; ++nt)
-                    if (nt < nth) {
-                        const int ga = a0 + (lane & 15);
-                        if (ga < B) {
-                            const size_t j = ((size_t)ga * NB + (t0 + nt)) % (size_t)B;
-                            const f32x4 gv = *(const f32x4 *)(P.gbuf + j * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[mt][nt][r] += gv[r];
-                        }
-                    }
-            gemm_tiles<ENC_MT, ENC_NH>(P.a1e, mt0, buf_a, ENC_YS, nth, acc);
-            __syncthreads();   // every wave is done reading buf_h (v2) and buf_a (a1e)
-            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_h, ENC_YS);
-            __syncthreads();
-            init_bias<ENC_MT, ENC_NH>(P.a2, mt0, acc);
-            gemm_tiles<ENC_MT, ENC_NH>(P.a2, mt0, buf_h, ENC_YS, nth, acc);
-            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_a, ENC_YS);
-            __syncthreads();
-            if (wave == 0) {   // last score layer 256 -> 1 (padded to one 16-feature tile): feature 0 = row 0 of D = lanes 0..15, register 0
-                f32x4 sc[1][ENC_NH];
-                init_bias<1, ENC_NH>(P.a3, 0, sc);
-                gemm_tiles<1, ENC_NH>(P.a3, 0, buf_a, ENC_YS, nth, sc);
-#pragma unroll
-                for (int nt = 0; nt < ENC_NH; ++nt)
-                    if (nt < nth) { if (half == 0) alpha[nt] = sc[0][nt][0]; else alpha[ENC_NH + nt] = sc[0][nt][0]; }
-            }
-        }
-        if (wave == 0 && lane < 16) {   // softmax over the neighbours of agent `lane` (:95-96)
-            float mx = -3.0e38f, den = 0.0f, ex[ENC_MAX_NBR];
-#pragma unroll
-            for (int k = 0; k < ENC_MAX_NBR; ++k) if (k < NB) mx = fmaxf(mx, alpha[k]);
-#pragma unroll
-            for (int k = 0; k < ENC_MAX_NBR; ++k) { ex[k] = (k < NB) ? __expf(alpha[k] - mx) : 0.0f; den += ex[k]; }
-            const float rden = 1.0f / den;
-#pragma unroll
-            for (int k = 0; k < ENC_MAX_NBR; ++k) s_w[k * 16 + lane] = ex[k] * rden;
-        }
-        __syncthreads();
-        // sum_i softmax_i * h_i (:98-100): the weight of (neighbour k, agent lane & 15) is the same for all features
-#pragma unroll
-        for (int mt = 0; mt < ENC_MT; ++mt) {
-            f32x4 o = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < ENC_MAX_NBR; ++k)
-                if (k < NB) {
-                    const float wgt = s_w[k * 16 + (lane & 15)];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] += wgt * hval[mt][k][r];
-                }
-            bf16x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)o[r];
-            *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
-        }
-    } else if (!ATT && nbr_enc && mode == ENC_NBR_MLP) {
+    if (nbr_enc && mode == ENC_NBR_MLP) {
         // mlp neighbour encoder (:104-122): three layers on the concatenated neighbour observations of the agent
         f32x4 acc[ENC_MT][1];
         init_bias<ENC_MT, 1>(P.n1, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.n1, mt0, x_nbr, ENC_XW, 1, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_a, ENC_YS);
+        gemm_tiles<ENC_MT, 1>(P.n1, mt0, x_nbr, ENC_XW, acc);
+        store_tanh<ENC_MT, 1>(acc, mt0, buf_a, ENC_YS);
         __syncthreads();
-        init_bias<ENC_MT, 1>(P.n2, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.n2, mt0, buf_a, ENC_YS, 1, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, 1, buf_a + ENC_TA * ENC_YS, ENC_YS);
-        __syncthreads();
-        init_bias<ENC_MT, 1>(P.n3, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.n3, mt0, buf_a + ENC_TA * ENC_YS, ENC_YS, 1, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, 1, cat, ENC_CS, col_nbr);
-    } else if (!ATT && nbr_enc) {
+        mlp2_one_tile(P.n2, P.n3, mt0, buf_a, ENC_YS, buf_a + ENC_TA * ENC_YS, cat, ENC_CS, col_nbr);
+    } else if (nbr_enc) {
+        // mean_embed (:22-43) in passes of up to ENC_NH neighbour tiles: the hidden layer of the neighbour MLP is the largest LDS
+        // buffer, and at half its size two workgroups fit one CU (the layer chain of one workgroup is latency-bound, a second overlaps it)
         f32x4 mean[ENC_MT];
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
-        for (int half = 0; half < 2; ++half) {
-            const int t0 = half * ENC_NH, nth = (NB - t0) < ENC_NH ? (NB - t0) : ENC_NH;
-            if (nth <= 0) break;
-            f32x4 acc[ENC_MT][ENC_NH];
-            init_bias<ENC_MT, ENC_NH>(P.n1, mt0, acc);
-            gemm_tiles<ENC_MT, ENC_NH>(P.n1, mt0, x_nbr + t0 * ENC_TA * ENC_XS, ENC_XS, nth, acc);
-            ENC_STAMP(4);
-            if (half) __syncthreads();   // the previous half's second layer is done reading buf_a
-            store_tanh<ENC_MT, ENC_NH>(acc, mt0, nth, buf_a, ENC_YS);
-            __syncthreads();
-            ENC_STAMP(5);
-            init_bias<ENC_MT, ENC_NH>(P.n2, mt0, acc);
-            gemm_tiles<ENC_MT, ENC_NH>(P.n2, mt0, buf_a, ENC_YS, nth, acc);
-            ENC_STAMP(6);
-            // e_i = tanh(.); the mean over neighbours is a sum over the row tiles (same lane, same register)
-#pragma unroll
-            for (int mt = 0; mt < ENC_MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < ENC_NH; ++nt)
-                    if (nt < nth) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) mean[mt][r] += fast_tanh(acc[mt][nt][r]);
-                    }
+        for (int t0 = 0; t0 < NB; t0 += ENC_NH) {
+#define ENC_CALL(n) mean_pass<n>(P, t0, x_nbr, buf_a, mean)
+            ENC_DISPATCH_NT(NB - t0, ENC_CALL)
+#undef ENC_CALL
         }
-        // mean_embed: torch.mean(neighbor_embeds, dim=1) (:41-42)
-        const float inv = 1.0f / (float)NB;
+        const float inv = 1.0f / (float)NB;   // torch.mean(neighbor_embeds, dim=1) (:41-42)
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) {
             bf16x4 v;
@@ -448,37 +544,13 @@ __device__ __forceinline__ void encoder_body(const float *__restrict__ obs, int 
     __syncthreads();
 
     ENC_STAMP(7);
-    // ---- feed forward: tanh(F [self | neighbourhood | obstacles]) -> out[a][0:512] (fp32) ----
-    {
-        f32x4 acc[ENC_MTF][1];
-        const int mf0 = wave * ENC_MTF;   // 512 features = 32 tiles
-        init_bias<ENC_MTF, 1>(P.f, mf0, acc);
-        gemm_tiles<ENC_MTF, 1>(P.f, mf0, cat, ENC_CS, 1, acc);
-        ENC_STAMP(8);
-        const int ga = a0 + (lane & 15);
-        if (ga < B) {
-#pragma unroll
-            for (int mt = 0; mt < ENC_MTF; ++mt) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fast_tanh(acc[mt][0][r]);
-                *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4) = v;
-            }
-        }
-    }
+    feed_forward(P, cat, a0, B, out);
     ENC_STAMP(9);
 }
 
 // ------------------------------------------------------------------------------------------------
 // C ABI (include/quadswarm_encoder.h)
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
-    encoder_body<false>(obs, B, P, out);
-}
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_attn_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
-    encoder_body<true>(obs, B, P, out);
-}
-
 static thread_local std::string g_enc_error;
 extern "C" {
 
@@ -486,9 +558,8 @@ const char *qs_enc_last_error(void) { return g_enc_error.c_str(); }
 size_t qs_enc_sizeof_params(void) { return sizeof(EncParams); }
 
 static size_t lds_main(int attention) {
-    size_t b = sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
-    if (attention) b += sizeof(uint16_t) * ENC_NH * ENC_TA * ENC_YS + sizeof(float) * ENC_MAX_NBR * 16;
-    return b;
+    if (attention) return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + 2 * ENC_ANH * ENC_TA * ENC_YS + ENC_TA * ENC_CS) + sizeof(float) * ENC_ANH * 16;
+    return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
 }
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
 size_t qs_enc_lds_bytes(void) { return lds_main(0); }
@@ -504,6 +575,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         return -4;
     }
     if (att && (!P.ebuf || !P.gbuf)) { g_enc_error = "the attention neighbour encoder needs the ebuf / gbuf scratch buffers"; return -1; }
+    if (att && (int64_t)B * P.num_nbr * (ENC_H * 2) > 0x7fffffffll) { g_enc_error = "attention: batch x neighbours too large for 32-bit scratch offsets"; return -4; }
     if (B == 0) return 0;
     static bool attr_set = false;
     const size_t lds = lds_main(att);
@@ -536,13 +608,13 @@ int qs_enc_benchmark(const float *obs, int32_t B, const EncParams *params, float
     if (rc != 0) return rc;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { g_enc_error = "hipEventCreate failed"; return -2; }
-    hipEventRecord(e0, (hipStream_t)stream);
+    (void)hipEventRecord(e0, (hipStream_t)stream);
     for (int i = 0; i < iters && rc == 0; ++i) rc = qs_enc_forward(obs, B, params, out, stream);
-    hipEventRecord(e1, (hipStream_t)stream);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1, (hipStream_t)stream);
+    (void)hipEventSynchronize(e1);
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *avg_ms = (double)ms / iters;
     return rc;
 }
