@@ -5,7 +5,8 @@
  * (swarm_rl/models/quad_multi_model.py:250-350): self MLP, neighbour encoder, optional obstacle MLP, feed-forward; tanh;
  * hidden size 256; output [B, 512] fp32.  All four --quads_neighbor_encoder_type choices: `mean_embed` (:22-43, per-neighbour
  * MLP + mean), `attention` (:46-101; two launches, needs the two scratch buffers below), `mlp` (:104-122) and `no_encoder`
- * (:289-291: the neighbour columns are part of the row but are not read).
+ * (:289-291: the neighbour columns are part of the row but are not read).  QS_ENC_MODEL_MHA selects the other encoder class
+ * of that file, QuadMultiHeadAttentionEncoder (:124-196).
  * bf16 weights / activations, fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Weights are handed over pre-packed:
  *   layer with torch weight W[M_real, K_real], bias b[M_real]  ->  M = ceil16(M_real), K = ceil32(K_real), zero padded,
  *   w[((mt * (K/32) + ks) * 64 + lane) * 8 + j] = bf16(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),  b as fp32[M].
@@ -19,7 +20,8 @@
 extern "C" {
 #endif
 
-enum { QS_ENC_NBR_MEAN_EMBED = 0, QS_ENC_NBR_ATTENTION = 1, QS_ENC_NBR_MLP = 2, QS_ENC_NBR_NONE = 3 };
+enum { QS_ENC_NBR_MEAN_EMBED = 0, QS_ENC_NBR_ATTENTION = 1, QS_ENC_NBR_MLP = 2, QS_ENC_NBR_NONE = 3,
+       QS_ENC_MODEL_MHA = 4 /* QuadMultiHeadAttentionEncoder instead of QuadMultiEncoder */ };
 
 typedef struct qs_enc_layer { const uint16_t *w; const float *b; int32_t M, K; } qs_enc_layer;
 
@@ -38,6 +40,12 @@ typedef struct qs_enc_params {
     uint16_t *ebuf;        /* attention scratch, device, bf16 [B * num_nbr, 256] */
     float *gbuf;           /* attention scratch, device, fp32 [B, 256] */
     qs_enc_layer f;        /* feed forward      (:329-332): K = 256 * (1 + (neighbour encoder present) + (obst_dim > 0)), M = 512 */
+    /* QS_ENC_MODEL_MHA only (quad_multi_model.py:124-196, --quads_encoder_type=attention; needs num_nbr >= 1, obst_dim >= 1):
+       s1/s2 = self_embed_layer, n1/n2 = neighbor_embed_layer (input = all neighbour columns, <= 64), o1/o2 = obstacle_embed_layer,
+       f = feed_forward (K = 768); MultiHeadAttention(4, 256, 256, 256) of swarm_rl/models/attention_layer.py:12-56: */
+    qs_enc_layer mq, mk, mv; /* w_qs, w_ks, w_vs: M = 1024 (head-major), K = 256; no bias (b is not read) */
+    qs_enc_layer mfc;        /* fc: M = 256, K = 1024; no bias */
+    const float *ln_w, *ln_b;/* layer_norm weight / bias, fp32 [256] */
 } qs_enc_params;
 
 size_t qs_enc_sizeof_params(void);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""One-off check, run in the build container only (needs /root/reference): the `attention` neighbour encoder restated in
+"""One-off check, run in the build container only (needs /root/reference): the `attention` neighbour encoder (and, at the end, the
+QuadMultiHeadAttentionEncoder class) restated in
 quad-swarm-rl_amd/policy.py (QuadMultiEncoderRef, attention=True) against the reference class
 swarm_rl/models/quad_multi_model.py:46-101 with the same weights.  Sample Factory is not installed, so its four imports are
 stubbed (fc_layer = nn.Linear, nonlinearity = tanh, as in the reference's runs); numba/gymnasium come from ./stubs.
@@ -27,7 +28,12 @@ for name in ("sample_factory", "sample_factory.algo", "sample_factory.algo.utils
     mod(name)
 mod("sample_factory.algo.utils.context", global_model_factory=lambda: None)
 mod("sample_factory.algo.utils.torch_utils", calc_num_elements=lambda *a: 0)
-mod("sample_factory.model.encoder", Encoder=nn.Module)
+class _Encoder(nn.Module):   # sample_factory.model.encoder.Encoder: an nn.Module that takes cfg
+    def __init__(self, cfg=None):
+        super().__init__()
+
+
+mod("sample_factory.model.encoder", Encoder=_Encoder)
 mod("sample_factory.model.model_utils", fc_layer=lambda i, o, **k: nn.Linear(i, o), nonlinearity=lambda cfg: nn.Tanh())
 
 from swarm_rl.models import quad_multi_model as ref_model   # noqa: E402
@@ -48,4 +54,25 @@ for K, B in ((6, 37), (2, 8), (8, 1), (5, 64)):
         got = mine(obs)[:, 256:512]
     worst = max(worst, (want - got).abs().max().item())
 print("max abs diff vs the reference class:", worst)
-sys.exit(0 if worst == 0.0 else 1)
+
+# QuadMultiHeadAttentionEncoder (:124-196) against policy.make_reference_mha_encoder with the same weights
+worst_mha = 0.0
+for K, B in ((2, 33), (6, 5), (8, 1)):
+    mine = policy.make_reference_mha_encoder(seed=10 + K, num_nbr=K)
+    cfg = types.SimpleNamespace(quads_obs_repr="xyz_vxyz_R_omega_floor", quads_neighbor_hidden_size=256, quads_use_obstacles=True,
+                                quads_neighbor_visible_num=K, quads_num_agents=8, quads_neighbor_obs_type="pos_vel",
+                                quads_obstacle_obs_type="octomap", rnn_size=256)
+    theirs = ref_model.QuadMultiHeadAttentionEncoder(cfg, None)
+    theirs.self_embed_layer.load_state_dict(mine.self_encoder.state_dict())
+    theirs.neighbor_embed_layer.load_state_dict(mine.neighbor_encoder.state_dict())
+    theirs.obstacle_embed_layer.load_state_dict(mine.obstacle_encoder.state_dict())
+    theirs.attention_layer.load_state_dict(mine.attention_layer.state_dict())
+    theirs.feed_forward.load_state_dict(mine.feed_forward.state_dict())
+    with torch.no_grad():
+        mine.attention_layer.layer_norm.weight.uniform_(0.5, 1.5)
+        mine.attention_layer.layer_norm.bias.uniform_(-0.3, 0.3)
+        theirs.attention_layer.load_state_dict(mine.attention_layer.state_dict())
+        obs = torch.rand(B, 19 + 6 * K + 9) * 2 - 1
+        worst_mha = max(worst_mha, (theirs({"obs": obs}) - mine(obs)).abs().max().item())
+print("multi-head attention encoder, max abs diff vs the reference class:", worst_mha)
+sys.exit(0 if worst == 0.0 and worst_mha < 1e-6 else 1)

@@ -43,12 +43,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define ENC_YS (ENC_H + 8)   // row stride of a 256-wide activation buffer
 #define ENC_CS (3 * ENC_H + 8)
 
-enum { ENC_NBR_MEAN_EMBED = 0, ENC_NBR_ATTENTION = 1, ENC_NBR_MLP = 2, ENC_NBR_NONE = 3 };
+enum { ENC_NBR_MEAN_EMBED = 0, ENC_NBR_ATTENTION = 1, ENC_NBR_MLP = 2, ENC_NBR_NONE = 3, ENC_MODEL_MHA = 4 };
 #define ENC_XW 72   // row stride of the mlp neighbour encoder's input rows (all neighbours of one agent, K padded to 64)
 struct EncLayer { const uint16_t *w; const float *b; int32_t M, K; };   // K padded to a multiple of 32, M to a multiple of 16
 struct EncParams {
     int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;
-    int32_t nbr_encoder;        // ENC_NBR_*: mean_embed (:22-43), attention (:46-101), mlp (:104-122), no_encoder (:289-291)
+    int32_t nbr_encoder;        // ENC_NBR_*: mean_embed (:22-43), attention (:46-101), mlp (:104-122), no_encoder (:289-291); ENC_MODEL_MHA
     EncLayer s1, s2;            // self encoder        :303-309
     EncLayer n1, n2, n3;        // neighbour embedding :29-34 (input = neighbour obs) / :52-57 (attention: input = [self obs | neighbour obs])
                                 // / :110-117 (mlp: input = all neighbour obs of the agent, three layers)
@@ -58,6 +58,11 @@ struct EncParams {
     uint16_t *ebuf;             // attention scratch: e_i of every (agent, neighbour) row, bf16 [B*num_nbr, 256]
     float *gbuf;                // attention scratch: W_m e_mean of every agent, fp32 [B, 256]
     EncLayer f;                 // feed forward        :329-332
+    // QuadMultiHeadAttentionEncoder (:124-196, nbr_encoder == ENC_MODEL_MHA): n1 / n2 = neighbor_embed_layer on all neighbour
+    // columns, o1 / o2 = obstacle_embed_layer; MultiHeadAttention(4, 256, 256, 256) (attention_layer.py:12-56) over the token pair
+    EncLayer mq, mk, mv;        // w_qs, w_ks, w_vs: 256 -> 4 x 256, no bias (bias pointer not read)
+    EncLayer mfc;               // fc: 1024 -> 256, no bias
+    const float *ln_w, *ln_b;   // LayerNorm(256, eps 1e-6) weight / bias
 };
 
 #ifdef ENC_TIMING   // phase stamps of workgroup 0, wave 0 (tools/enc_quick.py prints them)
@@ -427,6 +432,180 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 }
 
 // ------------------------------------------------------------------------------------------------
+// QuadMultiHeadAttentionEncoder (:124-196, --quads_encoder_type=attention): self / neighbour / obstacle MLPs, 4-head scaled
+// dot-product attention over the token pair [neighbour embedding, obstacle embedding] (attention_layer.py:12-56: projections
+// without bias, q / sqrt(d_k), softmax over the keys, output projection, residual, LayerNorm eps 1e-6), feed-forward.
+// Wave w owns features [128w, 128w+128) of the 1024-wide projections = half of head w/2, in two chunks of 4 feature tiles:
+// the 2x2 scores of a head are sums over its features, so they accumulate chunk by chunk and only one chunk of q, k is live;
+// lane groups are reduced with two shuffles, the two waves of a head and (for LayerNorm) the eight waves through LDS.
+// ------------------------------------------------------------------------------------------------
+#define ENC_OS (4 * ENC_H + 8)   // row stride of the concatenated-heads buffer
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
+}
+__device__ __forceinline__ float lane_groups_sum(float v) {   // sum over the 4 lane groups that hold the same row (lane & 15)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+// 16-row MLP like mlp2_one_tile, but the fp32 result also stays in registers (the attention block's residual)
+__device__ __forceinline__ void mlp2_keep(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride, uint16_t *hid, uint16_t *Y,
+                                          f32x4 (&keep)[ENC_MT]) {
+    const int lane = threadIdx.x & 63;
+    f32x4 acc[ENC_MT][1];
+    init_bias<ENC_MT, 1>(L1, mt0, acc);
+    gemm_tiles<ENC_MT, 1>(L1, mt0, X, xstride, acc);
+    store_tanh<ENC_MT, 1>(acc, mt0, hid, ENC_YS);
+    __syncthreads();
+    init_bias<ENC_MT, 1>(L2, mt0, acc);
+    gemm_tiles<ENC_MT, 1>(L2, mt0, hid, ENC_YS, acc);
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { keep[mt][r] = fast_tanh(acc[mt][0][r]); v[r] = (__bf16)keep[mt][r]; }
+        *(bf16x4 *)(Y + (lane & 15) * ENC_YS + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
+    uint16_t *x_obst = x_self + ENC_TA * ENC_XS;                      // [16][XS]
+    uint16_t *x_nbr = x_obst + ENC_TA * ENC_XS;                       // [16][XW]  all neighbour columns of the agent, K padded to 64
+    uint16_t *hid = x_nbr + ENC_TA * ENC_XW;                          // [16][YS]  hidden layer of the three MLPs
+    uint16_t *tok = hid + ENC_TA * ENC_YS;                            // [2][16][YS]  tokens: neighbour embedding, obstacle embedding
+    uint16_t *obuf = tok + 2 * ENC_TA * ENC_YS;                       // [2][16][OS]  attention output, heads concatenated
+    uint16_t *cat = obuf + 2 * ENC_TA * ENC_OS;                       // [16][CS]: self | token 0 | token 1
+    float *red_s = (float *)(cat + ENC_TA * ENC_CS);                  // [4 heads][2 waves][4 (i,j)][16]  partial scores
+    float *red_ln = red_s + 4 * 2 * 4 * 16;                           // [8 waves][2 tokens][2 (sum, sum of squares)][16]
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
+    const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT, nbw = P.nbr_dim * NB;
+
+    for (int idx = tid; idx < ENC_TA * 128; idx += 64 * ENC_WAVES) {   // columns as bf16, zero padded: [self 32 | obstacle 32 | neighbours 64]
+        const int a = idx >> 7, c = idx & 127, ga = a0 + a;
+        int col = -1;
+        uint16_t *dst;
+        if (c < 32) { dst = x_self + a * ENC_XS + c; if (c < P.self_dim) col = c; }
+        else if (c < 64) { dst = x_obst + a * ENC_XS + (c - 32); if (c - 32 < P.obst_dim) col = P.self_dim + nbw + (c - 32); }
+        else { dst = x_nbr + a * ENC_XW + (c - 64); if (c - 64 < nbw) col = P.self_dim + (c - 64); }
+        const float v = (ga < B && col >= 0) ? obs[(size_t)ga * D + col] : 0.0f;
+        *dst = __builtin_bit_cast(uint16_t, (__bf16)v);
+    }
+    __syncthreads();
+    f32x4 resid[2][ENC_MT];   // fp32 tokens: features of this wave, rows lane & 15
+    mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, hid, cat, ENC_CS, 0);
+    __syncthreads();
+    mlp2_keep(P.n1, P.n2, mt0, x_nbr, ENC_XW, hid, tok, resid[0]);
+    __syncthreads();
+    mlp2_keep(P.o1, P.o2, mt0, x_obst, ENC_XS, hid, tok + ENC_TA * ENC_YS, resid[1]);
+    __syncthreads();
+
+    // ---- scores: s[i][j] = q_i . k_j over the head's 256 features, accumulated over this wave's two chunks ----
+    float sc[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {
+        f32x4 q[4][2], k[4][2];
+        zero_acc<4, 2>(q);
+        gemm_tiles<4, 2>(P.mq, wave * 8 + c * 4, tok, ENC_YS, q);
+        zero_acc<4, 2>(k);
+        gemm_tiles<4, 2>(P.mk, wave * 8 + c * 4, tok, ENC_YS, k);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sc[i][j] += q[mt][i][r] * k[mt][j][r];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float t = lane_groups_sum(sc[i][j]);
+            if (lane < 16) red_s[(((wave >> 1) * 2 + (wave & 1)) * 4 + i * 2 + j) * 16 + lane] = t;
+        }
+    __syncthreads();
+    float pr[2][2];   // softmax over the keys j of (q_i / sqrt(d_k)) . k_j   (attention_layer.py:118-125)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float t[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            t[j] = (red_s[(((wave >> 1) * 2 + 0) * 4 + i * 2 + j) * 16 + (lane & 15)] + red_s[(((wave >> 1) * 2 + 1) * 4 + i * 2 + j) * 16 + (lane & 15)]) * (1.0f / 16.0f);
+        const float m = fmaxf(t[0], t[1]), e0 = __expf(t[0] - m), e1 = __expf(t[1] - m), rd = 1.0f / (e0 + e1);
+        pr[i][0] = e0 * rd;
+        pr[i][1] = e1 * rd;
+    }
+    // ---- o_i = sum_j p_ij v_j -> obuf[i][row][head * 256 + feature] ----
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {
+        f32x4 v[4][2];
+        zero_acc<4, 2>(v);
+        gemm_tiles<4, 2>(P.mv, wave * 8 + c * 4, tok, ENC_YS, v);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (__bf16)(pr[i][0] * v[mt][0][r] + pr[i][1] * v[mt][1][r]);
+                *(bf16x4 *)(obuf + (i * ENC_TA + (lane & 15)) * ENC_OS + (wave * 8 + c * 4 + mt) * 16 + (lane >> 4) * 4) = o;
+            }
+    }
+    __syncthreads();
+    // ---- fc, residual, LayerNorm -> cat[:, 256 + token * 256 + feature]   (attention_layer.py:47-54) ----
+    f32x4 y[ENC_MT][2];
+    zero_acc<ENC_MT, 2>(y);
+    gemm_tiles<ENC_MT, 2>(P.mfc, mt0, obuf, ENC_OS, y);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y[mt][i][r] += resid[i][mt][r];
+                s1 += y[mt][i][r];
+                s2 += y[mt][i][r] * y[mt][i][r];
+            }
+        s1 = lane_groups_sum(s1);
+        s2 = lane_groups_sum(s2);
+        if (lane < 16) {
+            red_ln[((wave * 2 + i) * 2 + 0) * 16 + lane] = s1;
+            red_ln[((wave * 2 + i) * 2 + 1) * 16 + lane] = s2;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ENC_WAVES; ++w) {
+            s1 += red_ln[((w * 2 + i) * 2 + 0) * 16 + (lane & 15)];
+            s2 += red_ln[((w * 2 + i) * 2 + 1) * 16 + (lane & 15)];
+        }
+        const float mean = s1 * (1.0f / ENC_H), var = fmaxf(s2 * (1.0f / ENC_H) - mean * mean, 0.0f), rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            const int f0 = (mt0 + mt) * 16 + (lane >> 4) * 4;
+            const f32x4 g = *(const f32x4 *)(P.ln_w + f0), bb = *(const f32x4 *)(P.ln_b + f0);
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (__bf16)((y[mt][i][r] - mean) * rstd * g[r] + bb[r]);
+            *(bf16x4 *)(cat + (lane & 15) * ENC_CS + ENC_H * (1 + i) + f0) = o;
+        }
+    }
+    __syncthreads();
+    feed_forward(P, cat, a0, B, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // mean_embed / mlp / no_encoder: one launch
 // ------------------------------------------------------------------------------------------------
 template <int NTH>
@@ -561,6 +740,9 @@ static size_t lds_main(int attention) {
     if (attention) return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + 2 * ENC_ANH * ENC_TA * ENC_YS + ENC_TA * ENC_CS) + sizeof(float) * ENC_ANH * 16;
     return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
 }
+static size_t lds_mha(void) {
+    return sizeof(uint16_t) * (2 * ENC_TA * ENC_XS + ENC_TA * ENC_XW + 3 * ENC_TA * ENC_YS + 2 * ENC_TA * ENC_OS + ENC_TA * ENC_CS) + sizeof(float) * (4 * 2 * 4 * 16 + ENC_WAVES * 2 * 2 * 16);
+}
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
 size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 
@@ -568,9 +750,10 @@ size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
     if (!obs || !params || !out || B < 0) { g_enc_error = "bad argument"; return -1; }
     const EncParams &P = *params;
-    const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0;
-    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0 || P.nbr_encoder > ENC_NBR_NONE ||
-        (att && P.self_dim + P.nbr_dim > 32) || (P.nbr_encoder == ENC_NBR_MLP && P.nbr_dim * P.num_nbr > 64)) {
+    const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, mha = P.nbr_encoder == ENC_MODEL_MHA;
+    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0 || P.nbr_encoder > ENC_MODEL_MHA ||
+        (att && P.self_dim + P.nbr_dim > 32) || ((P.nbr_encoder == ENC_NBR_MLP || mha) && P.nbr_dim * P.num_nbr > 64) ||
+        (mha && (P.num_nbr < 1 || P.obst_dim < 1 || !P.ln_w || !P.ln_b))) {
         g_enc_error = "unsupported encoder shape (inputs wider than 32 - 64 for the mlp neighbour encoder - or more than 8 neighbours)";
         return -4;
     }
@@ -582,13 +765,16 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(0)) != hipSuccess ||
             hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
+            hipFuncSetAttribute((const void *)qs_encoder_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
             hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed()) != hipSuccess) {
             g_enc_error = "cannot raise the dynamic LDS limit";
             return -2;
         }
         attr_set = true;
     }
-    if (att) {
+    if (mha)
+        hipLaunchKernelGGL(qs_encoder_mha_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);
+    else if (att) {
         hipLaunchKernelGGL(qs_encoder_embed_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_embed(), (hipStream_t)stream, obs, B, P);
         hipLaunchKernelGGL(qs_encoder_attn_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
     } else

@@ -38,7 +38,8 @@ class EncParams(C.Structure):
                 ("nbr_encoder", C.c_int32),
                 ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("n3", EncLayer), ("o1", EncLayer), ("o2", EncLayer),
                 ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3", EncLayer),
-                ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer)]
+                ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer),
+                ("mq", EncLayer), ("mk", EncLayer), ("mv", EncLayer), ("mfc", EncLayer), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p)]
 
 
 _lib = None
@@ -62,6 +63,7 @@ def lib():
     return _lib
 
 
+MODELS = ("mean_embed", "attention", "mlp", "no_encoder", "multi_head_attention")   # qs_enc_params.nbr_encoder
 NBR_ENCODERS = ("mean_embed", "attention", "mlp", "no_encoder")   # --quads_neighbor_encoder_type (quadrotor_params.py:38-40); index = QS_ENC_NBR_*
 
 
@@ -123,6 +125,54 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
     return QuadMultiEncoderRef()
 
 
+def make_reference_mha_encoder(self_dim=19, nbr_dim=6, num_nbr=2, obst_dim=9, hidden=HIDDEN, seed=0, n_head=4):
+    """QuadMultiHeadAttentionEncoder (quad_multi_model.py:124-196, --quads_encoder_type=attention) with the MultiHeadAttention block
+    of swarm_rl/models/attention_layer.py:12-56 as a plain torch module; random init."""
+    import torch
+    from torch import nn
+
+    class MultiHeadAttentionRef(nn.Module):                                     # attention_layer.py:12-56
+        def __init__(self):
+            super().__init__()
+            self.w_qs = nn.Linear(hidden, n_head * hidden, bias=False)
+            self.w_ks = nn.Linear(hidden, n_head * hidden, bias=False)
+            self.w_vs = nn.Linear(hidden, n_head * hidden, bias=False)
+            self.fc = nn.Linear(n_head * hidden, hidden, bias=False)
+            self.layer_norm = nn.LayerNorm(hidden, eps=1e-6)
+
+        def forward(self, x):                                                   # q = k = v = x: [B, L, hidden]
+            Bq, L = x.shape[0], x.shape[1]
+            q = self.w_qs(x).view(Bq, L, n_head, hidden).transpose(1, 2)
+            k = self.w_ks(x).view(Bq, L, n_head, hidden).transpose(1, 2)
+            v = self.w_vs(x).view(Bq, L, n_head, hidden).transpose(1, 2)
+            attn = torch.softmax(torch.matmul(q / hidden ** 0.5, k.transpose(2, 3)), dim=-1)   # :118-125
+            o = torch.matmul(attn, v).transpose(1, 2).contiguous().view(Bq, L, -1)
+            return self.layer_norm(self.fc(o) + x)
+
+    class QuadMultiHeadAttentionEncoderRef(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_dim, self.nbr_dim, self.num_nbr, self.obst_dim = self_dim, nbr_dim, num_nbr, obst_dim
+            self.nbr_encoder = "multi_head_attention"
+            mlp = lambda i: nn.Sequential(nn.Linear(i, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
+            self.self_encoder = mlp(self_dim)                                   # self_embed_layer      :148-153
+            self.neighbor_encoder = mlp(nbr_dim * num_nbr)                      # neighbor_embed_layer  :154-159
+            self.obstacle_encoder = mlp(obst_dim)                               # obstacle_embed_layer  :161-166
+            self.attention_layer = MultiHeadAttentionRef()                      # :169
+            self.feed_forward = nn.Sequential(nn.Linear(3 * hidden, 2 * hidden), nn.Tanh())   # :173-174
+
+        def forward(self, obs):                                                 # :176-196
+            nb = self.nbr_dim * self.num_nbr
+            s = self.self_encoder(obs[:, :self.self_dim])
+            n = self.neighbor_encoder(obs[:, self.self_dim:self.self_dim + nb])
+            o = self.obstacle_encoder(obs[:, self.self_dim + nb:])
+            tokens = self.attention_layer(torch.stack((n, o), dim=1))
+            return self.feed_forward(torch.cat((s, tokens.reshape(obs.shape[0], -1)), dim=1))
+
+    torch.manual_seed(seed)
+    return QuadMultiHeadAttentionEncoderRef()
+
+
 def pack_linear(linear, device, cols=None):
     """nn.Linear (or its input columns cols[0]:cols[1]) -> (packed bf16 weights in MFMA A-fragment order, padded fp32 bias, M, K);
     see include/quadswarm_encoder.h."""
@@ -130,7 +180,7 @@ def pack_linear(linear, device, cols=None):
     W = linear.weight.detach().float().cpu().numpy()
     if cols is not None:
         W = W[:, cols[0]:cols[1]]
-    b = linear.bias.detach().float().cpu().numpy()
+    b = linear.bias.detach().float().cpu().numpy() if linear.bias is not None else np.zeros(W.shape[0], dtype=np.float32)
     m_real, k_real = W.shape
     M, K = -(-m_real // 16) * 16, -(-k_real // 32) * 32
     Wp = np.zeros((M, K), dtype=np.float32)
@@ -169,7 +219,15 @@ class FusedQuadEncoder:
             P.n1, P.n2 = layer(module.neighbor_encoder[0]), layer(module.neighbor_encoder[2])
         if module.obstacle_encoder is not None:
             P.o1, P.o2 = layer(module.obstacle_encoder[0]), layer(module.obstacle_encoder[2])
-        P.nbr_encoder = NBR_ENCODERS.index(getattr(module, "nbr_encoder", "mean_embed"))
+        P.nbr_encoder = MODELS.index(getattr(module, "nbr_encoder", "mean_embed"))
+        if P.nbr_encoder == 4:
+            if module.nbr_dim * module.num_nbr > 64:
+                raise ValueError("multi-head attention encoder: num_nbr * nbr_dim must fit two 32-wide K steps")
+            att = module.attention_layer
+            P.mq, P.mk, P.mv, P.mfc = layer(att.w_qs), layer(att.w_ks), layer(att.w_vs), layer(att.fc)
+            ln = [att.layer_norm.weight.detach().float().to(self.device).contiguous(), att.layer_norm.bias.detach().float().to(self.device).contiguous()]
+            self._keep += ln
+            P.ln_w, P.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
         self.attention = P.nbr_encoder == 1
         if P.nbr_encoder == 2:
             if module.nbr_dim * module.num_nbr > 64:
