@@ -4,7 +4,7 @@
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for v in mean attention; do
+for v in mean attention mha; do
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/enc_${tag}_$v -o k -- python $R/tools/bench_encoder.py 8192 $v > $R/gpurun_out/enc_${tag}_${v}_prof.json 2> $R/gpurun_out/enc_${tag}_$v.err
   db=$(ls $R/gpurun_out/enc_${tag}_$v/*.db $R/gpurun_out/enc_${tag}_$v/*/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python $R/tools/rocprof_summary.py $db "rocprofv3 --kernel-trace --stats -- python tools/bench_encoder.py 8192 $v" | head -12 > $R/gpurun_out/enc_${tag}_${v}_stats.txt
