@@ -101,3 +101,51 @@ def test_spec_build_without_gpu(tmp_path, monkeypatch):
     blob = open(p1, "rb").read()
     for sym in (b"qs_spec_step", b"qs_spec_rollout", b"qs_spec_reset"):
         assert sym in blob
+
+
+def test_encoder_library_exports_and_layout():
+    """include/quadswarm_encoder.h: every declared symbol is exported by libquadswarm_encoder.so, qs_enc_params has the layout
+    of the ctypes mirror, bad arguments are rejected before anything touches a GPU, and there is no CPU fallback."""
+    from quad_swarm_rl_amd import policy
+    policy.build()
+    lib = C.CDLL(policy.ENC_LIB_PATH)
+    h = open(os.path.join(REPO, "include", "quadswarm_encoder.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int|size_t|const char \*)\s*\*?(qs_enc_\w+)\(", h, flags=re.M)))
+    assert declared == ["qs_enc_benchmark", "qs_enc_forward", "qs_enc_last_error", "qs_enc_lds_bytes", "qs_enc_sizeof_params"]
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    lib.qs_enc_sizeof_params.restype = C.c_size_t
+    lib.qs_enc_lds_bytes.restype = C.c_size_t
+    lib.qs_enc_last_error.restype = C.c_char_p
+    assert lib.qs_enc_sizeof_params() == C.sizeof(policy.EncParams)
+    assert lib.qs_enc_lds_bytes() <= 80 * 1024            # two workgroups per CU
+    enum = re.search(r"enum \{ QS_ENC_NBR_MEAN_EMBED = 0,(.*?)\};", h, flags=re.S).group(0)
+    for i, name in enumerate(("MEAN_EMBED", "ATTENTION", "MLP", "NONE")):
+        assert f"QS_ENC_NBR_{name} = {i}" in enum and policy.MODELS[i] == policy.NBR_ENCODERS[i]
+    assert "QS_ENC_MODEL_MHA = 4" in enum and policy.MODELS[4] == "multi_head_attention"
+    lib.qs_enc_forward.argtypes = [C.c_void_p, C.c_int32, C.POINTER(policy.EncParams), C.c_void_p, C.c_void_p]
+    P = policy.EncParams()
+    assert lib.qs_enc_forward(None, 4, C.byref(P), None, None) == -1 and b"bad argument" in lib.qs_enc_last_error()
+    P.num_nbr = 9                                          # more neighbours than a workgroup's row tiles
+    assert lib.qs_enc_forward(C.c_void_p(16), 4, C.byref(P), C.c_void_p(16), None) == -4
+    P.num_nbr, P.nbr_encoder = 2, 7
+    assert lib.qs_enc_forward(C.c_void_p(16), 4, C.byref(P), C.c_void_p(16), None) == -4
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(native.QsError):
+            policy.FusedQuadEncoder(policy.make_reference_encoder(num_nbr=2))
+        from quad_swarm_rl_amd import rollout
+        with pytest.raises(native.QsError):
+            rollout.GraphedRollout(None, None, None, 4)
+
+
+def test_reference_encoder_modules_cover_the_flag_choices():
+    """--quads_neighbor_encoder_type choices (quadrotor_params.py:38-40) and both encoder classes build and run on the CPU in torch."""
+    import torch
+    from quad_swarm_rl_amd import policy
+    for enc in policy.NBR_ENCODERS:
+        m = policy.make_reference_encoder(num_nbr=2, obst_dim=9, self_dim=19, nbr_encoder=enc)
+        assert m(torch.zeros(3, 40)).shape == (3, 512)
+    with pytest.raises(NotImplementedError):
+        policy.make_reference_encoder(nbr_encoder="transformer")
+    assert policy.make_reference_mha_encoder()(torch.zeros(3, 40)).shape == (3, 512)
