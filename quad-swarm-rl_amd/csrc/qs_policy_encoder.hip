@@ -30,7 +30,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define ENC_H 256            // hidden size of every MLP (rnn_size = neighbor_hidden_size = obst_hidden_size = 256)
 #define ENC_TA 16            // agents per workgroup = one 16-row tile
 #define ENC_MAX_NBR 8        // neighbours per agent (6 or 2 in the reference's configurations)
+#ifndef ENC_NH
 #define ENC_NH (ENC_MAX_NBR / 2)   // neighbour row tiles per pass of the neighbour MLP
+#endif
 #ifndef ENC_WAVES
 #define ENC_WAVES 8   // 2 waves per SIMD: the layer chain of one workgroup is latency-bound, a second wave hides part of it (49 -> 40 us at 8192 agents)
 #endif
@@ -213,12 +215,13 @@ __device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t 
     }
 }
 
-#define ENC_DISPATCH_NT(n, CALL) \
-    switch (n) {                 \
-    case 1: CALL(1); break;      \
-    case 2: CALL(2); break;      \
-    case 3: CALL(3); break;      \
-    default: CALL(4); break;     \
+// run CALL(<tile count>) for min(n, LIMIT) tiles; only the counts a pass size of LIMIT can see are instantiated
+#define ENC_CASE_NT(k, LIMIT, CALL) case k: if constexpr (k <= (LIMIT)) { CALL(k); } break;
+#define ENC_DISPATCH_NT(n, LIMIT, CALL)                                        \
+    switch ((n) < (LIMIT) ? (n) : (LIMIT)) {                                   \
+        ENC_CASE_NT(1, LIMIT, CALL) ENC_CASE_NT(2, LIMIT, CALL) ENC_CASE_NT(3, LIMIT, CALL) ENC_CASE_NT(4, LIMIT, CALL) \
+        ENC_CASE_NT(5, LIMIT, CALL) ENC_CASE_NT(6, LIMIT, CALL) ENC_CASE_NT(7, LIMIT, CALL) ENC_CASE_NT(8, LIMIT, CALL) \
+    default: break;                                                            \
     }
 
 // ------------------------------------------------------------------------------------------------
@@ -269,7 +272,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
     for (int t0 = 0; t0 < NB; t0 += ENC_NH) {
 #define ENC_CALL(n) embed_pass<n>(P, B, a0, t0, t0 == 0, x_in, buf_a, mean)
-        ENC_DISPATCH_NT(NB - t0, ENC_CALL)
+        ENC_DISPATCH_NT(NB - t0, ENC_NH, ENC_CALL)
 #undef ENC_CALL
     }
     const float inv = 1.0f / (float)NB;   // e_mean (:90-91), then its half of the score MLP's first layer once per agent
@@ -298,7 +301,9 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 // maximum and denominator per agent, the partial sum rescaled when the maximum moves), so that the h_i of earlier groups do not
 // have to be kept: 78 KB of LDS and <= 128 VGPRs, two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
+#ifndef ENC_ANH
 #define ENC_ANH 3
+#endif
 struct AttnState { f32x4 o[ENC_MT]; float mx, den; };
 
 template <int NTH>
@@ -413,11 +418,9 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) st.o[mt] = (f32x4){0, 0, 0, 0};
     for (int t0 = 0; t0 < NB; t0 += ENC_ANH) {
-        switch (NB - t0) {
-        case 1: attn_pass<1>(P, B, a0, t0, buf_a, buf_h, s_alpha, st); break;
-        case 2: attn_pass<2>(P, B, a0, t0, buf_a, buf_h, s_alpha, st); break;
-        default: attn_pass<3>(P, B, a0, t0, buf_a, buf_h, s_alpha, st); break;
-        }
+#define ENC_CALL(n) attn_pass<n>(P, B, a0, t0, buf_a, buf_h, s_alpha, st)
+        ENC_DISPATCH_NT(NB - t0, ENC_ANH, ENC_CALL)
+#undef ENC_CALL
     }
     const float rden = 1.0f / st.den;
 #pragma unroll
@@ -708,7 +711,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
         for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
         for (int t0 = 0; t0 < NB; t0 += ENC_NH) {
 #define ENC_CALL(n) mean_pass<n>(P, t0, x_nbr, buf_a, mean)
-            ENC_DISPATCH_NT(NB - t0, ENC_CALL)
+            ENC_DISPATCH_NT(NB - t0, ENC_NH, ENC_CALL)
 #undef ENC_CALL
         }
         const float inv = 1.0f / (float)NB;   // torch.mean(neighbor_embeds, dim=1) (:41-42)
