@@ -46,13 +46,20 @@ typedef struct qs_enc_params {
     qs_enc_layer mq, mk, mv; /* w_qs, w_ks, w_vs: M = 1024 (head-major), K = 256; no bias (b is not read) */
     qs_enc_layer mfc;        /* fc: M = 256, K = 1024; no bias */
     const float *ln_w, *ln_b;/* layer_norm weight / bias, fp32 [256] */
+    /* optional linear head on the encoder output, fused into the last kernel's epilogue (Sample Factory's action-parameter or
+       value layer): head_out[B, head_dim] = features . head_w^T + head_b.  With a head, `out` of qs_enc_forward may be NULL and
+       the [B, 512] features are then never written. */
+    const float *head_w, *head_b;   /* fp32 [head_dim, 512], [head_dim] */
+    float *head_out;                /* fp32 [B, head_dim] */
+    int32_t head_dim;               /* 0: none; <= 8 */
 } qs_enc_params;
 
 size_t qs_enc_sizeof_params(void);
 size_t qs_enc_lds_bytes(void);
 const char *qs_enc_last_error(void);
 
-/* out[B, 512] = encoder(obs[B, obs_dim]) on `stream`.  0 on success, < 0 on error (qs_enc_last_error()). */
+/* out[B, 512] = encoder(obs[B, obs_dim]) on `stream` (out may be NULL when params->head_dim > 0).  0 on success, < 0 on error
+ * (qs_enc_last_error()). */
 int qs_enc_forward(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream);
 
 /* `iters` back-to-back forward passes timed with HIP events on `stream` (no host work in between): average ms per pass. */

@@ -65,6 +65,10 @@ struct EncParams {
     EncLayer mq, mk, mv;        // w_qs, w_ks, w_vs: 256 -> 4 x 256, no bias (bias pointer not read)
     EncLayer mfc;               // fc: 1024 -> 256, no bias
     const float *ln_w, *ln_b;   // LayerNorm(256, eps 1e-6) weight / bias
+    // optional linear head on the encoder output, fused into the epilogue: head_out[B, head_dim] = out . head_w^T + head_b
+    const float *head_w, *head_b;   // fp32 [head_dim, 512], [head_dim]
+    float *head_out;
+    int32_t head_dim;               // 0: no head; <= 8
 };
 
 #ifdef ENC_TIMING   // phase stamps of workgroup 0, wave 0 (tools/enc_quick.py prints them)
@@ -195,8 +199,17 @@ __device__ __forceinline__ void mlp2_one_tile(const EncLayer &L1, const EncLayer
     store_tanh<ENC_MT, 1>(acc, mt0, Y, ystride, col0);
 }
 
-// feed forward: tanh(F [self | neighbourhood | obstacles]) -> out[a][0:512] (fp32)   (:329-332, :349)
-__device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t *cat, int a0, int B, float *__restrict__ out) {
+__device__ __forceinline__ float lane_groups_sum(float v) {   // sum over the 4 lane groups that hold the same row (lane & 15)
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// feed forward: tanh(F [self | neighbourhood | obstacles]) -> out[a][0:512] (fp32)   (:329-332, :349), and optionally a linear
+// head on it (Sample Factory's action-parameter or value layer, 512 -> head_dim <= 8) so that a rollout does not have to write
+// and re-read the features: per-lane partial dot products, two shuffles over the lane groups, the eight waves through `red`
+// (LDS scratch, >= ENC_WAVES * 8 * 16 floats in a buffer nobody reads any more and that is not `cat`).
+__device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t *cat, int a0, int B, float *__restrict__ out, float *red) {
     const int wave = wave_id(), lane = threadIdx.x & 63;
     f32x4 acc[ENC_MTF][1];
     const int mf0 = wave * ENC_MTF;   // 512 features = 32 tiles
@@ -204,13 +217,32 @@ __device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t 
     gemm_tiles<ENC_MTF, 1>(P.f, mf0, cat, ENC_CS, acc);
     ENC_STAMP(8);
     const int ga = a0 + (lane & 15);
-    if (ga < B) {
+    f32x4 v[ENC_MTF];
 #pragma unroll
-        for (int mt = 0; mt < ENC_MTF; ++mt) {
-            f32x4 v;
+    for (int mt = 0; mt < ENC_MTF; ++mt) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fast_tanh(acc[mt][0][r]);
-            *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4) = v;
+        for (int r = 0; r < 4; ++r) v[mt][r] = fast_tanh(acc[mt][0][r]);
+        if (out && ga < B) *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4) = v[mt];
+    }
+    if (P.head_dim > 0) {
+        for (int h = 0; h < P.head_dim; ++h) {
+            float s = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < ENC_MTF; ++mt) {
+                const f32x4 w = *(const f32x4 *)(P.head_w + h * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s += v[mt][r] * w[r];
+            }
+            s = lane_groups_sum(s);
+            if (lane < 16) red[(wave * 8 + h) * 16 + lane] = s;
+        }
+        __syncthreads();
+        const int tid = threadIdx.x, h = tid >> 4, row = tid & 15;
+        if (h < P.head_dim && a0 + row < B) {
+            float s = P.head_b[h];
+#pragma unroll
+            for (int w = 0; w < ENC_WAVES; ++w) s += red[(w * 8 + h) * 16 + row];
+            P.head_out[(size_t)(a0 + row) * P.head_dim + h] = s;
         }
     }
 }
@@ -431,7 +463,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
         *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
     }
     __syncthreads();
-    feed_forward(P, cat, a0, B, out);
+    feed_forward(P, cat, a0, B, out, (float *)buf_a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -449,11 +481,6 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
-}
-__device__ __forceinline__ float lane_groups_sum(float v) {   // sum over the 4 lane groups that hold the same row (lane & 15)
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
 }
 // 16-row MLP like mlp2_one_tile, but the fp32 result also stays in registers (the attention block's residual)
 __device__ __forceinline__ void mlp2_keep(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride, uint16_t *hid, uint16_t *Y,
@@ -605,7 +632,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_k
         }
     }
     __syncthreads();
-    feed_forward(P, cat, a0, B, out);
+    feed_forward(P, cat, a0, B, out, (float *)hid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -726,7 +753,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     __syncthreads();
 
     ENC_STAMP(7);
-    feed_forward(P, cat, a0, B, out);
+    feed_forward(P, cat, a0, B, out, (float *)buf_a);
     ENC_STAMP(9);
 }
 
@@ -751,8 +778,12 @@ size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 
 // out[B, 512] = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
-    if (!obs || !params || !out || B < 0) { g_enc_error = "bad argument"; return -1; }
+    if (!obs || !params || B < 0) { g_enc_error = "bad argument"; return -1; }
     const EncParams &P = *params;
+    if (P.head_dim < 0 || P.head_dim > 8 || (P.head_dim > 0 && (!P.head_w || !P.head_b || !P.head_out)) || (!out && P.head_dim == 0)) {
+        g_enc_error = "bad argument";   // neither the features nor a head output requested, or an incomplete head
+        return -1;
+    }
     const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, mha = P.nbr_encoder == ENC_MODEL_MHA;
     if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0 || P.nbr_encoder > ENC_MODEL_MHA ||
         (att && P.self_dim + P.nbr_dim > 32) || ((P.nbr_encoder == ENC_NBR_MLP || mha) && P.nbr_dim * P.num_nbr > 64) ||

@@ -39,7 +39,8 @@ class EncParams(C.Structure):
                 ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("n3", EncLayer), ("o1", EncLayer), ("o2", EncLayer),
                 ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3", EncLayer),
                 ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer),
-                ("mq", EncLayer), ("mk", EncLayer), ("mv", EncLayer), ("mfc", EncLayer), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p)]
+                ("mq", EncLayer), ("mk", EncLayer), ("mv", EncLayer), ("mfc", EncLayer), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p), ("head_dim", C.c_int32)]
 
 
 _lib = None
@@ -254,10 +255,39 @@ class FusedQuadEncoder:
         if out is None:
             out = torch.empty((B, self.out_dim), device=obs.device, dtype=torch.float32)
         self._scratch(B)
+        self.params.head_dim = 0
         rc = lib().qs_enc_forward(obs.data_ptr(), B, C.byref(self.params), out.data_ptr(), C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
         if rc != 0:
             raise native.QsError(f"qs_enc_forward failed ({rc}): {lib().qs_enc_last_error().decode()}")
         return out
+
+    def set_head(self, weight, bias):
+        """Linear head on the 512 features (SF's action-parameter / value layer), evaluated in the encoder's epilogue by forward_head."""
+        torch = self._torch
+        w = weight.detach().to(self.device, torch.float32).contiguous()
+        b = bias.detach().to(self.device, torch.float32).contiguous()
+        if w.dim() != 2 or w.shape[1] != self.out_dim or not 1 <= w.shape[0] <= 8 or b.shape != (w.shape[0],):
+            raise ValueError("head: weight [h, 512] with 1 <= h <= 8, bias [h]")
+        self._head = (w, b)
+
+    def forward_head(self, obs, head_out=None, features=None):
+        """head(encoder(obs)) -> [B, h] float32; the [B, 512] features are written only if a `features` tensor is passed."""
+        torch = self._torch
+        assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.params.obs_dim
+        w, b = self._head
+        B = obs.shape[0]
+        if head_out is None:
+            head_out = torch.empty((B, w.shape[0]), device=obs.device, dtype=torch.float32)
+        assert head_out.is_contiguous() and head_out.shape == (B, w.shape[0]) and head_out.dtype == torch.float32
+        self._scratch(B)
+        P = self.params
+        P.head_w, P.head_b, P.head_out, P.head_dim = w.data_ptr(), b.data_ptr(), head_out.data_ptr(), w.shape[0]
+        rc = lib().qs_enc_forward(obs.data_ptr(), B, C.byref(P), C.c_void_p(features.data_ptr() if features is not None else None),
+                                  C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
+        P.head_dim = 0
+        if rc != 0:
+            raise native.QsError(f"qs_enc_forward failed ({rc}): {lib().qs_enc_last_error().decode()}")
+        return head_out
 
     __call__ = forward
 
@@ -274,6 +304,7 @@ class FusedQuadEncoder:
         """Average seconds per forward pass over `iters` back-to-back launches (HIP events, no host work in between)."""
         torch = self._torch
         ms = C.c_double(0)
+        self.params.head_dim = 0
         self._scratch(obs.shape[0])
         rc = lib().qs_enc_benchmark(obs.data_ptr(), obs.shape[0], C.byref(self.params), out.data_ptr(),
                                     C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream), iters, C.byref(ms))

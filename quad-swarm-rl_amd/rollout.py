@@ -27,7 +27,11 @@ class GaussianActionHead:
 
     def __call__(self, features):
         import torch
-        mean = torch.addmm(self.bias, features, self.weight.t())
+        return self.from_mean(torch.addmm(self.bias, features, self.weight.t()))
+
+    def from_mean(self, mean):
+        """action from the Linear's output; GraphedRollout gets that from the encoder's fused epilogue (FusedQuadEncoder.forward_head)"""
+        import torch
         if not self.sample:
             return mean
         return mean + torch.exp(self.log_std) * torch.randn_like(mean)
@@ -51,7 +55,12 @@ class GraphedRollout:
         self.actions = torch.empty((steps, A, 4), device=dev)
         self.rewards = torch.empty((steps, A), device=dev)
         self.dones = torch.empty((steps, A), device=dev, dtype=torch.uint8)
-        self._feat = torch.empty((A, encoder.out_dim), device=dev)
+        self._fused_head = hasattr(head, "from_mean") and hasattr(head, "weight") and hasattr(encoder, "set_head")
+        if self._fused_head:   # the Linear runs in the encoder's epilogue: the [A, 512] features are never written
+            encoder.set_head(head.weight, head.bias)
+            self._mean = torch.empty((A, 4), device=dev)
+        else:
+            self._feat = torch.empty((A, encoder.out_dim), device=dev)
         self.graph = None
         if graph:
             side = torch.cuda.Stream(device=dev)
@@ -68,8 +77,12 @@ class GraphedRollout:
     def _step(self, t):
         import torch
         self.obs[t].copy_(self._obs)
-        self.encoder(self._obs, out=self._feat)
-        self.actions[t].copy_(self.head(self._feat))
+        if self._fused_head:
+            self.encoder.forward_head(self._obs, head_out=self._mean)
+            self.actions[t].copy_(self.head.from_mean(self._mean))
+        else:
+            self.encoder(self._obs, out=self._feat)
+            self.actions[t].copy_(self.head(self._feat))
         self.env.stepper.step(self.actions[t].data_ptr(), stream=torch.cuda.current_stream(self._obs.device))
         self.rewards[t].copy_(self._rew)
         self.dones[t].copy_(self._done)
