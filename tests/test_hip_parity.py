@@ -74,6 +74,24 @@ CASES = {
     "s_mix_obst": dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
                        rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="mix",
                        obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.12),
+    # size edges: the 64-drone maximum (pair / id sets fill the 64-bit masks), all-neighbour and K > 8 ranked observations, a drone
+    # count that leaves most of a wave idle, the 2- and 1-drone minimum
+    "e_n64_k6": dict(num_agents=64, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                     collision_falloff_radius=4.0, rew_coeff=REW, ep_time=0.5),
+    "e_n40_kall": dict(num_agents=40, neighbor_visible_num=-1, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                       collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swarm_vs_swarm"),
+    "e_n64_k20": dict(num_agents=64, neighbor_visible_num=20, neighbor_obs_type="pos_vel", use_numba=True,
+                      collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="dynamic_formations", ep_time=0.4),
+    "e_n33_k8": dict(num_agents=33, neighbor_visible_num=8, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=False,
+                     collision_falloff_radius=4.0, rew_coeff=REW, obs_repr="xyz_vxyz_R_omega_wall"),
+    "e_n17_kall_obst": dict(num_agents=17, neighbor_visible_num=-1, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                            collision_falloff_radius=4.0, rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6,
+                            obst_spawn_area=(8.0, 8.0), quads_mode="o_random", obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.4),
+    "e_n2_k1": dict(num_agents=2, neighbor_visible_num=1, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                    collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swap_goals", ep_time=0.5),
+    "e_n1_obst": dict(num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none", use_numba=True, use_obstacles=True, obst_density=0.2,
+                      obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_static_same_goal", obs_repr="xyz_vxyz_R_omega_floor",
+                      rew_coeff=REW, ep_time=0.3),
     "c4_n12_svs_short": dict(num_agents=12, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True,
                              use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swarm_vs_swarm", ep_time=0.1),
 }
@@ -216,7 +234,20 @@ LONG = {"s_run_away": 320, "s_o_ep_bezier": 640, "s_dynamic_same": 640, "s_dynam
 
 @pytest.mark.parametrize("case", list(CASES))
 def test_rollout_f64_bit_exact_discrete(case):
-    E, steps, tol = (3, LONG[case], 1e-7) if case in LONG else (11, 70, 1e-8)
+    E, steps, tol = (3, LONG[case], 1e-7) if case in LONG else (3, 60, 1e-8) if case.startswith("e_") else (11, 70, 1e-8)
+    rollout_f64(case, E, steps, tol)
+
+
+@pytest.mark.parametrize("case", ["e_n64_k20", "e_n64_k6", "e_n33_k8", "e_n40_kall", "c2_n8_dw", "c3_n8_obst"])
+def test_rollout_f64_single_wave_kernels(case, monkeypatch):
+    """The same rollouts through the one-wave-per-workgroup kernels that large batches select (QS_TEAM=0)."""
+    monkeypatch.setenv("QS_TEAM", "0")
+    pr = rollout_f64(case, 3, 40, 1e-8, keep=True)
+    assert not pr.hip.team
+    pr.close()
+
+
+def rollout_f64(case, E, steps, tol, keep=False):
     pr = Pair(case, E, "f64")
     rng = np.random.RandomState(5)
     oobs, hobs = pr.reset()
@@ -244,12 +275,15 @@ def test_rollout_f64_bit_exact_discrete(case):
             for e, oe in enumerate(pr.oenvs):
                 assert sid[e] == oe.info().scenario, f"scenario id step {t} env {e}"
     pr.hip.check_errors()
+    if keep:
+        return pr
     pr.close()
 
 
 @pytest.mark.parametrize("case", ["c1_single", "c2_n8_dw", "c3_n8_obst", "c4_n32_svs", "c2_n8_k2_numpy_wall",
                                   "s_static_diff", "s_dynamic_formations", "s_lissajous", "s_o_random", "s_mix", "s_mix_obst",
-                                  "s_dynamic_diff", "s_bezier", "s_o_swap", "s_o_ep_bezier", "s_o_ep_bezier_short", "s_run_away"])
+                                  "s_dynamic_diff", "s_bezier", "s_o_swap", "s_o_ep_bezier", "s_o_ep_bezier_short", "s_run_away",
+                                  "e_n64_k6", "e_n64_k20", "e_n33_k8", "e_n17_kall_obst", "e_n40_kall"])
 def test_teacher_forced_f32(case):
     E, steps, tol = (3, LONG[case], 1e-5) if case in LONG else (7, 60, 1e-5)
     pr = Pair(case, E, "f32")
@@ -270,6 +304,14 @@ def test_teacher_forced_f32(case):
             if hover.any():
                 s[hover, 2] = thr + 1e-4
                 changed = True
+            # Same for a drone resting exactly on a wall (64-drone formations are wider than the room, so spawn points get clipped
+            # onto it): `crashed_wall` is "the clip changed x or y" (quadrotor_dynamics.py:360-367), and while the drone has not
+            # tilted yet its drift per sub-step (1e-9 m) is below ulp(5.0) = 4.8e-7 in fp32.  Move it inside by 1 mm in BOTH states.
+            for a, half in ((0, pr.cfg.room_hi[0]), (1, pr.cfg.room_hi[1])):
+                wall = np.abs(np.abs(s[:, a]) - half) < 1e-5
+                if wall.any():
+                    s[wall, a] = np.sign(s[wall, a]) * (half - 1e-3)
+                    changed = True
             if changed:
                 o.set_state(s, tick)
             pr.hip.set_state(e, s, tick)          # teacher forcing: device state <- oracle state (rounded to f32)
@@ -283,6 +325,29 @@ def test_teacher_forced_f32(case):
     print(f"{case}: worst f32 state error {worst:.2e}")
     pr.hip.check_errors()
     pr.close()
+
+
+def test_largest_observation_rows():
+    """64 drones that all see each other: 396 observation columns.  The float32 stepper stages them in LDS (99 KiB); the float64
+    one would need 198 KiB and is refused with a clear error instead of a wrong result."""
+    from quad_swarm_rl_amd import native
+    kw = dict(num_agents=64, neighbor_visible_num=-1, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True, collision_falloff_radius=4.0)
+    with pytest.raises(native.QsError, match="LDS"):
+        native.Stepper(qcfg.make_config(num_envs=2, precision="f64", **kw), device=0)
+    st = native.Stepper(qcfg.make_config(num_envs=2, precision="f32", **kw), device=0)
+    assert st.obs_dim == 18 + 6 * 63
+    st.reset()
+    st.from_host("actions", np.zeros((128, 4), dtype=np.float32))
+    st.step()
+    st.sync()
+    obs = st.to_host("obs").reshape(2, 64, -1)
+    pos = soa(st.to_host("pos"), 2, 64)
+    vel = soa(st.to_host("vel"), 2, 64)
+    for d in (0, 17, 63):   # K = N-1: all the others in index order, relative position / velocity (clipped at the room / 2 v_max)
+        others = [j for j in range(64) if j != d]
+        want = np.concatenate([np.clip(pos[0][others] - pos[0][d], -10, 10), np.clip(vel[0][others] - vel[0][d], -6, 6)], axis=1).reshape(-1)
+        np.testing.assert_allclose(obs[0, d, 18:], want, atol=1e-5)
+    st.close()
 
 
 def test_c_abi_error_paths():
