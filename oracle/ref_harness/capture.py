@@ -524,6 +524,19 @@ _scen_case("s_run_away", 330, 65, quads_mode="run_away", ep_time=2.5, num_agents
 _scen_case("s_mix", 420, 61, quads_mode="mix", ep_time=0.2, num_agents=6, neighbor_visible_num=3)
 _scen_case("s_mix_obst", 200, 62, quads_mode="mix", ep_time=0.2, **dict(OBST, num_agents=4))
 _scen_case("s_mix_single", 200, 63, quads_mode="mix", ep_time=0.2, num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none")
+# size edges and configuration corners (the same configurations tests/test_hip_parity.py runs on the GPU), few steps each
+_scen_case("e_n64_k20", 24, 70, quads_mode="dynamic_formations", ep_time=0.4, num_agents=64, neighbor_visible_num=20, use_downwash=False)
+_scen_case("e_n33_k8_numpy_wall", 30, 71, num_agents=33, neighbor_visible_num=8, use_numba=False, obs_repr="xyz_vxyz_R_omega_wall")
+_scen_case("e_n40_kall_svs", 10, 72, num_agents=40, neighbor_visible_num=-1, quads_mode="swarm_vs_swarm")
+_scen_case("x_n8_blind", 60, 73, neighbor_visible_num=0, neighbor_obs_type="none", ep_time=0.5)
+_scen_case("x_no_noise", 60, 74, sense_noise=None, thrust_noise_ratio=0.0)
+_scen_case("x_dense_obst", 60, 75, quads_mode="o_random", ep_time=0.4, **dict(OBST, obst_density=0.8, obst_size=0.5))
+_scen_case("x_small_room", 80, 76, quads_mode="dynamic_diff_goal", ep_time=0.6, room_dims=[6.0, 6.0, 4.0], obs_repr="xyz_vxyz_R_omega_wall")
+_scen_case("x_ep_len2", 40, 77, quads_mode="static_diff_goal", ep_time=0.02, num_agents=5, neighbor_visible_num=2)
+_scen_case("x_hitbox", 60, 78, collision_hitbox_radius=3.0, collision_falloff_radius=6.0,
+           rew_coeff=dict(pos=0.5, effort=0.1, spin=0.2, vel=0.0, crash=2.0, orient=0.7, yaw=0.0, quadcol_bin=3.0,
+                          quadcol_bin_smooth_max=7.0, quadcol_bin_obst=5.0))
+_scen_case("x_svs_odd", 50, 79, quads_mode="swarm_vs_swarm", ep_time=0.3, num_agents=9)
 
 
 if __name__ == "__main__":

@@ -17,6 +17,9 @@ from tests import golden_util as gu
 SCEN_CASES = ["s_static_diff_goal", "s_dynamic_same_goal", "s_dynamic_diff_goal", "s_dynamic_formations", "s_swap_goals",
               "s_ep_lissajous3D", "s_ep_rand_bezier", "s_o_random", "s_o_dynamic_same_goal", "s_o_swap_goals", "s_o_ep_rand_bezier", "s_run_away", "s_mix", "s_mix_obst",
               "s_mix_single"]
+# size edges / configuration corners, the configurations tests/test_hip_parity.py runs on the GPU (e_*, x_*)
+EDGE_CASES = ["e_n64_k20", "e_n33_k8_numpy_wall", "e_n40_kall_svs", "x_n8_blind", "x_no_noise", "x_dense_obst", "x_small_room", "x_ep_len2",
+              "x_hitbox", "x_svs_odd"]
 CASES = ["c1_single_numpy", "c1_single_numba", "c2_n8_random", "c2_n8_hover_svd", "c2_n8_events", "c2_n8_episode",
          "c2_n8_k2_numpy", "c2_n8_kall", "c3_n8_obst", "c3_n8_obst_episode", "c4_n32_svs", "c4_n6_svs_switch",
          "c4_svs_resets"]
@@ -52,7 +55,7 @@ def check_episode_stats(st, info, n, use_obstacles):
         assert cnt[9] == st["num_collisions_obst_quad_3_5"] and cnt[10] == st["num_collisions_obst_quad_5"]
 
 
-@pytest.mark.parametrize("name", CASES + SCEN_CASES)
+@pytest.mark.parametrize("name", CASES + SCEN_CASES + EDGE_CASES)
 def test_replay(name):
     g, cfgd = gu.load(name)
     cfg = gu.config_from_golden(cfgd)
