@@ -537,6 +537,10 @@ _scen_case("x_hitbox", 60, 78, collision_hitbox_radius=3.0, collision_falloff_ra
            rew_coeff=dict(pos=0.5, effort=0.1, spin=0.2, vel=0.0, crash=2.0, orient=0.7, yaw=0.0, quadcol_bin=3.0,
                           quadcol_bin_smooth_max=7.0, quadcol_bin_obst=5.0))
 _scen_case("x_svs_odd", 50, 79, quads_mode="swarm_vs_swarm", ep_time=0.3, num_agents=9)
+_scen_case("e_n17_kall_obst", 50, 80, quads_mode="o_random", ep_time=0.4, **dict(OBST, num_agents=17, neighbor_visible_num=-1))
+_scen_case("x_n40_obst", 45, 81, quads_mode="o_random", ep_time=0.4, **dict(OBST, num_agents=40, neighbor_visible_num=6))
+_scen_case("e_n2_k1_swap", 60, 82, quads_mode="swap_goals", ep_time=0.5, num_agents=2, neighbor_visible_num=1)
+_scen_case("e_n1_obst", 50, 83, quads_mode="o_static_same_goal", ep_time=0.3, **dict(OBST, num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none"))
 
 
 if __name__ == "__main__":

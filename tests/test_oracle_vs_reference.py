@@ -19,7 +19,7 @@ SCEN_CASES = ["s_static_diff_goal", "s_dynamic_same_goal", "s_dynamic_diff_goal"
               "s_mix_single"]
 # size edges / configuration corners, the configurations tests/test_hip_parity.py runs on the GPU (e_*, x_*)
 EDGE_CASES = ["e_n64_k20", "e_n33_k8_numpy_wall", "e_n40_kall_svs", "x_n8_blind", "x_no_noise", "x_dense_obst", "x_small_room", "x_ep_len2",
-              "x_hitbox", "x_svs_odd"]
+              "x_hitbox", "x_svs_odd", "e_n17_kall_obst", "x_n40_obst", "e_n2_k1_swap", "e_n1_obst"]
 CASES = ["c1_single_numpy", "c1_single_numba", "c2_n8_random", "c2_n8_hover_svd", "c2_n8_events", "c2_n8_episode",
          "c2_n8_k2_numpy", "c2_n8_kall", "c3_n8_obst", "c3_n8_obst_episode", "c4_n32_svs", "c4_n6_svs_switch",
          "c4_svs_resets"]
