@@ -274,6 +274,8 @@ class FusedQuadEncoder:
         """head(encoder(obs)) -> [B, h] float32; the [B, 512] features are written only if a `features` tensor is passed."""
         torch = self._torch
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.params.obs_dim
+        if getattr(self, "_head", None) is None:
+            raise native.QsError("forward_head: call set_head(weight, bias) first")
         w, b = self._head
         B = obs.shape[0]
         if head_out is None:
