@@ -36,7 +36,10 @@ typedef struct qs_enc_params {
     qs_enc_layer v1, v2;   /* attention: neighbor_value_mlp (:60-65) */
     qs_enc_layer a1e, a1m; /* attention: attention_mlp[0] (:69) split by input columns: W[:, 0:256] with the bias (e_i half),
                               W[:, 256:512] (e_mean half; its bias pointer is not read) */
-    qs_enc_layer a2, a3;   /* attention: attention_mlp[2], attention_mlp[4] (256 -> 1, padded to M = 16) */
+    qs_enc_layer a2;       /* attention: attention_mlp[2] */
+    const float *a3w;      /* attention: attention_mlp[4] (256 -> 1): fp32 weight row [256] ... */
+    float a3b;             /* ... and bias */
+    int32_t pad0;
     uint16_t *ebuf;        /* attention scratch, device, bf16 [B * num_nbr, 256] */
     float *gbuf;           /* attention scratch, device, fp32 [B, 256] */
     qs_enc_layer f;        /* feed forward      (:329-332): K = 256 * (1 + (neighbour encoder present) + (obst_dim > 0)), M = 512 */

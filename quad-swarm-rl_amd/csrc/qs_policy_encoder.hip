@@ -56,7 +56,10 @@ struct EncParams {
                                 // / :110-117 (mlp: input = all neighbour obs of the agent, three layers)
     EncLayer o1, o2;            // obstacle encoder    :315-322
     EncLayer v1, v2;            // attention: value MLP :60-65
-    EncLayer a1e, a1m, a2, a3;  // attention: score MLP :68-75; its first layer split into the e_i half (with the bias) and the e_mean half
+    EncLayer a1e, a1m, a2;      // attention: score MLP :68-75; its first layer split into the e_i half (with the bias) and the e_mean half
+    const float *a3w;           // attention: last score layer 256 -> 1, fp32 weight row [256] ...
+    float a3b;                  // ... and bias
+    int32_t pad0;
     uint16_t *ebuf;             // attention scratch: e_i of every (agent, neighbour) row, bf16 [B*num_nbr, 256]
     float *gbuf;                // attention scratch: W_m e_mean of every agent, fp32 [B, 256]
     EncLayer f;                 // feed forward        :329-332
@@ -349,8 +352,9 @@ __device__ __forceinline__ void attn_load_e(const EncParams &P, int B, int a0, i
     }
 }
 
-// One group of NTH neighbour row tiles: scores first (their second layer overwrites the e_i tile), then e_i again (an L2 hit) for
-// the values, which go straight into the running sum - the h_i are never live together with another layer's accumulators.
+// One group of NTH neighbour row tiles: scores first (the 256 -> 1 layer is reduced from the accumulators of the layer before it),
+// then the values from the same e_i tile, which go straight into the running sum - the h_i are never live together with another
+// layer's accumulators.  Four barriers per group.
 template <int NTH>
 __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a, uint16_t *buf_h, float *s_alpha, AttnState &st) {
     const int wave = wave_id(), lane = threadIdx.x & 63, mt0 = wave * ENC_MT;
@@ -379,18 +383,22 @@ __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int
     __syncthreads();
     init_bias<ENC_MT, NTH>(P.a2, mt0, acc);
     gemm_tiles<ENC_MT, NTH>(P.a2, mt0, buf_h, ENC_YS, acc);
-    store_tanh<ENC_MT, NTH>(acc, mt0, buf_a, ENC_YS);
-    __syncthreads();
-    if (wave < NTH) {   // last score layer 256 -> 1 (padded to one 16-feature tile), wave w takes row tile w: feature 0 = lanes 0..15, register 0
-        f32x4 sc[1][1];
-        init_bias<1, 1>(P.a3, 0, sc);
-        gemm_tiles<1, 1>(P.a3, 0, buf_a + wave * ENC_TA * ENC_YS, ENC_YS, sc);
-        if (lane < 16) s_alpha[wave * 16 + lane] = sc[0][0][0];
+    // last score layer 256 -> 1 straight from the accumulators: per-lane partial dot product with the fp32 weight row, two shuffles
+    // over the lane groups, the eight waves' partials through LDS - no activation store, no extra MFMA pass, and e_i stays in buf_a
+#pragma unroll
+    for (int nt = 0; nt < NTH; ++nt) {
+        float sp = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            const f32x4 w = *(const f32x4 *)(P.a3w + (mt0 + mt) * 16 + (lane >> 4) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp += fast_tanh(acc[mt][nt][r]) * w[r];
+        }
+        sp = lane_groups_sum(sp);
+        if (lane < 16) s_alpha[(wave * ENC_ANH + nt) * 16 + lane] = sp;
     }
-    __syncthreads();
+    __syncthreads();   // partial scores visible; every wave is done reading buf_h (second score layer)
     // h_i = neighbor_value_mlp(e_i)   (:88)
-    attn_load_e<NTH>(P, B, a0, t0, buf_a);
-    __syncthreads();
     init_bias<ENC_MT, NTH>(P.v1, mt0, acc);
     gemm_tiles<ENC_MT, NTH>(P.v1, mt0, buf_a, ENC_YS, acc);
     store_tanh<ENC_MT, NTH>(acc, mt0, buf_h, ENC_YS);
@@ -400,7 +408,12 @@ __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int
     // online softmax over the neighbours of agent (lane & 15)   (:95-100)
     float al[NTH], mx = st.mx;
 #pragma unroll
-    for (int nt = 0; nt < NTH; ++nt) { al[nt] = s_alpha[nt * 16 + (lane & 15)]; mx = fmaxf(mx, al[nt]); }
+    for (int nt = 0; nt < NTH; ++nt) {
+        al[nt] = P.a3b;
+#pragma unroll
+        for (int w = 0; w < ENC_WAVES; ++w) al[nt] += s_alpha[(w * ENC_ANH + nt) * 16 + (lane & 15)];
+        mx = fmaxf(mx, al[nt]);
+    }
     const float scale = __expf(st.mx - mx);
     st.den *= scale;
 #pragma unroll
@@ -426,7 +439,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [ANH*16][YS]  e_i of the group, later the second score layer
     uint16_t *buf_h = buf_a + ENC_ANH * ENC_TA * ENC_YS;              // [ANH*16][YS]  hidden layers; first the self / obstacle MLPs' (one tile)
     uint16_t *cat = buf_h + ENC_ANH * ENC_TA * ENC_YS;                // [16][CS]: self | neighbourhood | obstacles
-    float *s_alpha = (float *)(cat + ENC_TA * ENC_CS);                // [ANH][16] scores of the group
+    float *s_alpha = (float *)(cat + ENC_TA * ENC_CS);                // [8 waves][ANH][16] partial scores of the group
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
     const int col_nbr = ENC_H, col_obst = 2 * ENC_H;
@@ -767,7 +780,7 @@ const char *qs_enc_last_error(void) { return g_enc_error.c_str(); }
 size_t qs_enc_sizeof_params(void) { return sizeof(EncParams); }
 
 static size_t lds_main(int attention) {
-    if (attention) return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + 2 * ENC_ANH * ENC_TA * ENC_YS + ENC_TA * ENC_CS) + sizeof(float) * ENC_ANH * 16;
+    if (attention) return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + 2 * ENC_ANH * ENC_TA * ENC_YS + ENC_TA * ENC_CS) + sizeof(float) * ENC_WAVES * ENC_ANH * 16;
     return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
 }
 static size_t lds_mha(void) {
@@ -791,6 +804,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         g_enc_error = "unsupported encoder shape (inputs wider than 32 - 64 for the mlp neighbour encoder - or more than 8 neighbours)";
         return -4;
     }
+    if (att && !P.a3w) { g_enc_error = "the attention neighbour encoder needs the last score layer's weight row (a3w)"; return -1; }
     if (att && (!P.ebuf || !P.gbuf)) { g_enc_error = "the attention neighbour encoder needs the ebuf / gbuf scratch buffers"; return -1; }
     if (att && (int64_t)B * P.num_nbr * (ENC_H * 2) > 0x7fffffffll) { g_enc_error = "attention: batch x neighbours too large for 32-bit scratch offsets"; return -4; }
     if (B == 0) return 0;

@@ -37,7 +37,7 @@ class EncParams(C.Structure):
     _fields_ = [("self_dim", C.c_int32), ("nbr_dim", C.c_int32), ("num_nbr", C.c_int32), ("obst_dim", C.c_int32), ("obs_dim", C.c_int32),
                 ("nbr_encoder", C.c_int32),
                 ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("n3", EncLayer), ("o1", EncLayer), ("o2", EncLayer),
-                ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3", EncLayer),
+                ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3w", C.c_void_p), ("a3b", C.c_float), ("pad0", C.c_int32),
                 ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer),
                 ("mq", EncLayer), ("mk", EncLayer), ("mv", EncLayer), ("mfc", EncLayer), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p), ("head_dim", C.c_int32)]
@@ -239,7 +239,11 @@ class FusedQuadEncoder:
                 raise ValueError("attention encoder: self_dim + nbr_dim must fit one 32-wide K step")
             P.v1, P.v2 = layer(module.neighbor_value_mlp[0]), layer(module.neighbor_value_mlp[2])
             P.a1e, P.a1m = layer(module.attention_mlp[0], (0, HIDDEN)), layer(module.attention_mlp[0], (HIDDEN, 2 * HIDDEN))
-            P.a2, P.a3 = layer(module.attention_mlp[2]), layer(module.attention_mlp[4])
+            P.a2 = layer(module.attention_mlp[2])
+            a3 = module.attention_mlp[4]   # 256 -> 1: reduced from the second score layer's accumulators, fp32 weights
+            a3w = a3.weight.detach().float().reshape(-1).to(self.device).contiguous()
+            self._keep.append(a3w)
+            P.a3w, P.a3b = a3w.data_ptr(), float(a3.bias.detach().float().item())
         self._scratch_rows = 0
         P.f = layer(module.feed_forward[0])
         if P.f.M != 2 * HIDDEN or P.s1.M != HIDDEN:

@@ -29,7 +29,7 @@ def bf16_emulation(module, obs):
         W1 = r(a[0].weight)
         x = torch.tanh(e @ W1[:, :e.shape[1]].T + (e_mean @ W1[:, e.shape[1]:].T).repeat(K, 1) + a[0].bias)
         x = torch.tanh(r(x) @ r(a[2].weight).T + a[2].bias)
-        alpha = (r(x) @ r(a[4].weight).T + a[4].bias).view(B, K)
+        alpha = (x @ a[4].weight.T + a[4].bias).view(B, K)     # last layer in fp32 from the accumulators
         emb.append(r((torch.softmax(alpha, dim=1).view(-1, 1) * h).view(B, K, -1).sum(dim=1)))
     elif getattr(module, "nbr_encoder", "") == "mlp":
         x = obs[:, module.self_dim:module.self_dim + nb]
