@@ -129,6 +129,10 @@ class ExperienceReplayWrapper:
                                          f"episode checkpoints: {len(self.episode_checkpoints)}, {tick}")
                     slot, host, cp_obs = self.episode_checkpoints[-steps_ago]
                     self.replay_buffer.write_cp_to_buffer(env, slot, host, cp_obs)
+                    # the reference unpacks the checkpoint into its local `obs` (`env, obs = self.episode_checkpoints[-steps_ago]`,
+                    # :151) and returns that: on the step that files an event the caller gets the 1.5-s-old observation of the
+                    # checkpoint, not the current one.  Reproduced (pinned by tests/test_wrappers_vs_reference.py).
+                    obs = np.array(cp_obs, copy=True)
                     env.collision_occurred = False
                     self.last_tick_added_to_buffer = tick
         return obs, rewards, dones, infos

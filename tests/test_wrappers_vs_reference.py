@@ -1,0 +1,85 @@
+"""sf_env.RewardShapingWrapper against the reference's QuadsRewardShapingWrapper (swarm_rl/env_wrappers/reward_shaping.py:19-123).
+tests/golden/wrapper_reward_shaping.json holds what the reference wrapper produced over the scripted env of tests/fake_env.py
+(oracle/ref_harness/capture_wrappers.py, build container); here the repo's wrapper runs over the same script.  CPU only."""
+import json
+import os
+
+import pytest
+
+from quad_swarm_rl_amd import sf_env
+from tests.fake_env import FakeQuadEnv, drive
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wrapper_reward_shaping.json")
+
+
+def close(a, b):
+    if a is None or b is None:
+        return a is b
+    if isinstance(a, dict):
+        return sorted(a) == sorted(b) and all(close(a[k], b[k]) for k in a)
+    if isinstance(a, list):
+        return len(a) == len(b) and all(close(x, y) for x, y in zip(a, b))
+    if isinstance(a, bool) or isinstance(b, bool):
+        return a == b
+    return a == pytest.approx(b, rel=1e-12, abs=1e-12)
+
+
+@pytest.mark.parametrize("case,seed", [("annealed", 1), ("plain", 2)])
+def test_reward_shaping_wrapper_equals_reference(case, seed):
+    want = json.load(open(GOLDEN))[case]
+    annealing = [sf_env.AnnealSchedule("quadcol_bin", 5.0, 600000), sf_env.AnnealSchedule("quadcol_bin_smooth_max", 10.0, 300000)] if case == "annealed" else None
+    scheme = dict(quad_rewards=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0,
+                                    quadcol_bin=0.0 if annealing else 5.0, quadcol_bin_smooth_max=0.0 if annealing else 10.0, quadcol_bin_obst=5.0))
+    env = FakeQuadEnv(seed=seed)
+    got = drive(sf_env.RewardShapingWrapper(env, reward_shaping_scheme=scheme, annealing=annealing), env, steps=30, seed=seed)
+    assert len(got["steps"]) == len(want["steps"]) == 30
+    for t, (g, w) in enumerate(zip(got["steps"], want["steps"])):
+        for key in ("rewards", "dones", "true_reward", "rew_coeff"):
+            assert close(g[key], w[key]), (t, key, g[key], w[key])
+        assert close(g["extra"], w["extra"]), (t, "episode_extra_stats", g["extra"], w["extra"])
+    assert close(got["coeff_seen_by_env"], want["coeff_seen_by_env"])
+    # the script crosses four episode ends; the annealed coefficients grow and saturate at their final values
+    ends = [s for s in want["steps"] if s["dones"][0]]
+    assert len(ends) == 4 and all(e["true_reward"][0] is not None for e in ends)
+    if case == "annealed":
+        assert ends[0]["rew_coeff"]["quadcol_bin"] < ends[-1]["rew_coeff"]["quadcol_bin"] <= 5.0
+        assert ends[-1]["rew_coeff"]["quadcol_bin_smooth_max"] == 10.0
+
+
+class _ReplayedDraws:
+    """the reference wrapper's random draws (np.random.uniform for 'replay or new episode', random.randint for the event index),
+    served in order to this repo's wrapper, whose generator is a RandomState-like object"""
+
+    def __init__(self, draws):
+        self.u, self.i = list(draws["uniform"]), list(draws["randint"])
+
+    def uniform(self, lo, hi):
+        return self.u.pop(0)
+
+    def randint(self, lo, hi):
+        v = self.i.pop(0)
+        assert lo <= v < hi
+        return v
+
+
+def test_experience_replay_wrapper_equals_reference():
+    """replay.ExperienceReplayWrapper (device snapshots + host attributes) against the reference's wrapper (deepcopy of the env),
+    quad_experience_replay.py:66-209, over the scripted FakeReplayEnv: same checkpoints taken, same collision events filed, same
+    episodes replayed from the same states, same replay statistics."""
+    from quad_swarm_rl_amd import replay
+    from tests.fake_env import FakeReplayEnv, drive_replay
+    want = json.load(open(os.path.join(os.path.dirname(GOLDEN), "wrapper_experience_replay.json")))
+    env = FakeReplayEnv(seed=3)
+    w = replay.ExperienceReplayWrapper(env, 0.75, 0.2, 0.6)
+    draws = _ReplayedDraws(want["draws"])
+    w.rng = w.replay_buffer.rng = draws
+    got = drive_replay(w, want["steps"])
+    ref = want["trajectory"]
+    assert got["tick"] == ref["tick"] and got["episode"] == ref["episode"]
+    assert got["x"] == pytest.approx(ref["x"], rel=0, abs=0)
+    assert sorted(got["ends"]) == sorted(ref["ends"]) and len(ref["ends"]) >= 15
+    for t in ref["ends"]:
+        assert close(got["ends"][t], ref["ends"][t]), (t, got["ends"][t], ref["ends"][t])
+    assert not draws.u and not draws.i                                   # every draw of the reference was asked for, in order
+    replayed = sum(1 for a, b in zip(ref["tick"][:-1], ref["tick"][1:]) if b < a and b > 0)
+    assert replayed >= 10                                                # episodes that restarted mid-way: replays from a checkpoint
