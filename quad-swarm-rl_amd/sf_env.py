@@ -63,11 +63,16 @@ def add_quadrotors_env_args(env, parser):
     p.add_argument("--quads_obst_collision_reward", default=0.0, type=float)
     p.add_argument("--quads_use_downwash", default=False, type=str2bool)
     p.add_argument("--quads_use_numba", default=False, type=str2bool)
-    p.add_argument("--quads_mode", default="static_same_goal", type=str)
+    p.add_argument("--quads_mode", default="static_same_goal", type=str,   # the reference's choices verbatim (quadrotor_params.py:77-83):
+                   choices=["static_same_goal", "static_diff_goal", "dynamic_same_goal", "dynamic_diff_goal", "ep_lissajous3D",   # they name
+                            "ep_rand_bezier", "swarm_vs_swarm", "swap_goals", "dynamic_formations", "mix",   # four scenarios that have no
+                            "o_uniform_same_goal_spawn", "o_random", "o_dynamic_diff_goal", "o_dynamic_same_goal", "o_diagonal",   # file and
+                            "o_static_same_goal", "o_static_diff_goal", "o_swap_goals", "o_ep_rand_bezier"])   # omit run_away
     p.add_argument("--quads_room_dims", nargs="+", default=[10.0, 10.0, 10.0], type=float)
     p.add_argument("--replay_buffer_sample_prob", default=0.0, type=float)
     p.add_argument("--anneal_collision_steps", default=0.0, type=float)
-    p.add_argument("--quads_view_mode", nargs="+", default=["topdown", "chase", "global"], type=str)
+    p.add_argument("--quads_view_mode", nargs="+", default=["topdown", "chase", "global"], type=str,
+                   choices=["topdown", "chase", "side", "global", "corner0", "corner1", "corner2", "corner3", "topdownfollow"])
     p.add_argument("--quads_render", default=False, type=bool)
     p.add_argument("--visualize_v_value", action="store_true")
     p.add_argument("--quads_sim2real", default=False, type=str2bool)

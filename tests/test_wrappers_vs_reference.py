@@ -83,3 +83,25 @@ def test_experience_replay_wrapper_equals_reference():
     assert not draws.u and not draws.i                                   # every draw of the reference was asked for, in order
     replayed = sum(1 for a, b in zip(ref["tick"][:-1], ref["tick"][1:]) if b < a and b > 0)
     assert replayed >= 10                                                # episodes that restarted mid-way: replays from a checkpoint
+
+
+def test_command_line_flags_equal_reference():
+    """`--quads_*` surface of swarm_rl/env_wrappers/quadrotor_params.py (tests/golden/flags.json, oracle/ref_harness/capture_flags.py):
+    every flag with the same default, choices and arity; this repo only ADDS the four flags of the device path."""
+    import argparse
+    ref = json.load(open(os.path.join(os.path.dirname(GOLDEN), "flags.json")))
+    p = argparse.ArgumentParser()
+    sf_env.add_quadrotors_env_args("quadrotor_multi", p)
+    mine = {a.dest: a for a in p._actions if a.dest != "help"}
+    assert sorted(set(mine) - set(ref["flags"])) == ["quads_device", "quads_num_envs", "quads_precision", "quads_seed"]
+    assert len(ref["flags"]) == 37
+    for name, r in ref["flags"].items():
+        a = mine[name]
+        assert a.default == r["default"], name
+        assert (list(a.choices) if a.choices else None) == r["choices"], name
+        assert a.nargs == r["nargs"], name
+    p2 = argparse.ArgumentParser()
+    for k in ref["override_defaults"]:
+        p2.add_argument("--" + k, default=None)
+    sf_env.quadrotors_override_defaults("quadrotor_multi", p2)
+    assert vars(p2.parse_args([])) == ref["override_defaults"]
