@@ -149,3 +149,25 @@ def test_reference_encoder_modules_cover_the_flag_choices():
     with pytest.raises(NotImplementedError):
         policy.make_reference_encoder(nbr_encoder="transformer")
     assert policy.make_reference_mha_encoder()(torch.zeros(3, 40)).shape == (3, 512)
+
+
+def test_weight_packing_follows_the_header_formula():
+    """policy.pack_linear == the fragment order include/quadswarm_encoder.h documents:
+    w[((mt * (K/32) + ks) * 64 + lane) * 8 + j] = bf16(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]), zero padded to M % 16 == 0, K % 32 == 0."""
+    import torch
+    from quad_swarm_rl_amd import policy
+    for m_real, k_real in ((256, 18), (256, 256), (1, 256), (512, 768), (256, 48)):
+        lin = torch.nn.Linear(k_real, m_real)
+        w, b, M, K = policy.pack_linear(lin, "cpu")
+        assert M == -(-m_real // 16) * 16 and K == -(-k_real // 32) * 32 and w.dtype == torch.bfloat16 and w.numel() == M * K
+        W = torch.zeros(M, K)
+        W[:m_real, :k_real] = lin.weight.detach()
+        flat = w.float().reshape(-1)
+        rng = np.random.RandomState(m_real + k_real)
+        for _ in range(200):
+            mt, ks, lane, j = rng.randint(M // 16), rng.randint(K // 32), rng.randint(64), rng.randint(8)
+            want = W[mt * 16 + (lane & 15), ks * 32 + 8 * (lane >> 4) + j].to(torch.bfloat16).float()
+            assert flat[((mt * (K // 32) + ks) * 64 + lane) * 8 + j] == want
+        assert torch.equal(b[:m_real], lin.bias.detach()) and (b[m_real:] == 0).all()
+    half = policy.pack_linear(torch.nn.Linear(512, 256), "cpu", cols=(256, 512))   # the e_mean half of the attention score layer
+    assert half[3] == 256
