@@ -116,6 +116,39 @@ class QuadSwarmVecEnv:
         self.stepper.close()
 
 
+def assemble_episode_extra_stats(eps, cnt, name, n, use_obstacles):
+    """infos[i]['episode_extra_stats'] of quadrotor_multi.py:637-718 from the episode snapshot the step kernel leaves behind:
+    eps[6, n] = per-agent distance_to_goal_{1,3,5}s, reached-goal / no-drone-collision / no-obstacle-collision flags;
+    cnt[11] = episode counters (config.COUNTER_KEYS order); name = scenario name without its `Scenario_` prefix."""
+    ok = np.logical_and(eps[4], eps[5])
+    succ = float(np.sum(np.logical_and(ok, eps[3])) / n)
+    dead = float(np.sum(np.logical_and(ok, 1 - eps[3])) / n)
+    col, ncol, ocol = float(1.0 - np.sum(ok) / n), float(1.0 - np.sum(eps[4]) / n), float(1.0 - np.sum(eps[5]) / n)
+    out = []
+    for i in range(n):
+        d = {
+            "num_collisions": int(cnt[0]), "num_collisions_with_room": int(cnt[3]), "num_collisions_with_floor": int(cnt[4]),
+            "num_collisions_with_wall": int(cnt[5]), "num_collisions_with_ceiling": int(cnt[6]),
+            "num_collisions_after_settle": int(cnt[1]), f"{name}/num_collisions": int(cnt[1]),
+            "num_collisions_final_5_s": int(cnt[2]), f"{name}/num_collisions_final_5_s": int(cnt[2]),
+            "distance_to_goal_1s": float(eps[0, i]), "distance_to_goal_3s": float(eps[1, i]), "distance_to_goal_5s": float(eps[2, i]),
+            f"{name}/distance_to_goal_1s": float(eps[0, i]), f"{name}/distance_to_goal_3s": float(eps[1, i]),
+            f"{name}/distance_to_goal_5s": float(eps[2, i]),
+            "metric/agent_success_rate": succ, f"{name}/agent_success_rate": succ,
+            "metric/agent_deadlock_rate": dead, f"{name}/agent_deadlock_rate": dead,
+            "metric/agent_col_rate": col, f"{name}/agent_col_rate": col,
+            "metric/agent_neighbor_col_rate": ncol, f"{name}/agent_neighbor_col_rate": ncol,
+            "metric/agent_obst_col_rate": ocol, f"{name}/agent_obst_col_rate": ocol,
+        }
+        if use_obstacles:
+            d.update({"num_collisions_obst_quad": int(cnt[7]), "num_collisions_obst_quad_after_settle": int(cnt[8]),
+                      f"{name}/num_collisions_obst": int(cnt[7]), "num_collisions_obst_quad_3_5": int(cnt[9]),
+                      f"{name}/num_collisions_obst_quad_3_5": int(cnt[9]), "num_collisions_obst_quad_5": int(cnt[10]),
+                      f"{name}/num_collisions_obst_quad_5": int(cnt[10])})
+        out.append(d)
+    return out
+
+
 class QuadrotorEnvMulti:
     """Reference-compatible single environment (constructor keywords of quadrotor_multi.py:24-41)."""
 
@@ -252,36 +285,9 @@ class QuadrotorEnvMulti:
 
     def episode_extra_stats(self):
         """Per-agent dicts with the keys of quadrotor_multi.py:637-718, from the device-side episode snapshot."""
-        st, n = self._vec.stepper, self.num_agents
+        st = self._vec.stepper
         eps, cnt = st.to_host("ep_stats").astype(np.float64), st.to_host("ep_counters")[:, 0]
-        name = self.scenario.name(finished_episode=True)[9:]
-        ok = np.logical_and(eps[4], eps[5])
-        succ = float(np.sum(np.logical_and(ok, eps[3])) / n)
-        dead = float(np.sum(np.logical_and(ok, 1 - eps[3])) / n)
-        col, ncol, ocol = float(1.0 - np.sum(ok) / n), float(1.0 - np.sum(eps[4]) / n), float(1.0 - np.sum(eps[5]) / n)
-        out = []
-        for i in range(n):
-            d = {
-                "num_collisions": int(cnt[0]), "num_collisions_with_room": int(cnt[3]), "num_collisions_with_floor": int(cnt[4]),
-                "num_collisions_with_wall": int(cnt[5]), "num_collisions_with_ceiling": int(cnt[6]),
-                "num_collisions_after_settle": int(cnt[1]), f"{name}/num_collisions": int(cnt[1]),
-                "num_collisions_final_5_s": int(cnt[2]), f"{name}/num_collisions_final_5_s": int(cnt[2]),
-                "distance_to_goal_1s": float(eps[0, i]), "distance_to_goal_3s": float(eps[1, i]), "distance_to_goal_5s": float(eps[2, i]),
-                f"{name}/distance_to_goal_1s": float(eps[0, i]), f"{name}/distance_to_goal_3s": float(eps[1, i]),
-                f"{name}/distance_to_goal_5s": float(eps[2, i]),
-                "metric/agent_success_rate": succ, f"{name}/agent_success_rate": succ,
-                "metric/agent_deadlock_rate": dead, f"{name}/agent_deadlock_rate": dead,
-                "metric/agent_col_rate": col, f"{name}/agent_col_rate": col,
-                "metric/agent_neighbor_col_rate": ncol, f"{name}/agent_neighbor_col_rate": ncol,
-                "metric/agent_obst_col_rate": ocol, f"{name}/agent_obst_col_rate": ocol,
-            }
-            if self.use_obstacles:
-                d.update({"num_collisions_obst_quad": int(cnt[7]), "num_collisions_obst_quad_after_settle": int(cnt[8]),
-                          f"{name}/num_collisions_obst": int(cnt[7]), "num_collisions_obst_quad_3_5": int(cnt[9]),
-                          f"{name}/num_collisions_obst_quad_3_5": int(cnt[9]), "num_collisions_obst_quad_5": int(cnt[10]),
-                          f"{name}/num_collisions_obst_quad_5": int(cnt[10])})
-            out.append(d)
-        return out
+        return assemble_episode_extra_stats(eps, cnt, self.scenario.name(finished_episode=True)[9:], self.num_agents, self.use_obstacles)
 
     def render(self, *a, **k):
         raise NotImplementedError("rendering is out of scope of the stepper")
