@@ -86,3 +86,20 @@ def test_scenario_table_matches_header():
     # obstacle scenarios need obstacles and vice versa (quadrotor_multi.py:118-125, scenarios/mix.py:16-29)
     with pytest.raises((AssertionError, ValueError, NotImplementedError)):
         qcfg.make_config(quads_mode="o_random", use_obstacles=False)
+
+
+def test_bench_workloads_follow_the_baseline_and_the_cpu_leg_runs():
+    """bench.py: the headline workload is BASELINE.json's (8 drones x 1024 envs), the algorithmic bytes per drone-control-step are
+    SURVEY 8(d)'s, and the cpu_baseline leg (the only part of bench.py that may touch the oracle) produces a sane record."""
+    import json
+    import os
+    import bench
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = json.load(open(os.path.join(repo, "BASELINE.json")))
+    assert "8 drones" in base["metric"] and "1024" in base["metric"]
+    c2 = bench.WORKLOADS["c2"]
+    assert c2["num_envs"] == 1024 and c2["kw"]["num_agents"] == 8 and c2["kw"]["neighbor_visible_num"] == 6
+    assert bench.ALGO_BYTES_PER_DRONE_STEP == {"c2": 500, "c3": 456, "c4": 500, "c1": 356}
+    assert bench.HBM_PEAK_GBS == 8000.0
+    rec = bench.cpu_baseline("c1", 0.2)
+    assert rec["kind"] == "port" and rec["unit"] == "env-steps/s" and rec["value"] > 0 and rec["cores"] >= 1 and "C oracle" in rec["sample"]
