@@ -27,7 +27,7 @@ def mod(name, **kw):
 for name in ("sample_factory", "sample_factory.algo", "sample_factory.algo.utils", "sample_factory.model"):
     mod(name)
 mod("sample_factory.algo.utils.context", global_model_factory=lambda: None)
-mod("sample_factory.algo.utils.torch_utils", calc_num_elements=lambda *a: 0)
+mod("sample_factory.algo.utils.torch_utils", calc_num_elements=lambda module, shape: module(torch.zeros(1, *shape)).numel())
 class _Encoder(nn.Module):   # sample_factory.model.encoder.Encoder: an nn.Module that takes cfg
     def __init__(self, cfg=None):
         super().__init__()
@@ -75,4 +75,34 @@ for K, B in ((2, 33), (6, 5), (8, 1)):
         obs = torch.rand(B, 19 + 6 * K + 9) * 2 - 1
         worst_mha = max(worst_mha, (theirs({"obs": obs}) - mine(obs)).abs().max().item())
 print("multi-head attention encoder, max abs diff vs the reference class:", worst_mha)
-sys.exit(0 if worst == 0.0 and worst_mha < 1e-6 else 1)
+
+# the whole QuadMultiEncoder (:250-350) with each --quads_neighbor_encoder_type, with and without the obstacle encoder
+worst_full = 0.0
+for enc in policy.NBR_ENCODERS:
+    for obst in (False, True):
+        K, B = 2 if obst else 6, 19
+        self_dim = 19 if obst else 18
+        mine = policy.make_reference_encoder(seed=20, nbr_encoder=enc, num_nbr=K, obst_dim=9 if obst else 0, self_dim=self_dim)
+        cfg = types.SimpleNamespace(quads_obs_repr="xyz_vxyz_R_omega_floor" if obst else "xyz_vxyz_R_omega", quads_neighbor_hidden_size=256,
+                                    quads_use_obstacles=obst, quads_neighbor_visible_num=K, quads_num_agents=8, quads_neighbor_obs_type="pos_vel",
+                                    quads_obstacle_obs_type="octomap", quads_obst_hidden_size=256, quads_neighbor_encoder_type=enc, rnn_size=256)
+        theirs = ref_model.QuadMultiEncoder(cfg, None)
+        theirs.self_encoder.load_state_dict(mine.self_encoder.state_dict())
+        theirs.feed_forward.load_state_dict(mine.feed_forward.state_dict())
+        if obst:
+            theirs.obstacle_encoder.load_state_dict(mine.obstacle_encoder.state_dict())
+        if enc == "mean_embed":
+            theirs.neighbor_encoder.embedding_mlp.load_state_dict(mine.neighbor_encoder.state_dict())
+        elif enc == "mlp":
+            theirs.neighbor_encoder.neighbor_mlp.load_state_dict(mine.neighbor_encoder.state_dict())
+        elif enc == "attention":
+            theirs.neighbor_encoder.embedding_mlp.load_state_dict(mine.neighbor_encoder.state_dict())
+            theirs.neighbor_encoder.neighbor_value_mlp.load_state_dict(mine.neighbor_value_mlp.state_dict())
+            theirs.neighbor_encoder.attention_mlp.load_state_dict(mine.attention_mlp.state_dict())
+        obs = torch.rand(B, self_dim + 6 * K + (9 if obst else 0)) * 2 - 1
+        with torch.no_grad():
+            d = (theirs({"obs": obs}) - mine(obs)).abs().max().item()
+        worst_full = max(worst_full, d)
+        print(f"  QuadMultiEncoder {enc:11s} obstacles={obst}: max abs diff {d}")
+print("QuadMultiEncoder, all neighbour encoder types, max abs diff vs the reference class:", worst_full)
+sys.exit(0 if worst == 0.0 and worst_mha < 1e-6 and worst_full < 1e-6 else 1)
