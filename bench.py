@@ -5,19 +5,29 @@
   (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one control step (= 2 physics sub-steps) of all environments of the workload on synthetic
-U(-1,1)^4 actions that are already resident in HBM.  Workload at N=1 (BASELINE.json configs[1], "C2"):
-8 drones x 1024 envs, static_same_goal, 6 visible neighbours (obs 54), downwash on, Numba-path semantics,
-sensor + thrust noise on, auto-resets included.  Each extra GPU gets its own 1024-env shard (weak scaling); the shards
-are independent (no cross-env term on this path), so the timed region has no data-path collective.  The optional
-variant of north_star / SURVEY.md 8e - ONE RCCL all-gather of the observations after every step - is timed right after
-and reported as config.with_obs_allgather (or becomes the headline with --gather): it moves 12.4 MB per GPU per step and
-is xGMI-link-bound at >= ~28 us per step whatever the implementation.
+U(-1,1)^4 actions that are already resident in HBM.
+
+N = 1 (BASELINE.json configs[1], "C2", the configuration the metric is quoted on): 8 drones x 1024 envs,
+static_same_goal, 6 visible neighbours (obs 54), downwash on, Numba-path semantics, sensor + thrust noise on,
+auto-resets included.
+N > 1 (BASELINE.json configs[3], "C4"): 32 drones x 512 envs PER GPU (4096 envs at 8 GPUs), swarm_vs_swarm, and ONE
+RCCL all-gather of the observations after every step INSIDE the timed region (north_star: "a single RCCL gather of
+observations over xGMI per rollout step"), double-buffered so that gather(t) overlaps step(t+1).  The rate of the same
+shards stepping with no collective is measured right after and reported as config.independent_shards
+(--no-gather makes it the headline; --workload / --envs-per-gpu override the shape).
+
+Timing.  W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize.  `value` / `ms_per_step` come from
+HIP events recorded on the launch stream right after the opening synchronize and right after the K-th step (for the
+gather variant: after the last gather has drained into the stream), MAX over ranks: at K = 20 the timed region is a few
+hundred microseconds and the closing host synchronize alone is worth several steps, so the host clock would time the
+synchronize, not the steps.  The host-clock figures of the same region are printed beside them (config.host_clock).
 
 metric:  env-steps/s = drones x envs x sim_steps(2) x control-steps/s   (BASELINE.md "Metric")
 roofline: HBM-bound; algorithmic bytes per drone-control-step = 500 B (read state 120 + flags 4 +
           goal 12 + action 16, write state 120 + flags 4 + obs 216 + reward 4 + done 4); achieved = 500 B x drones
           per launch / average step-kernel duration, measured here with HIP events on the launch stream.
-cpu_baseline: the validated C oracle (oracle/, OpenMP over envs) on this box's host cores, rank 0, N=1 only.
+cpu_baseline: the validated C oracle (oracle/, float64, OpenMP over envs) on this box's host cores, rank 0, N=1 only:
+          a sweep over thread counts {1, physical cores, usable hardware threads}; value = the best, single_thread beside it.
 """
 import argparse
 import json
@@ -32,6 +42,7 @@ if REPO not in sys.path:
 import numpy as np  # noqa: E402
 
 ALGO_BYTES_PER_DRONE_STEP = {"c2": 500, "c3": 456, "c4": 500, "c1": 356}
+ALGO_BYTES_F64_PER_DRONE_STEP = {"c2": 988, "c3": 900, "c4": 988, "c1": 700}   # the same arrays with 8-byte reals (flags / done stay 4 / 4 bytes)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 WORKLOADS = {
@@ -51,13 +62,47 @@ WORKLOADS = {
 }
 
 
+def _host_cpu():
+    """(model string, usable hardware threads, physical cores among them, cgroup CPU quota or None)."""
+    usable = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    model, cores = "unknown", set()
+    try:
+        with open("/proc/cpuinfo") as f:
+            phys = core = proc = None
+            for line in f:
+                if line.startswith("processor"):
+                    proc = int(line.split(":")[1])
+                elif line.startswith("model name") and model == "unknown":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if proc in usable and core is not None:
+                        cores.add((phys, core))
+                    phys = core = proc = None
+    except OSError:
+        pass
+    quota = None
+    try:   # cgroup v2 CPU bandwidth limit ("max" or "<quota> <period>")
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return model, len(usable), (len(cores) or len(usable)), quota
+
+
 def cpu_baseline(workload, seconds):
-    """Times the oracle (kind 'port': the validated C restatement of the reference) on the host cores.  Each env runs its
-    control steps back to back inside one OpenMP region (envs are independent), float64, all hardware threads."""
+    """Times the oracle (kind 'port': the validated C restatement of the reference, float64) on the host cores.  Each env runs
+    its control steps back to back inside one OpenMP region (envs are independent).  Sweep over thread counts {1, physical
+    cores, usable hardware threads}: `value` is the best of them, `single_thread` the 1-thread rate."""
     from oracle import oracle as orc
     from quad_swarm_rl_amd import config as qcfg
     w = WORKLOADS[workload]
-    threads = os.cpu_count() or 1
+    model, usable, physical, quota = _host_cpu()
     num_envs = w["num_envs"]
     cfg = qcfg.make_config(num_envs=num_envs, seed=0, **w["kw"])
     batch = orc.OracleBatch(cfg, num_envs)
@@ -65,29 +110,51 @@ def cpu_baseline(workload, seconds):
     n = cfg.num_agents
     rng = np.random.RandomState(0)
     acts = rng.uniform(-1, 1, size=(16, num_envs, n, 4))
-    chunk = 50
-    batch.rollout(acts, chunk)                     # warm-up (thread pool, caches)
-    steps, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        batch.rollout(acts, chunk)
-        steps += chunk
-    dt = time.perf_counter() - t0
-    return dict(value=num_envs * n * 2 * steps / dt, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{num_envs} envs x {n} drones x {steps} control steps ({dt:.1f} s), C oracle (float64), one OpenMP region, "
-                       f"{threads} threads")
+    counts = {1, physical, usable}
+    if quota:
+        counts.add(max(1, min(usable, int(round(quota)))))
+    if usable > 64:
+        counts.add(32)   # one point in between: a box whose cgroup gives this process fewer cores than it shows
+    counts = sorted(counts)
+    per = max(seconds / len(counts), 1.0)
+    sweep, total_steps, total_dt = [], 0, 0.0
+    for th in counts:
+        batch.rollout(acts, 2, th)                      # warm-up (thread pool, caches)
+        t0 = time.perf_counter()
+        batch.rollout(acts, 4, th)
+        chunk = int(max(4, min(400, 4 * 0.25 / max(time.perf_counter() - t0, 1e-4))))   # ~0.25 s of work per call
+        steps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < per:
+            batch.rollout(acts, chunk, th)
+            steps += chunk
+        dt = time.perf_counter() - t0
+        sweep.append({"threads": th, "value": num_envs * n * 2 * steps / dt, "control_steps": steps, "seconds": dt})
+        total_steps += steps
+        total_dt += dt
+    best = max(sweep, key=lambda r: r["value"])
+    single = sweep[0]["value"]
+    return dict(value=best["value"], unit="env-steps/s", cores=best["threads"], kind="port",
+                sample=f"{num_envs} envs x {n} drones, C oracle (float64), one OpenMP region over envs; thread sweep {counts} x ~{per:.0f} s each "
+                       f"({total_steps} control steps, {total_dt:.1f} s in total); value = best of the sweep",
+                single_thread=single, drone_control_steps_per_s_per_thread=single / 2.0, sweep=sweep,
+                cpu_model=model, usable_hw_threads=usable, physical_cores=physical, cgroup_cpu_quota=quota,
+                os_cpu_count=os.cpu_count())
 
 
 def pmc_traffic(workload, num_envs, kernel):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC pass (profiles/r01_pmc_traffic.json, produced by
-    tools_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units and gfx950 corrections of MI355X_MICROARCH.md);
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC pass (profiles/rNN_pmc_traffic.json, produced by
+    tools/pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units and gfx950 corrections of MI355X_MICROARCH.md);
     None when no measurement of this workload / batch / kernel is on file."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f).get(f"{workload}:{num_envs}:{kernel}")
-        return rec["fetch_bytes"] + rec["write_bytes"] if rec else None
-    except (OSError, ValueError, KeyError):
-        return None
+    import glob
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:   # newest round first
+            with open(path) as f:
+                rec = json.load(f).get(f"{workload}:{num_envs}:{kernel}")
+            if rec:
+                return rec["fetch_bytes"] + rec["write_bytes"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def main():
@@ -95,15 +162,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 at --gpus 1, c4 (512 envs per GPU) at --gpus N>1")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's env count per GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
-    ap.add_argument("--profile-steps", type=int, default=400, help="steps of the HIP-event kernel-duration pass")
-    ap.add_argument("--gather", action="store_true", help="N>1: put ONE RCCL all-gather of the observations after every step inside the timed region "
-                                                          "(default: shards step independently; the gather variant is measured separately and reported in config)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample length in total (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=400, help="steps of the HIP-event-pair-per-launch pass")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: headline = independent shards (no collective in the timed region); the gather "
+                                                            "variant is then the secondary measurement")
+    ap.add_argument("--gather", action="store_true", help="(default at N>1) ONE RCCL all-gather of the observations after every step inside the timed region")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL obs all-gather path even at N=1 (exercises the multi-GPU code on a 1-GPU box)")
-    ap.add_argument("--no-gather", action="store_true", help="skip the separate all-gather measurement at N>1")
-    ap.add_argument("--no-overlap", action="store_true", help="N>1: gather on the compute stream instead of overlapping it with the next step")
+    ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
+    ap.add_argument("--no-overlap", action="store_true", help="gather on the compute stream instead of overlapping it with the next step")
+    ap.add_argument("--no-f64", action="store_true", help="skip the f64 line (same workload through the float64 kernels)")
     ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a workload keyword (python literal)")
     ap.add_argument("--graph", type=int, default=0, help="headline mode: step the timed region as open-loop rollouts of this many steps per "
@@ -122,8 +191,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP stepper has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    use_gather = (world > 1 and not args.no_gather) or args.force_gather or (world == 1 and args.gather)
     dist = None
-    if world > 1 or args.force_gather:
+    if world > 1 or use_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -132,7 +203,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import ast
-    w = WORKLOADS[args.workload]
+    workload = args.workload or ("c2" if world == 1 else "c4")
+    w = WORKLOADS[workload]
     kw = dict(w["kw"])
     for item in args.set:
         key, val = item.split("=", 1)
@@ -144,76 +216,78 @@ def main():
     stream = torch.cuda.current_stream(local_rank)
 
     # synthetic actions, resident in HBM before the timed region: a ring of pre-drawn U(-1,1)^4 batches
-    gen = torch.Generator(device=f"cuda:{local_rank}")
+    gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     ring = 64
-    actions = (torch.rand((ring, T, 4), device=f"cuda:{local_rank}", generator=gen, dtype=torch.float32) * 2.0 - 1.0).contiguous()
+    actions = (torch.rand((ring, T, 4), device=dev, generator=gen, dtype=torch.float32) * 2.0 - 1.0).contiguous()
     aptr, astride = actions.data_ptr(), T * 4 * 4
     obs = st.tensor("obs")
-    gather = gather_variant = None
-    if (world > 1 or args.force_gather) and not args.no_gather:
+    gather_obj = None
+    if dist is not None and (use_gather or not args.no_secondary):
         from quad_swarm_rl_amd import parallel
-        gather_variant = parallel.ObsGather(obs, overlap=not args.no_overlap)   # ONE RCCL all-gather of the obs per rollout step
-        if args.gather or args.force_gather:
-            gather = gather_variant
+        gather_obj = parallel.ObsGather(obs, overlap=not args.no_overlap)   # ONE RCCL all-gather of the obs per rollout step
 
-    def run(k, offset=0, gather=gather):
+    def run(stepper, base_ptr, stride, k, offset=0, gather=None):
         if args.graph > 0 and gather is None:
             # open-loop rollout over the action ring: qs_step_many keeps the state in registers across the steps of a launch
             g = min(args.graph, ring)
             done_steps = 0
             while done_steps + g <= k:
-                st.step_many(aptr, g, stream=stream)
+                stepper.step_many(base_ptr, g, stream=stream)
                 done_steps += g
             for t in range(k - done_steps):
-                st.step(aptr + (t % ring) * astride, stream=stream)
+                stepper.step(base_ptr + (t % ring) * stride, stream=stream)
             return
         for t in range(k):
-            st.step(aptr + ((offset + t) % ring) * astride, stream=stream)
+            stepper.step(base_ptr + ((offset + t) % ring) * stride, stream=stream)
             if gather is not None:
                 gather.gather()
         if gather is not None:
-            gather.drain()
+            gather.drain()   # the launch stream waits for the in-flight collectives: the closing event sees them
+
+    def timed(stepper, base_ptr, stride, warmup, k, gather=None):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize; HIP events on the launch stream right inside
+        the bracket.  Returns (device-event seconds, host-clock seconds), each the MAX over ranks."""
+        run(stepper, base_ptr, stride, warmup, 0, gather)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        run(stepper, base_ptr, stride, k, warmup, gather)
+        ev1.record(stream)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        host = time.perf_counter() - t0
+        devs = ev0.elapsed_time(ev1) * 1e-3
+        if dist is not None:
+            tmax = torch.tensor([devs, host], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            devs, host = (float(x) for x in tmax.tolist())
+        return devs, host
 
     st.reset(stream=stream)
-    run(args.warmup)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # HIP events on the launch stream (= torch's current stream) bracket the timed region: device-side duration of the K
-    # back-to-back step-kernel launches, i.e. the average launch-to-launch duration rocprofv3 --kernel-trace also reports
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    run(args.steps, args.warmup)
-    ev1.record(stream)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    region_kernel_ms = ev0.elapsed_time(ev1) / args.steps
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None)
     st.check_errors()
+    gather_desc = "rccl all_gather_into_tensor of the obs per step" + ("" if args.no_overlap else ", double-buffered: gather(t) overlaps step(t+1)")
 
-    # N>1: the optional collective variant (north_star: one RCCL all-gather of the observations per rollout step), timed
-    # separately with the same bracketing; `value` above is the independent-shard rate unless --gather was given
-    with_gather = None
-    if gather_variant is not None and gather is None:
-        gk = min(args.steps, 1000)
-        run(50, 0, gather_variant)
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        run(gk, 50, gather_variant)
-        dist.barrier()
-        torch.cuda.synchronize()
-        gdt = torch.tensor([time.perf_counter() - t0], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(gdt, op=dist.ReduceOp.MAX)
-        with_gather = {"value": world * T * 2 * gk / float(gdt.item()), "unit": "env-steps/s", "ms_per_step": 1e3 * float(gdt.item()) / gk, "steps": gk,
-                       "collective": "rccl all_gather_into_tensor of the obs per step" + ("" if args.no_overlap else ", overlapped with the next step")}
+    # N>1 / --force-gather: the other variant with the same bracketing (independent shards when the gather is the headline, and
+    # the other way round); its step-kernel-only region is also where the kernel duration of the roofline comes from
+    secondary = None
+    kernel_region_s, kernel_region_steps = (None, 0) if use_gather else (head_dev, args.steps)
+    if dist is not None and not args.no_secondary:
+        sk = max(args.steps, 50) if use_gather else min(max(args.steps, 50), 1000)
+        sdev, shost = timed(st, aptr, astride, min(args.warmup, 50), sk, None if use_gather else gather_obj)
+        secondary = {"value": world * T * 2 * sk / sdev, "unit": "env-steps/s", "ms_per_step": 1e3 * sdev / sk, "steps": sk,
+                     "host_clock_ms_per_step": 1e3 * shost / sk,
+                     "what": "independent shards: no data-path collective in the timed region" if use_gather else gather_desc}
+        if use_gather:
+            kernel_region_s, kernel_region_steps = sdev, sk
+    if kernel_region_s is None:   # gather headline without secondary: a short step-only region for the roofline
+        kernel_region_steps = max(args.steps, 50)
+        kernel_region_s, _ = timed(st, aptr, astride, 10, kernel_region_steps, None)
 
     # extra: the same workload as open-loop rollouts (pre-generated actions, K control steps per launch)
     rollout = None
@@ -235,36 +309,58 @@ def main():
         st.step(aptr + (t % ring) * astride, stream=stream)
     kernel_ms, launches = st.kernel_time()
     st.set_profiling(False)
+    kernel_name, flavor = st.kernel_name, ("config-specialised, " if st.specialized else "generic, ") + f"{st.waves_per_workgroup} wave{'s' if st.waves_per_workgroup > 1 else ''} per workgroup"
+    st.close()
+
+    # the same workload through the float64 instantiation (the one whose free-running flags are bit-exact against the oracle)
+    f64 = None
+    if world == 1 and not args.no_f64:
+        cfg64 = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f64", write_rew_info=args.rew_info, **kw)
+        st64 = native.Stepper(cfg64, device=local_rank)
+        act64 = actions[:16].double().contiguous()
+        st64.reset(stream=stream)
+        k64 = min(max(args.steps, 50), 500)
+        ring_save, ring = ring, 16
+        d64, h64 = timed(st64, act64.data_ptr(), T * 4 * 8, min(args.warmup, 50), k64)
+        ring = ring_save
+        st64.check_errors()
+        f64 = {"value": T * 2 * k64 / d64, "unit": "env-steps/s", "dtype": "f64", "steps": k64, "kernel_avg_us": 1e6 * d64 / k64,
+               "host_clock_ms_per_step": 1e3 * h64 / k64, "kernel": st64.kernel_name,
+               "achieved_GBs": ALGO_BYTES_F64_PER_DRONE_STEP.get(workload, 0) * T / (d64 / k64) / 1e9}
+        st64.close()
 
     if rank == 0:
-        value = world * T * 2 * args.steps / elapsed
-        algo = ALGO_BYTES_PER_DRONE_STEP[args.workload]
+        value = world * T * 2 * args.steps / head_dev
+        algo = ALGO_BYTES_PER_DRONE_STEP[workload]
+        region_kernel_ms = 1e3 * kernel_region_s / kernel_region_steps
         achieved = algo * T / (region_kernel_ms * 1e-3) / 1e9 if region_kernel_ms > 0 else 0.0
         out = {
             "metric": "env-steps/s (drones x envs x sim_steps)", "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * head_dev / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {N} drones x {E} envs per GPU, {WORKLOADS[args.workload]['kw'].get('quads_mode', 'static_same_goal')}, "
+            "config": {"workload": f"{workload}: {N} drones x {E} envs per GPU ({world * E} envs in total), {kw.get('quads_mode', 'static_same_goal')}, "
                                    f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
                        "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N,
-                       "obs_gather": ("rccl all_gather_into_tensor per step" + ("" if args.no_overlap else ", overlapped with the next step")) if gather is not None
-                                     else ("none: env shards are independent, no data-path collective (DESIGN.md 7)" if world > 1 else "none"),
-                       "with_obs_allgather": with_gather,
-                       "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and world == 1 else "one launch per control step",
-                       "open_loop_rollout": rollout, "rew_info": bool(args.rew_info),
+                       "timing": "HIP events on the launch stream inside the barrier+synchronize bracket of the K timed steps, max over ranks",
+                       "host_clock": {"ms_per_step": 1e3 * head_host / args.steps, "value": world * T * 2 * args.steps / head_host,
+                                      "note": "perf_counter over the same K steps incl. the closing barrier + synchronize"},
+                       "obs_gather": gather_desc if use_gather else ("none: env shards are independent, no data-path collective (--no-gather)" if world > 1 else "none"),
+                       "gather_bytes_per_gpu_per_step": (world - 1) * T * D * 4 if use_gather else 0,
+                       "secondary": secondary,
+                       "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and not use_gather else "one launch per control step",
+                       "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info),
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, E, st.kernel_name), "kernel": st.kernel_name,
-                         "kernel_flavor": ("config-specialised, " if st.specialized else "generic, ") + f"{st.waves_per_workgroup} wave{'s' if st.waves_per_workgroup > 1 else ''} per workgroup", "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": args.steps,
+                         "traffic": pmc_traffic(workload, E, kernel_name), "kernel": kernel_name,
+                         "kernel_flavor": flavor, "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": kernel_region_steps,
                          "kernel_avg_us_event_pair_per_launch": kernel_ms * 1e3, "event_pair_launches": launches,
                          "algorithmic_bytes_per_launch": algo * T},
         }
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(workload, args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    st.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -59,6 +59,7 @@ def lib():
         _lib.qso_set_reward_coeffs.argtypes = [C.c_void_p, dp]
         _lib.qso_step_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, dp, dp, u8p]
         _lib.qso_rollout_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, u8p]
+        _lib.qso_rollout_batch_threads.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, u8p, C.c_int32]
         _lib.qso_sizeof_config.restype = C.c_size_t
         _lib.qso_sizeof_info.restype = C.c_size_t
         _lib.qso_obs_dim.argtypes = [C.c_void_p]
@@ -153,18 +154,20 @@ class OracleBatch:
         self.envs = [OracleEnv(cfg, env_global_id=env_id_offset + k) for k in range(num_envs or cfg.num_envs)]
         self.n, self.obs_dim, self.e = cfg.num_agents, self.envs[0].obs_dim, len(self.envs)
         self._handles = (C.c_void_p * self.e)(*[e._h for e in self.envs])
+        self._out = None
 
     def reset(self):
         return np.stack([e.reset() for e in self.envs])
 
-    def rollout(self, action_ring, steps):
-        """`steps` control steps of every env inside one OpenMP region (no per-step fork/join): the CPU baseline."""
+    def rollout(self, action_ring, steps, threads=0):
+        """`steps` control steps of every env inside one OpenMP region of `threads` threads (0 = the OpenMP default; no
+        per-step fork/join): the CPU baseline."""
         a = np.ascontiguousarray(action_ring, dtype=np.float64).reshape(-1, self.e, self.n, 4)
-        obs = np.zeros((self.e, self.n, self.obs_dim))
-        rew = np.zeros((self.e, self.n))
-        done = np.zeros((self.e, self.n), dtype=np.uint8)
-        lib().qso_rollout_batch(self._handles, self.e, _dp(a), a.shape[0], steps, _dp(obs), _dp(rew),
-                                done.ctypes.data_as(C.POINTER(C.c_uint8)))
+        if self._out is None:
+            self._out = (np.zeros((self.e, self.n, self.obs_dim)), np.zeros((self.e, self.n)), np.zeros((self.e, self.n), dtype=np.uint8))
+        obs, rew, done = self._out
+        lib().qso_rollout_batch_threads(self._handles, self.e, _dp(a), a.shape[0], steps, _dp(obs), _dp(rew),
+                                        done.ctypes.data_as(C.POINTER(C.c_uint8)), int(threads))
         return obs, rew, done
 
     def step(self, actions):

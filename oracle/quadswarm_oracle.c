@@ -17,6 +17,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define GRAV 9.81
 #define EPS_DYN 1e-6 /* quadrotor_dynamics.py:13 */
@@ -645,8 +648,7 @@ static void collide_room(qso_env *e, int i, int is_wall) {
 static int downwash(qso_env *e) {
     const qs_config *c = &e->c;
     int N = c->num_agents, any = 0;
-    double dt = 1.0 / (1.0 / (c->dt * c->sim_steps)); /* control_dt = 1/control_freq */
-    dt = c->dt * c->sim_steps; /* 0.01 */
+    const double dt = c->dt * c->sim_steps; /* control_dt = 1/control_freq = 0.01 */
     double pos[MAXN][3], zax[MAXN][3];
     for (int i = 0; i < N; ++i) {
         memcpy(pos[i], e->d[i].pos, sizeof pos[i]);
@@ -1529,20 +1531,42 @@ void qso_set_state(qso_env *e, const double *s, int32_t tick) {
 
 /* CPU-baseline rollout: every env runs `steps` control steps back to back inside ONE parallel region (envs are
  * independent, so there is no per-step fork/join).  actions: ring[ring_len][num][N*4]; obs/rew/done receive the last
- * step's outputs ([num][N*obs_dim] etc.). */
+ * step's outputs ([num][N*obs_dim] etc.).  Each env steps into thread-local scratch and publishes its last outputs once:
+ * the shared `done` / `rew` arrays hold 8 / 64 bytes per env, so stepping straight into them makes neighbouring envs (=
+ * different threads) fight over cache lines on every step.  threads <= 0: the OpenMP default. */
+void qso_rollout_batch_threads(qso_env **envs, int32_t num, const double *actions, int32_t ring_len, int32_t steps,
+                               double *obs, double *rew, uint8_t *done, int32_t threads) {
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+#endif
+    {
+        double *lobs = NULL, lrew[MAXN];
+        uint8_t ldone[MAXN];
+        size_t lobs_n = 0;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int32_t k = 0; k < num; ++k) {
+            qso_env *e = envs[k];
+            const int N = e->c.num_agents;
+            const size_t per_step = (size_t)num * N * 4, need = (size_t)N * e->obs_dim;
+            if (need > lobs_n) { free(lobs); lobs = (double *)malloc(need * sizeof(double)); lobs_n = need; }
+            for (int32_t t = 0; t < steps; ++t)
+                qso_step(e, actions + per_step * (size_t)(t % ring_len) + (size_t)k * N * 4, lobs, lrew, ldone, NULL);
+            if (steps > 0) {
+                memcpy(obs + (size_t)k * need, lobs, need * sizeof(double));
+                memcpy(rew + (size_t)k * N, lrew, (size_t)N * sizeof(double));
+                memcpy(done + (size_t)k * N, ldone, (size_t)N);
+            }
+        }
+        free(lobs);
+    }
+}
+
 void qso_rollout_batch(qso_env **envs, int32_t num, const double *actions, int32_t ring_len, int32_t steps,
                        double *obs, double *rew, uint8_t *done) {
-#ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1)
-#endif
-    for (int32_t k = 0; k < num; ++k) {
-        qso_env *e = envs[k];
-        const int N = e->c.num_agents;
-        const size_t per_step = (size_t)num * N * 4;
-        for (int32_t t = 0; t < steps; ++t)
-            qso_step(e, actions + per_step * (size_t)(t % ring_len) + (size_t)k * N * 4, obs + (size_t)k * N * e->obs_dim,
-                     rew + (size_t)k * N, done + (size_t)k * N, NULL);
-    }
+    qso_rollout_batch_threads(envs, num, actions, ring_len, steps, obs, rew, done, 0);
 }
 
 void qso_step_batch(qso_env **envs, int32_t num, const double *actions, double *obs, double *rew, uint8_t *done) {

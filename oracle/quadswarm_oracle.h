@@ -62,6 +62,9 @@ void qso_step_batch(qso_env **envs, int32_t num, const double *actions, double *
 
 void qso_rollout_batch(qso_env **envs, int32_t num, const double *actions, int32_t ring_len, int32_t steps,
                        double *obs, double *rew, uint8_t *done);
+/* the same on `threads` OpenMP threads (<= 0: the OpenMP default) */
+void qso_rollout_batch_threads(qso_env **envs, int32_t num, const double *actions, int32_t ring_len, int32_t steps,
+                               double *obs, double *rew, uint8_t *done, int32_t threads);
 
 /* exposed pieces for unit tests (known-answer tests of the reference's own test-suite) */
 void qso_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

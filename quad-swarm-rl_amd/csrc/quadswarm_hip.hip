@@ -185,7 +185,7 @@ static bool spec_key(const std::string &header, std::string &key) {
     uint64_t h = fnv1a(14695981039346656037ull, header);
     h = fnv1a(h, kSpecFlags);
     h = fnv1a(h, kSpecFlagsF32);
-    if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools_phase_timing.py
+    if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools/phase_timing.py
     const std::string dir = lib_dir();
     for (const char *src : kSpecSources) {
         std::string text;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> <workload> [bench args...]   (run on the GPU box through gpurun)
+# usage: tools/pmc.sh <tag> <workload> [bench args...]   (run on the GPU box through gpurun)
 # rocprofv3 PMC passes of the step kernel, each in its own run with --kernel-trace only (the node pool refuses PMC together
 # with other trace domains).  Writes gpurun_out/pmc_<tag>_summary.txt and gpurun_out/pmc_<tag>_traffic.json
 # (per-launch means; FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3).

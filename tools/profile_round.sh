@@ -11,5 +11,5 @@ for wl in c2 c3 c4; do
   cat $R/gpurun_out/kt_${tag}_${wl}_stats.txt
 done
 cd $R
-for wl in c2 c4; do bash tools_pmc.sh ${tag}_$wl $wl | tail -3; done
-bash tools_pmc.sh ${tag}_c2_E131072 c2 --envs-per-gpu 131072 | tail -3
+for wl in c2 c4; do bash tools/pmc.sh ${tag}_$wl $wl | tail -3; done
+bash tools/pmc.sh ${tag}_c2_E131072 c2 --envs-per-gpu 131072 | tail -3
