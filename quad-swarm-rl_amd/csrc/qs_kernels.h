@@ -90,26 +90,35 @@ __device__ __forceinline__ unsigned long long nbr_key(float m, int idx) {
 #endif
 
 struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
-                   int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit; };
-#define QS_RESET_SCRATCH_INTS 160   // per env: virtual-pool index/value lists (2x64) + two DP rows (2x16)
+                   int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit;
+                   int stage_cols, nbr_per_pass, scr_cap; };   // single-wave kernels: observation columns staged per pass (see obs_flush)
+#define QS_RESET_SCRATCH_INTS 160   // per env, full scenario set: virtual-pool index/value lists (2x64) + two DP rows (2x16)
 
-static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K, int team /* waves per workgroup of the team kernels, 0 = single-wave */) {
+// Single-wave (throughput) kernels stage the observation rows in column groups - the self part, then the neighbours a few at a
+// time, then the SDF cells - through one small buffer (obs_flush), so that a workgroup needs ~9-10 KB of LDS instead of ~21 KB
+// and 16 of them fit a CU (4 waves per SIMD); the team kernels (small batches, occupancy irrelevant) keep whole rows.
+static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K, int team /* waves per workgroup of the team kernels, 0 = single-wave */,
+                            bool full /* kernels of the full scenario set: per-env scenario state in LDS */, int scenario = -1) {
     LdsLayout L;
     memset(&L, 0, sizeof L);
     int o = 0;
     L.off_mask = o; o += 8 * B;                       // u64 per lane: new-pair masks for the serial response path
-    L.off_omap = o; o += 8 * 4 * epb;                 // full-scenario kernels: obstacle map bitset, scenario ints / reals per env
-    L.off_si = o; o += 4 * SI_COUNT * epb;
-    L.off_sr = o; o += real_size * SR_COUNT * epb;
+    L.off_omap = o; o += full ? 8 * 4 * epb : 0;      // full-scenario kernels: obstacle map bitset, scenario ints / reals per env
+    L.off_si = o; o += full ? 4 * SI_COUNT * epb : 0;
+    L.off_sr = o; o += full ? real_size * SR_COUNT * epb : 0;
     o = (o + 15) & ~15;
     L.off_envflag = o; o += 4 * ((2 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods
-    L.off_scratch = o; o += num_obst > 0 ? 4 * QS_RESET_SCRATCH_INTS * epb : 0;   // only the obstacle-map / free-cell code uses it
+    // reset scratch per env: virtual-pool index / value lists (2 x cap: at most one entry per obstacle / per drone) + two DP rows
+    // (2 x 16); the full scenario set keeps the fixed 2 x 64 split its scenario code addresses
+    L.scr_cap = full ? 64 : (num_obst > N ? num_obst : N);
+    L.off_scratch = o; o += num_obst > 0 ? 4 * (2 * L.scr_cap + 32) * epb : 0;   // only the obstacle-map / free-cell code uses it
     o = (o + 15) & ~15;
     L.off_pos = o; o += real_size * 3 * B;
     L.off_vel = o; o += real_size * 3 * B;
     L.off_zax = o; o += real_size * 3 * B;            // body z axes (downwash); spawn points in the reset tail
     L.off_om = o; o += real_size * 3 * B;
-    L.goal_rows = 2 * N + 8;
+    // goal scratch rows per env: two formations (+ sphere padding) for swarm_vs_swarm and the full scenario set, one otherwise
+    L.goal_rows = (full || scenario < 0 || scenario == QS_SCENARIO_SWARM_VS_SWARM) ? 2 * N + 8 : (N < 3 ? 3 : N);
     L.off_goal = o; o += real_size * 3 * L.goal_rows * epb;
     L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
     // neighbour metric rows [N][B]; team kernels with N > 8: one sorted top-8 list per wave, metrics [8W][B] + indices [8W][B]
@@ -124,7 +133,10 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
         L.off_t_ohit = o; o += 4 * B;
         o = (o + 15) & ~15;
     }
-    L.off_obs = o; o += real_size * obs_dim * B;      // observation staging, row-major, contiguous
+    const int self_dim = obs_dim - 6 * K - (num_obst > 0 ? 9 : 0);
+    L.nbr_per_pass = 3;
+    L.stage_cols = team ? obs_dim : (self_dim > 6 * L.nbr_per_pass ? self_dim : 6 * L.nbr_per_pass);
+    L.off_obs = o; o += real_size * L.stage_cols * B;   // observation staging: whole rows (team) / one column group (single-wave)
     L.total = (o + 15) & ~15;
     return L;
 }
@@ -268,6 +280,150 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streamed observation output of the single-wave kernels.  A column group [col0, col0 + ncols) of the workgroup's rows is
+// staged densely in LDS (row r at s_stage[r * ncols .. + ncols)) and copied to the row-major observation matrix by the whole
+// wave: consecutive lanes write consecutive words of a row's group, so a store instruction covers a few ncols*4-byte runs.
+// rowmask selects the rows to write (auto-reset rewrites only the rows of finished environments).  Must be called by the
+// whole wave, between barriers that order it against the staging writes.
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+__device__ __forceinline__ void obs_flush(real *__restrict__ dst_block, const real *s_stage, int D, int col0, int ncols, int nrows, uint64_t rowmask, int tid) {
+    if (sizeof(real) == 4 && ((D | col0 | ncols) & 1) == 0) {   // 8-byte elements: row starts (D*4 bytes apart) and group starts stay 8-byte aligned
+        const int half = ncols >> 1, total = nrows * half;
+        const float2 *src2 = (const float2 *)s_stage;
+        for (int idx = tid; idx < total; idx += QS_WAVE) {
+            const int row = idx / half, cp2 = idx - row * half;
+            if ((rowmask >> row) & 1) *(float2 *)((float *)dst_block + (size_t)row * D + col0 + 2 * cp2) = src2[idx];
+        }
+    } else {
+        const int total = nrows * ncols;
+        for (int idx = tid; idx < total; idx += QS_WAVE) {
+            const int row = idx / ncols, cc = idx - row * ncols;
+            if ((rowmask >> row) & 1) dst_block[(size_t)row * D + col0 + cc] = s_stage[idx];
+        }
+    }
+}
+
+// K-nearest neighbour selection of one drone, split into "select once" + "emit the neighbours of ranks [k0, k1)" so that the
+// rows can be staged a few neighbours at a time (same four cases and the same results as neighbor_obs above).
+template <typename real> struct NbrSel {
+    int bi[8];                 // K <= 8: indices of the (up to 8) nearest in order
+    uint64_t taken;            // 8 < K < N-1: drones already emitted (arg-min rounds over the LDS metric column)
+};
+template <typename real>
+__device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
+                                           real *s_metric, const real mypos[3], const real myvel[3], NbrSel<real> &S) {
+    const int K = c.num_neighbors;
+    S.taken = 1ull << i;
+    if (K <= 0 || K == N - 1) return;
+    if (N <= 8) {   // all candidates at once, rank-by-counting (independent compares), then the inverse permutation: only the 8 indices
+        real mj[8];  // stay live (the emit re-reads the chosen drones from LDS: registers decide the occupancy of this kernel)
+        int rank[8];
+        {
+            real rp[8][3], rv[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {        // 48 LDS reads issued before the first use: one round trip
+                const int j = (u < N) ? u : N - 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                real rd = M<real>::fmax(norm3<real>(rp[u]), (real)0.01);
+                real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) * M<real>::rcp(rd);
+                mj[u] = (u < N && u != i) ? m : (real)3.4e38;
+                rank[u] = 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank[u] += (int)((mj[k] < mj[u]) | ((mj[k] == mj[u]) & (k < u)));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int b = 0;
+#pragma unroll
+            for (int u = 1; u < 8; ++u) b = (rank[u] == k) ? u : b;   // the ranks are a permutation of 0..7
+            S.bi[k] = b;
+        }
+        return;
+    }
+    if (K <= 8) {   // streaming sorted top-8 (metric, index) list; a candidate goes behind entries with an equal metric (lower index first)
+        real bm[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { bm[k] = (real)3.4e38; S.bi[k] = 0; }
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            real rp[4][3], rv[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = (j0 + u < N) ? j0 + u : N - 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                real rd = M<real>::fmax(norm3<real>(rp[u]), (real)0.01);
+                real m = rd + (rp[u][0] * rv[u][0] + rp[u][1] * rv[u][1] + rp[u][2] * rv[u][2]) * M<real>::rcp(rd);
+                m = (j < N && j != i) ? m : (real)3.4e38;
+                int mi = j;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool lt = m < bm[k];
+                    const real tm = lt ? bm[k] : m;
+                    const int ti = lt ? S.bi[k] : mi;
+                    bm[k] = lt ? m : bm[k];
+                    S.bi[k] = lt ? mi : S.bi[k];
+                    m = tm; mi = ti;
+                }
+            }
+        }
+        return;
+    }
+    for (int j = 0; j < N; ++j) {   // 8 < K < N-1: metrics into this lane's LDS column
+        real rp[3] = {s_pos[0 * B + base + j] - mypos[0], s_pos[1 * B + base + j] - mypos[1], s_pos[2 * B + base + j] - mypos[2]};
+        real rv[3] = {s_vel[0 * B + base + j] - myvel[0], s_vel[1 * B + base + j] - myvel[1], s_vel[2 * B + base + j] - myvel[2]};
+        real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
+        real mm = rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) * M<real>::rcp(rd);
+        s_metric[j * B + tid] = (j == i) ? (real)3.4e38 : mm;
+    }
+}
+// neighbours of ranks [k0, k1) -> o[(rank - k0) * 6 ..]   (o = this lane's dense stage row of (k1 - k0) * 6 columns)
+template <typename real>
+__device__ __forceinline__ void nbr_emit(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
+                                         const real *s_metric, const real mypos[3], const real myvel[3], NbrSel<real> &S, int k0, int k1, real *o) {
+    const int K = c.num_neighbors;
+    for (int k = k0; k < k1; ++k) {
+        int j;
+        if (K == N - 1) j = (k < i) ? k : k + 1;   // all other drones in index order (:253-254)
+        else if (K <= 8) {
+            j = S.bi[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) j = (q == k) ? S.bi[q] : j;   // register array: select, no dynamic indexing
+        } else {   // arg-min round over the LDS metric column (lowest index wins ties)
+            int best = -1;
+            real bmin = (real)3.4e38;
+            for (int jj = 0; jj < N; ++jj) {
+                real mm = s_metric[jj * B + tid];
+                bool better = !(S.taken >> jj & 1) && (best < 0 || mm < bmin);
+                best = better ? jj : best;
+                bmin = better ? mm : bmin;
+            }
+            S.taken |= 1ull << best;
+            j = best;
+        }
+        real vals[6];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { vals[a] = s_pos[a * B + base + j] - mypos[a]; vals[3 + a] = s_vel[a * B + base + j] - myvel[a]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            o[(k - k0) * 6 + a] = clipr<real>(vals[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
+            o[(k - k0) * 6 + 3 + a] = clipr<real>(vals[3 + a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
+        }
+    }
+}
+
 // get_surround_sdfs obstacles/utils.py:5-27 (obstacle xy of the env in LDS)
 template <typename real>
 __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o) {
@@ -288,6 +444,30 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) o[q] = mind[q] - c.obst_radius;
+}
+
+// The neighbour and SDF columns of the wave's rows, staged and flushed a column group at a time.  Whole wave; `live` lanes
+// compute (their rows are the ones in rowmask).  s_stage must not hold anything still to be flushed.
+template <typename real>
+__device__ __forceinline__ void stream_nbr_sdf(const Consts<real> &c, const LdsLayout &L, real *__restrict__ dst_block, real *s_stage, int N, int i, int le, int base, int tid,
+                                               const real *s_pos, const real *s_vel, real *s_metric, const real *s_obst, const real mypos[3], const real myvel[3],
+                                               bool live, int nrows, uint64_t rowmask) {
+    const int B = QS_WAVE, K = c.num_neighbors, D = c.obs_dim, M_ = c.num_obstacles;
+    NbrSel<real> S;
+    if (live) nbr_select<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, S);
+    for (int k0 = 0; k0 < K; k0 += L.nbr_per_pass) {
+        const int k1 = (k0 + L.nbr_per_pass < K) ? k0 + L.nbr_per_pass : K, ncols = 6 * (k1 - k0);
+        __syncthreads();   // the previous group has been read out of the stage
+        if (live) nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, S, k0, k1, s_stage + tid * ncols);
+        __syncthreads();
+        obs_flush<real>(dst_block, s_stage, D, c.self_dim + 6 * k0, ncols, nrows, rowmask, tid);
+    }
+    if (c.use_obstacles) {
+        __syncthreads();
+        if (live) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], s_stage + tid * 9);
+        __syncthreads();
+        obs_flush<real>(dst_block, s_stage, D, c.self_dim + 6 * K, 9, nrows, rowmask, tid);
+    }
 }
 
 // perform_collision_between_drones collisions/quadrotors.py:24-59 on LDS-resident vel/omega (serial per env)
@@ -369,7 +549,7 @@ __device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLay
 // per-env global scratch (obstacle positions, scenario state).  `stale_vel` are the previous episode's final
 // velocities: the first neighbour obs of an episode is computed from them (SURVEY App. A reset quirk).
 // ------------------------------------------------------------------------------------------------
-template <typename real, bool FULL, bool TEAM = false>
+template <typename real, bool FULL, bool TEAM = false, bool STREAM = false>
 __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem, int epb, const RngKey &key,
                                         bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3]) {
     const Consts<real> &c = *cp;
@@ -383,8 +563,8 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
     const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
     const int M_ = c.num_obstacles;
-    real *myobs = s_obs + tid * c.obs_dim;
-    int *tidx = (int *)(smem + L.off_scratch) + le * QS_RESET_SCRATCH_INTS, *tval = tidx + 64, *prev_row = tidx + 128, *cur_row = tidx + 144;
+    real *myobs = s_obs + tid * (STREAM ? c.self_dim : c.obs_dim);   // STREAM: the stage holds one column group at a time
+    int *tidx = (int *)(smem + L.off_scratch) + le * (2 * L.scr_cap + 32), *tval = tidx + L.scr_cap, *prev_row = tidx + 2 * L.scr_cap, *cur_row = prev_row + 16;
 
     // ---- per-env part (one lane): obstacle map + scenario.reset() ----
     if (do_reset && i == 0) {
@@ -525,7 +705,14 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         self_obs<real>(c, sn, d, goal, myobs);
     }
     if (TEAM) QS_WAVE_SYNC(); else __syncthreads();
-    if (do_reset) {
+    if (STREAM) {   // single-wave kernels: rows of the re-initialised envs go out a column group at a time
+        const uint64_t rowmask = __ballot(do_reset);
+        const int first_env = blockIdx.x * epb;
+        int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
+        real *dst_block = p.obs + (size_t)first_env * N * c.obs_dim;
+        obs_flush<real>(dst_block, s_obs, c.obs_dim, 0, c.self_dim, nenv * N, rowmask, tid);
+        stream_nbr_sdf<real>(c, L, dst_block, s_obs, N, i, le, base, tid, s_pos, s_vel, s_metric, s_obst, d.pos, stale_vel, do_reset, nenv * N, rowmask);
+    } else if (do_reset) {
         neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, stale_vel, myobs + c.self_dim);
         if (c.use_obstacles)
             sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors);
@@ -547,7 +734,6 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
     extern __shared__ __align__(16) unsigned char smem[];
     const Consts<real> *cp = &c;
     const int N = c.num_agents, E = c.num_envs, T = E * N;
-    real *s_obs = (real *)(smem + L.off_obs);
     const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le;
     const bool in_range = (le < epb) && (e < E);
     const bool do_reset = in_range && p.reset_mask[e] != 0;
@@ -560,7 +746,7 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
     d.flags = p.flags[g];
     if (FULL && in_range) scen_lds_load<real>(p, L, smem, E, e, le, i, N);
     if (FULL) __syncthreads();
-    reset_body<real, FULL>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);
+    reset_body<real, FULL, false, true>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);   // writes the obs rows itself
     if (FULL) { __syncthreads(); if (do_reset) scen_lds_store<real>(p, L, smem, E, e, le, i, N); }
     if (do_reset) {
 #pragma unroll
@@ -576,9 +762,6 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
         if (c.episode_sums) {
             for (int q = 0; q < QS_SUM_COUNT; ++q) p.run_sums[q * T + g] = 0;
         }
-        const real *myobs = s_obs + tid * c.obs_dim;
-        real *dst = p.obs + (size_t)g * c.obs_dim;
-        for (int q = 0; q < c.obs_dim; ++q) dst[q] = myobs[q];
         if (i == 0) {
             for (int q = 0; q < QS_CNT_COUNT; ++q) p.counters[q * E + e] = 0;
             p.tick[e] = 0;

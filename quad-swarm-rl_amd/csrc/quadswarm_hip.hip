@@ -131,7 +131,7 @@ static int spec_team_waves(int num_agents) { return num_agents <= 8 ? 8 : 4; }
 
 static std::string spec_header_text(const qs_config *cfg, int team) {
     const int rs = cfg->precision == QS_PRECISION_F64 ? 8 : 4, epb = QS_WAVE / cfg->num_agents;
-    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team);
+    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team, scenario_is_full(cfg->scenario), cfg->scenario);
     std::vector<uint32_t> w;
     if (rs == 8) { Consts<double> k; fill_consts<double>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0; k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
                    w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
@@ -271,7 +271,8 @@ static int validate(const qs_config *c) {
         if (c->obst_area[0] * c->obst_area[1] - c->num_obstacles < c->num_agents) return fail(QS_ERR_INVALID, "not enough free cells to spawn the drones");
     }
     {
-        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents, qs_obs_dim(c), c->num_obstacles, c->num_neighbors, true);
+        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents, qs_obs_dim(c), c->num_obstacles, c->num_neighbors,
+                                 spec_team_waves(c->num_agents) /* the largest layout qs_create may pick */, scenario_is_full(c->scenario), c->scenario);
         if (L.total > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "observation staging does not fit the 160 KiB LDS of a CU");
     }
     if (c->sim_steps < 1 || c->ep_len < 1 || c->svd_period < 1 || c->svd_period > 255) return fail(QS_ERR_INVALID, "bad sim_steps/ep_len/svd_period");
@@ -441,7 +442,7 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         const char *ev = getenv("QS_SPEC"), *tv = getenv("QS_TEAM");
         const std::string mode = (ev && ev[0]) ? ev : "jit";
         const int spec_team = h->team ? ((tv && tv[0] == '4') ? 4 : ((tv && tv[0] == '8') ? 8 : spec_team_waves(cfg->num_agents))) : 0;
-        const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, spec_team);
+        const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, spec_team, scenario_is_full(cfg->scenario), cfg->scenario);
         if (mode != "off" && mode != "0" && sl.total <= 64 * 1024) {
             const std::string path = spec_ensure(cfg, spec_team, mode == "jit");
             if (!path.empty()) {
@@ -461,7 +462,7 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
             }
         }
     }
-    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team);
+    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team, scenario_is_full(cfg->scenario), cfg->scenario);
     h->full = scenario_is_full(cfg->scenario);
     rc = (h->real_size == 8) ? create_typed<double>(h) : create_typed<float>(h);
     if (rc == QS_OK) {

@@ -266,13 +266,27 @@ def test_rollout_f64_bit_exact_discrete(case):
     rollout_f64(case, E, steps, tol)
 
 
-@pytest.mark.parametrize("case", ["e_n64_k20", "e_n64_k6", "e_n33_k8", "e_n40_kall", "c2_n8_dw", "c3_n8_obst"])
+SINGLE_WAVE_CASES = ["c1_single", "c2_n8_dw", "c2_n8_k2_numpy_wall", "c2_n5_kall_short", "c3_n8_obst", "c3_n8_obst_short", "c4_n32_svs",
+                     "c4_n12_svs_short", "s_static_diff", "s_mix", "s_mix_obst", "s_o_random", "s_dynamic_formations",
+                     "e_n64_k20", "e_n64_k6", "e_n33_k8", "e_n40_kall", "e_n17_kall_obst", "e_n1_obst", "x_ep_len2", "x_svs_odd", "x_n40_obst",
+                     "x_n8_blind"]
+
+
+@pytest.mark.parametrize("case", SINGLE_WAVE_CASES)
 def test_rollout_f64_single_wave_kernels(case, monkeypatch):
-    """The same rollouts through the one-wave-per-workgroup kernels that large batches select (QS_TEAM=0)."""
+    """The same rollouts through the one-wave-per-workgroup kernels that large batches select (QS_TEAM=0): streamed observation
+    rows, late loads / early stores (qs_step_kernel.inc)."""
     monkeypatch.setenv("QS_TEAM", "0")
-    pr = rollout_f64(case, 3, 40, 1e-8, keep=True)
+    pr = rollout_f64(case, 11 if case.startswith(("c", "s_")) else 3, 45, 1e-8, keep=True)
     assert not pr.hip.team
     pr.close()
+
+
+@pytest.mark.parametrize("case", SINGLE_WAVE_CASES)
+def test_teacher_forced_f32_single_wave_kernels(case, monkeypatch):
+    """fp32 production precision through the single-wave kernels (the ones every batch above ~3000 envs runs)."""
+    monkeypatch.setenv("QS_TEAM", "0")
+    teacher_forced_f32(case, 7, 60, 1e-5, expect_team=False)
 
 
 def rollout_f64(case, E, steps, tol, keep=False):
@@ -316,7 +330,13 @@ def rollout_f64(case, E, steps, tol, keep=False):
                                   "x_n40_obst"])
 def test_teacher_forced_f32(case):
     E, steps, tol = (3, LONG[case], 1e-5) if case in LONG else (7, 60, 1e-5)
+    teacher_forced_f32(case, E, steps, tol)
+
+
+def teacher_forced_f32(case, E, steps, tol, expect_team=None):
     pr = Pair(case, E, "f32")
+    if expect_team is not None:
+        assert bool(pr.hip.team) == expect_team
     rng = np.random.RandomState(9)
     oobs, hobs = pr.reset()
     np.testing.assert_allclose(hobs, oobs, rtol=0, atol=2e-5)
