@@ -189,7 +189,8 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out);
 int qs_destroy(qs_handle *h);
 
 /* Episode reset (QuadrotorEnvMulti.reset, quadrotor_multi.py:339-411) of the envs whose byte in
- * env_mask_host is nonzero (NULL = all).  Asynchronous on `stream` (a hipStream_t, NULL = default). */
+ * env_mask_host is nonzero (NULL = all).  Asynchronous on `stream` (a hipStream_t, NULL = default).
+ * Takes the env's next draw counter (like a step), so consecutive resets start different episodes. */
 int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream);
 
 /* One control step for all envs (QuadrotorEnvMulti.step, quadrotor_multi.py:413-724), including the
@@ -229,6 +230,19 @@ int qs_check_errors(qs_handle *h);
  * profiling is enabled with qs_set_profiling(h, 1). */
 int qs_set_profiling(qs_handle *h, int32_t enable);
 int qs_get_kernel_time(qs_handle *h, double *avg_ms, int64_t *launches);
+
+/*
+ * Noise tape (test instrument).  tape_host = [num_envs][len_per_env] float64: for every
+ * environment the sequence of random draws the REFERENCE made (values in their final units, in its call order -
+ * oracle/ref_harness/capture.py records them from the reference's numpy streams).  While a tape is set, qs_reset /
+ * qs_step run a float64 flavour of the kernels in which every draw pops the tape instead of the counter-based stream,
+ * so that a fixture captured from the reference (actions + tape + outputs) is replayed straight through the HIP
+ * arithmetic (tests/test_hip_vs_reference.py) - the method of gym_art/quadrotor_multi/tests/test_numba_opt.py:59-119,
+ * which compares two implementations under identical injected noise.  Requires QS_PRECISION_F64; NULL / 0 returns to the
+ * Philox stream.  qs_get_tape_pos: draws consumed so far, per environment.
+ */
+int qs_set_noise_tape(qs_handle *h, const double *tape_host, int64_t len_per_env);
+int qs_get_tape_pos(qs_handle *h, int32_t *pos_host /* [num_envs] */);
 
 /*
  * Environment snapshots: device-side deep copies of single environments, replacing `deepcopy(self.env)` of the

@@ -1459,6 +1459,7 @@ void qso_step(qso_env *e, const double *actions, double *obs, double *rew, uint8
 
 void qso_reset(qso_env *e, double *obs_out) {
     double *tmp = obs_out ? obs_out : (double *)malloc(sizeof(double) * e->c.num_agents * e->obs_dim);
+    e->step_ctr += 1;   /* an explicit reset takes the next draw counter, like a step (include/quadswarm.h: qs_reset) */
     env_reset(e, tmp);
     e->info.tick = e->tick;
     for (int i = 0; i < e->c.num_agents; ++i) e->info.flags[i] = e->d[i].flags;

@@ -99,7 +99,24 @@ template <typename real> __device__ __forceinline__ real dot3(const real a[3], c
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10, the stream specified in include/quadswarm.h
 // ------------------------------------------------------------------------------------------------
-struct RngKey { uint32_t k0, k1, env, step; };
+// QS_TAPE builds (qs_tape_kernels.hip: the test-only "noise tape" flavour behind qs_set_noise_tape): a key also carries the
+// environment's sequential tape of reference draws (values in final units, in the reference's call order - SURVEY App. B) and
+// a lane-local cursor.  Every draw primitive below then pops the tape instead of running Philox; the kernels serialise
+// the lanes of an environment wherever the reference's draw order is data-dependent.
+struct RngKey { uint32_t k0, k1, env, step;
+#ifdef QS_TAPE
+                const double *tape; int *cur;
+#endif
+};
+#ifdef QS_TAPE
+#define QS_ON_TAPE(k) ((k).tape != nullptr)
+__device__ __forceinline__ double tape_pop(const RngKey &k) { return k.tape[(*k.cur)++]; }
+__device__ __forceinline__ void tape_skip(const RngKey &k, int n) { *k.cur += n; }
+#else
+#define QS_ON_TAPE(k) false
+__device__ __forceinline__ double tape_pop(const RngKey &) { return 0.0; }
+__device__ __forceinline__ void tape_skip(const RngKey &, int) {}
+#endif
 
 __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t w[4]) {
 #pragma unroll
@@ -138,8 +155,14 @@ __device__ __forceinline__ void philox4x32_x4(const uint32_t c0_in[4], uint32_t 
 
 template <typename real> __device__ __forceinline__ real u01(uint32_t x) { return ((real)(x >> 9) + (real)0.5) * (real)(1.0 / 8388608.0); }
 
-// n <= 4 standard normals (Box-Muller on word pairs (0,1),(2,3))
+// n <= 4 standard normals (Box-Muller on word pairs (0,1),(2,3)); on a tape: the next NN recorded draws (the tape holds the
+// reference's values in their final units, so tape-aware callers use rng_normal_s with the scale the reference passed)
 template <typename real, int NN> __device__ __forceinline__ void rng_normal(const RngKey &k, int site, int slot, int i, int j, real z[NN]) {
+    if (QS_ON_TAPE(k)) {
+#pragma unroll
+        for (int q = 0; q < NN; ++q) z[q] = (real)tape_pop(k);
+        return;
+    }
     uint32_t w[4];
     rng_words(k, site, slot, i, j, w);
     real r0 = M<real>::sqrt((real)-2.0 * M<real>::log_u01(u01<real>(w[0]))), s0, c0;
@@ -153,6 +176,14 @@ template <typename real, int NN> __device__ __forceinline__ void rng_normal(cons
         if (NN > 3) z[3] = r1 * s1;
     }
 }
+// NN <= 4 draws of normal(0, scale): scale * z from the stream, the recorded value from a tape
+template <typename real, int NN> __device__ __forceinline__ void rng_normal_s(const RngKey &k, int site, int slot, int i, int j, real scale, real out[NN]) {
+    rng_normal<real, NN>(k, site, slot, i, j, out);
+    if (!QS_ON_TAPE(k)) {
+#pragma unroll
+        for (int q = 0; q < NN; ++q) out[q] = scale * out[q];
+    }
+}
 template <typename real> __device__ __forceinline__ void box_muller4(const uint32_t w[4], real z[4]) {
     real r0 = M<real>::sqrt((real)-2.0 * M<real>::log_u01(u01<real>(w[0]))), s0, c0;
     M<real>::sincos2pi(u01<real>(w[1]), &s0, &c0);
@@ -162,6 +193,11 @@ template <typename real> __device__ __forceinline__ void box_muller4(const uint3
 }
 
 template <typename real, int NN> __device__ __forceinline__ void rng_uniform(const RngKey &k, int site, int slot, int i, int j, real lo, real hi, real u[NN]) {
+    if (QS_ON_TAPE(k)) {
+#pragma unroll
+        for (int q = 0; q < NN; ++q) u[q] = (real)tape_pop(k);
+        return;
+    }
     uint32_t w[4];
     rng_words(k, site, slot, i, j, w);
 #pragma unroll
@@ -401,36 +437,31 @@ template <typename real> struct SensNoise { real p[3], v[3], w[3], th[3]; };
 
 template <typename real>
 __device__ __forceinline__ void sensor_noise_draw(const Consts<real> &c, const RngKey &key, int drone, int pass, SensNoise<real> &n) {
-    real z[3], u[3];
-    rng_normal<real, 3>(key, QS_SITE_SENS_POS_N, pass, drone, 0, z);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) n.p[q] = c.pos_norm_std * z[q];
-    if (c.pos_unif_range != (real)0) {
+    // on a tape every group of sensor_noise.py:128-168 is present, also the uniform(-0, 0) ones and the accelerometer's 6 draws
+    const bool tape = QS_ON_TAPE(key);
+    real u[3];
+    rng_normal_s<real, 3>(key, QS_SITE_SENS_POS_N, pass, drone, 0, c.pos_norm_std, n.p);
+    if (tape || c.pos_unif_range != (real)0) {
         rng_uniform<real, 3>(key, QS_SITE_SENS_POS_U, pass, drone, 0, -c.pos_unif_range, c.pos_unif_range, u);
 #pragma unroll
         for (int q = 0; q < 3; ++q) n.p[q] += u[q];
     }
-    rng_normal<real, 3>(key, QS_SITE_SENS_VEL_N, pass, drone, 0, z);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) n.v[q] = c.vel_norm_std * z[q];
-    if (c.vel_unif_range != (real)0) {
+    rng_normal_s<real, 3>(key, QS_SITE_SENS_VEL_N, pass, drone, 0, c.vel_norm_std, n.v);
+    if (tape || c.vel_unif_range != (real)0) {
         rng_uniform<real, 3>(key, QS_SITE_SENS_VEL_U, pass, drone, 0, -c.vel_unif_range, c.vel_unif_range, u);
 #pragma unroll
         for (int q = 0; q < 3; ++q) n.v[q] += u[q];
     }
-    rng_normal<real, 3>(key, QS_SITE_SENS_OMEGA_N, pass, drone, 0, z);
+    rng_normal_s<real, 3>(key, QS_SITE_SENS_OMEGA_N, pass, drone, 0, c.gyro_noise_density, n.w);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { n.w[q] = c.gyro_noise_density * z[q]; n.th[q] = 0; }
-    if (c.quat_norm_std != (real)0) {
-        rng_normal<real, 3>(key, QS_SITE_SENS_THETA_N, pass, drone, 0, z);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) n.th[q] = c.quat_norm_std * z[q];
-    }
-    if (c.quat_unif_range != (real)0) {
+    for (int q = 0; q < 3; ++q) n.th[q] = 0;
+    if (tape || c.quat_norm_std != (real)0) rng_normal_s<real, 3>(key, QS_SITE_SENS_THETA_N, pass, drone, 0, c.quat_norm_std, n.th);
+    if (tape || c.quat_unif_range != (real)0) {
         rng_uniform<real, 3>(key, QS_SITE_SENS_THETA_U, pass, drone, 0, -c.quat_unif_range, c.quat_unif_range, u);
 #pragma unroll
         for (int q = 0; q < 3; ++q) n.th[q] += u[q];
     }
+    if (tape) tape_skip(key, 6);   // accelerometer noise: drawn by the reference, in no obs_repr
 }
 
 // The four always-needed normal groups of a control step (OU thrust noise + sensor pos / vel / omega noise, pass 0)
@@ -537,10 +568,10 @@ __device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const Rn
     real vmag = norm3<real>(d.vel), nv[3] = {vmag * n[0], vmag * n[1], vmag * n[2]}, noise[3] = {0, 0, 0};
     for (int t = 0; t < 3; ++t) {
         real cons[3], n1[3], tmp[3], chk[3];
-        rng_normal<real, 3>(key, QS_SITE_OBST_N, t * 2 + 0, drone, 0, cons);
-        rng_normal<real, 3>(key, QS_SITE_OBST_N, t * 2 + 1, drone, 0, n1);
+        rng_normal_s<real, 3>(key, QS_SITE_OBST_N, t * 2 + 0, drone, 0, (real)0.1, cons);
+        rng_normal_s<real, 3>(key, QS_SITE_OBST_N, t * 2 + 1, drone, 0, (real)0.05, n1);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { tmp[q] = (real)0.1 * cons[q] + (real)0.05 * n1[q]; chk[q] = nv[q] + tmp[q]; }
+        for (int q = 0; q < 3; ++q) { tmp[q] = cons[q] + n1[q]; chk[q] = nv[q] + tmp[q]; }
         if (dot3<real>(chk, n) > (real)0) { noise[0] = tmp[0]; noise[1] = tmp[1]; noise[2] = tmp[2]; break; }
     }
     real diff[3] = {d.pos[0] - ox, d.pos[1] - oy, d.pos[2] - c.room_mid_z};
@@ -549,9 +580,13 @@ __device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const Rn
                         : rng_uniform1<real>(key, QS_SITE_OBST_U, 0, drone, 0, (real)0.2, (real)0.8);
     real shift[3] = {nv[0] - d.vel[0] + noise[0], nv[1] - d.vel[1] + noise[1], nv[2] - d.vel[2] + noise[2]};
     compute_new_vel<real>(vmag, d.vel, shift, decay);
-    uint32_t w[4]; rng_words(key, QS_SITE_OBST_W, 0, drone, 0, w);
-    real u[4] = {(real)-1 + (real)2 * u01<real>(w[0]), (real)-1 + (real)2 * u01<real>(w[1]), (real)-1 + (real)2 * u01<real>(w[2]),
-                 (real)(0.5 * QS_PI_D) + (real)(QS_PI_D - 0.5 * QS_PI_D) * u01<real>(w[3])};
+    real u[4];
+    if (QS_ON_TAPE(key)) { for (int q = 0; q < 4; ++q) u[q] = (real)tape_pop(key); }   // uniform(-1,1,3), uniform(pi/2, pi)
+    else {
+        uint32_t w[4]; rng_words(key, QS_SITE_OBST_W, 0, drone, 0, w);
+        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]); u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
+        u[3] = (real)(0.5 * QS_PI_D) + (real)(QS_PI_D - 0.5 * QS_PI_D) * u01<real>(w[3]);
+    }
     real dw[3]; compute_new_omega<real>(u, dw);
 #pragma unroll
     for (int q = 0; q < 3; ++q) d.omega[q] += dw[q];
@@ -561,26 +596,35 @@ __device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const Rn
 template <typename real>
 __device__ __forceinline__ void collide_room(const Consts<real> &c, const RngKey &key, int drone, Drone<real> &d, bool is_wall) {
     int site = is_wall ? QS_SITE_WALL : QS_SITE_CEIL;
-    real speed = norm3<real>(d.vel), dir[3];
-    uint32_t w[4]; rng_words(key, site, 0, drone, 0, w);
-    real rs = (real)0.2 * speed + ((real)0.8 * speed - (real)0.2 * speed) * u01<real>(w[0]);
+    const bool tape = QS_ON_TAPE(key);
+    real speed = norm3<real>(d.vel), dir[3], rs;
+    uint32_t w[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
+    if (tape) { rs = (real)tape_pop(key); for (int q = 0; q < 3; ++q) dir[q] = (real)tape_pop(key); }   // the reference's call order, room.py:10-41
+    else {
+        rng_words(key, site, 0, drone, 0, w);
+        rs = (real)0.2 * speed + ((real)0.8 * speed - (real)0.2 * speed) * u01<real>(w[0]);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) dir[q] = (real)-1 + (real)2 * u01<real>(w[1 + q]);
-    rs = clipr<real>(rs, (real)0.1, (real)6);
-    uint32_t w1[4]; rng_words(key, site, 1, drone, 0, w1);
-    if (is_wall) {
-        if (d.pos[0] == c.room_lo[0]) dir[0] = (real)0.1 + (real)0.9 * u01<real>(w1[0]);
-        else if (d.pos[0] == c.room_hi[0]) dir[0] = (real)-1 + (real)0.9 * u01<real>(w1[0]);
-        if (d.pos[1] == c.room_lo[1]) dir[1] = (real)0.1 + (real)0.9 * u01<real>(w1[1]);
-        else if (d.pos[1] == c.room_hi[1]) dir[1] = (real)-1 + (real)0.9 * u01<real>(w1[1]);
+        for (int q = 0; q < 3; ++q) dir[q] = (real)-1 + (real)2 * u01<real>(w[1 + q]);
+        rng_words(key, site, 1, drone, 0, w1);
     }
-    dir[2] = (real)-1 + (real)0.5 * u01<real>(w1[2]);
+    rs = clipr<real>(rs, (real)0.1, (real)6);
+    if (is_wall) {
+        if (d.pos[0] == c.room_lo[0]) dir[0] = tape ? (real)tape_pop(key) : (real)0.1 + (real)0.9 * u01<real>(w1[0]);
+        else if (d.pos[0] == c.room_hi[0]) dir[0] = tape ? (real)tape_pop(key) : (real)-1 + (real)0.9 * u01<real>(w1[0]);
+        if (d.pos[1] == c.room_lo[1]) dir[1] = tape ? (real)tape_pop(key) : (real)0.1 + (real)0.9 * u01<real>(w1[1]);
+        else if (d.pos[1] == c.room_hi[1]) dir[1] = tape ? (real)tape_pop(key) : (real)-1 + (real)0.9 * u01<real>(w1[1]);
+    }
+    dir[2] = tape ? (real)tape_pop(key) : (real)-1 + (real)0.5 * u01<real>(w1[2]);
     real dm = norm3<real>(dir);
 #pragma unroll
     for (int q = 0; q < 3; ++q) d.vel[q] = rs * (dir[q] / (dm + (real)1e-5));
-    rng_words(key, site, 2, drone, 0, w);
-    real u[4] = {(real)-1 + (real)2 * u01<real>(w[0]), (real)-1 + (real)2 * u01<real>(w[1]), (real)-1 + (real)2 * u01<real>(w[2]),
-                 (real)(10.0 * QS_PI_D) + (real)(10.0 * QS_PI_D) * u01<real>(w[3])};
+    real u[4];
+    if (tape) { for (int q = 0; q < 4; ++q) u[q] = (real)tape_pop(key); }
+    else {
+        rng_words(key, site, 2, drone, 0, w);
+        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]); u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
+        u[3] = (real)(10.0 * QS_PI_D) + (real)(10.0 * QS_PI_D) * u01<real>(w[3]);
+    }
     real um = norm3<real>(u);
 #pragma unroll
     for (int q = 0; q < 3; ++q) { real dwq = u[q] / (um + (real)1e-5); dwq *= u[3]; d.omega[q] += dwq; }
@@ -671,6 +715,7 @@ __device__ __forceinline__ void scen_params(int scen, int *nform, float *lo, flo
     else if (scen == QS_SCENARIO_O_SWAP_GOALS) { *nform = 7; *lo = 0.4f; *hi = 0.8f; }
 }
 
+template <typename real> __device__ __forceinline__ int rng_index(const RngKey &k, int site, int slot, int n);
 // update_formation_and_relate_param scenarios/base.py:123-135
 template <typename real>
 __device__ void update_formation(int scen, const RngKey &key, int slot, int num_agents, Formation<real> &F) {
@@ -698,11 +743,13 @@ __device__ void update_formation(int scen, const RngKey &key, int slot, int num_
 // floor(u * n) and lo + (hi-lo)*u evaluated in double from the exactly-representable uniform: identical to the oracle
 // in both precisions (these decide indices / switching ticks, where an fp32 rounding would flip a discrete outcome)
 template <typename real> __device__ __forceinline__ int rng_index(const RngKey &k, int site, int slot, int n) {
+    if (QS_ON_TAPE(k)) return (int)tape_pop(k);   // the tape holds the index the reference drew (np.random.choice / randint)
     double u = (double)rng_uniform1<real>(k, site, slot, 0, 0, (real)0, (real)1);
     int j = (int)(u * (double)n);
     return j >= n ? n - 1 : j;
 }
 template <typename real> __device__ __forceinline__ int draw_period(const RngKey &k, int slot, double lo, double hi, int control_freq) {
+    if (QS_ON_TAPE(k)) return (int)(tape_pop(k) * (double)control_freq);   // the tape holds uniform(lo, hi) itself
     double u = (double)rng_uniform1<real>(k, QS_SITE_SCEN, slot, 0, 0, (real)0, (real)1);
     return (int)((lo + (hi - lo) * u) * (double)control_freq);
 }
@@ -710,6 +757,26 @@ template <typename real> __device__ __forceinline__ int draw_period(const RngKey
 // np.random.shuffle on rows [0,n) of buf (stride ld): Fisher-Yates with the QS_SITE_SCEN_SHUFFLE stream
 template <typename real>
 __device__ void shuffle_rows(const RngKey &key, real *buf, int ld, int n, int slot_base) {
+#ifdef QS_TAPE
+    if (QS_ON_TAPE(key)) {   // the tape holds the permutation itself: rows[k] = old[perm[k]], applied in place cycle by cycle (n <= 64)
+        const double *perm = key.tape + *key.cur;
+        uint64_t seen = 0;
+        for (int s0 = 0; s0 < n; ++s0) {
+            if (seen >> s0 & 1) continue;
+            real t[3] = {buf[s0 * ld], buf[s0 * ld + 1], buf[s0 * ld + 2]};
+            int k = s0;
+            for (;;) {
+                seen |= 1ull << k;
+                const int src = (int)perm[k];
+                if (src == s0) { for (int q = 0; q < 3; ++q) buf[k * ld + q] = t[q]; break; }
+                for (int q = 0; q < 3; ++q) buf[k * ld + q] = buf[src * ld + q];
+                k = src;
+            }
+        }
+        tape_skip(key, n);
+        return;
+    }
+#endif
     // the oracle builds perm by swapping from the top, then gathers rows[k] = old[perm[k]]; applying the same
     // swaps directly to the rows is the identical permutation.
     for (int i = n - 1; i >= 1; --i) {

@@ -52,6 +52,10 @@ template <typename real> struct Ptrs {
     real *run_sums, *ep_sums;   // [QS_SUM_COUNT, T] per-episode sums (running / last finished episode)
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
+    // noise tape (qs_set_noise_tape; consumed by the QS_TAPE kernels only): [E][tape_len] reference draws, per-env cursor
+    const double *tape;
+    int32_t *tape_pos;
+    int64_t tape_len;
 };
 
 // One component-major array inside the state block, seen from one lane: element type T, `row_bytes` between components, this
@@ -91,52 +95,76 @@ __device__ __forceinline__ unsigned long long nbr_key(float m, int idx) {
 
 struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
                    int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit;
-                   int stage_cols, nbr_per_pass, scr_cap; };   // single-wave kernels: observation columns staged per pass (see obs_flush)
+                   int off_self, off_rows, rows_per_pass, scr_cap;   // single-wave kernels: observation output (see obs_copy_rows)
+                   int off_cur; };   // QS_TAPE kernels: per-env tape cursor
+#define QS_NV_MAX 57   // neighbour + SDF columns a lane can keep in registers between the row passes (K <= 8)   // single-wave kernels: observation columns staged per pass (see obs_flush)
 #define QS_RESET_SCRATCH_INTS 160   // per env, full scenario set: virtual-pool index/value lists (2x64) + two DP rows (2x16)
 
-// Single-wave (throughput) kernels stage the observation rows in column groups - the self part, then the neighbours a few at a
-// time, then the SDF cells - through one small buffer (obs_flush), so that a workgroup needs ~9-10 KB of LDS instead of ~21 KB
-// and 16 of them fit a CU (4 waves per SIMD); the team kernels (small batches, occupancy irrelevant) keep whole rows.
+// Observation rows leave through LDS so that they reach HBM as whole, aligned cache lines (a first version wrote column
+// groups straight from a small stage: 72-byte runs at a 216-byte stride cost more than the rest of the step - see
+// profiles/r02_exp_colgroup_flush.txt).  Team kernels (small batches, occupancy irrelevant) stage the workgroup's complete
+// rows [64][D].  Single-wave (throughput) kernels keep the self columns in a dense block [64][S] (written early, read by
+// the bookkeeping) and pass the other D-S columns through a stage of `rows_per_pass` rows: each lane holds its neighbour / SDF
+// values in registers, the lanes of one row group store them, the whole wave copies that group's complete rows
+// (rows_per_pass * D * 4 contiguous bytes) out, next group.  The stage shares its LDS with the buffers of the rare paths
+// (collision responses, goal scratch rows, reset scratch), none of which is live while rows are being copied: a workgroup
+// needs ~9.5 KB instead of ~21 KB, and 16 of them fit a CU.
 static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, int num_obst, int K, int team /* waves per workgroup of the team kernels, 0 = single-wave */,
-                            bool full /* kernels of the full scenario set: per-env scenario state in LDS */, int scenario = -1) {
+                            bool full /* kernels of the full scenario set: per-env scenario state in LDS */, int scenario = -1, int rows_per_pass = 64) {
     LdsLayout L;
     memset(&L, 0, sizeof L);
+    const int self_dim = obs_dim - 6 * K - (num_obst > 0 ? 9 : 0), extra = obs_dim - self_dim;
+    // goal scratch rows per env: two formations (+ sphere padding) for swarm_vs_swarm and the full scenario set, one otherwise
+    L.goal_rows = (full || scenario < 0 || scenario == QS_SCENARIO_SWARM_VS_SWARM) ? 2 * N + 8 : (N < 3 ? 3 : N);
+    // reset scratch per env: virtual-pool index / value lists (2 x cap: at most one entry per obstacle / per drone) + two DP rows
+    // (2 x 16); the full scenario set keeps the fixed 2 x 64 split its scenario code addresses
+    L.scr_cap = full ? 64 : (num_obst > N ? num_obst : N);
+    const int goal_bytes = real_size * 3 * L.goal_rows * epb, scratch_bytes = num_obst > 0 ? 4 * (2 * L.scr_cap + 32) * epb : 0;
     int o = 0;
-    L.off_mask = o; o += 8 * B;                       // u64 per lane: new-pair masks for the serial response path
     L.off_omap = o; o += full ? 8 * 4 * epb : 0;      // full-scenario kernels: obstacle map bitset, scenario ints / reals per env
     L.off_si = o; o += full ? 4 * SI_COUNT * epb : 0;
     L.off_sr = o; o += full ? real_size * SR_COUNT * epb : 0;
     o = (o + 15) & ~15;
     L.off_envflag = o; o += 4 * ((2 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods
-    // reset scratch per env: virtual-pool index / value lists (2 x cap: at most one entry per obstacle / per drone) + two DP rows
-    // (2 x 16); the full scenario set keeps the fixed 2 x 64 split its scenario code addresses
-    L.scr_cap = full ? 64 : (num_obst > N ? num_obst : N);
-    L.off_scratch = o; o += num_obst > 0 ? 4 * (2 * L.scr_cap + 32) * epb : 0;   // only the obstacle-map / free-cell code uses it
+#ifdef QS_TAPE
+    L.off_cur = o; o += 4 * ((epb + 3) & ~3);
+#endif
     o = (o + 15) & ~15;
     L.off_pos = o; o += real_size * 3 * B;
     L.off_vel = o; o += real_size * 3 * B;
     L.off_zax = o; o += real_size * 3 * B;            // body z axes (downwash); spawn points in the reset tail
-    L.off_om = o; o += real_size * 3 * B;
-    // goal scratch rows per env: two formations (+ sphere padding) for swarm_vs_swarm and the full scenario set, one otherwise
-    L.goal_rows = (full || scenario < 0 || scenario == QS_SCENARIO_SWARM_VS_SWARM) ? 2 * N + 8 : (N < 3 ? 3 : N);
-    L.off_goal = o; o += real_size * 3 * L.goal_rows * epb;
     L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
     // neighbour metric rows [N][B]; team kernels with N > 8: one sorted top-8 list per wave, metrics [8W][B] + indices [8W][B]
     L.off_metric = o; o += ((team ? K > 0 : K > 8) && K < N - 1) ? ((team && N > 8) ? ((real_size + 4) * 8 * team > real_size * N ? (real_size + 4) * 8 * team : real_size * N) * B : real_size * N * B) : 0;
     o = (o + 15) & ~15;
-    if (team) {   // exchange rows of the 4-wave kernels
-        L.off_t_col = o; o += 8 * B;
+    if (team) {
+        L.off_mask = o; o += 8 * B;                   // u64 per lane: new-pair masks for the serial response path
+        L.off_om = o; o += real_size * 3 * B;
+        L.off_goal = o; o += goal_bytes;
+        L.off_scratch = o; o += scratch_bytes;
+        o = (o + 15) & ~15;
+        L.off_t_col = o; o += 8 * B;                  // exchange rows of the team kernels
         L.off_t_dw = o; o += 8 * B;
         L.off_t_rot = o; o += real_size * 6 * B;
         L.off_t_goal = o; o += real_size * 3 * B;
         L.off_t_prox = o; o += real_size * (team - 1) * B;
         L.off_t_ohit = o; o += 4 * B;
         o = (o + 15) & ~15;
+        L.rows_per_pass = B;
+        L.off_obs = o; L.off_self = o; L.off_rows = o + real_size * self_dim * B;   // complete rows [B][D]; the reset kernel sees them as
+        o += real_size * obs_dim * B;                                                // the self block followed by the rows stage
+    } else {
+        L.rows_per_pass = rows_per_pass < 1 ? 1 : (rows_per_pass > B ? B : rows_per_pass);
+        L.off_self = o; L.off_obs = o; o += real_size * self_dim * B;
+        o = (o + 15) & ~15;
+        // the rows stage and, in the same bytes, what only the rare paths touch: (a) collision responses: pair masks + angular
+        // velocities, (b) scenario goal switch / reset: goal scratch rows + reset scratch
+        const int stage_bytes = real_size * extra * L.rows_per_pass, rare_a = 8 * B + real_size * 3 * B, rare_b = goal_bytes + scratch_bytes;
+        int u = stage_bytes > rare_a ? stage_bytes : rare_a;
+        u = u > rare_b ? u : rare_b;
+        L.off_rows = o; L.off_mask = o; L.off_om = o + 8 * B; L.off_goal = o; L.off_scratch = o + goal_bytes;
+        o += u;
     }
-    const int self_dim = obs_dim - 6 * K - (num_obst > 0 ? 9 : 0);
-    L.nbr_per_pass = 3;
-    L.stage_cols = team ? obs_dim : (self_dim > 6 * L.nbr_per_pass ? self_dim : 6 * L.nbr_per_pass);
-    L.off_obs = o; o += real_size * L.stage_cols * B;   // observation staging: whole rows (team) / one column group (single-wave)
     L.total = (o + 15) & ~15;
     return L;
 }
@@ -281,26 +309,31 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
 }
 
 // ------------------------------------------------------------------------------------------------
-// Streamed observation output of the single-wave kernels.  A column group [col0, col0 + ncols) of the workgroup's rows is
-// staged densely in LDS (row r at s_stage[r * ncols .. + ncols)) and copied to the row-major observation matrix by the whole
-// wave: consecutive lanes write consecutive words of a row's group, so a store instruction covers a few ncols*4-byte runs.
-// rowmask selects the rows to write (auto-reset rewrites only the rows of finished environments).  Must be called by the
-// whole wave, between barriers that order it against the staging writes.
+// Observation output of the single-wave kernels: rows [r0, r0 + nr) of the workgroup's block, complete, to the row-major
+// observation matrix - self columns from the dense self block, the others from the rows stage.  Consecutive lanes write
+// consecutive words: every store instruction is one contiguous run.  rowmask (bit = row within the block) selects the rows to
+// write (an auto-reset rewrites only the rows of the finished environments).  Whole wave, between barriers.
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __forceinline__ void obs_flush(real *__restrict__ dst_block, const real *s_stage, int D, int col0, int ncols, int nrows, uint64_t rowmask, int tid) {
-    if (sizeof(real) == 4 && ((D | col0 | ncols) & 1) == 0) {   // 8-byte elements: row starts (D*4 bytes apart) and group starts stay 8-byte aligned
-        const int half = ncols >> 1, total = nrows * half;
-        const float2 *src2 = (const float2 *)s_stage;
+__device__ __forceinline__ void obs_copy_rows(real *__restrict__ dst_block, const real *s_self, const real *s_rows, int S, int D, int r0, int nr, uint64_t rowmask, int tid) {
+#ifdef QS_EXP_NOFLUSH   // experiment: how much of the step is the observation output path
+    if (rowmask != 0x1234567ull) return;
+#endif
+    const int X = D - S;
+    real *dst = dst_block + (size_t)r0 * D;
+    if (sizeof(real) == 4 && ((D | S) & 1) == 0) {   // 8-byte elements: rows (D*4 bytes) and the self / other boundary stay 8-byte aligned
+        const int half = D >> 1, total = nr * half;
         for (int idx = tid; idx < total; idx += QS_WAVE) {
-            const int row = idx / half, cp2 = idx - row * half;
-            if ((rowmask >> row) & 1) *(float2 *)((float *)dst_block + (size_t)row * D + col0 + 2 * cp2) = src2[idx];
+            const int row = idx / half, c2 = 2 * (idx - row * half);
+            const float *src = (c2 < S) ? (const float *)s_self + (r0 + row) * S + c2 : (const float *)s_rows + row * X + (c2 - S);
+            if ((rowmask >> (r0 + row)) & 1) *(float2 *)((float *)dst + 2 * idx) = *(const float2 *)src;
         }
     } else {
-        const int total = nrows * ncols;
+        const int total = nr * D;
         for (int idx = tid; idx < total; idx += QS_WAVE) {
-            const int row = idx / ncols, cc = idx - row * ncols;
-            if ((rowmask >> row) & 1) dst_block[(size_t)row * D + col0 + cc] = s_stage[idx];
+            const int row = idx / D, cc = idx - row * D;
+            const real v = (cc < S) ? s_self[(r0 + row) * S + cc] : s_rows[row * X + (cc - S)];
+            if ((rowmask >> (r0 + row)) & 1) dst[idx] = v;
         }
     }
 }
@@ -446,28 +479,44 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
     for (int q = 0; q < 9; ++q) o[q] = mind[q] - c.obst_radius;
 }
 
-// The neighbour and SDF columns of the wave's rows, staged and flushed a column group at a time.  Whole wave; `live` lanes
-// compute (their rows are the ones in rowmask).  s_stage must not hold anything still to be flushed.
+// The neighbour and SDF columns of the wave's rows -> rows stage -> HBM together with the self columns (obs_copy_rows), one row
+// group at a time.  Whole wave; `live` lanes compute (their rows are the ones in rowmask).  The stage shares LDS with the
+// rare-path buffers: nothing of those may be live here; ends with the stage free again (RP < 64) or still being read (RP = 64:
+// the caller's next barrier).
 template <typename real>
-__device__ __forceinline__ void stream_nbr_sdf(const Consts<real> &c, const LdsLayout &L, real *__restrict__ dst_block, real *s_stage, int N, int i, int le, int base, int tid,
-                                               const real *s_pos, const real *s_vel, real *s_metric, const real *s_obst, const real mypos[3], const real myvel[3],
-                                               bool live, int nrows, uint64_t rowmask) {
-    const int B = QS_WAVE, K = c.num_neighbors, D = c.obs_dim, M_ = c.num_obstacles;
-    NbrSel<real> S;
-    if (live) nbr_select<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, S);
-    for (int k0 = 0; k0 < K; k0 += L.nbr_per_pass) {
-        const int k1 = (k0 + L.nbr_per_pass < K) ? k0 + L.nbr_per_pass : K, ncols = 6 * (k1 - k0);
-        __syncthreads();   // the previous group has been read out of the stage
-        if (live) nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, S, k0, k1, s_stage + tid * ncols);
-        __syncthreads();
-        obs_flush<real>(dst_block, s_stage, D, c.self_dim + 6 * k0, ncols, nrows, rowmask, tid);
+__device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayout &L, real *__restrict__ dst_block, const real *s_self, real *s_rows, int N, int i, int le, int base, int tid,
+                                            const real *s_pos, const real *s_vel, real *s_metric, const real *s_obst, const real mypos[3], const real myvel[3],
+                                            bool live, int nrows, uint64_t rowmask) {
+    const int B = QS_WAVE, K = c.num_neighbors, D = c.obs_dim, S = c.self_dim, X = D - S, M_ = c.num_obstacles, RP = L.rows_per_pass;
+    NbrSel<real> sel;
+    if (live) nbr_select<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel);
+#ifdef QS_SPEC
+    if (RP < B) {   // (config-specialised kernels only: X is a literal <= QS_NV_MAX, the register array below has static indices)
+        real nv[QS_NV_MAX];
+        if (live) {
+            nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel, 0, K, nv);
+            if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], nv + 6 * K);
+        }
+        for (int r0 = 0; r0 < nrows; r0 += RP) {
+            if (live && tid >= r0 && tid < r0 + RP) {
+                real *o = s_rows + (tid - r0) * X;
+#pragma unroll
+                for (int q = 0; q < QS_NV_MAX; ++q) if (q < X) o[q] = nv[q];
+            }
+            __syncthreads();
+            obs_copy_rows<real>(dst_block, s_self, s_rows, S, D, r0, (nrows - r0) < RP ? (nrows - r0) : RP, rowmask, tid);
+            __syncthreads();   // the group has left the stage
+        }
+        return;
     }
-    if (c.use_obstacles) {
-        __syncthreads();
-        if (live) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], s_stage + tid * 9);
-        __syncthreads();
-        obs_flush<real>(dst_block, s_stage, D, c.self_dim + 6 * K, 9, nrows, rowmask, tid);
+#endif
+    if (live) {   // complete rows at once: straight into the stage
+        real *o = s_rows + tid * X;
+        nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel, 0, K, o);
+        if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], o + 6 * K);
     }
+    __syncthreads();
+    obs_copy_rows<real>(dst_block, s_self, s_rows, S, D, 0, nrows, rowmask, tid);
 }
 
 // perform_collision_between_drones collisions/quadrotors.py:24-59 on LDS-resident vel/omega (serial per env)
@@ -483,11 +532,11 @@ __device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int
     real s1[3] = {vc[0], vc[1], vc[2]}, s2[3] = {-vc[0], -vc[1], -vc[2]};
     for (int t = 0; t < 3; ++t) {
         real cons[3], n1[3], n2[3], t1[3], t2[3];
-        rng_normal<real, 3>(key, QS_SITE_DD_N, t * 3 + 0, i, j, cons);
-        rng_normal<real, 3>(key, QS_SITE_DD_N, t * 3 + 1, i, j, n1);
-        rng_normal<real, 3>(key, QS_SITE_DD_N, t * 3 + 2, i, j, n2);
+        rng_normal_s<real, 3>(key, QS_SITE_DD_N, t * 3 + 0, i, j, (real)0.8, cons);
+        rng_normal_s<real, 3>(key, QS_SITE_DD_N, t * 3 + 1, i, j, (real)0.15, n1);
+        rng_normal_s<real, 3>(key, QS_SITE_DD_N, t * 3 + 2, i, j, (real)0.15, n2);
         for (int q = 0; q < 3; ++q) {
-            real a = (real)0.8 * cons[q] + (real)0.15 * n1[q], b = -((real)0.8 * cons[q]) + (real)0.15 * n2[q];
+            real a = cons[q] + n1[q], b = -cons[q] + n2[q];
             s1[q] = vc[q] + a; s2[q] = -vc[q] + b;
             t1[q] = v1[q] + s1[q]; t2[q] = v2[q] + s2[q];
         }
@@ -497,9 +546,13 @@ __device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int
     real dec[2]; rng_uniform<real, 2>(key, QS_SITE_DD_U, 0, i, j, (real)0.2, (real)0.8, dec);
     compute_new_vel<real>(maxv, v1, s1, dec[0]);
     compute_new_vel<real>(maxv, v2, s2, dec[1]);
-    uint32_t w[4]; rng_words(key, QS_SITE_DD_W, 0, i, j, w);
-    real u[4] = {(real)-1 + (real)2 * u01<real>(w[0]), (real)-1 + (real)2 * u01<real>(w[1]), (real)-1 + (real)2 * u01<real>(w[2]),
-                 (real)(10.0 * QS_PI_D) + (real)(20.0 * QS_PI_D - 10.0 * QS_PI_D) * u01<real>(w[3])};
+    real u[4];
+    if (QS_ON_TAPE(key)) { for (int q = 0; q < 4; ++q) u[q] = (real)tape_pop(key); }   // uniform(-1,1,3), uniform(10 pi, 20 pi)
+    else {
+        uint32_t w[4]; rng_words(key, QS_SITE_DD_W, 0, i, j, w);
+        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]); u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
+        u[3] = (real)(10.0 * QS_PI_D) + (real)(20.0 * QS_PI_D - 10.0 * QS_PI_D) * u01<real>(w[3]);
+    }
     real dw[3]; compute_new_omega<real>(u, dw);
     for (int q = 0; q < 3; ++q) {
         s_vel[q * B + base + i] = v1[q]; s_vel[q * B + base + j] = v2[q];
@@ -563,11 +616,17 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
     const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
     const int M_ = c.num_obstacles;
-    real *myobs = s_obs + tid * (STREAM ? c.self_dim : c.obs_dim);   // STREAM: the stage holds one column group at a time
+    real *myobs = STREAM ? (real *)(smem + L.off_self) + tid * c.self_dim : s_obs + tid * c.obs_dim;   // STREAM: dense self block + rows stage
     int *tidx = (int *)(smem + L.off_scratch) + le * (2 * L.scr_cap + 32), *tval = tidx + L.scr_cap, *prev_row = tidx + 2 * L.scr_cap, *cur_row = prev_row + 16;
 
+#ifdef QS_TAPE
+    int *s_cur = (int *)(smem + L.off_cur);
+#endif
     // ---- per-env part (one lane): obstacle map + scenario.reset() ----
     if (do_reset && i == 0) {
+#ifdef QS_TAPE
+        if (QS_ON_TAPE(key)) *key.cur = s_cur[le];   // this lane consumes the env's tape sequentially
+#endif
         real *goals = s_goal + le * L.goal_rows * 3;
         uint32_t have_spawn = 0;
         uint64_t omap[4] = {0, 0, 0, 0};   // obstacle map bitset, cell id = rid*W + cid
@@ -577,10 +636,15 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             // np.random.choice(cells, M, replace=False): partial Fisher-Yates on a virtual pool
             int nt = 0;
             for (int k = 0; k < M_; ++k) {
-                int j = k + rng_index<real>(key, QS_SITE_OBST_MAP, k, cells - k);
-                int vk = k, vj = j, pj = -1;
-                for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
-                if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }   // pool[j] = pool[k]; the pick is old pool[j]
+                int vj;
+                if (QS_ON_TAPE(key)) vj = (int)tape_pop(key);   // the tape holds the chosen cell ids (quadrotor_multi.py:313)
+                else {
+                    int j = k + rng_index<real>(key, QS_SITE_OBST_MAP, k, cells - k);
+                    int vk = k, pj = -1;
+                    vj = j;
+                    for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
+                    if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }   // pool[j] = pool[k]; the pick is old pool[j]
+                }
                 int id = vj, rid = id / W, cid = id - rid * W;
                 omap[id >> 6] |= 1ull << (id & 63);
                 if (FULL) ((uint64_t *)(smem + L.off_omap))[le * 4 + (id >> 6)] |= 1ull << (id & 63);
@@ -604,23 +668,33 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         } else if (c.scenario == QS_SCENARIO_STATIC_SAME_GOAL) {
             update_formation<real>(c.scenario, key, 0, N, F);
             real center[3] = {0, 0, 2};
-            generate_goals<real>(F, N, 1, center, goals, 3);
+            const int rows = generate_goals<real>(F, N, 1, center, goals, 3);
+            if (QS_ON_TAPE(key)) tape_skip(key, rows);   // np.random.shuffle(goals) of base.py:151: the rows are all the same point
+            (void)rows;
         } else if (c.scenario == QS_SCENARIO_O_STATIC_SAME_GOAL) {
             // obstacles/o_static_same_goal.py:27-48 + o_base.py:69-81,:124-153
             int nfree = cells - M_;
             int nt = 0;
+            const bool on_tape = QS_ON_TAPE(key);
+            if (on_tape) tape_skip(key, 1);   // the duration draw of o_static_same_goal.py:29 (unused by a static goal)
             for (int k = 0; k < N; ++k) {
-                int j = k + rng_index<real>(key, QS_SITE_SCEN, 16 + k, nfree - k);
-                int vk = k, vj = j, pj = -1;
-                for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
-                if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }
+                int vj;
+                if (on_tape) vj = (int)tape_pop(key);   // np.random.choice(free cells, N, replace=False): the ids themselves
+                else {
+                    int j = k + rng_index<real>(key, QS_SITE_SCEN, 16 + k, nfree - k);
+                    int vk = k, pj = -1;
+                    vj = j;
+                    for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
+                    if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }
+                }
                 int seen = 0, cell = 0;   // vj-th free cell in row-major order (np.where(obst_map == 0))
                 for (int id = 0; id < cells; ++id) if (!(omap[id >> 6] >> (id & 63) & 1)) { if (seen == vj) { cell = id; break; } ++seen; }
                 int x = cell / W, y = cell - x * W, index = x + Lr * y, ii = index / W, jj = (W - 1) - (index - ii * W);
                 s_spawn[0 * B + base + k] = (real)ii + (real)0.5 - (real)(Lr / 2);
                 s_spawn[1 * B + base + k] = (real)jj + (real)0.5 - (real)(W / 2);
-                s_spawn[2 * B + base + k] = rng_uniform1<real>(key, QS_SITE_SCEN, 96 + k, 0, 0, (real)1, (real)3);
+                if (!on_tape) s_spawn[2 * B + base + k] = rng_uniform1<real>(key, QS_SITE_SCEN, 96 + k, 0, 0, (real)1, (real)3);
             }
+            if (on_tape) for (int k = 0; k < N; ++k) s_spawn[2 * B + base + k] = (real)tape_pop(key);   // the N heights follow the N ids (o_base.py:69-81)
             have_spawn = 1;
             // max_square_area_center o_base.py:124-153 (two-row dynamic programme)
             int max_size = 0, cx = 0, cy = 0;
@@ -643,6 +717,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             int index = cx + W * cy, ii = index / W, jj = (W - 1) - (index - ii * W);
             real end[3] = {(real)ii + (real)0.5 - (real)(Lr / 2), (real)jj + (real)0.5 - (real)(W / 2), 0};
             end[2] = rng_uniform1<real>(key, QS_SITE_SCEN, 9, 0, 0, (real)1.5, (real)3);
+            if (on_tape) tape_skip(key, 3);   // update_formation_and_relate_param (:41): formation index, size, layer distance - unused here
             for (int k = 0; k < N; ++k) for (int q = 0; q < 3; ++q) goals[k * 3 + q] = end[q];
         } else {
             // swarm_vs_swarm.py:80-94 (reset) + :17-50 (formation_centers) + scenarios/utils.py:170-181 (get_z_value)
@@ -672,11 +747,14 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, false, goals);
         }
         s_envflag[le] = have_spawn;
+#ifdef QS_TAPE
+        if (QS_ON_TAPE(key)) s_cur[le] = *key.cur;
+#endif
     }
     if (TEAM) QS_WAVE_SYNC(); else __syncthreads();   // team kernels: only wave 0 is here
 
-    if (do_reset) {
-        // ---- per-drone part: QuadrotorSingle._reset quadrotor_single.py:387-447 ----
+    // ---- per-drone part: QuadrotorSingle._reset quadrotor_single.py:387-447 ----
+    auto per_drone = [&]() {
         real spawn[3];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -703,15 +781,23 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         SensNoise<real> sn;
         if (c.sense_noise) sensor_noise_draw<real>(c, key, i, 0, sn);
         self_obs<real>(c, sn, d, goal, myobs);
-    }
+    };
+#ifdef QS_TAPE
+    if (QS_ON_TAPE(key)) {   // the reference resets the drones one after the other (spawn draw, yaw rejection loop, sensor noise): take turns
+        for (int turn = 0; turn < N; ++turn) {
+            if (do_reset && i == turn) { *key.cur = s_cur[le]; per_drone(); s_cur[le] = *key.cur; }
+            __syncthreads();
+        }
+    } else
+#endif
+    if (do_reset) per_drone();
     if (TEAM) QS_WAVE_SYNC(); else __syncthreads();
-    if (STREAM) {   // single-wave kernels: rows of the re-initialised envs go out a column group at a time
+    if (STREAM) {   // single-wave kernels: the rows of the re-initialised envs go out through the rows stage
         const uint64_t rowmask = __ballot(do_reset);
         const int first_env = blockIdx.x * epb;
         int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
-        real *dst_block = p.obs + (size_t)first_env * N * c.obs_dim;
-        obs_flush<real>(dst_block, s_obs, c.obs_dim, 0, c.self_dim, nenv * N, rowmask, tid);
-        stream_nbr_sdf<real>(c, L, dst_block, s_obs, N, i, le, base, tid, s_pos, s_vel, s_metric, s_obst, d.pos, stale_vel, do_reset, nenv * N, rowmask);
+        stream_rows<real>(c, L, p.obs + (size_t)first_env * N * c.obs_dim, (const real *)(smem + L.off_self), (real *)(smem + L.off_rows), N, i, le, base, tid,
+                          s_pos, s_vel, s_metric, s_obst, d.pos, stale_vel, do_reset, nenv * N, rowmask);
     } else if (do_reset) {
         neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, stale_vel, myobs + c.self_dim);
         if (c.use_obstacles)
@@ -738,7 +824,19 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
     const bool in_range = (le < epb) && (e < E);
     const bool do_reset = in_range && p.reset_mask[e] != 0;
     const int g = in_range ? e * N + i : 0;
-    RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + (in_range ? e : 0)), in_range ? p.step_ctr[e] : 0u};
+    // an explicit reset takes the env's next draw counter, like a step does: consecutive resets (or a reset right after the
+    // auto-reset of a finished episode) start different episodes
+    const uint32_t ctr = in_range ? p.step_ctr[e] + 1u : 0u;
+#ifdef QS_TAPE
+    int *s_cur = (int *)(smem + L.off_cur);
+    int cursor = 0;
+    const double *tape_env = p.tape ? p.tape + (size_t)(in_range ? e : 0) * (size_t)p.tape_len : nullptr;
+    if (tape_env && in_range && i == 0) s_cur[le] = p.tape_pos[e];
+    __syncthreads();
+    RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + (in_range ? e : 0)), ctr, tape_env, &cursor};
+#else
+    RngKey key = {c.seed_lo, c.seed_hi, (uint32_t)(c.env_id_offset + (in_range ? e : 0)), ctr};
+#endif
     Drone<real> d;
     real goal[3] = {0, 0, 0}, stale_vel[3];
 #pragma unroll
@@ -767,6 +865,10 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
             p.tick[e] = 0;
             p.unique_col[e] = 0; p.obst_new[e] = 0; p.room_new[e] = 0;
             p.reset_mask[e] = 0;
+            p.step_ctr[e] = ctr;
+#ifdef QS_TAPE
+            if (tape_env) p.tape_pos[e] = s_cur[le];
+#endif
         }
     }
 }
@@ -809,6 +911,27 @@ extern "C" __global__ void __launch_bounds__(QS_WAVE) qs_spec_reset(const Consts
     qs_reset_impl<real, (QS_SPEC_FULL != 0)>(c, p, L, epb);
 }
 #undef QS_SCEN_FULL
+
+#elif defined(QS_TAPE)   // ---- noise-tape flavour (qs_tape_kernels.hip): single-wave single-step kernels + reset, own names ----
+#define QS_KARGS const Consts<real> c, Ptrs<real> p, const real *__restrict__ actions, LdsLayout L
+#define QS_EPB_ARG epb
+#define QS_SPEC_PROLOGUE
+#define qs_step_kernel qs_tape_step_kernel
+#define qs_step_kernel_full qs_tape_step_kernel_full
+#define QS_MULTI 0
+#define QS_SCEN_FULL 0
+#include "qs_step_kernel.inc"
+#undef QS_SCEN_FULL
+#define QS_SCEN_FULL 1
+#include "qs_step_kernel.inc"
+#undef QS_SCEN_FULL
+#undef QS_MULTI
+#undef qs_step_kernel
+#undef qs_step_kernel_full
+template <typename real, bool FULL>
+__global__ void __launch_bounds__(QS_WAVE) qs_tape_reset_kernel(const Consts<real> c, Ptrs<real> p, LdsLayout L, int epb) {
+    qs_reset_impl<real, FULL>(c, p, L, epb);
+}
 
 #else   // ---- generic kernels ----
 #define QS_KARGS const Consts<real> c, Ptrs<real> p, const real *__restrict__ actions, LdsLayout L
@@ -857,6 +980,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c,
 }
 #endif
 
+#ifndef QS_TAPE
 // state get/set for one env (qs_get_state / qs_set_state)
 template <typename real>
 __global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf, int32_t *tick_io, int set) {
@@ -883,4 +1007,4 @@ __global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf
         if (i == 0 && *tick_io >= 0) p.tick[env] = *tick_io;
     }
 }
-
+#endif

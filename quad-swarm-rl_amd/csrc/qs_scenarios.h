@@ -51,17 +51,27 @@ template <typename real>
 __device__ void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *tidx, int *tval, int slot_choice, int slot_z,
                                bool to_spawn) {
     const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - c.num_obstacles, N = x.N;
+    const bool on_tape = QS_ON_TAPE(key);   // a tape holds the N chosen free-cell indices, then the N heights (o_base.py:69-81)
     int nt = 0;
     for (int k = 0; k < N; ++k) {
-        int j = k + rng_index<real>(key, QS_SITE_SCEN, slot_choice + k, nfree - k);
-        int vk = k, vj = j, pj = -1;
-        for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
-        if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }
+        int vj;
+        if (on_tape) vj = (int)tape_pop(key);
+        else {
+            int j = k + rng_index<real>(key, QS_SITE_SCEN, slot_choice + k, nfree - k);
+            int vk = k, pj = -1;
+            vj = j;
+            for (int q = 0; q < nt; ++q) { if (tidx[q] == k) vk = tval[q]; if (tidx[q] == j) { vj = tval[q]; pj = q; } }
+            if (pj >= 0) tval[pj] = vk; else { tidx[nt] = j; tval[nt] = vk; ++nt; }
+        }
         int cell = kth_free_cell(x.omap, cells, vj), cx = cell / W, cy = cell - cx * W;
-        real px, py, pz = rng_uniform1<real>(key, QS_SITE_SCEN, slot_z + k, 0, 0, (real)1, (real)3);
+        real px, py, pz = on_tape ? (real)0 : rng_uniform1<real>(key, QS_SITE_SCEN, slot_z + k, 0, 0, (real)1, (real)3);
         cell_center<real>(Lr, W, cx, cy, &px, &py);
         if (to_spawn) { x.spawn[0 * x.B + x.base + k] = px; x.spawn[1 * x.B + x.base + k] = py; x.spawn[2 * x.B + x.base + k] = pz; }
         else { x.goals[k * 3 + 0] = px; x.goals[k * 3 + 1] = py; x.goals[k * 3 + 2] = pz; }
+    }
+    if (on_tape) for (int k = 0; k < N; ++k) {
+        const real pz = (real)tape_pop(key);
+        if (to_spawn) x.spawn[2 * x.B + x.base + k] = pz; else x.goals[k * 3 + 2] = pz;
     }
 }
 // Scenario_o_base.generate_pos_obst_map o_base.py:48-67 (no surroundings check): one free cell + z ~ U(0.75,3)
@@ -122,6 +132,7 @@ __device__ void standard_reset(const Consts<real> &c, const RngKey &key, const S
     shuffle_rows<real>(key, x.goals, 3, rows, 0);
 }
 
+// u < 0: -(k+1) encodes the list index k the reference drew (noise tape)
 __device__ __forceinline__ int mix_pick(int num_agents, bool use_obstacles, double u) {   // scenarios/mix.py:84-90 + utils.py:10-25
     const int LIST_MULTI[9] = {QS_SCENARIO_STATIC_SAME_GOAL, QS_SCENARIO_STATIC_DIFF_GOAL, QS_SCENARIO_EP_LISSAJOUS3D, QS_SCENARIO_EP_RAND_BEZIER,
                                QS_SCENARIO_DYNAMIC_SAME_GOAL, QS_SCENARIO_DYNAMIC_DIFF_GOAL, QS_SCENARIO_DYNAMIC_FORMATIONS, QS_SCENARIO_SWAP_GOALS,
@@ -130,7 +141,7 @@ __device__ __forceinline__ int mix_pick(int num_agents, bool use_obstacles, doub
     if (num_agents == 1) { if (use_obstacles) { n = 1; base_list = 1; } else { n = 5; base_list = 0; } }
     else if (!use_obstacles) { n = 9; base_list = 0; }
     else { n = 2; base_list = 1; }
-    int k = (int)(u * (double)n);
+    int k = (u < 0.0) ? (int)(-u) - 1 : (int)(u * (double)n);
     if (k >= n) k = n - 1;
     if (base_list == 1) return k == 0 ? QS_SCENARIO_O_RANDOM : QS_SCENARIO_O_STATIC_SAME_GOAL;
     if (n == 5) { const int LIST_SINGLE[5] = {QS_SCENARIO_STATIC_SAME_GOAL, QS_SCENARIO_STATIC_DIFF_GOAL, QS_SCENARIO_EP_LISSAJOUS3D,
@@ -146,8 +157,8 @@ __device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, co
     int sc, constructed;
     if (c.scenario == QS_SCENARIO_MIX) {
         // the pick uses a double-precision-equivalent index: u*n with u exact in fp32 (23-bit grid) and n <= 9
-        real u = rng_uniform1<real>(key, QS_SITE_SCEN, 288, 0, 0, (real)0, (real)1);
-        sc = mix_pick(c.num_agents, c.use_obstacles != 0, (double)u);
+        real u = rng_uniform1<real>(key, QS_SITE_SCEN, 288, 0, 0, (real)0, (real)1);   // (a tape holds the list index itself)
+        sc = mix_pick(c.num_agents, c.use_obstacles != 0, QS_ON_TAPE(key) ? -((double)(int)u + 1.0) : (double)u);
         constructed = 1;
     } else { sc = c.scenario; constructed = !x.si[SI_CONSTRUCTED]; x.si[SI_CONSTRUCTED] = 1; }
     x.si[SI_SCEN] = sc;
@@ -194,13 +205,32 @@ __device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, co
         x.si[SI_HAVE_SPAWN] = 1;
         real end[3];
         pos_obst_map_1<real>(c, key, x.omap, 9, end);
-        // (:72-90 sample ten "trajectory points" that step() never uses: with the counter-based stream there is nothing to skip)
+        // :72-90 sample ten "trajectory points" that step() never uses: with the counter-based stream there is nothing to skip; a tape
+        // holds those draws (np.random.choice over the free cells, rejected while farther than 4 m from an accepted one - the
+        // reference indexes its cell-centre table with the free-space index, reproduced here)
+        if (QS_ON_TAPE(key)) {
+            const int Lr = c.obst_area[0], W = c.obst_area[1];
+            int ns = 0;
+            while (ns < 10) {
+                const int idx = (int)tape_pop(key);
+                const int ii = idx / W, jj = (W - 1) - (idx - ii * W);
+                const real px = (real)ii + (real)0.5 - (real)(Lr / 2), py = (real)jj + (real)0.5 - (real)(W / 2);
+                bool reject = false;
+                for (int q = 0; q < ns; ++q) {
+                    const int sq = tidx[q], si2 = sq / W, sj2 = (W - 1) - (sq - si2 * W);
+                    const real dx = ((real)si2 + (real)0.5 - (real)(Lr / 2)) - px, dy = ((real)sj2 + (real)0.5 - (real)(W / 2)) - py;
+                    if (M<real>::sqrt(dx * dx + dy * dy) > (real)4) reject = true;
+                }
+                if (!reject) tidx[ns++] = idx;
+            }
+        }
         Formation<real> F;
         update_formation<real>(sc, key, 0, N, F);
         store_formation<real>(x, F);
         for (int q = 0; q < 3; ++q) x.sr[SR_END + q] = end[q];
         for (int k = 0; k < N; ++k) for (int q = 0; q < 3; ++q) x.goals[k * 3 + q] = end[q];
     } else if (sc == QS_SCENARIO_O_RANDOM) {
+        if (QS_ON_TAPE(key)) tape_skip(key, 4 * N);   // o_random.py:30-36: N x generate_pos_obst_map() twice, overwritten right below
         pos_obst_map_2<real>(c, key, x, tidx, tval, 16, 96, true);
         x.si[SI_HAVE_SPAWN] = 1;
         pos_obst_map_2<real>(c, key, x, tidx, tval, 160, 224, false);
@@ -287,7 +317,8 @@ __device__ void scenario_step_serial(const Consts<real> &c, const RngKey &key, c
         real ctr[3] = {x.sr[SR_C1], x.sr[SR_C1 + 1], x.sr[SR_C1 + 2]};
         generate_goals<real>(F, N, c.cube_fd_all, ctr, x.goals, 3);
     } else if (sc == QS_SCENARIO_RUN_AWAY) {            // run_away.py:15-27: drones 0 and 1 get the goals of two random others
-        const int g0 = 1 + rng_index<real>(key, QS_SITE_SCEN, 44, N - 1), g1 = 1 + rng_index<real>(key, QS_SITE_SCEN, 45, N - 1);
+        const int on_tape = QS_ON_TAPE(key) ? 1 : 0;   // np.random.randint(low=1, high=N, size=2): a tape holds the values themselves
+        const int g0 = (1 - on_tape) + rng_index<real>(key, QS_SITE_SCEN, 44, N - 1), g1 = (1 - on_tape) + rng_index<real>(key, QS_SITE_SCEN, 45, N - 1);
         for (int q = 0; q < 3; ++q) x.goals[0 * 3 + q] = x.goals[g0 * 3 + q];
         for (int q = 0; q < 3; ++q) x.goals[1 * 3 + q] = x.goals[g1 * 3 + q];
     } else {                                            // swap_goals.py:13-24 / o_swap_goals.py:14-25
@@ -330,7 +361,7 @@ __device__ void scenario_step_local(const Consts<real> &c, const RngKey &key, co
                 real u[6];
                 for (int k = 0; k < 6; ++k) { int ax = k % 3; u[k] = rng_uniform1<real>(key, QS_SITE_SCEN, 300 + 8 * it + k, 0, 0, -high[ax], high[ax]); }
                 int lo_i = (int)floorf((float)min_dist), hi_i = (int)max_dist + 1;   // np.random.randint truncates a float low
-                int r = lo_i + rng_index<real>(key, QS_SITE_SCEN, 300 + 8 * it + 6, hi_i - lo_i);
+                int r = (QS_ON_TAPE(key) ? 0 : lo_i) + rng_index<real>(key, QS_SITE_SCEN, 300 + 8 * it + 6, hi_i - lo_i);   // (tape: the randint value itself)
                 bool ok = true;
                 for (int col = 0; col < 2; ++col) {
                     real v[3] = {u[0 + col], u[2 + col], u[4 + col]}, n = norm3<real>(v);

@@ -13,6 +13,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
 #include <sys/stat.h>
@@ -28,6 +29,9 @@
 // ------------------------------------------------------------------------------------------------
 extern "C" int qs_obs_dim(const qs_config *c);
 extern "C" int qs_destroy(struct qs_handle *h);
+// noise-tape flavour of the kernels (qs_tape_kernels.hip, compiled with QS_TAPE)
+extern "C" int qs_tape_lds_bytes(const qs_config *cfg, int obs_dim, int full);
+extern "C" int qs_tape_launch(int which, const qs_config *cfg, int obs_dim, int full, const void *consts_f64, const void *ptrs, const void *actions, void *stream);
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(QS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
@@ -63,6 +67,10 @@ struct qs_handle {
     const void *graph_actions = nullptr;
     int32_t graph_k = 0;
     uint8_t *h_mask = nullptr;   // pinned staging for qs_reset masks
+    // noise tape (qs_set_noise_tape): device copy [E][tape_len] + per-env cursor; while set, reset / step run the tape kernels
+    double *d_tape = nullptr;
+    int32_t *d_tape_pos = nullptr;
+    int64_t tape_len = 0;
     // profiling of the step kernel
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -129,9 +137,21 @@ static bool team_default(int blocks, int cus, int num_agents) { return (long)blo
 // N > 8 the merge of 8 sorted lists outweighs that (C4 24.6 -> 28.3 us), so those keep 4 waves.
 static int spec_team_waves(int num_agents) { return num_agents <= 8 ? 8 : 4; }
 
+// Rows per pass of the observation output of a config-specialised single-wave kernel (qs_kernels.h, lds_layout): 16 rows keep a
+// workgroup under 10 KB of LDS (16 workgroups per CU); the register-held row values need D - S <= QS_NV_MAX, i.e. K <= 8.
+// QS_OBS_RP=16|32|64 overrides (64 = complete rows at once, the generic kernels' layout).
+static int spec_rows_per_pass(const qs_config *cfg, int team) {
+    const int self = cfg->obs_repr == 0 ? 18 : (cfg->obs_repr == 1 ? 19 : 24);
+    if (team || qs_obs_dim(cfg) - self > QS_NV_MAX) return QS_WAVE;
+    int rp = 16;
+    if (const char *ev = getenv("QS_OBS_RP")) { const int v = atoi(ev); if (v == 16 || v == 32 || v == 64) rp = v; }
+    return rp;
+}
+
 static std::string spec_header_text(const qs_config *cfg, int team) {
     const int rs = cfg->precision == QS_PRECISION_F64 ? 8 : 4, epb = QS_WAVE / cfg->num_agents;
-    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team, scenario_is_full(cfg->scenario), cfg->scenario);
+    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team, scenario_is_full(cfg->scenario), cfg->scenario,
+                             spec_rows_per_pass(cfg, team));
     std::vector<uint32_t> w;
     if (rs == 8) { Consts<double> k; fill_consts<double>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0; k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
                    w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
@@ -442,7 +462,8 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         const char *ev = getenv("QS_SPEC"), *tv = getenv("QS_TEAM");
         const std::string mode = (ev && ev[0]) ? ev : "jit";
         const int spec_team = h->team ? ((tv && tv[0] == '4') ? 4 : ((tv && tv[0] == '8') ? 8 : spec_team_waves(cfg->num_agents))) : 0;
-        const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, spec_team, scenario_is_full(cfg->scenario), cfg->scenario);
+        const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, spec_team, scenario_is_full(cfg->scenario), cfg->scenario,
+                                           spec_rows_per_pass(cfg, spec_team));
         if (mode != "off" && mode != "0" && sl.total <= 64 * 1024) {
             const std::string path = spec_ensure(cfg, spec_team, mode == "jit");
             if (!path.empty()) {
@@ -462,7 +483,8 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
             }
         }
     }
-    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team, scenario_is_full(cfg->scenario), cfg->scenario);
+    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team, scenario_is_full(cfg->scenario), cfg->scenario,
+                        h->spec_step ? spec_rows_per_pass(cfg, h->team) : QS_WAVE);
     h->full = scenario_is_full(cfg->scenario);
     rc = (h->real_size == 8) ? create_typed<double>(h) : create_typed<float>(h);
     if (rc == QS_OK) {
@@ -506,6 +528,8 @@ int qs_destroy(qs_handle *h) {
     if (h->d_state_buf) (void)hipFree(h->d_state_buf);
     if (h->d_tick_io) (void)hipFree(h->d_tick_io);
     if (h->h_mask) (void)hipHostFree(h->h_mask);
+    if (h->d_tape) (void)hipFree(h->d_tape);
+    if (h->d_tape_pos) (void)hipFree(h->d_tape_pos);
     for (auto &ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -514,6 +538,11 @@ int qs_destroy(qs_handle *h) {
 }
 
 static int launch_reset(qs_handle *h, hipStream_t s) {
+    if (h->d_tape) {
+        hipError_t e = (hipError_t)qs_tape_launch(0, &h->cfg, h->obs_dim, h->full ? 1 : 0, &h->kd, &h->pf, nullptr, s);
+        if (e != hipSuccess) return fail(QS_ERR_HIP, std::string("tape reset kernel: ") + hipGetErrorString(e));
+        return QS_OK;
+    }
     if (h->spec_reset) {
         Ptrs<double> pd; memcpy(&pd, &h->pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&h->pf, &h->lds, &h->epb};
@@ -556,6 +585,15 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
         e0 = h->events[h->events_used].first; e1 = h->events[h->events_used].second;
         ++h->events_used;
         HIP_TRY(hipEventRecord(e0, s));
+    }
+    if (h->d_tape) {   // noise-tape flavour: one launch per control step
+        const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * sizeof(double);
+        for (int t = 0; t < ksteps; ++t) {
+            hipError_t e = (hipError_t)qs_tape_launch(1, &h->cfg, h->obs_dim, h->full ? 1 : 0, &h->kd, &h->pf, (const char *)actions + stride * t, s);
+            if (e != hipSuccess) return fail(QS_ERR_HIP, std::string("tape step kernel: ") + hipGetErrorString(e));
+        }
+        if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
+        return QS_OK;
     }
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &h->pf, sizeof pd);
@@ -717,6 +755,47 @@ int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *str
     HIP_TRY(hipMemcpyAsync(h->snap_pool + h->snap_bytes * (size_t)dst_slot, h->snap_pool + h->snap_bytes * (size_t)src_slot, h->snap_bytes,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return QS_OK;
+}
+
+/* Noise tape (test instrument): see include/quadswarm.h. */
+int qs_set_noise_tape(qs_handle *h, const double *tape_host, int64_t len_per_env) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->d_tape) { (void)hipFree(h->d_tape); h->d_tape = nullptr; }
+    if (h->d_tape_pos) { (void)hipFree(h->d_tape_pos); h->d_tape_pos = nullptr; }
+    h->tape_len = 0;
+    h->pf.tape = nullptr; h->pf.tape_pos = nullptr; h->pf.tape_len = 0;
+    if (!tape_host || len_per_env <= 0) return QS_OK;   // back to the counter-based stream
+    if (h->real_size != 8) return fail(QS_ERR_UNSUPPORTED, "the noise tape is replayed by the float64 kernels: create the handle with QS_PRECISION_F64");
+    if (len_per_env > 0x7fffff00ll) return fail(QS_ERR_INVALID, "tape too long");
+    if (qs_tape_lds_bytes(&h->cfg, h->obs_dim, h->full ? 1 : 0) > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "noise tape: the single-wave layout does not fit the LDS");
+    const size_t E = h->cfg.num_envs, bytes = E * (size_t)len_per_env * sizeof(double);
+    HIP_TRY(hipMalloc((void **)&h->d_tape, bytes));
+    HIP_TRY(hipMalloc((void **)&h->d_tape_pos, E * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(h->d_tape, tape_host, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->d_tape_pos, 0, E * sizeof(int32_t)));
+    h->tape_len = len_per_env;
+    h->pf.tape = h->d_tape; h->pf.tape_pos = h->d_tape_pos; h->pf.tape_len = len_per_env;
+    return QS_OK;
+}
+
+int qs_get_tape_pos(qs_handle *h, int32_t *pos_host) {
+    if (!h || !pos_host) return fail(QS_ERR_INVALID, "null argument");
+    if (!h->d_tape) return fail(QS_ERR_INVALID, "no noise tape set");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(pos_host, h->d_tape_pos, (size_t)h->cfg.num_envs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return QS_OK;
+}
+
+/* debug / tools: dynamic LDS bytes per workgroup of the layout qs_create would use (team: waves per workgroup, 0 = single-wave;
+ * spec: 1 = config-specialised kernels) */
+int qs_debug_lds_bytes(const qs_config *cfg, int team, int spec) {
+    if (!cfg) return -1;
+    const int rs = cfg->precision == QS_PRECISION_F64 ? 8 : 4;
+    return lds_layout(rs, QS_WAVE, cfg->num_agents, QS_WAVE / cfg->num_agents, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team,
+                      scenario_is_full(cfg->scenario), cfg->scenario, spec ? spec_rows_per_pass(cfg, team) : QS_WAVE).total;
 }
 
 int qs_debug_timing(qs_handle *h, unsigned long long *out128) {   // [4 waves][32 stamps] of workgroup 0 (QS_TIMING builds)

@@ -15,7 +15,7 @@ from . import config as qcfg
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("QS_LIB", os.path.join(CSRC, "libquadswarm_hip.so"))   # QS_LIB: A/B builds (tools only)
-SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_kernels.h"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_step_team.inc"),
+SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_tape_kernels.hip"), os.path.join(CSRC, "qs_kernels.h"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_step_team.inc"),
            os.path.join(CSRC, "qs_device.h"),
            os.path.join(CSRC, "qs_scenarios.h"),
            os.path.join(os.path.dirname(HERE), "include", "quadswarm.h")]
@@ -38,10 +38,24 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= newest:
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, SOURCES[0]]
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+    objs = [os.path.join(CSRC, "quadswarm_hip.o"), os.path.join(CSRC, "qs_tape_kernels.o")]
+    # the noise-tape flavour replays the reference's float64 arithmetic: no FMA contraction there (NumPy has none)
+    cmds = [base + ["-c", SOURCES[0], "-o", objs[0]], base + ["-ffp-contract=off", "-c", SOURCES[1], "-o", objs[1]],
+            [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs]
+    procs = []
+    for cmd in cmds[:2]:
+        if verbose:
+            print(" ".join(cmd))
+        procs.append(subprocess.Popen(cmd))
+    for pr, cmd in zip(procs, cmds[:2]):
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(cmds[2]))
+    subprocess.check_call(cmds[2])
+    for o in objs:
+        os.remove(o)
     return LIB_PATH
 
 
@@ -107,6 +121,8 @@ def lib():
         L.qs_snapshot_save.argtypes = [vp, C.c_int32, C.c_int32, vp]
         L.qs_snapshot_load.argtypes = [vp, C.c_int32, C.c_int32, vp]
         L.qs_snapshot_copy.argtypes = [vp, C.c_int32, C.c_int32, vp]
+        L.qs_set_noise_tape.argtypes = [vp, C.POINTER(C.c_double), C.c_int64]
+        L.qs_get_tape_pos.argtypes = [vp, C.POINTER(C.c_int32)]
         if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
             raise RuntimeError("qs_config layout mismatch between config.py and libquadswarm_hip.so")
         _lib = L
@@ -117,7 +133,8 @@ EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_defau
                     "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor",
-                    "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy"]
+                    "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
+                    "qs_set_noise_tape", "qs_get_tape_pos"]
 
 
 class QsError(RuntimeError):
@@ -238,6 +255,20 @@ class Stepper:
 
     def snapshot_copy(self, src_slot, dst_slot, stream=None):
         _check(lib().qs_snapshot_copy(self._h, src_slot, dst_slot, self._stream_ptr(stream)))
+
+    # ---- noise tape (test instrument, include/quadswarm.h) ---------------------------------------------
+    def set_noise_tape(self, tape):
+        """tape: [E, len] float64 reference draws per environment (None = back to the Philox stream)."""
+        if tape is None:
+            _check(lib().qs_set_noise_tape(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(tape, dtype=np.float64).reshape(self.E, -1)
+        _check(lib().qs_set_noise_tape(self._h, a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[1]))
+
+    def tape_pos(self):
+        out = np.zeros(self.E, dtype=np.int32)
+        _check(lib().qs_get_tape_pos(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
 
     @property
     def specialized(self):
