@@ -672,14 +672,17 @@ __device__ int generate_goals(const Formation<real> &F, int n, int fd, const rea
         }
     } else if (f == 3) {
         int m = n < 3 ? 3 : n;
-        real x = (real)0.1 + (real)1.2 * m, start = (real)-1 + (real)1 / (m - (real)1), inc = ((real)2 - (real)2 / (m - (real)1)) / (m - (real)1);
+        // in double throughout: the azimuth s * x reaches +-(0.1 + 1.2 m) rad (77 rad for 64 drones), where fp32 resolves 4e-6 rad and the
+        // fp32 fast-math sin / cos lose 1e-4 - times a formation radius of a few metres that is more than the 1e-5 the fp32 path is
+        // specified to (cold per-episode code)
+        const double x = 0.1 + 1.2 * m, start = -1.0 + 1.0 / (m - 1.0), inc = (2.0 - 2.0 / (m - 1.0)) / (m - 1.0);
         for (int j = 0; j < m; ++j) {
-            real s = start + j * inc, sg = (real)((s > 0) - (s < 0));
-            real xx = s * x, yy = (real)(QS_PI_D / 2.) * sg * ((real)1 - M<real>::sqrt((real)1 - M<real>::fabs(s)));
-            real sx, cx, sy, cy; M<real>::sincos(xx, &sx, &cx); M<real>::sincos(yy, &sy, &cy);
-            out[j * ld + 0] = size * (cx * cy) + center[0];
-            out[j * ld + 1] = size * (sx * cy) + center[1];
-            out[j * ld + 2] = size * sy + center[2];
+            const double sj = start + j * inc, sg = (double)((sj > 0) - (sj < 0));
+            const double xx = sj * x, yy = (QS_PI_D / 2.) * sg * (1.0 - ::sqrt(1.0 - ::fabs(sj)));
+            const double sx = ::sin(xx), cx = ::cos(xx), sy = ::sin(yy), cy = ::cos(yy);
+            out[j * ld + 0] = (real)((double)size * (cx * cy) + (double)center[0]);
+            out[j * ld + 1] = (real)((double)size * (sx * cy) + (double)center[1]);
+            out[j * ld + 2] = (real)((double)size * sy + (double)center[2]);
         }
         rows = m;
     } else if (f_is_grid(f)) {

@@ -52,6 +52,7 @@ template <typename real> struct Ptrs {
     real *run_sums, *ep_sums;   // [QS_SUM_COUNT, T] per-episode sums (running / last finished episode)
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
+    const real *rew_rt;   // [QS_REW_COUNT + 1] run-time reward coefficients + proximity slope (qs_set_reward_coeffs)
     // noise tape (qs_set_noise_tape; consumed by the QS_TAPE kernels only): [E][tape_len] reference draws, per-env cursor
     const double *tape;
     int32_t *tape_pos;
@@ -813,7 +814,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
 // literals - loops over drones / neighbours / obstacles unroll, LDS addresses fold into instruction offsets and the
 // scalar bookkeeping of the generic kernels disappears (a lone wave per SIMD issues one instruction every ~4.5 cycles
 // whatever its type, so instruction count is what the per-step latency is made of).  What stays a run-time argument:
-// reward coefficients (annealed by the reward-shaping wrapper), seed, env_id_offset, num_envs.
+// seed, env_id_offset, num_envs; the reward coefficients (annealed by the reward-shaping wrapper) are read from device memory.
 // ------------------------------------------------------------------------------------------------
 template <typename real, bool FULL>
 __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> &p, const LdsLayout &L, int epb) {
@@ -881,9 +882,7 @@ typedef float real;
 #endif
 __device__ __forceinline__ Consts<real> qs_spec_consts(const Consts<real> &rt) {
     Consts<real> c = __builtin_bit_cast(Consts<real>, qs_spec_cw);
-#pragma unroll
-    for (int q = 0; q < QS_REW_COUNT; ++q) c.rew_coeff[q] = rt.rew_coeff[q];
-    c.prox_ratio = rt.prox_ratio; c.seed_lo = rt.seed_lo; c.seed_hi = rt.seed_hi; c.env_id_offset = rt.env_id_offset; c.num_envs = rt.num_envs;
+    c.seed_lo = rt.seed_lo; c.seed_hi = rt.seed_hi; c.env_id_offset = rt.env_id_offset; c.num_envs = rt.num_envs;
     return c;
 }
 #define QS_KARGS const Consts<real> c_rt, Ptrs<real> p, const real *__restrict__ actions, LdsLayout L_rt

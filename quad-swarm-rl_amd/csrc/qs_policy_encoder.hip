@@ -19,6 +19,7 @@
 // the row tile index IS the neighbour index and the mean over neighbours is a lane-local sum across accumulator tiles.
 // Operand layout verified on hardware by tools/mfma_layout_probe.hip.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 #include <string>
@@ -808,17 +809,29 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
     if (att && (!P.ebuf || !P.gbuf)) { g_enc_error = "the attention neighbour encoder needs the ebuf / gbuf scratch buffers"; return -1; }
     if (att && (int64_t)B * P.num_nbr * (ENC_H * 2) > 0x7fffffffll) { g_enc_error = "attention: batch x neighbours too large for 32-bit scratch offsets"; return -4; }
     if (B == 0) return 0;
-    static bool attr_set = false;
+    // launch on the device that owns `obs` (a process may drive several GPUs); the > 64 KB dynamic-LDS attribute is per device
+    int dev = 0;
+    {
+        hipPointerAttribute_t pa;
+        if (hipPointerGetAttributes(&pa, obs) == hipSuccess) dev = pa.device; else { (void)hipGetLastError(); (void)hipGetDevice(&dev); }
+        if (hipSetDevice(dev) != hipSuccess) { g_enc_error = "hipSetDevice failed"; return -2; }
+    }
     const size_t lds = lds_main(att);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(0)) != hipSuccess ||
-            hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
-            hipFuncSetAttribute((const void *)qs_encoder_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
-            hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed()) != hipSuccess) {
-            g_enc_error = "cannot raise the dynamic LDS limit";
-            return -2;
+    {
+        static std::mutex attr_mutex;
+        static uint64_t attr_set = 0;   // bit d: attributes set on device d
+        std::lock_guard<std::mutex> lock(attr_mutex);
+        if (dev < 0 || dev >= 64) { g_enc_error = "device index out of range"; return -2; }
+        if (!(attr_set >> dev & 1)) {
+            if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(0)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed()) != hipSuccess) {
+                g_enc_error = "cannot raise the dynamic LDS limit";
+                return -2;
+            }
+            attr_set |= 1ull << dev;
         }
-        attr_set = true;
     }
     if (mha)
         hipLaunchKernelGGL(qs_encoder_mha_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);

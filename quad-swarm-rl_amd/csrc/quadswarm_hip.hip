@@ -343,6 +343,17 @@ template <typename real> static int create_typed(qs_handle *h) {
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
     DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128);
 #undef DA
+    {   // run-time reward coefficients (+ proximity slope), read by every launch
+        real *rw = nullptr;
+        if ((rc = dalloc(h, &rw, QS_REW_COUNT + 1)) != QS_OK) return rc;
+        p.rew_rt = rw;
+        Consts<real> k;
+        fill_consts<real>(c, k);
+        real host[QS_REW_COUNT + 1];
+        for (int q = 0; q < QS_REW_COUNT; ++q) host[q] = k.rew_coeff[q];
+        host[QS_REW_COUNT] = k.prox_ratio;
+        HIP_TRY(hipMemcpy(rw, host, sizeof host, hipMemcpyHostToDevice));
+    }
     real *act = nullptr;
     if ((rc = dalloc(h, &act, 4 * T)) != QS_OK) return rc;
     h->d_actions = act;
@@ -671,7 +682,18 @@ int qs_set_reward_coeffs(qs_handle *h, const double *coeffs) {
     for (int q = 0; q < QS_REW_COUNT; ++q) h->cfg.rew_coeff[q] = coeffs[q];
     fill_consts<float>(h->cfg, h->kf);
     fill_consts<double>(h->cfg, h->kd);
-    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }   // constants are baked into the nodes
+    // the kernels read the coefficients from this buffer on every launch - also launches replayed from a captured HIP graph
+    if (h->real_size == 8) {
+        double host[QS_REW_COUNT + 1];
+        for (int q = 0; q < QS_REW_COUNT; ++q) host[q] = h->kd.rew_coeff[q];
+        host[QS_REW_COUNT] = h->kd.prox_ratio;
+        HIP_TRY(hipMemcpy((void *)h->pf.rew_rt, host, sizeof host, hipMemcpyHostToDevice));
+    } else {
+        float host[QS_REW_COUNT + 1];
+        for (int q = 0; q < QS_REW_COUNT; ++q) host[q] = h->kf.rew_coeff[q];
+        host[QS_REW_COUNT] = h->kf.prox_ratio;
+        HIP_TRY(hipMemcpy((void *)h->pf.rew_rt, host, sizeof host, hipMemcpyHostToDevice));
+    }
     return QS_OK;
 }
 

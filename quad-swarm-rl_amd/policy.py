@@ -82,7 +82,9 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
             super().__init__()
             self.self_dim, self.nbr_dim, self.num_nbr, self.obst_dim = self_dim, nbr_dim, num_nbr, obst_dim
             mlp = lambda i: nn.Sequential(nn.Linear(i, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
-            self.self_encoder = mlp(self_dim)                                   # :303-309
+            # Parameters are created in the reference's order (neighbour encoder :279-293, self encoder :300-309, obstacle encoder
+            # :313-322, feed forward :329-332), so that the same torch seed gives the same weights as the reference class - that is
+            # what lets tests/golden/encoder_*.npz hold a seed instead of megabytes of weights.
             self.nbr_encoder = nbr_encoder if num_nbr > 0 else "no_encoder"
             self.attention = self.nbr_encoder == "attention"
             if self.nbr_encoder == "mlp":                                       # :110-117
@@ -96,6 +98,7 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
                 self.neighbor_value_mlp = mlp(hidden)                           # :60-65
                 self.attention_mlp = nn.Sequential(nn.Linear(2 * hidden, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
                                                    nn.Linear(hidden, 1))        # :68-75
+            self.self_encoder = mlp(self_dim)                                   # :303-309
             self.obstacle_encoder = mlp(obst_dim) if obst_dim > 0 else None     # :315-322
             total = hidden * (1 + (self.neighbor_encoder is not None) + (obst_dim > 0))
             self.feed_forward = nn.Sequential(nn.Linear(total, 2 * hidden), nn.Tanh())   # :329-332
@@ -172,6 +175,60 @@ def make_reference_mha_encoder(self_dim=19, nbr_dim=6, num_nbr=2, obst_dim=9, hi
 
     torch.manual_seed(seed)
     return QuadMultiHeadAttentionEncoderRef()
+
+
+# reference / Sample Factory parameter names -> the names of the restatements above (the encoder sits under "encoder." in an SF
+# actor-critic checkpoint; any such prefix is stripped)
+_KEYMAP_MULTI = (("neighbor_encoder.embedding_mlp.", "neighbor_encoder."), ("neighbor_encoder.neighbor_mlp.", "neighbor_encoder."),
+                 ("neighbor_encoder.neighbor_value_mlp.", "neighbor_value_mlp."), ("neighbor_encoder.attention_mlp.", "attention_mlp."))
+_KEYMAP_MHA = (("self_embed_layer.", "self_encoder."), ("neighbor_embed_layer.", "neighbor_encoder."), ("obstacle_embed_layer.", "obstacle_encoder."))
+
+
+def _strip_prefix(sd, probe):
+    keys = [k for k in sd if k.endswith(probe)]
+    if not keys:
+        raise KeyError(f"state dict has no '{probe}': not a QuadMultiEncoder / QuadMultiHeadAttentionEncoder checkpoint")
+    prefix = keys[0][:-len(probe)]
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def encoder_from_state_dict(sd, num_nbr, nbr_dim=6):
+    """A restatement module (make_reference_encoder / make_reference_mha_encoder) carrying the weights of a reference checkpoint:
+    `sd` is the state_dict of the reference's QuadMultiEncoder (swarm_rl/models/quad_multi_model.py:250-350) or
+    QuadMultiHeadAttentionEncoder (:124-196), or of a whole Sample Factory actor-critic (keys under "...encoder.").  Shapes (self /
+    obstacle observation widths, hidden size) and the neighbour encoder type are read off the tensors; `num_nbr` (neighbours per
+    row) is not recoverable from mean_embed / attention weights and must be given.  FusedQuadEncoder(encoder_from_state_dict(...))
+    runs a trained reference policy's encoder on the fused kernel."""
+    import torch
+    mha = any(k.endswith("self_embed_layer.0.weight") for k in sd)
+    sd = _strip_prefix(sd, "self_embed_layer.0.weight" if mha else "self_encoder.0.weight")
+    out = {}
+    for k, v in sd.items():
+        for a, b in (_KEYMAP_MHA if mha else _KEYMAP_MULTI):
+            if k.startswith(a):
+                k = b + k[len(a):]
+                break
+        out[k] = v
+    if mha:
+        hidden, self_dim = out["self_encoder.0.weight"].shape
+        obst_dim = out["obstacle_encoder.0.weight"].shape[1]
+        module = make_reference_mha_encoder(self_dim=self_dim, nbr_dim=nbr_dim, num_nbr=out["neighbor_encoder.0.weight"].shape[1] // nbr_dim,
+                                            obst_dim=obst_dim, hidden=hidden)
+        out = {k: v for k, v in out.items() if not k.startswith("attention_layer.attention")}
+    else:
+        hidden, self_dim = out["self_encoder.0.weight"].shape
+        obst_dim = out["obstacle_encoder.0.weight"].shape[1] if "obstacle_encoder.0.weight" in out else 0
+        if "attention_mlp.0.weight" in out:
+            kind = "attention"
+        elif "neighbor_encoder.4.weight" in out:
+            kind, num_nbr = "mlp", out["neighbor_encoder.0.weight"].shape[1] // nbr_dim
+        elif "neighbor_encoder.0.weight" in out:
+            kind = "mean_embed"
+        else:
+            kind = "no_encoder"
+        module = make_reference_encoder(self_dim=self_dim, nbr_dim=nbr_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=hidden, nbr_encoder=kind)
+    module.load_state_dict({k: torch.as_tensor(v) for k, v in out.items()}, strict=True)
+    return module
 
 
 def pack_linear(linear, device, cols=None):

@@ -47,3 +47,28 @@ def test_graphed_rollout_samples_fresh_noise_on_every_replay():
     assert not torch.equal(a, b)                      # the environments moved on and the sampler drew new noise
     assert (a[1:] - a[:-1]).abs().max() > 0
     env.close()
+
+
+def test_reward_coefficient_updates_reach_a_captured_graph():
+    """The reward-shaping wrapper anneals env.rew_coeff during training (swarm_rl/env_wrappers/reward_shaping.py:111-118).  The step
+    kernels read the coefficients from device memory on every launch, so a segment captured BEFORE an update must compute the
+    rewards with the new values when it is replayed afterwards."""
+    import torch
+    from quad_swarm_rl_amd import policy, rollout
+    from quad_swarm_rl_amd.env import QuadSwarmVecEnv
+    kw = dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0)
+    enc = policy.FusedQuadEncoder(policy.make_reference_encoder(seed=2, nbr_encoder="mean_embed").cuda())
+    head = rollout.GaussianActionHead(sample=False, seed=4)
+    rewards = []
+    for update in (False, True):
+        env = QuadSwarmVecEnv(4, seed=9, **kw)
+        env.reset()
+        seg = rollout.GraphedRollout(env, enc, head, steps=6)
+        if update:
+            coeffs = [float(x) for x in env.stepper.cfg.rew_coeff]
+            coeffs[0] *= 3.0                                   # pos: the dominant term of every step's reward
+            env.stepper.set_reward_coeffs(coeffs)
+        rewards.append(seg.run()["rewards"].clone())
+        torch.cuda.synchronize()
+        env.close()
+    assert (rewards[1] < rewards[0] - 1e-4).all()             # -dt * 3 * pos * dist  vs  -dt * pos * dist
