@@ -141,6 +141,27 @@ def cpu_baseline(workload, seconds):
                 os_cpu_count=os.cpu_count())
 
 
+def c5_record(run_training):
+    """BASELINE.json configs[4] ("C5": C2 inside Sample Factory APPO).  Sample Factory is not part of this image and cannot be
+    installed (no network): the bench line records the exact import error, or - where it imports - the FPS of tools/train_c5.py
+    (the reference's train_local.sh flag set, 2e5 env steps)."""
+    import subprocess
+    try:
+        import sample_factory  # noqa: F401
+    except Exception as exc:   # noqa: BLE001 - the exact error is what is recorded
+        return {"status": "not run", "error": f"{type(exc).__name__}: {exc}",
+                "stand_in": "tests/test_sf_protocol_gpu.py drives the batched env through Sample Factory's vectorised-env protocol; tools/bench_rollout.py "
+                            "times the device-resident encoder -> head -> step loop"}
+    if not run_training:
+        return {"status": "sample_factory importable; training skipped (--no-c5-train)"}
+    try:
+        out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "train_c5.py")], capture_output=True, text=True, timeout=1200)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else {"status": "failed", "stderr_tail": out.stderr[-500:]}
+    except Exception as exc:   # noqa: BLE001
+        return {"status": "failed", "error": f"{type(exc).__name__}: {exc}"}
+
+
 def pmc_traffic(workload, num_envs, kernel):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC pass (profiles/rNN_pmc_traffic.json, produced by
     tools/pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units and gfx950 corrections of MI355X_MICROARCH.md);
@@ -172,6 +193,7 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL obs all-gather path even at N=1 (exercises the multi-GPU code on a 1-GPU box)")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
     ap.add_argument("--no-overlap", action="store_true", help="gather on the compute stream instead of overlapping it with the next step")
+    ap.add_argument("--no-c5-train", action="store_true", help="where sample_factory imports: do not run the C5 training (tools/train_c5.py)")
     ap.add_argument("--no-f64", action="store_true", help="skip the f64 line (same workload through the float64 kernels)")
     ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a workload keyword (python literal)")
@@ -349,6 +371,7 @@ def main():
                        "secondary": secondary,
                        "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and not use_gather else "one launch per control step",
                        "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info),
+                       "c5": c5_record(not args.no_c5_train) if world == 1 else None,
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(workload, E, kernel_name), "kernel": kernel_name,

@@ -258,6 +258,36 @@ int qs_snapshot_load(qs_handle *h, int32_t slot, int32_t env, void *stream);
 int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *stream);
 
 /*
+ * Batched experience replay on the device: ExperienceReplayWrapper of the reference
+ * (gym_art/quadrotor_multi/quad_experience_replay.py:66-209, wired at swarm_rl/env_wrappers/quad_utils.py:67-70) for ALL
+ * environments of the handle at once.  Every environment has its own checkpoint ring (one checkpoint per 0.5 s, the last
+ * 3 s = QS_REPLAY_RING slots) and its own buffer of QS_REPLAY_EVENTS collision events - what one wrapped env of the reference
+ * has - as device-side snapshots (the arrays of qs_snapshot_*).  After qs_replay_enable(), every qs_step() is followed on the
+ * same stream by one launch of the replay kernel, which per environment does what the wrapper's step() / new_episode() do:
+ *   - an episode ended: count it; with probability sample_prob (if the env's replay buffer is active and not empty) restore a
+ *     randomly chosen event - state, observation, counters of collisions zeroed (:176-187), replay count, clean-up of events
+ *     replayed 10 times (:50-56) - else keep the fresh episode the step kernel's auto-reset started (the reference resets a
+ *     second time there, :191-206: a redundant re-draw unless per-episode obstacle randomisation is on, see below);
+ *   - otherwise: every 0.5 s save a checkpoint (:141-144); on a collision after the 1.5 s grace period, at most once per 5 s,
+ *     file the checkpoint of 1.5 s ago as an event (:146-165) - and, like the reference (whose `obs` variable is rebound there),
+ *     return that checkpoint's observation for this one step;
+ *   - `activate_replay_buffer` (quadrotor_multi.py:284-287,:356-359): on after >= 10 recorded episodes with a mean crash
+ *     reward above -1, both reset() calls of an episode end recording, as in the reference.
+ * Draws come from the counter-based stream (QS_SITE_REPLAY).  Needs episode_sums = 1 (the per-episode crash reward).
+ * qs_replay_stats copies out, per environment: [0] episodes, [1] replayed episodes, [2] events in the buffer, [3] sum of their
+ * replay counts, [4] replay buffer active, [5] checkpoints in the ring, [6] filing attempts without 3 checkpoints (the
+ * reference raises IndexError there), [7] the episode that ended last was a replayed one (its statistics are then the two
+ * `*_replay` counters of quadrotor_multi.py:629-633), [8] control steps of that episode (a replayed one starts at its checkpoint's
+ * tick).  qs_replay_set_active overrides the activation rule (NULL = all on).
+ */
+#define QS_REPLAY_RING 6
+#define QS_REPLAY_EVENTS 20
+#define QS_REPLAY_STATS 9
+int qs_replay_enable(qs_handle *h, double sample_prob);
+int qs_replay_stats(qs_handle *h, int32_t *stats_host /* [QS_REPLAY_STATS][num_envs] */);
+int qs_replay_set_active(qs_handle *h, const uint8_t *active_host /* [num_envs] or NULL */);
+
+/*
  * Config-specialised kernels (no counterpart in the reference; the analogue of Numba compiling the env's hot
  * functions for the argument types it sees, gym_art/quadrotor_multi/quadrotor_dynamics.py:498,:570).  Besides
  * the generic kernels of the library, qs_create() can run a code object compiled for exactly one
@@ -286,7 +316,8 @@ enum { QS_SITE_OU = 0, QS_SITE_SENS_POS_N, QS_SITE_SENS_POS_U, QS_SITE_SENS_VEL_
        QS_SITE_DD_N, QS_SITE_DD_U, QS_SITE_DD_W,
        QS_SITE_OBST_N, QS_SITE_OBST_U, QS_SITE_OBST_W,
        QS_SITE_WALL, QS_SITE_CEIL,
-       QS_SITE_SPAWN, QS_SITE_SPAWN_YAW, QS_SITE_OBST_MAP, QS_SITE_SCEN, QS_SITE_SCEN_SHUFFLE };
+       QS_SITE_SPAWN, QS_SITE_SPAWN_YAW, QS_SITE_OBST_MAP, QS_SITE_SCEN, QS_SITE_SCEN_SHUFFLE,
+       QS_SITE_REPLAY /* slot 0: replay-or-new-episode draw, slot 1: which event, slot 2 / 3: obstacle density / size choice */ };
 
 #ifdef __cplusplus
 }

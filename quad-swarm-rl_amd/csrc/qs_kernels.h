@@ -979,7 +979,158 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c,
 }
 #endif
 
-#ifndef QS_TAPE
+#if !defined(QS_TAPE) && !defined(QS_SPEC)
+// ------------------------------------------------------------------------------------------------
+// Batched experience replay (include/quadswarm.h: qs_replay_enable): one wave per environment, launched after every step.
+// Lane 0 runs the wrapper's decision logic on the env's scalars; the whole wave then moves the snapshot it decided on.
+// A snapshot = every per-drone / per-env array of one environment (the list of qs_snapshot_*), packed array after array.
+// ------------------------------------------------------------------------------------------------
+#define QS_REPLAY_MAX_ARR 40
+struct ReplayArr { char *base; uint32_t elem, comps, per_env, off; uint64_t comp_stride; };   // strides / counts in elements, off in bytes
+struct ReplayParams {
+    ReplayArr arr[QS_REPLAY_MAX_ARR];
+    int32_t narr, N, E, use_obstacles, cp_every, grace_ticks, min_gap, obs_arr, tick_arr, ep_len;   // obs_arr / tick_arr: index of that array in arr[]
+    uint32_t snap_bytes, seed_lo, seed_hi;
+    int32_t env_id_offset;
+    float sample_prob;
+    char *pool;                                  // [E][QS_REPLAY_RING + QS_REPLAY_EVENTS][snap_bytes]
+    const uint8_t *done; const int32_t *tick; const uint32_t *step_ctr; const uint64_t *unique_col, *obst_new;
+    int32_t *counters;                           // [QS_CNT_COUNT][E]
+    const void *ep_sums; int32_t real_size, T;   // per-episode crash reward of drone 0: ep_sums[QS_RI_REW_CRASH][e*N]
+    // per-env wrapper state
+    uint8_t *active, *saved, *ep_saved;          // ep_saved: was the episode that just ended a replayed one (quadrotor_multi.py:629-633)
+    float *crash_hist; int32_t *crash_n, *crash_pos;    // deque(maxlen=100) of crashes_last_episode
+    int32_t *ck_count, *ck_head, *last_added;    // checkpoint ring: entries, slot of the oldest; tick of the last filed event
+    int32_t *ev_len, *ev_idx, *ev_replayed;      // event buffer: entries, buffer_idx, num_replayed [QS_REPLAY_EVENTS][E]
+    int32_t *ev_slot;                            // [QS_REPLAY_EVENTS][E]: pool slot of the k-th event (the deque order of the reference)
+    int32_t *episodes, *replayed, *errors;
+    int32_t *start_tick, *last_steps;            // tick the running episode started at (a replayed one: its checkpoint's); control steps of the last finished one
+};
+
+__device__ __forceinline__ void replay_copy(const ReplayParams &P, int e, char *snap, bool save, int lane) {
+    for (int a = 0; a < P.narr; ++a) {
+        const ReplayArr A = P.arr[a];
+        const int total = (int)(A.comps * A.per_env);
+        char *sp = snap + A.off;
+        for (int idx = lane; idx < total; idx += QS_WAVE) {
+            const int cpt = idx / (int)A.per_env, k = idx - cpt * (int)A.per_env;
+            char *live = A.base + ((size_t)cpt * A.comp_stride + (size_t)e * A.per_env + k) * A.elem;
+            char *sn = sp + (size_t)idx * A.elem;
+            if (A.elem == 8) { if (save) *(uint64_t *)sn = *(const uint64_t *)live; else *(uint64_t *)live = *(const uint64_t *)sn; }
+            else if (A.elem == 4) { if (save) *(uint32_t *)sn = *(const uint32_t *)live; else *(uint32_t *)live = *(const uint32_t *)sn; }
+            else { if (save) *sn = *live; else *live = *sn; }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(QS_WAVE) qs_replay_kernel(const ReplayParams P) {
+    __shared__ int s_act[4];   // action, source slot, destination slot, flags
+    const int e = blockIdx.x, lane = threadIdx.x, E = P.E, SLOTS = QS_REPLAY_RING + QS_REPLAY_EVENTS;
+    enum { ACT_NONE = 0, ACT_SAVE = 1, ACT_FILE = 2, ACT_RESTORE = 3 };
+    if (lane == 0) {
+        int act = ACT_NONE, src = 0, dst = 0;
+        const bool done = P.done[(size_t)e * P.N] != 0;
+        const int tick = P.tick[e];
+        RngKey key = {P.seed_lo, P.seed_hi, (uint32_t)(P.env_id_offset + e), P.step_ctr[e]};
+        auto record_reset = [&](float crashes) {   // QuadrotorEnvMulti.reset, quadrotor_multi.py:356-359 (+ can_drones_fly :284-287)
+            if (P.active[e]) return;
+            int n = P.crash_n[e], pos = P.crash_pos[e];
+            P.crash_hist[(size_t)pos * E + e] = crashes;
+            pos = (pos + 1) % 100; n = n < 100 ? n + 1 : 100;
+            P.crash_n[e] = n; P.crash_pos[e] = pos;
+            float sum = 0;
+            for (int q = 0; q < n; ++q) sum += P.crash_hist[(size_t)q * E + e];
+            if (fabsf(sum / (float)n) < 1.0f && n >= 10) P.active[e] = 1;
+        };
+        if (done) {   // ExperienceReplayWrapper.new_episode, quad_experience_replay.py:167-209
+            const float crashes = P.real_size == 8 ? (float)((const double *)P.ep_sums)[(size_t)QS_RI_REW_CRASH * P.T + (size_t)e * P.N]
+                                                   : ((const float *)P.ep_sums)[(size_t)QS_RI_REW_CRASH * P.T + (size_t)e * P.N];
+            record_reset(crashes);                 // the auto-reset inside QuadrotorEnvMulti.step
+            P.ep_saved[e] = P.saved[e];
+            P.last_steps[e] = P.ep_len + 1 - P.start_tick[e];
+            P.start_tick[e] = 0;
+            P.episodes[e] += 1;
+            P.last_added[e] = -1000000000;
+            P.ck_count[e] = 0; P.ck_head[e] = 0;
+            const float u = rng_uniform1<float>(key, QS_SITE_REPLAY, 0, 0, 0, 0.f, 1.f);
+            int len = P.ev_len[e];
+            if (u < P.sample_prob && P.active[e] && len > 0) {
+                P.replayed[e] += 1;
+                int idx = (int)(rng_uniform1<float>(key, QS_SITE_REPLAY, 1, 0, 0, 0.f, 1.f) * (float)len);   // random.randint(0, len - 1)
+                idx = idx >= len ? len - 1 : idx;
+                P.ev_replayed[(size_t)idx * E + e] += 1;
+                act = ACT_RESTORE; src = P.ev_slot[(size_t)idx * E + e];
+                P.start_tick[e] = *(const int32_t *)(P.pool + ((size_t)e * SLOTS + src) * P.snap_bytes + P.arr[P.tick_arr].off);
+                // ReplayBuffer.cleanup (:50-56): drop the events replayed 10 times, order kept, buffer_idx untouched
+                int w = 0;
+                for (int q = 0; q < len; ++q) {
+                    const int nr = P.ev_replayed[(size_t)q * E + e], sl = P.ev_slot[(size_t)q * E + e];
+                    if (nr < 10) { P.ev_replayed[(size_t)w * E + e] = nr; P.ev_slot[(size_t)w * E + e] = sl; ++w; }
+                }
+                P.ev_len[e] = w;
+                P.saved[e] = 1;                    // the event's copy of the env was marked saved_in_replay_buffer (:28)
+            } else {
+                record_reset(0.f);                 // the wrapper's own env.reset() (:203): crashes_last_episode is 0 again by then
+                P.saved[e] = 0;
+            }
+        } else if (P.active[e] && !P.saved[e]) {
+            int cnt = P.ck_count[e], head = P.ck_head[e];
+            if (tick % P.cp_every == 0) {          // save_checkpoint (:141-144): deque(maxlen = QS_REPLAY_RING)
+                if (cnt < QS_REPLAY_RING) { dst = (head + cnt) % QS_REPLAY_RING; ++cnt; }
+                else { dst = head; head = (head + 1) % QS_REPLAY_RING; }
+                P.ck_count[e] = cnt; P.ck_head[e] = head;
+                act = ACT_SAVE;
+            }
+            const bool collision = (P.unique_col[e] & ~1ull) != 0 || (P.use_obstacles && P.obst_new[e] != 0);   // `.any()` on the id array
+            if (collision && tick > P.grace_ticks && tick - P.last_added[e] > P.min_gap) {
+                if (cnt < 3) P.errors[e] += 1;     // the reference raises IndexError here
+                else {
+                    // checkpoints[-3]; if this very step also saved one, the wave saves first and files afterwards
+                    src = (head + cnt - 3) % QS_REPLAY_RING;
+                    int len = P.ev_len[e], bi = P.ev_idx[e], k;
+                    if (len < QS_REPLAY_EVENTS) {  // append: take a pool slot no listed event uses
+                        uint32_t used = 0;
+                        for (int q = 0; q < len; ++q) used |= 1u << (P.ev_slot[(size_t)q * E + e] - QS_REPLAY_RING);
+                        int fs = 0; while (used >> fs & 1) ++fs;
+                        k = len; P.ev_slot[(size_t)k * E + e] = QS_REPLAY_RING + fs; P.ev_len[e] = len + 1;
+                    } else k = bi;                 // overwrite buffer[buffer_idx]
+                    P.ev_replayed[(size_t)k * E + e] = 0;
+                    P.ev_idx[e] = (bi + 1) % QS_REPLAY_EVENTS;
+                    P.last_added[e] = tick;
+                    dst = (act == ACT_SAVE ? dst : 0) | (P.ev_slot[(size_t)k * E + e] << 8);
+                    act = act == ACT_SAVE ? (ACT_SAVE | (ACT_FILE << 4)) : ACT_FILE;
+                    s_act[3] = src;
+                }
+            }
+        }
+        s_act[0] = act; s_act[1] = src; s_act[2] = dst;
+    }
+    __syncthreads();
+    const int act = s_act[0];
+    if (act == ACT_NONE) return;
+    char *pool = P.pool + (size_t)e * SLOTS * P.snap_bytes;
+    if ((act & 15) == ACT_SAVE) { replay_copy(P, e, pool + (size_t)(s_act[2] & 255) * P.snap_bytes, true, lane); __threadfence_block(); __syncthreads(); }
+    if ((act & 15) == ACT_FILE || (act >> 4) == ACT_FILE) {
+        const char *src = pool + (size_t)((act & 15) == ACT_FILE ? s_act[1] : s_act[3]) * P.snap_bytes;
+        char *dst = pool + (size_t)(s_act[2] >> 8) * P.snap_bytes;
+        for (uint32_t b = lane * 4; b < P.snap_bytes; b += QS_WAVE * 4) *(uint32_t *)(dst + b) = *(const uint32_t *)(src + b);
+        // the reference returns the filed checkpoint's observation on this step (quad_experience_replay.py:151 rebinds `obs`)
+        const ReplayArr A = P.arr[P.obs_arr];
+        for (int idx = lane; idx < (int)A.per_env; idx += QS_WAVE)
+            *(uint32_t *)(A.base + ((size_t)e * A.per_env + idx) * A.elem) = *(const uint32_t *)(src + A.off + (size_t)idx * A.elem);
+        if (A.elem == 8)
+            for (int idx = lane; idx < (int)A.per_env; idx += QS_WAVE)
+                *(uint32_t *)(A.base + ((size_t)e * A.per_env + idx) * A.elem + 4) = *(const uint32_t *)(src + A.off + (size_t)idx * A.elem + 4);
+    }
+    if (act == ACT_RESTORE) {
+        replay_copy(P, e, pool + (size_t)s_act[1] * P.snap_bytes, false, lane);
+        if (lane == 0) {   // counters the reference zeroes on the replayed env (:180-182)
+            P.counters[(size_t)QS_CNT_COLLISIONS * P.E + e] = 0; P.counters[(size_t)QS_CNT_COLLISIONS_AFTER_SETTLE * P.E + e] = 0;
+            P.counters[(size_t)QS_CNT_OBST * P.E + e] = 0; P.counters[(size_t)QS_CNT_OBST_AFTER_SETTLE * P.E + e] = 0;
+        }
+    }
+}
+
 // state get/set for one env (qs_get_state / qs_set_state)
 template <typename real>
 __global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf, int32_t *tick_io, int set) {

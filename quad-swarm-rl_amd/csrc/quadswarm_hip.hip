@@ -46,7 +46,7 @@ struct qs_handle {
     int team = 0;          // waves per workgroup of the team kernels (qs_step_team.inc): 4 generic, 8 (or 4) specialised; 0 = single-wave kernels
     // config-specialised code object (qs_spec_kernels.hip), when one is cached / could be built
     // environment snapshots (qs_snapshot_*): `snap_slots` packed copies of one environment's complete state
-    struct SnapArray { char *base; size_t elem, comps, comp_stride, per_env; };   // strides / counts in elements
+    struct SnapArray { char *base; size_t elem, comps, comp_stride, per_env; int kind; };   // strides / counts in elements; kind: 1 = obs, 2 = episode sums
     std::vector<SnapArray> snap_arrays;
     size_t snap_bytes = 0;
     char *snap_pool = nullptr;
@@ -67,6 +67,9 @@ struct qs_handle {
     const void *graph_actions = nullptr;
     int32_t graph_k = 0;
     uint8_t *h_mask = nullptr;   // pinned staging for qs_reset masks
+    // batched experience replay (qs_replay_enable)
+    bool replay_on = false;
+    ReplayParams rp;
     // noise tape (qs_set_noise_tape): device copy [E][tape_len] + per-env cursor; while set, reset / step run the tape kernels
     double *d_tape = nullptr;
     int32_t *d_tape_pos = nullptr;
@@ -374,15 +377,15 @@ template <typename real> static int create_typed(qs_handle *h) {
     // reference's does from the global numpy stream) and the per-step outputs
     auto &sa = h->snap_arrays;
     sa.clear();
-#define SNAP_T(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), T, N})
-#define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1})
+#define SNAP_T(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), T, N, 0})
+#define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1, 0})
     SNAP_T(pos, 3); SNAP_T(vel, 3); SNAP_T(rot, 9); SNAP_T(omega, 3); SNAP_T(rot_damp, 4); SNAP_T(cmds_damp, 4); SNAP_T(ou, 4); SNAP_T(goal, 3);
     SNAP_T(flags, 1); SNAP_T(pair_mask, 1); SNAP_T(new_pair_mask, 1); SNAP_T(obst_hit_idx, 1); SNAP_T(dist_ring, 4); SNAP_T(dist_sums, 3);
-    SNAP_T(run_sums, QS_SUM_COUNT);
-    sa.push_back({(char *)p.obs, sizeof(real), 1, T * D, N * D});                        // the observation that goes with the state
+    SNAP_T(run_sums, QS_SUM_COUNT); sa.back().kind = 2;
+    sa.push_back({(char *)p.obs, sizeof(real), 1, T * D, N * D, 1});                     // the observation that goes with the state
     SNAP_E(unique_col, 1); SNAP_E(obst_new, 1); SNAP_E(room_new, 1); SNAP_E(counters, QS_CNT_COUNT); SNAP_E(tick, 1);
     SNAP_E(scen_real, SR_COUNT); SNAP_E(scen_int, SI_COUNT); SNAP_E(scen_omap, 4); SNAP_E(scenario_id, 1);
-    sa.push_back({(char *)p.obst_pos, sizeof(real), 2, E * (M_ ? M_ : 1), (M_ ? M_ : 1)});
+    sa.push_back({(char *)p.obst_pos, sizeof(real), 2, E * (M_ ? M_ : 1), (M_ ? M_ : 1), 0});
 #undef SNAP_T
 #undef SNAP_E
     h->snap_bytes = 0;
@@ -636,19 +639,29 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     return QS_OK;   // the auto-reset is the tail of the step kernel itself
 }
 
+// the replay wrapper's step() / new_episode() for every environment, behind each control step (qs_replay_enable)
+static int launch_replay(qs_handle *h, hipStream_t s) {
+    hipLaunchKernelGGL(qs_replay_kernel, dim3(h->cfg.num_envs), dim3(QS_WAVE), 0, s, h->rp);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
 int qs_step(qs_handle *h, const void *actions_dev, void *stream) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    return launch_step(h, actions_dev ? actions_dev : h->d_actions, (hipStream_t)stream);
+    int rc = launch_step(h, actions_dev ? actions_dev : h->d_actions, (hipStream_t)stream);
+    if (rc == QS_OK && h->replay_on) rc = launch_replay(h, (hipStream_t)stream);
+    return rc;
 }
 
 int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream) {
     if (!h || !actions_dev || k < 0) return fail(QS_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * h->real_size;
-    if (h->profiling) {   // per-step HIP events: one launch per control step
+    if (h->profiling || h->replay_on) {   // per-step HIP events / the replay kernel behind every step: one launch per control step
         for (int32_t t = 0; t < k; ++t) {
             int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream, 1);
+            if (rc == QS_OK && h->replay_on) rc = launch_replay(h, (hipStream_t)stream);
             if (rc != QS_OK) return rc;
         }
         return QS_OK;
@@ -776,6 +789,95 @@ int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *str
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->snap_pool + h->snap_bytes * (size_t)dst_slot, h->snap_pool + h->snap_bytes * (size_t)src_slot, h->snap_bytes,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return QS_OK;
+}
+
+/* Batched experience replay on the device: see include/quadswarm.h. */
+int qs_replay_enable(qs_handle *h, double sample_prob) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    if (h->replay_on) return fail(QS_ERR_INVALID, "replay is already enabled on this handle");
+    if (!h->cfg.episode_sums) return fail(QS_ERR_INVALID, "qs_replay_enable needs a handle created with episode_sums = 1 (per-episode crash reward)");
+    if (!(sample_prob >= 0.0 && sample_prob <= 1.0)) return fail(QS_ERR_INVALID, "sample_prob must be in [0, 1]");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    ReplayParams &P = h->rp;
+    memset(&P, 0, sizeof P);
+    const size_t E = h->cfg.num_envs;
+    uint32_t off = 0;
+    for (const auto &a : h->snap_arrays) {
+        if (a.kind == 2) continue;   // the reward-shaping wrapper sits outside the replay wrapper: its sums restart with the episode
+        if (P.narr == QS_REPLAY_MAX_ARR) return fail(QS_ERR_UNSUPPORTED, "too many snapshot arrays");
+        if (a.kind == 1) P.obs_arr = P.narr;
+        if (a.base == (char *)h->pf.tick) P.tick_arr = P.narr;
+        P.arr[P.narr++] = {a.base, (uint32_t)a.elem, (uint32_t)a.comps, (uint32_t)a.per_env, off, (uint64_t)a.comp_stride};
+        off += (uint32_t)((a.elem * a.comps * a.per_env + 15) & ~(size_t)15);
+    }
+    P.snap_bytes = off;
+    const double control_freq = 1.0 / (h->cfg.dt * h->cfg.sim_steps);
+    P.N = h->cfg.num_agents; P.E = h->cfg.num_envs; P.use_obstacles = h->cfg.use_obstacles;
+    P.ep_len = h->cfg.ep_len;
+    P.cp_every = (int)(0.5 * control_freq + 0.5);        // cp_step_size_freq (:18-19)
+    P.grace_ticks = (int)(1.5 * control_freq + 0.5);     // collisions_grace_period_seconds * control_freq (:150)
+    P.min_gap = (int)(5.0 * control_freq + 0.5);         // :152
+    P.seed_lo = (uint32_t)(h->cfg.seed & 0xffffffffu); P.seed_hi = (uint32_t)(h->cfg.seed >> 32);
+    P.env_id_offset = h->cfg.env_id_offset;
+    P.sample_prob = (float)sample_prob;
+    P.done = h->pf.done; P.tick = h->pf.tick; P.step_ctr = h->pf.step_ctr; P.unique_col = h->pf.unique_col; P.obst_new = h->pf.obst_new;
+    P.counters = h->pf.counters; P.ep_sums = h->pf.ep_sums; P.real_size = h->real_size; P.T = (int32_t)(E * h->cfg.num_agents);
+    int rc;
+    if ((rc = dalloc(h, &P.pool, (size_t)P.snap_bytes * (QS_REPLAY_RING + QS_REPLAY_EVENTS) * E)) != QS_OK) return rc;
+    if ((rc = dalloc(h, &P.active, E)) != QS_OK || (rc = dalloc(h, &P.saved, E)) != QS_OK || (rc = dalloc(h, &P.ep_saved, E)) != QS_OK || (rc = dalloc(h, &P.crash_hist, 100 * E)) != QS_OK ||
+        (rc = dalloc(h, &P.crash_n, E)) != QS_OK || (rc = dalloc(h, &P.crash_pos, E)) != QS_OK || (rc = dalloc(h, &P.ck_count, E)) != QS_OK ||
+        (rc = dalloc(h, &P.ck_head, E)) != QS_OK || (rc = dalloc(h, &P.last_added, E)) != QS_OK || (rc = dalloc(h, &P.ev_len, E)) != QS_OK ||
+        (rc = dalloc(h, &P.ev_idx, E)) != QS_OK || (rc = dalloc(h, &P.ev_replayed, QS_REPLAY_EVENTS * E)) != QS_OK ||
+        (rc = dalloc(h, &P.ev_slot, QS_REPLAY_EVENTS * E)) != QS_OK || (rc = dalloc(h, &P.episodes, E)) != QS_OK ||
+        (rc = dalloc(h, &P.replayed, E)) != QS_OK || (rc = dalloc(h, &P.errors, E)) != QS_OK || (rc = dalloc(h, &P.start_tick, E)) != QS_OK ||
+        (rc = dalloc(h, &P.last_steps, E)) != QS_OK) return rc;
+    {   // the reset() that starts the first episode records crashes_last_episode = 0 (quadrotor_multi.py:356-359); last_added = -1e9
+        std::vector<int32_t> ones(E, 1), neg(E, -1000000000);
+        HIP_TRY(hipMemcpy(P.crash_n, ones.data(), E * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(P.crash_pos, ones.data(), E * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(P.last_added, neg.data(), E * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    h->replay_on = true;
+    return QS_OK;
+}
+
+int qs_replay_stats(qs_handle *h, int32_t *out) {
+    if (!h || !out) return fail(QS_ERR_INVALID, "null argument");
+    if (!h->replay_on) return fail(QS_ERR_INVALID, "replay is not enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t E = h->cfg.num_envs;
+    const ReplayParams &P = h->rp;
+    std::vector<int32_t> len(E), rep(QS_REPLAY_EVENTS * E);
+    std::vector<uint8_t> act(E), eps(E);
+    HIP_TRY(hipMemcpy(eps.data(), P.ep_saved, E, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + 0 * E, P.episodes, E * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + 1 * E, P.replayed, E * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(len.data(), P.ev_len, E * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rep.data(), P.ev_replayed, QS_REPLAY_EVENTS * E * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(act.data(), P.active, E, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + 5 * E, P.ck_count, E * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + 6 * E, P.errors, E * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out + 8 * E, P.last_steps, E * 4, hipMemcpyDeviceToHost));
+    for (size_t e = 0; e < E; ++e) {
+        int32_t sum = 0;
+        for (int q = 0; q < len[e]; ++q) sum += rep[(size_t)q * E + e];
+        out[2 * E + e] = len[e]; out[3 * E + e] = sum; out[4 * E + e] = act[e]; out[7 * E + e] = eps[e];
+    }
+    return QS_OK;
+}
+
+int qs_replay_set_active(qs_handle *h, const uint8_t *active_host) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    if (!h->replay_on) return fail(QS_ERR_INVALID, "replay is not enabled");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t E = h->cfg.num_envs;
+    std::vector<uint8_t> v(E, 1);
+    if (active_host) for (size_t e = 0; e < E; ++e) v[e] = active_host[e] ? 1 : 0;
+    HIP_TRY(hipMemcpy(h->rp.active, v.data(), E, hipMemcpyHostToDevice));
     return QS_OK;
 }
 

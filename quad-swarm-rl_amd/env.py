@@ -160,7 +160,7 @@ class QuadrotorEnvMulti:
                  dynamics_params="Crazyflie", raw_control=True, raw_control_zero_middle=True,
                  dynamics_randomize_every=None, dynamics_change=None, dyn_sampler_1=None,
                  sense_noise="default", init_random_state=False, render_mode="human",
-                 seed=0, device=0, precision="f32"):
+                 seed=0, device=0, precision="f32", replay_buffer_sample_prob=0.0):
         if dynamics_params != "Crazyflie" or not raw_control or not raw_control_zero_middle or init_random_state \
                 or dynamics_randomize_every is not None or dyn_sampler_1 is not None:
             raise NotImplementedError("only the configuration hard-coded by make_quadrotor_env_multi is supported "
@@ -177,7 +177,7 @@ class QuadrotorEnvMulti:
             collision_hitbox_radius=collision_hitbox_radius, collision_falloff_radius=collision_falloff_radius,
             use_obstacles=use_obstacles, obst_density=obst_density, obst_size=obst_size, obst_spawn_area=obst_spawn_area,
             use_downwash=use_downwash, use_numba=use_numba, quads_mode=quads_mode, room_dims=room_dims,
-            sense_noise=sense_noise, thrust_noise_ratio=tnr)
+            sense_noise=sense_noise, thrust_noise_ratio=tnr, episode_sums=bool(use_replay_buffer))
         v = self._vec
         self.num_agents = num_agents
         self.is_multiagent = True
@@ -190,12 +190,12 @@ class QuadrotorEnvMulti:
         self.last_step_unique_collisions = np.array([], dtype=np.int64)
         self.curr_quad_col = np.array([], dtype=np.int64)
         self._real = v.stepper.np_real
-        # replay-buffer bookkeeping of the reference env (quadrotor_multi.py:166-175, :280-287)
-        from collections import deque
-        self.activate_replay_buffer = False
-        self.saved_in_replay_buffer = False
-        self.crashes_in_recent_episodes = deque([], maxlen=100)
-        self.crashes_last_episode = 0
+        # Experience replay (gym_art/quadrotor_multi/quad_experience_replay.py, wired at swarm_rl/env_wrappers/quad_utils.py:67-70): the
+        # wrapper's bookkeeping and the env attributes it reads (activate_replay_buffer, saved_in_replay_buffer, the crash history of
+        # quadrotor_multi.py:166-175,:280-287) live on the device, per environment - qs_replay_enable, include/quadswarm.h
+        self.replay_buffer_sample_prob = float(replay_buffer_sample_prob)
+        if use_replay_buffer:
+            v.stepper.replay_enable(self.replay_buffer_sample_prob)
         self.collisions_grace_period_seconds = 1.5
         self.obst_density, self.obst_size = obst_density, obst_size
         self.envs = [_SingleView(self)]
@@ -204,49 +204,19 @@ class QuadrotorEnvMulti:
     def unwrapped(self):
         return self
 
-    def can_drones_fly(self):   # quadrotor_multi.py:280-287
-        c = self.crashes_in_recent_episodes
-        return len(c) >= 10 and abs(np.mean(c)) < 1
+    @property
+    def activate_replay_buffer(self):
+        return bool(self.use_replay_buffer and self._vec.stepper.replay_stats()["active"][0])
 
-    def _on_reset(self):   # quadrotor_multi.py:355-359, run by every reset incl. the one inside step
-        if self.use_replay_buffer and not self.activate_replay_buffer:
-            self.crashes_in_recent_episodes.append(self.crashes_last_episode)
-            self.activate_replay_buffer = self.can_drones_fly()
-            self.crashes_last_episode = 0
+    @activate_replay_buffer.setter
+    def activate_replay_buffer(self, value):
+        self._vec.stepper.replay_set_active([1 if value else 0])
 
     def reset(self, obst_density=None, obst_size=None):
         if (obst_density is not None and obst_density != self.obst_density) or (obst_size is not None and obst_size != self.obst_size):
             raise NotImplementedError("per-episode obstacle density / size randomisation is not part of the stepper (fixed at creation)")
         self._vec.stepper.reset()
-        self._on_reset()
         return self._vec.stepper.to_host("obs").astype(np.float64)
-
-    # ---- device-side deep copies for the replay wrapper (quad_experience_replay.py) ----
-    _HOST_STATE = ("activate_replay_buffer", "saved_in_replay_buffer", "crashes_last_episode", "obst_density", "obst_size")
-
-    def save_checkpoint(self, slot):
-        """`deepcopy(env)`: device state into snapshot slot `slot`, host-side attributes returned to the caller."""
-        self._vec.stepper.snapshot_save(0, slot)
-        host = {k: getattr(self, k) for k in self._HOST_STATE}
-        host["crashes_in_recent_episodes"] = list(self.crashes_in_recent_episodes)
-        return host
-
-    def load_checkpoint(self, slot, host):
-        st = self._vec.stepper
-        st.snapshot_load(slot, 0)
-        st.sync()
-        for k in self._HOST_STATE:
-            setattr(self, k, host[k])
-        self.crashes_in_recent_episodes.clear()
-        self.crashes_in_recent_episodes.extend(host["crashes_in_recent_episodes"])
-        self._read_masks(st)
-
-    def zero_collision_counters(self):
-        """collisions_per_episode = collisions_after_settle = obst_quad_... = 0 (quad_experience_replay.py:183-185)."""
-        st = self._vec.stepper
-        cnt = st.to_host("counters")
-        cnt[[0, 1, 7, 8], 0] = 0
-        st.from_host("counters", cnt)
 
     def _read_masks(self, st):
         ids = int(st.to_host("unique_col_mask")[0])
@@ -270,17 +240,22 @@ class QuadrotorEnvMulti:
         keys = qcfg.REW_INFO_KEYS if self.use_obstacles else qcfg.REW_INFO_KEYS[:15]
         infos = [{"rewards": {k: float(ri[j, i]) for j, k in enumerate(keys)}} for i in range(self.num_agents)]
         self._read_masks(st)
-        if self.use_replay_buffer and not self.activate_replay_buffer:   # quadrotor_multi.py:610-612
-            self.crashes_last_episode += infos[0]["rewards"]["rew_crash"]
         if any(dones):
-            if self.saved_in_replay_buffer:   # quadrotor_multi.py:629-633
+            rs = st.replay_stats() if self.use_replay_buffer else None
+            if rs is not None and rs["ep_was_replay"][0]:   # quadrotor_multi.py:629-633: a replayed episode reports these two only
                 cnt = st.to_host("ep_counters")[:, 0]
                 stats = [{"num_collisions_replay": int(cnt[0]), "num_collisions_obst_replay": int(cnt[7])} for _ in range(self.num_agents)]
             else:
                 stats = self.episode_extra_stats()
+            if rs is not None:   # what ExperienceReplayWrapper.step adds at an episode end (quad_experience_replay.py:126-138)
+                ep, rp, n = int(rs["episodes"][0]), int(rs["replayed"][0]), int(rs["buffer_len"][0])
+                extra = {"replay/replay_rate": rp / ep, "replay/new_episode_rate": (ep - rp) / ep, "replay/replay_buffer_size": n,
+                         "replay/avg_replayed": (int(rs["replayed_sum"][0]) / n) if n else 0,
+                         "replay/obst_density": self.obst_density, "replay/obst_size": self.obst_size}
+                for d in stats:
+                    d.update(extra)
             for i in range(self.num_agents):
                 infos[i]["episode_extra_stats"] = stats[i]
-            self._on_reset()   # the auto-reset inside step (:720-722)
         return obs, rewards, dones, infos
 
     def episode_extra_stats(self):

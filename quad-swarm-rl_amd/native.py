@@ -121,6 +121,9 @@ def lib():
         L.qs_snapshot_save.argtypes = [vp, C.c_int32, C.c_int32, vp]
         L.qs_snapshot_load.argtypes = [vp, C.c_int32, C.c_int32, vp]
         L.qs_snapshot_copy.argtypes = [vp, C.c_int32, C.c_int32, vp]
+        L.qs_replay_enable.argtypes = [vp, C.c_double]
+        L.qs_replay_stats.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.qs_replay_set_active.argtypes = [vp, C.POINTER(C.c_uint8)]
         L.qs_set_noise_tape.argtypes = [vp, C.POINTER(C.c_double), C.c_int64]
         L.qs_get_tape_pos.argtypes = [vp, C.POINTER(C.c_int32)]
         if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
@@ -134,7 +137,7 @@ EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_defau
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor",
                     "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
-                    "qs_set_noise_tape", "qs_get_tape_pos"]
+                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active"]
 
 
 class QsError(RuntimeError):
@@ -255,6 +258,21 @@ class Stepper:
 
     def snapshot_copy(self, src_slot, dst_slot, stream=None):
         _check(lib().qs_snapshot_copy(self._h, src_slot, dst_slot, self._stream_ptr(stream)))
+
+    # ---- batched experience replay on the device (include/quadswarm.h) --------------------------------------
+    def replay_enable(self, sample_prob):
+        _check(lib().qs_replay_enable(self._h, float(sample_prob)))
+
+    def replay_stats(self):
+        """dict of per-env int arrays: episodes, replayed, buffer_len, replayed_sum, active, checkpoints, errors, ep_was_replay, ep_steps"""
+        out = np.zeros((9, self.E), dtype=np.int32)
+        _check(lib().qs_replay_stats(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(zip(("episodes", "replayed", "buffer_len", "replayed_sum", "active", "checkpoints", "errors", "ep_was_replay", "ep_steps"), out))
+
+    def replay_set_active(self, active=None):
+        """override the activation rule of the replay buffers (None = all on)"""
+        a = None if active is None else np.ascontiguousarray(active, dtype=np.uint8).ctypes.data_as(C.POINTER(C.c_uint8))
+        _check(lib().qs_replay_set_active(self._h, a))
 
     # ---- noise tape (test instrument, include/quadswarm.h) ---------------------------------------------
     def set_noise_tape(self, tape):

@@ -122,6 +122,17 @@ class RewardShapingWrapper(_Wrapper):
     def set_training_info(self, training_info):
         self.training_info = training_info
 
+    # Sample Factory's RewardShapingInterface as the reference implements it (reward_shaping.py:36-47)
+    def get_default_reward_shaping(self):
+        return dict(quad_rewards=dict())
+
+    def get_current_reward_shaping(self, agent_idx):
+        return dict(quad_rewards=dict())
+
+    def set_reward_shaping(self, reward_shaping, unused_agent_idx):
+        self.reward_shaping_scheme = dict(quad_rewards=dict())
+        self.reward_shaping_updated = True
+
     def reset(self):
         obs = self.env.reset()
         self.cumulative_rewards = [dict() for _ in range(self.num_agents)]
@@ -169,15 +180,19 @@ class RewardShapingWrapper(_Wrapper):
 
 class BatchedQuadSwarm:
     """E environments x N drones behind one object with the batched-sampling shape of Sample Factory (num_agents = E*N,
-    device tensors in and out) and the semantics of QuadsRewardShapingWrapper + the compatibility wrapper
-    (reward_shaping.py:22-123, compatibility.py:21-50), with the per-step bookkeeping moved onto the GPU:
-    the step kernel keeps the per-episode sums of the reward terms and action moments (`episode_sums`), so a control step
-    costs one kernel launch and no device->host traffic; only the step on which episodes end reads the sums back and
-    builds the `infos` dicts.  SURVEY.md 8f rank 1.  (Sample Factory is not in this image: the call protocol follows its
-    documentation for vectorised GPU envs, i.e. `reset() -> (obs_dict, info)`, `step(actions) -> (obs_dict, rewards,
-    terminated, truncated, infos)` with torch tensors of leading dimension num_agents.)"""
+    device tensors in and out) and the semantics of the reference's wrapper stack - ExperienceReplayWrapper
+    (quad_experience_replay.py:66-209), QuadsRewardShapingWrapper (reward_shaping.py:22-123), QuadEnvCompatibility
+    (compatibility.py:21-50) - with the per-step bookkeeping on the GPU: the step kernel keeps the per-episode sums of the reward
+    terms and action moments (`episode_sums`), the replay kernel keeps every environment's checkpoint ring / event buffer /
+    activation state (include/quadswarm.h: qs_replay_enable).  A control step costs one kernel launch (two with replay) and no
+    device->host traffic; the host knows from the environments' ticks when the next episode can end and touches the device only
+    on those steps, to build the `infos` dicts of the finished environments (gathered on the device first, so the transfer is
+    proportional to what finished).  SURVEY.md 8f rank 1 / 3.
+    Call protocol (Sample Factory's vectorised-env convention, tests/test_sf_protocol_gpu.py): `reset() -> (obs_dict, info)`,
+    `step(actions) -> (obs_dict, rewards, terminated, truncated, infos)`, torch tensors of leading dimension num_agents; `infos`
+    is a list of num_agents dicts on steps where an episode ended (empty dicts for the others) and `[]` otherwise."""
 
-    def __init__(self, num_envs, reward_shaping_scheme=None, annealing=None, device=0, seed=0, **env_kwargs):
+    def __init__(self, num_envs, reward_shaping_scheme=None, annealing=None, device=0, seed=0, replay_buffer_sample_prob=0.0, **env_kwargs):
         import torch
         from . import config as qcfg
         from .env import QuadSwarmVecEnv
@@ -193,9 +208,13 @@ class BatchedQuadSwarm:
         self.reward_shaping_updated = True
         self.annealing = annealing
         self.training_info = {}
+        self.use_replay_buffer = replay_buffer_sample_prob > 0.0        # quad_utils.py:34
+        self.replay_buffer_sample_prob = float(replay_buffer_sample_prob)
+        if self.use_replay_buffer:
+            self.vec.stepper.replay_enable(self.replay_buffer_sample_prob)
         self._keys = qcfg.REW_INFO_KEYS
-        self._ep_steps = self.vec.cfg.ep_len + 1          # every episode ends by time: tick > ep_len (quadrotor_single.py:353)
-        self._ticks = np.zeros(num_envs, dtype=np.int64)  # host mirror of the per-env tick: tells when a done is due without a sync
+        self._ep_steps = self.vec.cfg.ep_len + 1          # an episode ends by time: tick > ep_len (quadrotor_single.py:353)
+        self._steps_to_done = self._ep_steps              # control steps until the earliest possible episode end
         self._truncated = None
 
     @property
@@ -205,9 +224,23 @@ class BatchedQuadSwarm:
     def set_training_info(self, training_info):
         self.training_info = training_info
 
+    # Sample Factory's RewardShapingInterface as the reference implements it (reward_shaping.py:36-47)
+    def get_default_reward_shaping(self):
+        return dict(quad_rewards=dict())
+
+    def get_current_reward_shaping(self, agent_idx):
+        return dict(quad_rewards=dict())
+
+    def set_reward_shaping(self, reward_shaping, unused_agent_idx):
+        self.reward_shaping_scheme = dict(quad_rewards=dict())
+        self.reward_shaping_updated = True
+
+    def render(self, *a, **k):
+        return None
+
     def reset(self, seed=None, options=None):
         obs = self.vec.reset()
-        self._ticks[:] = 0
+        self._steps_to_done = self._ep_steps
         return {"obs": obs}, {}
 
     def step(self, actions):
@@ -220,38 +253,68 @@ class BatchedQuadSwarm:
         obs, rew, done, _ = self.vec.step(actions)
         if self._truncated is None:
             self._truncated = torch.zeros_like(done, dtype=torch.bool)
-        self._ticks += 1
-        finished = np.nonzero(self._ticks >= self._ep_steps)[0]
-        infos = [{} for _ in range(self.num_agents)] if len(finished) else []
-        if len(finished):
-            self._ticks[finished] = 0
-            self._episode_infos(finished, infos)
+        infos = []
+        self._steps_to_done -= 1
+        if self._steps_to_done <= 0:      # the only steps on which the host looks at the device
+            st, n = self.vec.stepper, self.agents_per_env
+            finished = np.nonzero(st.to_host("done").reshape(self.num_envs, n)[:, 0])[0]
+            if len(finished):
+                infos = [{} for _ in range(self.num_agents)]
+                self._episode_infos(finished, infos)
+            # every environment's tick after this step (a replayed episode starts at its checkpoint's tick): next possible end
+            self._steps_to_done = int(self._ep_steps - st.to_host("tick").max())
         return {"obs": obs}, rew, done.bool(), self._truncated, infos
 
     def _episode_infos(self, finished, infos):
-        """The dicts QuadsRewardShapingWrapper attaches at episode end (reward_shaping.py:85-118) + the env's own
-        episode_extra_stats, for the agents of the finished envs, from the device-side sums."""
-        st, n = self.vec.stepper, self.agents_per_env
-        sums = st.to_host("ep_sums").astype(np.float64)
-        approx = self.training_info.get("approx_total_training_steps", 0)
-        scen_ids = st.to_host("ep_scenario")
+        """What the wrapper stack attaches at an episode end - the env's own episode_extra_stats (quadrotor_multi.py:626-718, or
+        the two `*_replay` counters of a replayed episode, :629-633), the replay wrapper's statistics
+        (quad_experience_replay.py:126-138), the reward-shaping wrapper's sums / action moments / annealed coefficients
+        (reward_shaping.py:85-118) - for the agents of the finished envs."""
         from . import config as qcfg
-        count = float(self._ep_steps * n)
-        for e in finished:
-            sl = slice(e * n, (e + 1) * n)
+        from .env import assemble_episode_extra_stats
+        torch = self._torch
+        st, n = self.vec.stepper, self.agents_per_env
+        dev = st.tensor("ep_sums").device
+        env_idx = torch.as_tensor(finished, device=dev, dtype=torch.long)
+        agent_idx = (env_idx[:, None] * n + torch.arange(n, device=dev)[None, :]).reshape(-1)
+        # gather on the device, then one transfer each: [25, F*n] sums, [6, F*n] episode stats, [11, F] counters, [F] scenario ids
+        sums = st.tensor("ep_sums").index_select(1, agent_idx).double().cpu().numpy()
+        eps = st.tensor("ep_stats").index_select(1, agent_idx).double().cpu().numpy()
+        cnt = st.tensor("ep_counters").index_select(1, env_idx).cpu().numpy()
+        scen_ids = st.tensor("ep_scenario").index_select(0, env_idx).cpu().numpy()
+        rs = st.replay_stats() if self.use_replay_buffer else None
+        approx = self.training_info.get("approx_total_training_steps", 0)
+        for f, e in enumerate(finished):
+            sl = slice(f * n, (f + 1) * n)
+            scenario_name = qcfg.SCENARIO_CLASS_NAMES[int(scen_ids[f])]
+            if rs is not None and rs["ep_was_replay"][e]:
+                env_stats = [{"num_collisions_replay": int(cnt[0, f]), "num_collisions_obst_replay": int(cnt[7, f])} for _ in range(n)]
+            else:
+                env_stats = assemble_episode_extra_stats(eps[:, sl], cnt[:, f], scenario_name[9:], n, bool(self.vec.cfg.use_obstacles))
+            if rs is not None:
+                ep, rp, nb = int(rs["episodes"][e]), int(rs["replayed"][e]), int(rs["buffer_len"][e])
+                replay_stats = {"replay/replay_rate": rp / ep, "replay/new_episode_rate": (ep - rp) / ep, "replay/replay_buffer_size": nb,
+                                "replay/avg_replayed": (int(rs["replayed_sum"][e]) / nb) if nb else 0,
+                                "replay/obst_density": float(self.vec.cfg.obst_density), "replay/obst_size": float(self.vec.cfg.obst_size)}
+            # action moments over agents x steps of the episode (np.mean / np.std of reward_shaping.py:103-108); a replayed episode
+            # starts at its checkpoint's tick and is shorter than ep_len + 1 steps
+            count = float((int(rs["ep_steps"][e]) if rs is not None else self._ep_steps) * n)
             a1, a2 = sums[17:21, sl].sum(axis=1) / count, sums[21:25, sl].sum(axis=1) / count
-            a_std = np.sqrt(np.maximum(a2 - a1 * a1, 0.0))    # np.std over agents x steps (:103-108)
-            scenario_name = qcfg.SCENARIO_CLASS_NAMES[int(scen_ids[e])]
-            for i in range(e * n, (e + 1) * n):
-                cum = {k: float(sums[j, i]) for j, k in enumerate(self._keys) if self.vec.cfg.use_obstacles or j < 15}
+            a_std = np.sqrt(np.maximum(a2 - a1 * a1, 0.0))
+            for k in range(n):
+                i, col = e * n + k, f * n + k
+                cum = {key: float(sums[j, col]) for j, key in enumerate(self._keys) if self.vec.cfg.use_obstacles or j < 15}
                 true_reward = cum["rewraw_main"] + 1000 * cum.get("rewraw_quadcol", 0)
                 cum["rewraw_main"] = true_reward
-                extra = dict(cum)
+                extra = dict(env_stats[k])
+                if rs is not None:
+                    extra.update(replay_stats)
+                extra.update(cum)
                 extra["z_approx_total_training_steps"] = approx
                 for rew_key in ("rew_pos", "rew_crash"):
                     extra[f"{scenario_name}/{rew_key}"] = cum[rew_key]
-                for k in range(4):
-                    extra[f"z_action{k}_mean"], extra[f"z_action{k}_std"] = float(a1[k]), float(a_std[k])
+                for q in range(4):
+                    extra[f"z_action{q}_mean"], extra[f"z_action{q}_std"] = float(a1[q]), float(a_std[q])
                 infos[i]["true_reward"] = true_reward
                 infos[i]["episode_extra_stats"] = extra
         if self.annealing:   # :111-118, once per step on which episodes ended (same values for every agent)
@@ -278,7 +341,7 @@ class Compatibility(_Wrapper):
 
 
 def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
-    """quad_utils.py:20-110 on the HIP stepper (replay wrapper / V-value wrapper: SURVEY 8f 'next')."""
+    """quad_utils.py:20-110 on the HIP stepper (the experience-replay wrapper of :67-70 is the device-side replay of the stepper)."""
     use_replay_buffer = getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0
     rew_coeff = DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]
     env = QuadrotorEnvMulti(
@@ -294,11 +357,10 @@ def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
         dynamics_params="Crazyflie", raw_control=True, raw_control_zero_middle=True, dynamics_randomize_every=None,
         dynamics_change=dict(noise=dict(thrust_noise_ratio=0.05), damp=dict(vel=0, omega_quadratic=0)), dyn_sampler_1=None,
         sense_noise="default", init_random_state=False, render_mode=render_mode,
-        seed=getattr(cfg, "quads_seed", 0), device=getattr(cfg, "quads_device", 0), precision=getattr(cfg, "quads_precision", "f32"))
-    if use_replay_buffer:   # quad_utils.py:67-70
-        from .replay import ExperienceReplayWrapper
-        env = ExperienceReplayWrapper(env, cfg.replay_buffer_sample_prob, cfg.quads_obst_density, cfg.quads_obst_size,
-                                      getattr(cfg, "quads_domain_random", False), seed=getattr(cfg, "quads_seed", 0))
+        seed=getattr(cfg, "quads_seed", 0), device=getattr(cfg, "quads_device", 0), precision=getattr(cfg, "quads_precision", "f32"),
+        replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0))   # the replay wrapper of quad_utils.py:67-70 runs on the device
+    if getattr(cfg, "quads_domain_random", False):
+        raise NotImplementedError("--quads_domain_random: per-episode obstacle density / size is not part of the stepper yet")
     reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
     reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
     reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty
@@ -327,8 +389,11 @@ def make_quadrotor_env_batched(cfg, **kwargs):
         annealing = [AnnealSchedule("quadcol_bin", cfg.quads_collision_reward, cfg.anneal_collision_steps),
                      AnnealSchedule("quadcol_bin_smooth_max", cfg.quads_collision_smooth_max_penalty, cfg.anneal_collision_steps),
                      AnnealSchedule("quadcol_bin_obst", cfg.quads_obst_collision_reward, cfg.anneal_collision_steps)]
+    if getattr(cfg, "quads_domain_random", False):
+        raise NotImplementedError("--quads_domain_random: per-episode obstacle density / size is not part of the stepper yet")
     return BatchedQuadSwarm(
         cfg.quads_num_envs, reward_shaping_scheme=reward_shaping, annealing=annealing,
+        replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0),
         device=getattr(cfg, "quads_device", 0), seed=getattr(cfg, "quads_seed", 0), precision=getattr(cfg, "quads_precision", "f32"),
         num_agents=cfg.quads_num_agents, ep_time=cfg.quads_episode_duration, rew_coeff=dict(DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]),
         obs_repr=cfg.quads_obs_repr, neighbor_visible_num=cfg.quads_neighbor_visible_num, neighbor_obs_type=cfg.quads_neighbor_obs_type,
@@ -347,6 +412,17 @@ def make_quadrotor_env(env_name, cfg=None, _env_config=None, render_mode=None, *
 
 
 def register_swarm_components():
-    """swarm_rl/train.py:16-19.  Needs sample_factory (not part of this repo)."""
+    """swarm_rl/train.py:16-19: the env factory and the encoder factory.  Needs sample_factory (not part of this repo)."""
     from sample_factory.envs.env_utils import register_env   # raises ImportError where SF is not installed
+    from .sf_models import register_models
     register_env("quadrotor_multi", make_quadrotor_env)
+    register_models()
+
+
+def parse_swarm_cfg(argv=None, evaluation=False):
+    """swarm_rl/train.py:22-27"""
+    from sample_factory.cfg.arguments import parse_full_cfg, parse_sf_args
+    parser, partial_cfg = parse_sf_args(argv=argv, evaluation=evaluation)
+    add_quadrotors_env_args(partial_cfg.env, parser)
+    quadrotors_override_defaults(partial_cfg.env, parser)
+    return parse_full_cfg(parser, argv)

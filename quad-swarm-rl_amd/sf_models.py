@@ -1,0 +1,43 @@
+"""Sample Factory model registration (swarm_rl/models/quad_multi_model.py:355-370): `make_quadmulti_encoder` hands SF an Encoder whose
+body is one of the restatements of quad-swarm-rl_amd/policy.py - the modules tests/golden/encoder_*.npz pin against the reference
+classes.  Training differentiates through the torch module; rollouts outside SF (rollout.py) run the same weights on the fused
+kernel (policy.FusedQuadEncoder).  Importing this module needs sample_factory."""
+from sample_factory.algo.utils.context import global_model_factory
+from sample_factory.model.encoder import Encoder
+
+from . import policy
+
+OBS_REPR = {"xyz_vxyz_R_omega": 18, "xyz_vxyz_R_omega_floor": 19, "xyz_vxyz_R_omega_wall": 24}   # quad_utils.py:30-34
+
+
+class QuadEncoder(Encoder):
+    def __init__(self, cfg, obs_space):
+        super().__init__(cfg)
+        self_dim = OBS_REPR[cfg.quads_obs_repr]
+        if cfg.quads_neighbor_obs_type == "none":
+            num_nbr = 0
+        else:
+            num_nbr = cfg.quads_num_agents - 1 if cfg.quads_neighbor_visible_num == -1 else cfg.quads_neighbor_visible_num
+        obst_dim = 9 if cfg.quads_use_obstacles else 0
+        if cfg.quads_encoder_type == "attention":
+            if getattr(cfg, "quads_sim2real", False):
+                raise NotImplementedError("QuadSingleHeadAttentionEncoder_Sim2Real is not restated here")
+            self.body = policy.make_reference_mha_encoder(self_dim=self_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=cfg.rnn_size)
+        else:
+            self.body = policy.make_reference_encoder(self_dim=self_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=cfg.rnn_size,
+                                                      nbr_encoder=cfg.quads_neighbor_encoder_type)
+        self.encoder_out_size = 2 * cfg.rnn_size
+
+    def forward(self, obs_dict):
+        return self.body(obs_dict["obs"])
+
+    def get_out_size(self):
+        return self.encoder_out_size
+
+
+def make_quadmulti_encoder(cfg, obs_space):
+    return QuadEncoder(cfg, obs_space)
+
+
+def register_models():
+    global_model_factory().register_encoder_factory(make_quadmulti_encoder)

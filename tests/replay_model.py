@@ -1,0 +1,81 @@
+"""Decision logic of the replay kernel (quad-swarm-rl_amd/csrc/qs_kernels.h: qs_replay_kernel) for ONE environment, in Python, with the
+random draws injected.  Test infrastructure: tests/test_replay_model_vs_reference.py drives it with the reference wrapper's recorded
+draws over the scripted env of tests/fake_env.py and requires the reference wrapper's trajectory
+(tests/golden/wrapper_experience_replay.json, captured from gym_art/quadrotor_multi/quad_experience_replay.py:66-209);
+tests/test_replay_gpu.py drives it with the device's own Philox draws and requires the kernel's per-environment state."""
+
+RING, EVENTS = 6, 20
+
+
+class ReplayModel:
+    def __init__(self, sample_prob, control_freq=100, use_obstacles=False, active=False):
+        self.sample_prob, self.use_obstacles = sample_prob, use_obstacles
+        self.cp_every, self.grace, self.min_gap = int(0.5 * control_freq + 0.5), int(1.5 * control_freq + 0.5), int(5.0 * control_freq + 0.5)
+        self.active, self.saved = active, False
+        self.crash_hist = [0.0]                 # the reset() that starts the first episode recorded crashes_last_episode = 0
+        self.ck = []                            # ring slots of the episode's checkpoints, oldest first (deque maxlen RING)
+        self.ck_head = 0
+        self.last_added = -10 ** 9
+        self.ev_slot, self.ev_replayed, self.ev_idx = [], [], 0   # the buffer deque (pool slots, replay counts) and buffer_idx
+        self.episodes = self.replayed = self.errors = 0
+
+    def _record_reset(self, crashes):           # quadrotor_multi.py:356-359, :284-287
+        if self.active:
+            return
+        self.crash_hist = (self.crash_hist + [crashes])[-100:]
+        n = len(self.crash_hist)
+        if abs(sum(self.crash_hist) / n) < 1.0 and n >= 10:
+            self.active = True
+
+    def step(self, done, tick, unique_col_mask, obst_new_mask, crash_sum, draw_u, draw_idx):
+        """-> list of actions: ('save', ring_slot) / ('file', ring_slot, event_slot) / ('restore', event_slot) / ('fresh',)"""
+        acts = []
+        if done:
+            self._record_reset(crash_sum)
+            self.episodes += 1
+            self.last_added = -10 ** 9
+            self.ck, self.ck_head = [], 0
+            u = draw_u()
+            if u < self.sample_prob and self.active and len(self.ev_slot) > 0:
+                self.replayed += 1
+                idx = draw_idx(len(self.ev_slot))
+                self.ev_replayed[idx] += 1
+                acts.append(("restore", self.ev_slot[idx]))
+                keep = [(s, r) for s, r in zip(self.ev_slot, self.ev_replayed) if r < 10]
+                self.ev_slot, self.ev_replayed = [s for s, _ in keep], [r for _, r in keep]
+                self.saved = True
+            else:
+                self._record_reset(0.0)
+                self.saved = False
+                acts.append(("fresh",))       # the reference calls env.reset() a second time here (quad_experience_replay.py:203): a redundant
+        elif self.active and not self.saved:
+            if tick % self.cp_every == 0:
+                if len(self.ck) < RING:
+                    slot = (self.ck_head + len(self.ck)) % RING
+                    self.ck.append(slot)
+                else:
+                    slot = self.ck_head
+                    self.ck_head = (self.ck_head + 1) % RING
+                    self.ck = self.ck[1:] + [slot]
+                acts.append(("save", slot))
+            collision = (unique_col_mask & ~1) != 0 or (self.use_obstacles and obst_new_mask != 0)
+            if collision and tick > self.grace and tick - self.last_added > self.min_gap:
+                if len(self.ck) < 3:
+                    self.errors += 1
+                else:
+                    src = self.ck[-3]
+                    if len(self.ev_slot) < EVENTS:
+                        free = next(s for s in range(RING, RING + EVENTS) if s not in self.ev_slot)
+                        self.ev_slot.append(free); self.ev_replayed.append(0)
+                        dst = free
+                    else:
+                        dst = self.ev_slot[self.ev_idx]
+                        self.ev_replayed[self.ev_idx] = 0
+                    self.ev_idx = (self.ev_idx + 1) % EVENTS
+                    self.last_added = tick
+                    acts.append(("file", src, dst))
+        return acts
+
+    def stats(self):
+        return dict(episodes=self.episodes, replayed=self.replayed, buffer_len=len(self.ev_slot), replayed_sum=sum(self.ev_replayed),
+                    active=int(self.active), checkpoints=len(self.ck), errors=self.errors)

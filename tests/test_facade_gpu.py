@@ -224,6 +224,7 @@ def test_batched_env_matches_the_single_env_wrapper_stack():
             for i in range(4):
                 assert inf_b[i]["true_reward"] == pytest.approx(inf_s[i]["true_reward"], abs=1e-9)
                 es, eb = inf_s[i]["episode_extra_stats"], inf_b[i]["episode_extra_stats"]
+                assert set(eb) == set(es), sorted(set(eb) ^ set(es))   # incl. the env's own episode_extra_stats (quadrotor_multi.py:637-718)
                 for k, v in eb.items():
                     assert k in es, k
                     assert v == pytest.approx(es[k], abs=1e-9), k
@@ -291,16 +292,16 @@ def test_snapshot_save_load_is_a_deep_copy_of_one_env():
     st.close()
 
 
-def test_experience_replay_wrapper_replays_a_collision_event():
-    """quad_experience_replay.py on device snapshots: checkpoints every 0.5 s, a collision after the grace period files the
-    checkpoint from 1.5 s earlier, and the next episode starts from that checkpoint."""
+def test_experience_replay_through_the_facade():
+    """quad_experience_replay.py on the device (qs_replay_enable) seen through the single-env facade: checkpoints every 0.5 s, a
+    collision after the grace period files the checkpoint from 1.5 s earlier - whose observation that step returns, like the
+    reference - and the next episode starts from that checkpoint and reports the replay statistics."""
     from quad_swarm_rl_amd import sf_env
-    from quad_swarm_rl_amd.replay import ExperienceReplayWrapper
     cfg = parse(["--quads_num_agents=4", "--quads_neighbor_visible_num=2", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
                  "--quads_episode_duration=3.0", "--replay_buffer_sample_prob=1.0", "--quads_precision=f64", "--quads_seed=2"])
     env = sf_env.make_quadrotor_env("quadrotor_multi", cfg=cfg)
-    replay, quad = env.env.env, env.unwrapped          # Compatibility -> RewardShaping -> ExperienceReplay -> QuadrotorEnvMulti
-    assert isinstance(replay, ExperienceReplayWrapper) and quad.use_replay_buffer and not quad.activate_replay_buffer
+    quad = env.unwrapped                                # Compatibility -> RewardShaping -> QuadrotorEnvMulti (replay on the device)
+    assert quad.use_replay_buffer and not quad.activate_replay_buffer
     env.reset()
     quad.activate_replay_buffer = True                 # (the reference switches it on after 10 episodes without crashes, :280-287)
     st = quad._vec.stepper
@@ -315,15 +316,17 @@ def test_experience_replay_wrapper_replays_a_collision_event():
         if t in (50, 100, 150, 200) and not term.any():
             cp_obs[t] = np.array(obs, copy=True)
         if t == 211:
-            assert len(replay.replay_buffer) == 1 and replay.last_tick_added_to_buffer == 211
-            assert len(replay.episode_checkpoints) == 4
+            rs = st.replay_stats()
+            assert rs["buffer_len"][0] == 1 and rs["checkpoints"][0] == 4 and rs["errors"][0] == 0
+            np.testing.assert_array_equal(obs, cp_obs[100])   # the filed checkpoint's observation (quad_experience_replay.py:151)
         if t < 301:
             assert not term.any()
     assert term.all()                                  # tick 301 > ep_len 300
     st_info = infos[0]["episode_extra_stats"]
     assert st_info["replay/replay_rate"] == 1.0 and st_info["replay/replay_buffer_size"] == 1 and st_info["replay/avg_replayed"] == 1.0
+    assert "num_collisions" in st_info and "true_reward" in infos[0]
     # steps_ago = 1.5 / 0.5 = 3 checkpoints before the collision: the one taken at tick 100
-    assert quad.envs[0].tick == 100 and quad.saved_in_replay_buffer
+    assert quad.envs[0].tick == 100
     np.testing.assert_array_equal(obs, cp_obs[100])
     for t in range(101, 302):                          # the replayed episode runs to its own end
         obs, rew, term, trunc, infos = env.step(hover)

@@ -1,0 +1,110 @@
+"""The device-side batched experience replay (qs_replay_enable: qs_replay_kernel behind every step) against its Python twin
+tests/replay_model.py - which tests/test_replay_model_vs_reference.py pins against the REFERENCE wrapper's recorded behaviour.
+
+24 environments with different collision histories run for ~4500 control steps: natural activation of the replay buffers (10
+episodes with a mean crash reward above -1), checkpoints every 0.5 s, collisions filed once per 5 s from the checkpoint of
+1.5 s ago, episodes restarted from events with probability 0.75.  After every step the kernel's per-environment state must equal
+the model's (same Philox draws), the observation returned on a filing step must be the filed checkpoint's, and a restored
+environment must equal the checkpoint bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.replay_model import ReplayModel
+
+pytestmark = pytest.mark.gpu
+SITE_REPLAY = 25
+
+
+def philox_u(seed, env, ctr, slot):
+    """u01 of word 0 of the Philox group the kernel draws: counter = {env, step_ctr, site | slot << 8, 0}"""
+    from oracle import oracle as orc
+    c = (C.c_uint32 * 4)(env, ctr, SITE_REPLAY | (slot << 8), 0)
+    k = (C.c_uint32 * 2)(seed & 0xffffffff, seed >> 32)
+    out = (C.c_uint32 * 4)()
+    orc.lib().qso_philox4x32(c, k, out)
+    return np.float32((np.float32(out[0] >> 9) + np.float32(0.5)) * np.float32(1.0 / 8388608.0))
+
+
+def test_replay_kernel_equals_the_model():
+    from quad_swarm_rl_amd import config as qcfg, native
+    E, N, seed, prob = 24, 4, 5, 0.75
+    cfg = qcfg.make_config(num_envs=E, num_agents=N, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, ep_time=2.6, seed=seed,
+                           env_id_offset=7, precision="f64", episode_sums=True, write_rew_info=False)
+    st = native.Stepper(cfg, device=0)
+    assert native.lib().qs_replay_enable(st._h, 2.0) != 0            # sample_prob outside [0, 1]
+    st.replay_enable(prob)
+    with pytest.raises(native.QsError):
+        st.replay_enable(prob)                                       # once per handle
+    st.reset()
+    forced = np.array([e % 2 for e in range(E)], dtype=np.uint8)      # half of the buffers switched on by hand, the others by the rule
+    st.replay_set_active(forced)
+    models = [ReplayModel(prob, control_freq=100, use_obstacles=False, active=bool(forced[e])) for e in range(E)]
+    D, T = st.obs_dim, E * N
+    rng = np.random.RandomState(1)
+    snaps = [dict() for _ in range(E)]                                # per env: pool slot -> (pos, vel, rot, tick, obs) of the snapshot
+    ticks = np.zeros(E, dtype=np.int64)
+    n_file = n_restore = n_save = 0
+    steps = 4600
+    for step in range(1, steps + 1):
+        # a collision (two drones 3 cm apart) at tick 170 in a third of the envs, in episodes that are not replays
+        for e in np.nonzero(ticks == 169)[0]:
+            if e % 3 == 0 and not models[e].saved:
+                s, tk = st.get_state(int(e))
+                s[1, 0:3] = s[0, 0:3] + np.array([0.03, 0.0, 0.0]); s[1, 3:6] = s[0, 3:6]
+                st.set_state(int(e), s, tk)
+        act = 0.06 + rng.uniform(-0.02, 0.02, size=(T, 4))           # hovering: the drones stay in the air, crash rewards stay at zero
+        st.from_host("actions", act)
+        st.step()
+        st.sync()
+        done = st.to_host("done").reshape(E, N)[:, 0].astype(bool)
+        ticks = st.to_host("tick").astype(np.int64)
+        uq = st.to_host("unique_col_mask")
+        ctr = 1 + step                                                # qs_reset took counter 1, step k takes 1 + k
+        need_state = False
+        acts = []
+        crash = st.to_host("ep_sums")[3].reshape(E, N)[:, 0] if done.any() else None
+        for e in range(E):
+            a = models[e].step(bool(done[e]), int(ticks[e]), int(uq[e]), 0, float(crash[e]) if done[e] else 0.0,
+                               lambda: philox_u(seed, 7 + e, ctr, 0),
+                               lambda n: min(int(np.float32(philox_u(seed, 7 + e, ctr, 1)) * np.float32(n)), n - 1))
+            a = [x for x in a if x[0] != "fresh"]
+            acts.append(a)
+            need_state |= bool(a)
+        rs = st.replay_stats()
+        for e in range(E):
+            ms = models[e].stats()
+            for k in ("episodes", "replayed", "buffer_len", "replayed_sum", "active", "checkpoints", "errors"):
+                assert rs[k][e] == ms[k], (step, e, k, rs[k][e], ms[k])
+        if need_state:
+            pos, vel, rot = st.to_host("pos").reshape(3, E, N), st.to_host("vel").reshape(3, E, N), st.to_host("rot").reshape(9, E, N)
+            obs = st.to_host("obs").reshape(E, N, D)
+            for e, a in enumerate(acts):
+                both = len(a) == 2     # a checkpoint saved AND an event filed on this step: the live observation was overwritten after the save
+                for x in a:
+                    if x[0] == "save":
+                        snaps[e][x[1]] = (pos[:, e].copy(), vel[:, e].copy(), rot[:, e].copy(), int(ticks[e]), None if both else obs[e].copy())
+                        n_save += 1
+                    elif x[0] == "file":
+                        snaps[e][x[2]] = snaps[e][x[1]]
+                        if snaps[e][x[1]][4] is not None:
+                            np.testing.assert_array_equal(obs[e], snaps[e][x[1]][4])  # the 1.5-s-old observation is returned on this step
+                        assert ticks[e] - snaps[e][x[1]][3] >= 100
+                        n_file += 1
+                    else:
+                        p0, v0, r0, t0, o0 = snaps[e][x[1]]
+                        np.testing.assert_array_equal(pos[:, e], p0); np.testing.assert_array_equal(vel[:, e], v0)
+                        np.testing.assert_array_equal(rot[:, e], r0)
+                        if o0 is not None:
+                            np.testing.assert_array_equal(obs[e], o0)
+                        assert ticks[e] == t0 and rs["ep_steps"][e] >= 1
+                        n_restore += 1
+            cnt = st.to_host("counters")
+            for e, a in enumerate(acts):
+                if a and a[-1][0] == "restore":
+                    assert cnt[0, e] == 0 and cnt[1, e] == 0                          # collision counters zeroed on the replayed env
+    st.check_errors()
+    assert all(m.active for m in models)                              # the rule switched the other half on after 10 clean episodes
+    assert n_save > 500 and n_file >= 8 and n_restore >= 6, (n_save, n_file, n_restore)
+    st.close()

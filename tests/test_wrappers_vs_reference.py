@@ -1,4 +1,5 @@
-"""sf_env.RewardShapingWrapper against the reference's QuadsRewardShapingWrapper (swarm_rl/env_wrappers/reward_shaping.py:19-123).
+"""(The experience-replay wrapper is pinned in tests/test_replay_model_vs_reference.py + tests/test_replay_gpu.py.)
+sf_env.RewardShapingWrapper against the reference's QuadsRewardShapingWrapper (swarm_rl/env_wrappers/reward_shaping.py:19-123).
 tests/golden/wrapper_reward_shaping.json holds what the reference wrapper produced over the scripted env of tests/fake_env.py
 (oracle/ref_harness/capture_wrappers.py, build container); here the repo's wrapper runs over the same script.  CPU only."""
 import json
@@ -44,45 +45,6 @@ def test_reward_shaping_wrapper_equals_reference(case, seed):
     if case == "annealed":
         assert ends[0]["rew_coeff"]["quadcol_bin"] < ends[-1]["rew_coeff"]["quadcol_bin"] <= 5.0
         assert ends[-1]["rew_coeff"]["quadcol_bin_smooth_max"] == 10.0
-
-
-class _ReplayedDraws:
-    """the reference wrapper's random draws (np.random.uniform for 'replay or new episode', random.randint for the event index),
-    served in order to this repo's wrapper, whose generator is a RandomState-like object"""
-
-    def __init__(self, draws):
-        self.u, self.i = list(draws["uniform"]), list(draws["randint"])
-
-    def uniform(self, lo, hi):
-        return self.u.pop(0)
-
-    def randint(self, lo, hi):
-        v = self.i.pop(0)
-        assert lo <= v < hi
-        return v
-
-
-def test_experience_replay_wrapper_equals_reference():
-    """replay.ExperienceReplayWrapper (device snapshots + host attributes) against the reference's wrapper (deepcopy of the env),
-    quad_experience_replay.py:66-209, over the scripted FakeReplayEnv: same checkpoints taken, same collision events filed, same
-    episodes replayed from the same states, same replay statistics."""
-    from quad_swarm_rl_amd import replay
-    from tests.fake_env import FakeReplayEnv, drive_replay
-    want = json.load(open(os.path.join(os.path.dirname(GOLDEN), "wrapper_experience_replay.json")))
-    env = FakeReplayEnv(seed=3)
-    w = replay.ExperienceReplayWrapper(env, 0.75, 0.2, 0.6)
-    draws = _ReplayedDraws(want["draws"])
-    w.rng = w.replay_buffer.rng = draws
-    got = drive_replay(w, want["steps"])
-    ref = want["trajectory"]
-    assert got["tick"] == ref["tick"] and got["episode"] == ref["episode"]
-    assert got["x"] == pytest.approx(ref["x"], rel=0, abs=0)
-    assert sorted(got["ends"]) == sorted(ref["ends"]) and len(ref["ends"]) >= 15
-    for t in ref["ends"]:
-        assert close(got["ends"][t], ref["ends"][t]), (t, got["ends"][t], ref["ends"][t])
-    assert not draws.u and not draws.i                                   # every draw of the reference was asked for, in order
-    replayed = sum(1 for a, b in zip(ref["tick"][:-1], ref["tick"][1:]) if b < a and b > 0)
-    assert replayed >= 10                                                # episodes that restarted mid-way: replays from a checkpoint
 
 
 def test_command_line_flags_equal_reference():
