@@ -31,6 +31,7 @@ extern "C" {
 #define QS_VERSION 100            /* 0.1.0 */
 #define QS_MAX_AGENTS 64          /* per environment (pair/id sets are 64-bit masks) */
 #define QS_MAX_OBSTACLES 64
+#define QS_MAX_DR_CHOICES 8       /* choices of obstacle density / size under --quads_domain_random */
 
 /* obs_repr (quad_utils.py:30-34 QUADS_OBS_REPR) */
 enum { QS_OBS_XYZ_VXYZ_R_OMEGA = 0, QS_OBS_XYZ_VXYZ_R_OMEGA_FLOOR = 1, QS_OBS_XYZ_VXYZ_R_OMEGA_WALL = 2 };
@@ -127,6 +128,14 @@ typedef struct qs_config {
     int32_t episode_sums;      /* 1: accumulate, per drone and episode, the sums the SF reward-shaping wrapper keeps on the
                                   host (swarm_rl/env_wrappers/reward_shaping.py:78-110): the 17 reward terms and the
                                   first / second moments of the 4 actions; snapshot into qs_buffers.ep_sums at done */
+
+    /* ---- per-episode obstacle randomisation, --quads_domain_random (quad_experience_replay.py:75-88,:106-118,:191-206 ->
+       QuadrotorEnvMulti.reset(obst_density, obst_size), quadrotor_multi.py:339-351).  Every reset of an environment draws one
+       of dr_num_density densities (np.arange(min, max, 0.05)) and one of dr_num_size sizes (np.arange(min, max, 0.1)); 0 = that
+       quantity is fixed.  num_obstacles above is then the LARGEST count: unused obstacle slots are parked far outside the room. */
+    int32_t dr_num_density, dr_num_size;
+    int32_t dr_obst_count[QS_MAX_DR_CHOICES];   /* int(cells * density_k) */
+    double dr_density[QS_MAX_DR_CHOICES], dr_size[QS_MAX_DR_CHOICES];
 } qs_config;
 
 /* Device pointers (element type = float for QS_PRECISION_F32, double for QS_PRECISION_F64 where
@@ -161,6 +170,9 @@ typedef struct qs_buffers {
     void *ep_scenario;        /* int32 [E]: scenario of the last finished episode (names the per-scenario episode stats) */
     void *run_sums;           /* real [QS_SUM_COUNT, E*N]: running sums of the current episode (episode_sums = 1) */
     void *ep_sums;            /* real [QS_SUM_COUNT, E*N]: the sums of the last finished episode */
+    void *obst_count;         /* int32 [E]: obstacles of the running episode (<= num_obstacles; domain randomisation) */
+    void *obst_size_env;      /* real  [E]: obstacle size of the running episode */
+    void *obst_density_env;   /* real  [E]: obstacle density of the running episode (statistics only) */
     int32_t obs_dim;
     int32_t real_size;        /* 4 or 8 */
 } qs_buffers;

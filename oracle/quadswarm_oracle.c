@@ -54,7 +54,9 @@ struct qso_env {
     double mpos[MAXN][3], mvel[MAXN][3]; /* QuadrotorEnvMulti.pos / .vel (quadrotor_multi.py:84-85) */
     uint64_t prev_pair[MAXN];
     qso_info info;
-    /* obstacles */
+    /* obstacles; cur_*: this episode's count / size / density (--quads_domain_random, quad_experience_replay.py:106-118,:191-206) */
+    int32_t cur_M;
+    double cur_size, cur_density;
     double obst_xy[QS_MAX_OBSTACLES][2];
     uint8_t obst_map[64][64];
     double *cell_centers; /* [L*W][2] */
@@ -495,7 +497,7 @@ static void obstacle_obs(qso_env *e, double *obs) { /* MultiObstacles.reset/step
     const qs_config *c = &e->c;
     if (!c->use_obstacles) return;
     for (int i = 0; i < c->num_agents; ++i)
-        qso_surround_sdf(e->mpos[i], &e->obst_xy[0][0], c->num_obstacles, c->obst_size / 2.0, 0.1,
+        qso_surround_sdf(e->mpos[i], &e->obst_xy[0][0], e->cur_M, e->cur_size / 2.0, 0.1,
                          obs + (size_t)i * e->obs_dim + e->self_dim + 6 * c->num_neighbors);
 }
 
@@ -594,7 +596,7 @@ static void collide_obstacle(qso_env *e, int i, int o) {
         if (dot3(chk, n) > 0) { memcpy(noise, tmp, sizeof noise); break; }
     }
     double diff[3] = {d->pos[0] - opos[0], d->pos[1] - opos[1], d->pos[2] - opos[2]};
-    int inside = norm3(diff) < c->obst_size / 2;
+    int inside = norm3(diff) < e->cur_size / 2;
     double decay = inside ? rng_uniform1(e, QS_SITE_OBST_U, 0, i, 0, 1.0, 1.0) : rng_uniform1(e, QS_SITE_OBST_U, 0, i, 0, 0.2, 0.8);
     double shift[3] = {nv[0] - d->vel[0] + noise[0], nv[1] - d->vel[1] + noise[1], nv[2] - d->vel[2] + noise[2]};
     compute_new_vel(vmag, d->vel, shift, decay);
@@ -1210,7 +1212,17 @@ static void env_reset(qso_env *e, double *obs) {
     const qs_config *c = &e->c;
     int N = c->num_agents;
     if (c->use_obstacles) {
-        int L = c->obst_area[0], W = c->obst_area[1], M = c->num_obstacles, cells = L * W;
+        /* --quads_domain_random: the wrapper draws this episode's density / size before reset(obst_density, obst_size) */
+        if (c->dr_num_density > 0 && !e->tape) {
+            int k = (int)(rng_uniform1(e, QS_SITE_REPLAY, 2, 0, 0, 0.0, 1.0) * c->dr_num_density); if (k >= c->dr_num_density) k = c->dr_num_density - 1;
+            e->cur_M = c->dr_obst_count[k]; e->cur_density = c->dr_density[k];
+        }
+        if (c->dr_num_size > 0 && !e->tape) {
+            int k = (int)(rng_uniform1(e, QS_SITE_REPLAY, 3, 0, 0, 0.0, 1.0) * c->dr_num_size); if (k >= c->dr_num_size) k = c->dr_num_size - 1;
+            e->cur_size = c->dr_size[k];
+        }
+        int L = c->obst_area[0], W = c->obst_area[1], M = e->cur_M, cells = L * W;
+        for (int k = M; k < c->num_obstacles; ++k) { e->info.obst_pos[k][0] = 1e6; e->info.obst_pos[k][1] = 1e6; }   /* unused slots: parked far away, like the device's */
         qso_cell_centers(L, W, e->cell_centers);
         int ids[QS_MAX_OBSTACLES];
         if (e->tape) { for (int k = 0; k < M; ++k) ids[k] = (int)tape_pop(e); }
@@ -1341,7 +1353,7 @@ void qso_step(qso_env *e, const double *actions, double *obs, double *rew, uint8
         uint64_t prev_hit = 0;
         for (int i = 0; i < N; ++i) {
             if (e->d[i].flags & F_PREV_OBST) prev_hit |= 1ull << i;
-            int o = qso_obst_first_hit(e->mpos[i], &e->obst_xy[0][0], c->num_obstacles, c->arm + c->obst_size / 2.0);
+            int o = qso_obst_first_hit(e->mpos[i], &e->obst_xy[0][0], e->cur_M, c->arm + e->cur_size / 2.0);
             e->info.obst_hit_idx[i] = o;
             if (o >= 0) obst_hit |= 1ull << i;
         }
@@ -1489,6 +1501,7 @@ qso_env *qso_create(const qs_config *cfg, int32_t env_global_id) {
     e->env_id = env_global_id;
     e->self_dim = self_obs_dim(cfg->obs_repr);
     e->obs_dim = qso_obs_dim(cfg);
+    e->cur_M = cfg->num_obstacles; e->cur_size = cfg->obst_size; e->cur_density = cfg->obst_density;
     for (int i = 0; i < cfg->num_agents; ++i) e->d[i].dist_hist = (double *)calloc((size_t)cfg->ep_len + 8, sizeof(double));
     e->cell_centers = (double *)calloc(64 * 64 * 2, sizeof(double));
     return e;

@@ -62,6 +62,8 @@ class QsConfig(C.Structure):
         ("obst_area", C.c_int32 * 2), ("num_obstacles", C.c_int32),
         ("write_rew_info", C.c_int32),
         ("episode_sums", C.c_int32),
+        ("dr_num_density", C.c_int32), ("dr_num_size", C.c_int32), ("dr_obst_count", C.c_int32 * 8),
+        ("dr_density", C.c_double * 8), ("dr_size", C.c_double * 8),
     ]
 
 
@@ -86,7 +88,9 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
                 use_obstacles=False, obst_density=0.2, obst_size=1.0, obst_spawn_area=(6.0, 6.0),
                 use_downwash=False, use_numba=False, quads_mode="static_same_goal", room_dims=(10.0, 10.0, 10.0),
                 sense_noise="default", thrust_noise_ratio=0.05, sim_freq=200.0, sim_steps=2,
-                seed=0, env_id_offset=0, precision="f32", write_rew_info=True, episode_sums=False):
+                seed=0, env_id_offset=0, precision="f32", write_rew_info=True, episode_sums=False,
+                domain_random=False, obst_density_random=False, obst_size_random=False,
+                obst_density_min=0.05, obst_density_max=0.2, obst_size_min=0.3, obst_size_max=0.6):
     """Build a QsConfig.  Argument names/defaults follow the reference's `--quads_*` flags
     (swarm_rl/env_wrappers/quadrotor_params.py:15-120) and QuadrotorEnvMulti.__init__."""
     if num_agents < 1 or num_agents > QS_MAX_AGENTS:
@@ -155,7 +159,29 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
     c.nbr_clip_vel[:] = [2.0 * af["vxyz_max"]] * 3                    # quadrotor_single.py:295
     c.obst_size, c.obst_density = obst_size, obst_density
     c.obst_area[:] = [int(obst_spawn_area[0]), int(obst_spawn_area[1])]
+    cells = int(obst_spawn_area[0]) * int(obst_spawn_area[1])
     c.num_obstacles = int(obst_density * obst_spawn_area[0] * obst_spawn_area[1]) if use_obstacles else 0
+    # --quads_domain_random (quad_experience_replay.py:75-88): choices as np.arange builds them, counts as
+    # obst_generation_given_density does (quadrotor_multi.py:304-313: int(num_room_grids * density))
+    c.dr_num_density = c.dr_num_size = 0
+    if domain_random and use_obstacles:
+        if obst_density_random:
+            dens = [float(d) for d in np.arange(obst_density_min, obst_density_max, 0.05)]
+            if not 1 <= len(dens) <= 8:
+                raise ValueError("obstacle density randomisation: 1..8 choices (np.arange(min, max, 0.05))")
+            c.dr_num_density = len(dens)
+            for k, d in enumerate(dens):
+                c.dr_density[k], c.dr_obst_count[k] = d, int(cells * d)
+            if min(c.dr_obst_count[k] for k in range(len(dens))) < 1:
+                raise ValueError("obstacle density randomisation: every choice must give at least one obstacle")
+            c.num_obstacles = max(c.dr_obst_count[k] for k in range(len(dens)))
+        if obst_size_random:
+            sizes = [float(x) for x in np.arange(obst_size_min, obst_size_max, 0.1)]
+            if not 1 <= len(sizes) <= 8:
+                raise ValueError("obstacle size randomisation: 1..8 choices (np.arange(min, max, 0.1))")
+            c.dr_num_size = len(sizes)
+            for k, x in enumerate(sizes):
+                c.dr_size[k] = x
     c.write_rew_info = int(bool(write_rew_info))
     c.episode_sums = int(bool(episode_sums))
     if c.num_obstacles > QS_MAX_OBSTACLES:

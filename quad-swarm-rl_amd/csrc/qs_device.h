@@ -235,6 +235,11 @@ template <typename real> struct Consts {
     real inv_win[3];           // 1/min(ep_len+1, {1,3,5} s of control steps): episode-stat window sizes
     int32_t write_rew_info;   // 0: skip the 17-term reward-info matrix (it is logging, not part of obs/reward/done)
     int32_t episode_sums;     // 1: per-episode sums of the reward terms and action moments (reward_shaping.py:78-110)
+    // --quads_domain_random: per-episode obstacle density / size (include/quadswarm.h); dr_on = 0 folds all of it away
+    // (the choice tables live in device memory, Ptrs::dr_*: a run-time index into this struct would move the whole constant block
+    // to scratch memory - and every literal of a config-specialised kernel with it: measured 8 -> 21 us per C2 step)
+    int32_t dr_on, dr_num_density, dr_num_size;
+    real arm_r;
 };
 
 // per-drone dynamic state held in registers
@@ -561,7 +566,7 @@ template <typename real> __device__ __forceinline__ void compute_new_omega(const
 
 // perform_collision_with_obstacle collisions/obstacles.py:23-50 (+ :9-20)
 template <typename real>
-__device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const RngKey &key, int drone, Drone<real> &d, real ox, real oy) {
+__device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const RngKey &key, int drone, Drone<real> &d, real ox, real oy, real obst_size) {
     real n[3] = {d.pos[0] - ox, d.pos[1] - oy, 0};
     real mag = norm3<real>(n), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
     n[0] /= den; n[1] /= den;
@@ -575,7 +580,7 @@ __device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const Rn
         if (dot3<real>(chk, n) > (real)0) { noise[0] = tmp[0]; noise[1] = tmp[1]; noise[2] = tmp[2]; break; }
     }
     real diff[3] = {d.pos[0] - ox, d.pos[1] - oy, d.pos[2] - c.room_mid_z};
-    bool inside = norm3<real>(diff) < c.obst_size / (real)2;
+    bool inside = norm3<real>(diff) < obst_size / (real)2;
     real decay = inside ? rng_uniform1<real>(key, QS_SITE_OBST_U, 0, drone, 0, (real)1, (real)1)
                         : rng_uniform1<real>(key, QS_SITE_OBST_U, 0, drone, 0, (real)0.2, (real)0.8);
     real shift[3] = {nv[0] - d.vel[0] + noise[0], nv[1] - d.vel[1] + noise[1], nv[2] - d.vel[2] + noise[2]};

@@ -50,6 +50,10 @@ template <typename real> struct Ptrs {
     int32_t *scenario_id;  // [E] active scenario (the sub-scenario under `mix`)
     int32_t *ep_scenario;  // [E] scenario of the last finished episode
     real *run_sums, *ep_sums;   // [QS_SUM_COUNT, T] per-episode sums (running / last finished episode)
+    int32_t *obst_count;   // [E] obstacles of the running episode (domain randomisation; the other slots are parked far away)
+    real *obst_size_env, *obst_density_env;   // [E] obstacle size / density of the running episode
+    const int32_t *dr_count;                  // [QS_MAX_DR_CHOICES] --quads_domain_random choice tables: obstacle count,
+    const real *dr_density, *dr_size;         //                     density, size
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
     const real *rew_rt;   // [QS_REW_COUNT + 1] run-time reward coefficients + proximity slope (qs_set_reward_coeffs)
@@ -126,7 +130,7 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     L.off_si = o; o += full ? 4 * SI_COUNT * epb : 0;
     L.off_sr = o; o += full ? real_size * SR_COUNT * epb : 0;
     o = (o + 15) & ~15;
-    L.off_envflag = o; o += 4 * ((2 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods
+    L.off_envflag = o; o += 4 * ((3 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods + [epb] obstacle-size choice
 #ifdef QS_TAPE
     L.off_cur = o; o += 4 * ((epb + 3) & ~3);
 #endif
@@ -460,7 +464,7 @@ __device__ __forceinline__ void nbr_emit(const Consts<real> &c, int N, int i, in
 
 // get_surround_sdfs obstacles/utils.py:5-27 (obstacle xy of the env in LDS)
 template <typename real>
-__device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o) {
+__device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o, real radius) {
     const real res = (real)0.1;
     real gx[3] = {px - res, px, px + res}, gy[3] = {py - res, py, py + res};
     real mind[9];
@@ -477,7 +481,7 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
             }
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) o[q] = mind[q] - c.obst_radius;
+    for (int q = 0; q < 9; ++q) o[q] = mind[q] - radius;
 }
 
 // The neighbour and SDF columns of the wave's rows -> rows stage -> HBM together with the self columns (obs_copy_rows), one row
@@ -487,7 +491,7 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
 template <typename real>
 __device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayout &L, real *__restrict__ dst_block, const real *s_self, real *s_rows, int N, int i, int le, int base, int tid,
                                             const real *s_pos, const real *s_vel, real *s_metric, const real *s_obst, const real mypos[3], const real myvel[3],
-                                            bool live, int nrows, uint64_t rowmask) {
+                                            bool live, int nrows, uint64_t rowmask, real obst_radius) {
     const int B = QS_WAVE, K = c.num_neighbors, D = c.obs_dim, S = c.self_dim, X = D - S, M_ = c.num_obstacles, RP = L.rows_per_pass;
     NbrSel<real> sel;
     if (live) nbr_select<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel);
@@ -496,7 +500,7 @@ __device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayo
         real nv[QS_NV_MAX];
         if (live) {
             nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel, 0, K, nv);
-            if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], nv + 6 * K);
+            if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], nv + 6 * K, obst_radius);
         }
         for (int r0 = 0; r0 < nrows; r0 += RP) {
             if (live && tid >= r0 && tid < r0 + RP) {
@@ -514,7 +518,7 @@ __device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayo
     if (live) {   // complete rows at once: straight into the stage
         real *o = s_rows + tid * X;
         nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel, 0, K, o);
-        if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], o + 6 * K);
+        if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], o + 6 * K, obst_radius);
     }
     __syncthreads();
     obs_copy_rows<real>(dst_block, s_self, s_rows, S, D, 0, nrows, rowmask, tid);
@@ -563,12 +567,13 @@ __device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int
 
 // rare per-drone responses kept out of line so the hot path stays compact
 template <typename real>
-__device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, const RngKey &key, int i, uint32_t bits, real ox, real oy, real pos[3], real vel[3], real omega[3]) {
+__device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, const RngKey &key, int i, uint32_t bits, real ox, real oy, real pos[3], real vel[3], real omega[3],
+                                                    real obst_size) {
     const Consts<real> &c = *cp;
     Drone<real> d;
 #pragma unroll
     for (int q = 0; q < 3; ++q) { d.pos[q] = pos[q]; d.vel[q] = vel[q]; d.omega[q] = omega[q]; }
-    if (bits & B_OBST_NEW) collide_obstacle<real>(c, key, i, d, ox, oy);      // collisions/obstacles.py:23-50
+    if (bits & B_OBST_NEW) collide_obstacle<real>(c, key, i, d, ox, oy, obst_size);      // collisions/obstacles.py:23-50
     if (bits & B_WALL_NEW) collide_room<real>(c, key, i, d, true);            // collisions/room.py:6-44
     if (bits & B_CEIL_NEW) collide_room<real>(c, key, i, d, false);           // collisions/room.py:91-113
 #pragma unroll
@@ -633,10 +638,29 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         uint64_t omap[4] = {0, 0, 0, 0};   // obstacle map bitset, cell id = rid*W + cid
         const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W;
         if (FULL) for (int q = 0; q < 4; ++q) ((uint64_t *)(smem + L.off_omap))[le * 4 + q] = 0;
+        int Me = M_;   // obstacles of this episode
         if (c.use_obstacles) {
+            if (c.dr_on) {   // --quads_domain_random: this episode's density / size (quad_experience_replay.py:106-118,:191-206 -> reset(obst_density, obst_size))
+                if (c.dr_num_density > 0) {
+                    const int k = rng_index<real>(key, QS_SITE_REPLAY, 2, c.dr_num_density);
+                    Me = p.dr_count[k];
+                    p.obst_density_env[e] = p.dr_density[k];
+                }
+                if (c.dr_num_size > 0) {
+                    const int k = rng_index<real>(key, QS_SITE_REPLAY, 3, c.dr_num_size);
+                    p.obst_size_env[e] = p.dr_size[k];
+                    s_envflag[2 * epb + le] = (uint32_t)k;   // for the first observation of the episode, later in this launch
+                }
+                p.obst_count[e] = Me;
+            }
             // np.random.choice(cells, M, replace=False): partial Fisher-Yates on a virtual pool
             int nt = 0;
             for (int k = 0; k < M_; ++k) {
+                if (k >= Me) {   // unused slot: parked where no first-hit test and no SDF minimum can see it
+                    p.obst_pos[(size_t)e * M_ + k] = (real)1e6; p.obst_pos[(size_t)E * M_ + (size_t)e * M_ + k] = (real)1e6;
+                    s_obst[(le * 2 + 0) * M_ + k] = (real)1e6; s_obst[(le * 2 + 1) * M_ + k] = (real)1e6;
+                    continue;
+                }
                 int vj;
                 if (QS_ON_TAPE(key)) vj = (int)tape_pop(key);   // the tape holds the chosen cell ids (quadrotor_multi.py:313)
                 else {
@@ -674,7 +698,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             (void)rows;
         } else if (c.scenario == QS_SCENARIO_O_STATIC_SAME_GOAL) {
             // obstacles/o_static_same_goal.py:27-48 + o_base.py:69-81,:124-153
-            int nfree = cells - M_;
+            int nfree = cells - Me;
             int nt = 0;
             const bool on_tape = QS_ON_TAPE(key);
             if (on_tape) tape_skip(key, 1);   // the duration draw of o_static_same_goal.py:29 (unused by a static goal)
@@ -798,11 +822,13 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         const int first_env = blockIdx.x * epb;
         int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
         stream_rows<real>(c, L, p.obs + (size_t)first_env * N * c.obs_dim, (const real *)(smem + L.off_self), (real *)(smem + L.off_rows), N, i, le, base, tid,
-                          s_pos, s_vel, s_metric, s_obst, d.pos, stale_vel, do_reset, nenv * N, rowmask);
+                          s_pos, s_vel, s_metric, s_obst, d.pos, stale_vel, do_reset, nenv * N, rowmask,
+                          c.dr_num_size > 0 ? (real)0.5 * p.dr_size[s_envflag[2 * epb + (le < epb ? le : 0)] & 7] : c.obst_radius);
     } else if (do_reset) {
         neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, stale_vel, myobs + c.self_dim);
         if (c.use_obstacles)
-            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors);
+            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors,
+                          c.dr_num_size > 0 ? (real)0.5 * p.dr_size[s_envflag[2 * epb + le] & 7] : c.obst_radius);
     }
 }
 

@@ -37,6 +37,7 @@ template <typename real> __device__ __forceinline__ void cell_center(int Lr, int
     *px = (real)ii + (real)0.5 - (real)(Lr / 2);
     *py = (real)jj + (real)0.5 - (real)(W / 2);
 }
+__device__ __forceinline__ int map_count(const uint64_t *omap) { return __popcll(omap[0]) + __popcll(omap[1]) + __popcll(omap[2]) + __popcll(omap[3]); }
 // k-th free cell in np.where(obst_map == 0) order
 __device__ __forceinline__ int kth_free_cell(const uint64_t *omap, int cells, int k) {
     int seen = 0;
@@ -50,7 +51,8 @@ __device__ __forceinline__ int kth_free_cell(const uint64_t *omap, int cells, in
 template <typename real>
 __device__ void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *tidx, int *tval, int slot_choice, int slot_z,
                                bool to_spawn) {
-    const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - c.num_obstacles, N = x.N;
+    // free cells = cells not in the obstacle map (the episode's obstacle count varies under --quads_domain_random)
+    const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - map_count(x.omap), N = x.N;
     const bool on_tape = QS_ON_TAPE(key);   // a tape holds the N chosen free-cell indices, then the N heights (o_base.py:69-81)
     int nt = 0;
     for (int k = 0; k < N; ++k) {
@@ -77,7 +79,7 @@ __device__ void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const S
 // Scenario_o_base.generate_pos_obst_map o_base.py:48-67 (no surroundings check): one free cell + z ~ U(0.75,3)
 template <typename real>
 __device__ void pos_obst_map_1(const Consts<real> &c, const RngKey &key, const uint64_t *omap, int slot, real out[3]) {
-    const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - c.num_obstacles;
+    const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - map_count(omap);
     int idx = rng_index<real>(key, QS_SITE_SCEN, slot, nfree);
     int cell = kth_free_cell(omap, cells, idx), cx = cell / W, cy = cell - cx * W;
     cell_center<real>(Lr, W, cx, cy, &out[0], &out[1]);

@@ -115,6 +115,9 @@ template <typename real> static void fill_consts(const qs_config &c, Consts<real
     k.env_id_offset = c.env_id_offset; k.num_envs = c.num_envs; k.num_agents = c.num_agents;
     k.write_rew_info = c.write_rew_info;
     k.episode_sums = c.episode_sums;
+    k.dr_num_density = c.use_obstacles ? c.dr_num_density : 0; k.dr_num_size = c.use_obstacles ? c.dr_num_size : 0;
+    k.dr_on = (k.dr_num_density > 0 || k.dr_num_size > 0) ? 1 : 0;
+    k.arm_r = (real)c.arm;
     k.inv_dt = (real)(1.0 / c.dt);
     k.prox_ratio = (real)(-c.rew_coeff[QS_REW_QUADCOL_SMOOTH_MAX] / c.collision_falloff_threshold);
     for (int w = 0; w < 3; ++w) {
@@ -298,6 +301,11 @@ static int validate(const qs_config *c) {
                                  spec_team_waves(c->num_agents) /* the largest layout qs_create may pick */, scenario_is_full(c->scenario), c->scenario);
         if (L.total > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "observation staging does not fit the 160 KiB LDS of a CU");
     }
+    if (c->dr_num_density < 0 || c->dr_num_density > QS_MAX_DR_CHOICES || c->dr_num_size < 0 || c->dr_num_size > QS_MAX_DR_CHOICES)
+        return fail(QS_ERR_INVALID, "bad number of domain-randomisation choices");
+    if (c->use_obstacles)
+        for (int q = 0; q < c->dr_num_density; ++q)
+            if (c->dr_obst_count[q] < 1 || c->dr_obst_count[q] > c->num_obstacles) return fail(QS_ERR_INVALID, "domain randomisation: obstacle counts must be in [1, num_obstacles]");
     if (c->sim_steps < 1 || c->ep_len < 1 || c->svd_period < 1 || c->svd_period > 255) return fail(QS_ERR_INVALID, "bad sim_steps/ep_len/svd_period");
     return QS_OK;
 }
@@ -343,6 +351,24 @@ template <typename real> static int create_typed(qs_handle *h) {
     DA(unique_col, E); DA(obst_new, E); DA(room_new, E); DA(counters, QS_CNT_COUNT * E); DA(tick, E); DA(step_ctr, E);
     DA(obst_pos, 2 * E * (M_ ? M_ : 1)); DA(ep_stats, QS_EPS_COUNT * T); DA(ep_counters, QS_CNT_COUNT * E);
     DA(run_sums, QS_SUM_COUNT * T); DA(ep_sums, QS_SUM_COUNT * T);
+    DA(obst_count, E); DA(obst_size_env, E); DA(obst_density_env, E);
+    {   // --quads_domain_random choice tables
+        int32_t *dc = nullptr; real *dd = nullptr, *ds = nullptr;
+        if ((rc = dalloc(h, &dc, QS_MAX_DR_CHOICES)) != QS_OK || (rc = dalloc(h, &dd, QS_MAX_DR_CHOICES)) != QS_OK || (rc = dalloc(h, &ds, QS_MAX_DR_CHOICES)) != QS_OK) return rc;
+        real hd[QS_MAX_DR_CHOICES], hs[QS_MAX_DR_CHOICES];
+        for (int q = 0; q < QS_MAX_DR_CHOICES; ++q) { hd[q] = (real)c.dr_density[q]; hs[q] = (real)c.dr_size[q]; }
+        HIP_TRY(hipMemcpy(dc, c.dr_obst_count, sizeof c.dr_obst_count, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dd, hd, sizeof hd, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ds, hs, sizeof hs, hipMemcpyHostToDevice));
+        p.dr_count = dc; p.dr_density = dd; p.dr_size = ds;
+    }
+    {   // until the first reset draws: the configured density / size
+        std::vector<int32_t> cnt(E, c.num_obstacles);
+        std::vector<real> sz(E, (real)c.obst_size), dn(E, (real)c.obst_density);
+        HIP_TRY(hipMemcpy(p.obst_count, cnt.data(), E * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p.obst_size_env, sz.data(), E * sizeof(real), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(p.obst_density_env, dn.data(), E * sizeof(real), hipMemcpyHostToDevice));
+    }
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
     DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128);
 #undef DA
@@ -371,6 +397,7 @@ template <typename real> static int create_typed(qs_handle *h) {
     b.ou_state = p.ou; b.goal = p.goal; b.flags = p.flags; b.obst_hit_idx = p.obst_hit_idx; b.col_pair_mask = p.pair_mask;
     b.new_pair_mask = p.new_pair_mask; b.unique_col_mask = p.unique_col; b.obst_new_mask = p.obst_new; b.room_new_mask = p.room_new;
     b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters; b.run_sums = p.run_sums; b.ep_sums = p.ep_sums;
+    b.obst_count = p.obst_count; b.obst_size_env = p.obst_size_env; b.obst_density_env = p.obst_density_env;
     b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
     // what a deep copy of one reference env carries (quad_experience_replay.py:99-104 deep-copies the whole env): every
     // per-drone and per-env array except the noise-stream position (step_ctr: a restored env draws fresh noise, as the
@@ -385,6 +412,7 @@ template <typename real> static int create_typed(qs_handle *h) {
     sa.push_back({(char *)p.obs, sizeof(real), 1, T * D, N * D, 1});                     // the observation that goes with the state
     SNAP_E(unique_col, 1); SNAP_E(obst_new, 1); SNAP_E(room_new, 1); SNAP_E(counters, QS_CNT_COUNT); SNAP_E(tick, 1);
     SNAP_E(scen_real, SR_COUNT); SNAP_E(scen_int, SI_COUNT); SNAP_E(scen_omap, 4); SNAP_E(scenario_id, 1);
+    SNAP_E(obst_count, 1); SNAP_E(obst_size_env, 1); SNAP_E(obst_density_env, 1);
     sa.push_back({(char *)p.obst_pos, sizeof(real), 2, E * (M_ ? M_ : 1), (M_ ? M_ : 1), 0});
 #undef SNAP_T
 #undef SNAP_E

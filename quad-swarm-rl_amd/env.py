@@ -160,7 +160,7 @@ class QuadrotorEnvMulti:
                  dynamics_params="Crazyflie", raw_control=True, raw_control_zero_middle=True,
                  dynamics_randomize_every=None, dynamics_change=None, dyn_sampler_1=None,
                  sense_noise="default", init_random_state=False, render_mode="human",
-                 seed=0, device=0, precision="f32", replay_buffer_sample_prob=0.0):
+                 seed=0, device=0, precision="f32", replay_buffer_sample_prob=0.0, **domain_random_kwargs):
         if dynamics_params != "Crazyflie" or not raw_control or not raw_control_zero_middle or init_random_state \
                 or dynamics_randomize_every is not None or dyn_sampler_1 is not None:
             raise NotImplementedError("only the configuration hard-coded by make_quadrotor_env_multi is supported "
@@ -177,7 +177,7 @@ class QuadrotorEnvMulti:
             collision_hitbox_radius=collision_hitbox_radius, collision_falloff_radius=collision_falloff_radius,
             use_obstacles=use_obstacles, obst_density=obst_density, obst_size=obst_size, obst_spawn_area=obst_spawn_area,
             use_downwash=use_downwash, use_numba=use_numba, quads_mode=quads_mode, room_dims=room_dims,
-            sense_noise=sense_noise, thrust_noise_ratio=tnr, episode_sums=bool(use_replay_buffer))
+            sense_noise=sense_noise, thrust_noise_ratio=tnr, episode_sums=bool(use_replay_buffer), **domain_random_kwargs)
         v = self._vec
         self.num_agents = num_agents
         self.is_multiagent = True
@@ -213,8 +213,10 @@ class QuadrotorEnvMulti:
         self._vec.stepper.replay_set_active([1 if value else 0])
 
     def reset(self, obst_density=None, obst_size=None):
-        if (obst_density is not None and obst_density != self.obst_density) or (obst_size is not None and obst_size != self.obst_size):
-            raise NotImplementedError("per-episode obstacle density / size randomisation is not part of the stepper (fixed at creation)")
+        """(obst_density / obst_size: the reference's replay wrapper passes its per-episode draw here; on the stepper the draw is
+        made by the reset itself - --quads_domain_random, include/quadswarm.h - so explicit values are not accepted)"""
+        if obst_density is not None or obst_size is not None:
+            raise NotImplementedError("pass --quads_domain_random / the domain_random keywords instead: the reset draws density and size itself")
         self._vec.stepper.reset()
         return self._vec.stepper.to_host("obs").astype(np.float64)
 
@@ -251,7 +253,7 @@ class QuadrotorEnvMulti:
                 ep, rp, n = int(rs["episodes"][0]), int(rs["replayed"][0]), int(rs["buffer_len"][0])
                 extra = {"replay/replay_rate": rp / ep, "replay/new_episode_rate": (ep - rp) / ep, "replay/replay_buffer_size": n,
                          "replay/avg_replayed": (int(rs["replayed_sum"][0]) / n) if n else 0,
-                         "replay/obst_density": self.obst_density, "replay/obst_size": self.obst_size}
+                         "replay/obst_density": float(st.to_host("obst_density_env")[0]), "replay/obst_size": float(st.to_host("obst_size_env")[0])}
                 for d in stats:
                     d.update(extra)
             for i in range(self.num_agents):

@@ -29,7 +29,7 @@ class QsBuffers(C.Structure):
         "obs", "reward", "done", "rew_info", "actions", "pos", "vel", "omega", "rot", "thrust_rot_damp",
         "thrust_cmds_damp", "ou_state", "goal", "flags", "obst_hit_idx", "col_pair_mask", "new_pair_mask",
         "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_pos", "ep_stats",
-        "ep_counters", "error_flag", "scenario_id", "ep_scenario", "run_sums", "ep_sums")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
+        "ep_counters", "error_flag", "scenario_id", "ep_scenario", "run_sums", "ep_sums", "obst_count", "obst_size_env", "obst_density_env")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
 
 
 def build(force=False, verbose=False):
@@ -196,7 +196,8 @@ class Stepper:
             tick=((self.E,), "i4"), obst_pos=((2, self.E * max(cfg.num_obstacles, 1)), "real"),
             ep_stats=((6, self.T), "real"), ep_counters=((11, self.E), "i4"), error_flag=((1,), "u4"),
             scenario_id=((self.E,), "i4"), ep_scenario=((self.E,), "i4"),
-            run_sums=((25, self.T), "real"), ep_sums=((25, self.T), "real"))
+            run_sums=((25, self.T), "real"), ep_sums=((25, self.T), "real"),
+            obst_count=((self.E,), "i4"), obst_size_env=((self.E,), "real"), obst_density_env=((self.E,), "real"))
         self._torch_cache = {}
 
     # ---- lifecycle -------------------------------------------------------------------------

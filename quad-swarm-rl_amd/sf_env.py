@@ -283,6 +283,8 @@ class BatchedQuadSwarm:
         cnt = st.tensor("ep_counters").index_select(1, env_idx).cpu().numpy()
         scen_ids = st.tensor("ep_scenario").index_select(0, env_idx).cpu().numpy()
         rs = st.replay_stats() if self.use_replay_buffer else None
+        if rs is not None:   # what the wrapper calls curr_obst_density / curr_obst_size: the values of the episode that starts now
+            obst_density, obst_size = st.to_host("obst_density_env"), st.to_host("obst_size_env")
         approx = self.training_info.get("approx_total_training_steps", 0)
         for f, e in enumerate(finished):
             sl = slice(f * n, (f + 1) * n)
@@ -295,7 +297,7 @@ class BatchedQuadSwarm:
                 ep, rp, nb = int(rs["episodes"][e]), int(rs["replayed"][e]), int(rs["buffer_len"][e])
                 replay_stats = {"replay/replay_rate": rp / ep, "replay/new_episode_rate": (ep - rp) / ep, "replay/replay_buffer_size": nb,
                                 "replay/avg_replayed": (int(rs["replayed_sum"][e]) / nb) if nb else 0,
-                                "replay/obst_density": float(self.vec.cfg.obst_density), "replay/obst_size": float(self.vec.cfg.obst_size)}
+                                "replay/obst_density": float(obst_density[e]), "replay/obst_size": float(obst_size[e])}
             # action moments over agents x steps of the episode (np.mean / np.std of reward_shaping.py:103-108); a replayed episode
             # starts at its checkpoint's tick and is shorter than ep_len + 1 steps
             count = float((int(rs["ep_steps"][e]) if rs is not None else self._ep_steps) * n)
@@ -340,6 +342,18 @@ class Compatibility(_Wrapper):
         return obs, reward, done, np.zeros_like(done, dtype=bool), info
 
 
+def _domain_random_kwargs(cfg, use_replay_buffer):
+    """--quads_domain_random and its companions (quadrotor_params.py:52-60).  In the reference the per-episode draw of obstacle density
+    / size is made by the replay wrapper (quad_experience_replay.py:75-88,:106-118,:191-206), which only exists with
+    --replay_buffer_sample_prob > 0 (quad_utils.py:67-70): without it the flags have no effect there, and none here."""
+    if not (use_replay_buffer and getattr(cfg, "quads_domain_random", False) and cfg.quads_use_obstacles):
+        return {}
+    return dict(domain_random=True, obst_density_random=bool(getattr(cfg, "quads_obst_density_random", False)),
+                obst_size_random=bool(getattr(cfg, "quads_obst_size_random", False)),
+                obst_density_min=cfg.quads_obst_density_min, obst_density_max=cfg.quads_obst_density_max,
+                obst_size_min=cfg.quads_obst_size_min, obst_size_max=cfg.quads_obst_size_max)
+
+
 def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
     """quad_utils.py:20-110 on the HIP stepper (the experience-replay wrapper of :67-70 is the device-side replay of the stepper)."""
     use_replay_buffer = getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0
@@ -358,9 +372,8 @@ def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
         dynamics_change=dict(noise=dict(thrust_noise_ratio=0.05), damp=dict(vel=0, omega_quadratic=0)), dyn_sampler_1=None,
         sense_noise="default", init_random_state=False, render_mode=render_mode,
         seed=getattr(cfg, "quads_seed", 0), device=getattr(cfg, "quads_device", 0), precision=getattr(cfg, "quads_precision", "f32"),
-        replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0))   # the replay wrapper of quad_utils.py:67-70 runs on the device
-    if getattr(cfg, "quads_domain_random", False):
-        raise NotImplementedError("--quads_domain_random: per-episode obstacle density / size is not part of the stepper yet")
+        replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0),   # the replay wrapper of quad_utils.py:67-70 runs on the device
+        **_domain_random_kwargs(cfg, use_replay_buffer))
     reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
     reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
     reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty
@@ -389,8 +402,6 @@ def make_quadrotor_env_batched(cfg, **kwargs):
         annealing = [AnnealSchedule("quadcol_bin", cfg.quads_collision_reward, cfg.anneal_collision_steps),
                      AnnealSchedule("quadcol_bin_smooth_max", cfg.quads_collision_smooth_max_penalty, cfg.anneal_collision_steps),
                      AnnealSchedule("quadcol_bin_obst", cfg.quads_obst_collision_reward, cfg.anneal_collision_steps)]
-    if getattr(cfg, "quads_domain_random", False):
-        raise NotImplementedError("--quads_domain_random: per-episode obstacle density / size is not part of the stepper yet")
     return BatchedQuadSwarm(
         cfg.quads_num_envs, reward_shaping_scheme=reward_shaping, annealing=annealing,
         replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0),
@@ -400,7 +411,8 @@ def make_quadrotor_env_batched(cfg, **kwargs):
         collision_hitbox_radius=cfg.quads_collision_hitbox_radius, collision_falloff_radius=cfg.quads_collision_falloff_radius,
         use_obstacles=cfg.quads_use_obstacles, obst_density=cfg.quads_obst_density, obst_size=cfg.quads_obst_size,
         obst_spawn_area=cfg.quads_obst_spawn_area, use_downwash=cfg.quads_use_downwash, use_numba=cfg.quads_use_numba,
-        quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims)
+        quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims,
+        **_domain_random_kwargs(cfg, getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0))
 
 
 def make_quadrotor_env(env_name, cfg=None, _env_config=None, render_mode=None, **kwargs):

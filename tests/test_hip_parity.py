@@ -118,6 +118,15 @@ CASES = {
     "x_n40_obst": dict(num_agents=40, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
                        collision_falloff_radius=4.0, rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6,
                        obst_spawn_area=(8.0, 8.0), quads_mode="o_random", obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.4),
+    # --quads_domain_random: every episode draws one of 4 obstacle densities (3 / 6 / 9 / 12 obstacles of an 8 x 8 area) and one of 3 sizes
+    "x_domain_random": dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_downwash=True, use_numba=True,
+                            collision_falloff_radius=4.0, rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6,
+                            obst_spawn_area=(8.0, 8.0), quads_mode="o_random", obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.25,
+                            domain_random=True, obst_density_random=True, obst_size_random=True),
+    "x_domain_random_static": dict(num_agents=5, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True,
+                                   collision_falloff_radius=4.0, rew_coeff=REW, use_obstacles=True, obst_density=0.2, obst_size=0.6,
+                                   obst_spawn_area=(8.0, 8.0), quads_mode="o_static_same_goal", obs_repr="xyz_vxyz_R_omega_floor", ep_time=0.2,
+                                   domain_random=True, obst_density_random=True, obst_size_random=False, obst_density_min=0.1, obst_density_max=0.3),
     "c4_n12_svs_short": dict(num_agents=12, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_downwash=True,
                              use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW, quads_mode="swarm_vs_swarm", ep_time=0.1),
 }
@@ -269,7 +278,7 @@ def test_rollout_f64_bit_exact_discrete(case):
 SINGLE_WAVE_CASES = ["c1_single", "c2_n8_dw", "c2_n8_k2_numpy_wall", "c2_n5_kall_short", "c3_n8_obst", "c3_n8_obst_short", "c4_n32_svs",
                      "c4_n12_svs_short", "s_static_diff", "s_mix", "s_mix_obst", "s_o_random", "s_dynamic_formations",
                      "e_n64_k20", "e_n64_k6", "e_n33_k8", "e_n40_kall", "e_n17_kall_obst", "e_n1_obst", "x_ep_len2", "x_svs_odd", "x_n40_obst",
-                     "x_n8_blind"]
+                     "x_n8_blind", "x_domain_random", "x_domain_random_static"]
 
 
 @pytest.mark.parametrize("case", SINGLE_WAVE_CASES)
@@ -317,6 +326,12 @@ def rollout_f64(case, E, steps, tol, keep=False):
             for e, oe in enumerate(pr.oenvs):
                 assert sid[e] == oe.info().scenario, f"scenario id step {t} env {e}"
     pr.hip.check_errors()
+    if pr.cfg.dr_num_density > 0:   # --quads_domain_random: the environments ended up with different obstacle counts, unused slots parked
+        cnt = pr.hip.to_host("obst_count")
+        assert len(set(cnt.tolist())) > 1 and cnt.max() <= pr.cfg.num_obstacles and cnt.min() >= 1
+        for e in range(E):
+            xy = pr.obst_xy(e)
+            assert (np.abs(xy[:cnt[e]]) < 100).all() and (xy[cnt[e]:] == 1e6).all()
     if keep:
         return pr
     pr.close()
@@ -327,7 +342,7 @@ def rollout_f64(case, E, steps, tol, keep=False):
                                   "s_dynamic_diff", "s_bezier", "s_o_swap", "s_o_ep_bezier", "s_o_ep_bezier_short", "s_run_away",
                                   "e_n64_k6", "e_n64_k20", "e_n33_k8", "e_n17_kall_obst", "e_n40_kall",
                                   "x_n8_blind", "x_no_noise", "x_dense_obst", "x_small_room", "x_ep_len2", "x_svs_odd", "x_sim4", "x_hitbox",
-                                  "x_n40_obst"])
+                                  "x_n40_obst", "x_domain_random", "x_domain_random_static"])
 def test_teacher_forced_f32(case):
     E, steps, tol = (3, LONG[case], 1e-5) if case in LONG else (7, 60, 1e-5)
     teacher_forced_f32(case, E, steps, tol)

@@ -108,3 +108,35 @@ def test_replay_kernel_equals_the_model():
     assert all(m.active for m in models)                              # the rule switched the other half on after 10 clean episodes
     assert n_save > 500 and n_file >= 8 and n_restore >= 6, (n_save, n_file, n_restore)
     st.close()
+
+
+def test_domain_random_through_the_batched_env():
+    """--quads_domain_random with the replay wrapper (quad_experience_replay.py:75-88,:106-118,:191-206): every new episode of every
+    environment draws its obstacle density and size; the wrapper's statistics report them."""
+    import argparse
+    import torch
+    from quad_swarm_rl_amd import sf_env
+    p = argparse.ArgumentParser()
+    p.add_argument("--with_pbt", default=False)
+    sf_env.add_quadrotors_env_args("quadrotor_multi", p)
+    cfg = p.parse_args(["--quads_num_agents=8", "--quads_neighbor_visible_num=2", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
+                        "--quads_use_obstacles=True", "--quads_obstacle_obs_type=octomap", "--quads_obst_spawn_area", "8", "8", "--quads_obst_size=0.6",
+                        "--quads_mode=o_random", "--quads_obs_repr=xyz_vxyz_R_omega_floor", "--quads_episode_duration=0.3", "--quads_num_envs=32",
+                        "--replay_buffer_sample_prob=0.5", "--quads_domain_random=True", "--quads_obst_density_random=True", "--quads_obst_size_random=True",
+                        "--quads_obst_density_min=0.05", "--quads_obst_density_max=0.2", "--quads_obst_size_min=0.3", "--quads_obst_size_max=0.6"])
+    env = sf_env.make_quadrotor_env("quadrotor_multi", cfg=cfg)
+    assert env.vec.cfg.dr_num_density == 4 and env.vec.cfg.dr_num_size == 3 and env.vec.cfg.num_obstacles == 12
+    env.reset()
+    seen_d, seen_s = set(), set()
+    act = torch.full((env.num_agents, 4), 0.06, device="cuda")
+    for t in range(100):
+        obs, rew, term, trunc, infos = env.step(act)
+        if term.any():
+            for inf in infos:
+                seen_d.add(round(inf["episode_extra_stats"]["replay/obst_density"], 6))
+                seen_s.add(round(inf["episode_extra_stats"]["replay/obst_size"], 6))
+    assert seen_d == {0.05, 0.1, 0.15, 0.2} and seen_s == {0.3, 0.4, 0.5}
+    cnt = env.vec.stepper.to_host("obst_count")
+    assert set(cnt.tolist()) <= {3, 6, 9, 12} and len(set(cnt.tolist())) > 1
+    assert torch.isfinite(obs["obs"]).all()
+    env.close()

@@ -1,0 +1,21 @@
+"""Register / scratch footprint of the config-specialised bench kernels (hipcc cross-compiles for gfx950 without a GPU).
+
+A regression guard, not a tuning tool: a run-time index into the kernel-constant block once moved the whole block to scratch
+memory (564 bytes per lane) and turned the 8 us C2 step into 21 us without failing a single parity test.  The throughput
+(single-wave) kernels must stay at <= 128 VGPRs: that is what lets 4 waves share a SIMD."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+@pytest.mark.parametrize("workload,team,max_vgpr,max_scratch", [("c2", 8, 160, 0), ("c2", 0, 128, 0), ("c4", 4, 200, 0), ("c4", 0, 128, 64)])
+def test_no_scratch_and_register_budget(workload, team, max_vgpr, max_scratch, tmp_path):
+    import spec_resources
+    res, _ = spec_resources.resources(workload, team, out=str(tmp_path / "k.s"))
+    step = res["qs_spec_step"]
+    assert step["scratch"] <= max_scratch, step        # (the 128-register cap of the throughput kernels may spill a few dwords at N = 32)
+    assert step["next_free_vgpr"] <= max_vgpr, step
+    assert res["qs_spec_reset"]["scratch"] == 0, res["qs_spec_reset"]
