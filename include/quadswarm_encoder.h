@@ -6,7 +6,8 @@
  * hidden size 256; output [B, 512] fp32.  All four --quads_neighbor_encoder_type choices: `mean_embed` (:22-43, per-neighbour
  * MLP + mean), `attention` (:46-101; two launches, needs the two scratch buffers below), `mlp` (:104-122) and `no_encoder`
  * (:289-291: the neighbour columns are part of the row but are not read).  QS_ENC_MODEL_MHA selects the other encoder class
- * of that file, QuadMultiHeadAttentionEncoder (:124-196).
+ * of that file, QuadMultiHeadAttentionEncoder (:124-196); QS_ENC_MODEL_S2R its --quads_sim2real subclass
+ * QuadSingleHeadAttentionEncoder_Sim2Real (:199-248; output [B, 256]).
  * bf16 weights / activations, fp32 accumulation (v_mfma_f32_16x16x32_bf16).  Weights are handed over pre-packed:
  *   layer with torch weight W[M_real, K_real], bias b[M_real]  ->  M = ceil16(M_real), K = ceil32(K_real), zero padded,
  *   w[((mt * (K/32) + ks) * 64 + lane) * 8 + j] = bf16(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),  b as fp32[M].
@@ -21,7 +22,8 @@ extern "C" {
 #endif
 
 enum { QS_ENC_NBR_MEAN_EMBED = 0, QS_ENC_NBR_ATTENTION = 1, QS_ENC_NBR_MLP = 2, QS_ENC_NBR_NONE = 3,
-       QS_ENC_MODEL_MHA = 4 /* QuadMultiHeadAttentionEncoder instead of QuadMultiEncoder */ };
+       QS_ENC_MODEL_MHA = 4 /* QuadMultiHeadAttentionEncoder instead of QuadMultiEncoder */,
+       QS_ENC_MODEL_S2R = 5 /* QuadSingleHeadAttentionEncoder_Sim2Real */ };
 
 typedef struct qs_enc_layer { const uint16_t *w; const float *b; int32_t M, K; } qs_enc_layer;
 
@@ -49,6 +51,8 @@ typedef struct qs_enc_params {
     qs_enc_layer mq, mk, mv; /* w_qs, w_ks, w_vs: M = 1024 (head-major), K = 256; no bias (b is not read) */
     qs_enc_layer mfc;        /* fc: M = 256, K = 1024; no bias */
     const float *ln_w, *ln_b;/* layer_norm weight / bias, fp32 [256] */
+    /* QS_ENC_MODEL_S2R (:199-248): one-layer embeddings s1, n1, o1 (s2, n2, o2 are not read), OneHeadAttention(256)
+       (attention_layer.py:56-97): mq, mk, mv, mfc all M = 256, K = 256; f: K = 768, M = 256; head_w is [head_dim, 256] */
     /* optional linear head on the encoder output, fused into the last kernel's epilogue (Sample Factory's action-parameter or
        value layer): head_out[B, head_dim] = features . head_w^T + head_b.  With a head, `out` of qs_enc_forward may be NULL and
        the [B, 512] features are then never written. */
@@ -61,7 +65,7 @@ size_t qs_enc_sizeof_params(void);
 size_t qs_enc_lds_bytes(void);
 const char *qs_enc_last_error(void);
 
-/* out[B, 512] = encoder(obs[B, obs_dim]) on `stream` (out may be NULL when params->head_dim > 0).  0 on success, < 0 on error
+/* out[B, 512] (QS_ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]) on `stream` (out may be NULL when params->head_dim > 0).  0 on success, < 0 on error
  * (qs_enc_last_error()). */
 int qs_enc_forward(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream);
 

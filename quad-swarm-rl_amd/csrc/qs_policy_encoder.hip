@@ -46,7 +46,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define ENC_YS (ENC_H + 8)   // row stride of a 256-wide activation buffer
 #define ENC_CS (3 * ENC_H + 8)
 
-enum { ENC_NBR_MEAN_EMBED = 0, ENC_NBR_ATTENTION = 1, ENC_NBR_MLP = 2, ENC_NBR_NONE = 3, ENC_MODEL_MHA = 4 };
+enum { ENC_NBR_MEAN_EMBED = 0, ENC_NBR_ATTENTION = 1, ENC_NBR_MLP = 2, ENC_NBR_NONE = 3, ENC_MODEL_MHA = 4, ENC_MODEL_S2R = 5 };
 #define ENC_XW 72   // row stride of the mlp neighbour encoder's input rows (all neighbours of one agent, K padded to 64)
 struct EncLayer { const uint16_t *w; const float *b; int32_t M, K; };   // K padded to a multiple of 32, M to a multiple of 16
 struct EncParams {
@@ -65,9 +65,11 @@ struct EncParams {
     float *gbuf;                // attention scratch: W_m e_mean of every agent, fp32 [B, 256]
     EncLayer f;                 // feed forward        :329-332
     // QuadMultiHeadAttentionEncoder (:124-196, nbr_encoder == ENC_MODEL_MHA): n1 / n2 = neighbor_embed_layer on all neighbour
-    // columns, o1 / o2 = obstacle_embed_layer; MultiHeadAttention(4, 256, 256, 256) (attention_layer.py:12-56) over the token pair
-    EncLayer mq, mk, mv;        // w_qs, w_ks, w_vs: 256 -> 4 x 256, no bias (bias pointer not read)
-    EncLayer mfc;               // fc: 1024 -> 256, no bias
+    // columns, o1 / o2 = obstacle_embed_layer; MultiHeadAttention(4, 256, 256, 256) (attention_layer.py:12-56) over the token pair.
+    // QuadSingleHeadAttentionEncoder_Sim2Real (:199-248, ENC_MODEL_S2R): one-layer embeddings (s1, n1, o1; the second layers are
+    // not read), OneHeadAttention(256) (attention_layer.py:56-97), feed forward 768 -> 256
+    EncLayer mq, mk, mv;        // w_qs, w_ks, w_vs: 256 -> heads x 256, no bias (bias pointer not read)
+    EncLayer mfc;               // fc: heads x 256 -> 256, no bias
     const float *ln_w, *ln_b;   // LayerNorm(256, eps 1e-6) weight / bias
     // optional linear head on the encoder output, fused into the epilogue: head_out[B, head_dim] = out . head_w^T + head_b
     const float *head_w, *head_b;   // fp32 [head_dim, 512], [head_dim]
@@ -213,27 +215,29 @@ __device__ __forceinline__ float lane_groups_sum(float v) {   // sum over the 4 
 // head on it (Sample Factory's action-parameter or value layer, 512 -> head_dim <= 8) so that a rollout does not have to write
 // and re-read the features: per-lane partial dot products, two shuffles over the lane groups, the eight waves through `red`
 // (LDS scratch, >= ENC_WAVES * 8 * 16 floats in a buffer nobody reads any more and that is not `cat`).
+template <int MTF = ENC_MTF>   // 16-feature tiles per wave: 512 outputs = 32 tiles; the Sim2Real encoder's 256 = 16 tiles
 __device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t *cat, int a0, int B, float *__restrict__ out, float *red) {
     const int wave = wave_id(), lane = threadIdx.x & 63;
-    f32x4 acc[ENC_MTF][1];
-    const int mf0 = wave * ENC_MTF;   // 512 features = 32 tiles
-    init_bias<ENC_MTF, 1>(P.f, mf0, acc);
-    gemm_tiles<ENC_MTF, 1>(P.f, mf0, cat, ENC_CS, acc);
+    constexpr int OUT = MTF * ENC_WAVES * 16;
+    f32x4 acc[MTF][1];
+    const int mf0 = wave * MTF;
+    init_bias<MTF, 1>(P.f, mf0, acc);
+    gemm_tiles<MTF, 1>(P.f, mf0, cat, ENC_CS, acc);
     ENC_STAMP(8);
     const int ga = a0 + (lane & 15);
-    f32x4 v[ENC_MTF];
+    f32x4 v[MTF];
 #pragma unroll
-    for (int mt = 0; mt < ENC_MTF; ++mt) {
+    for (int mt = 0; mt < MTF; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[mt][r] = fast_tanh(acc[mt][0][r]);
-        if (out && ga < B) *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4) = v[mt];
+        if (out && ga < B) *(f32x4 *)(out + (size_t)ga * OUT + (mf0 + mt) * 16 + (lane >> 4) * 4) = v[mt];
     }
     if (P.head_dim > 0) {
         for (int h = 0; h < P.head_dim; ++h) {
             float s = 0.0f;
 #pragma unroll
-            for (int mt = 0; mt < ENC_MTF; ++mt) {
-                const f32x4 w = *(const f32x4 *)(P.head_w + h * (2 * ENC_H) + (mf0 + mt) * 16 + (lane >> 4) * 4);
+            for (int mt = 0; mt < MTF; ++mt) {
+                const f32x4 w = *(const f32x4 *)(P.head_w + h * OUT + (mf0 + mt) * 16 + (lane >> 4) * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s += v[mt][r] * w[r];
             }
@@ -516,7 +520,28 @@ __device__ __forceinline__ void mlp2_keep(const EncLayer &L1, const EncLayer &L2
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+// one-layer embedding of 16 rows: Y[:, col..] = tanh(L X); KEEP: the fp32 result also stays in registers (the attention block's residual)
+template <bool KEEP>
+__device__ __forceinline__ void mlp1_keep(const EncLayer &L1, int mt0, const uint16_t *X, int xstride, uint16_t *Y, int ystride, f32x4 (&keep)[ENC_MT]) {
+    const int lane = threadIdx.x & 63;
+    f32x4 acc[ENC_MT][1];
+    init_bias<ENC_MT, 1>(L1, mt0, acc);
+    gemm_tiles<ENC_MT, 1>(L1, mt0, X, xstride, acc);
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float t = fast_tanh(acc[mt][0][r]);
+            if constexpr (KEEP) keep[mt][r] = t;
+            v[r] = (__bf16)t;
+        }
+        *(bf16x4 *)(Y + (lane & 15) * ystride + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+    }
+}
+
+template <bool S2R>
+__device__ __forceinline__ void mha_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_obst = x_self + ENC_TA * ENC_XS;                      // [16][XS]
@@ -542,24 +567,32 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_k
     }
     __syncthreads();
     f32x4 resid[2][ENC_MT];   // fp32 tokens: features of this wave, rows lane & 15
-    mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, hid, cat, ENC_CS, 0);
-    __syncthreads();
-    mlp2_keep(P.n1, P.n2, mt0, x_nbr, ENC_XW, hid, tok, resid[0]);
-    __syncthreads();
-    mlp2_keep(P.o1, P.o2, mt0, x_obst, ENC_XS, hid, tok + ENC_TA * ENC_YS, resid[1]);
+    if constexpr (S2R) {   // one layer per embedding (:229-240): nothing between them to wait for
+        mlp1_keep<false>(P.s1, mt0, x_self, ENC_XS, cat, ENC_CS, resid[0]);
+        mlp1_keep<true>(P.n1, mt0, x_nbr, ENC_XW, tok, ENC_YS, resid[0]);
+        mlp1_keep<true>(P.o1, mt0, x_obst, ENC_XS, tok + ENC_TA * ENC_YS, ENC_YS, resid[1]);
+    } else {
+        mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, hid, cat, ENC_CS, 0);
+        __syncthreads();
+        mlp2_keep(P.n1, P.n2, mt0, x_nbr, ENC_XW, hid, tok, resid[0]);
+        __syncthreads();
+        mlp2_keep(P.o1, P.o2, mt0, x_obst, ENC_XS, hid, tok + ENC_TA * ENC_YS, resid[1]);
+    }
     __syncthreads();
 
     // ---- scores: s[i][j] = q_i . k_j over the head's 256 features, accumulated over this wave's two chunks ----
+    // (one head: wave w owns features [32w, 32w+32) of the 256-wide projections, one chunk of 2 feature tiles)
+    constexpr int QT = S2R ? 2 : 4, QC = S2R ? 1 : 2;   // feature tiles per chunk, chunks per wave
     float sc[2][2] = {{0, 0}, {0, 0}};
 #pragma unroll 1
-    for (int c = 0; c < 2; ++c) {
-        f32x4 q[4][2], k[4][2];
-        zero_acc<4, 2>(q);
-        gemm_tiles<4, 2>(P.mq, wave * 8 + c * 4, tok, ENC_YS, q);
-        zero_acc<4, 2>(k);
-        gemm_tiles<4, 2>(P.mk, wave * 8 + c * 4, tok, ENC_YS, k);
+    for (int c = 0; c < QC; ++c) {
+        f32x4 q[QT][2], k[QT][2];
+        zero_acc<QT, 2>(q);
+        gemm_tiles<QT, 2>(P.mq, (wave * QC + c) * QT, tok, ENC_YS, q);
+        zero_acc<QT, 2>(k);
+        gemm_tiles<QT, 2>(P.mk, (wave * QC + c) * QT, tok, ENC_YS, k);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < QT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -572,7 +605,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_k
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float t = lane_groups_sum(sc[i][j]);
-            if (lane < 16) red_s[(((wave >> 1) * 2 + (wave & 1)) * 4 + i * 2 + j) * 16 + lane] = t;
+            if (lane < 16) red_s[(wave * 4 + i * 2 + j) * 16 + lane] = t;
         }
     __syncthreads();
     float pr[2][2];   // softmax over the keys j of (q_i / sqrt(d_k)) . k_j   (attention_layer.py:118-125)
@@ -580,26 +613,33 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_k
     for (int i = 0; i < 2; ++i) {
         float t[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            t[j] = (red_s[(((wave >> 1) * 2 + 0) * 4 + i * 2 + j) * 16 + (lane & 15)] + red_s[(((wave >> 1) * 2 + 1) * 4 + i * 2 + j) * 16 + (lane & 15)]) * (1.0f / 16.0f);
+        for (int j = 0; j < 2; ++j) {
+            float acc_s = 0.0f;
+            if constexpr (S2R) {   // one head over all eight waves   (attention_layer.py:83)
+#pragma unroll
+                for (int w = 0; w < ENC_WAVES; ++w) acc_s += red_s[(w * 4 + i * 2 + j) * 16 + (lane & 15)];
+            } else
+                acc_s = red_s[((wave & ~1) * 4 + i * 2 + j) * 16 + (lane & 15)] + red_s[((wave | 1) * 4 + i * 2 + j) * 16 + (lane & 15)];
+            t[j] = acc_s * (1.0f / 16.0f);
+        }
         const float m = fmaxf(t[0], t[1]), e0 = __expf(t[0] - m), e1 = __expf(t[1] - m), rd = 1.0f / (e0 + e1);
         pr[i][0] = e0 * rd;
         pr[i][1] = e1 * rd;
     }
     // ---- o_i = sum_j p_ij v_j -> obuf[i][row][head * 256 + feature] ----
 #pragma unroll 1
-    for (int c = 0; c < 2; ++c) {
-        f32x4 v[4][2];
-        zero_acc<4, 2>(v);
-        gemm_tiles<4, 2>(P.mv, wave * 8 + c * 4, tok, ENC_YS, v);
+    for (int c = 0; c < QC; ++c) {
+        f32x4 v[QT][2];
+        zero_acc<QT, 2>(v);
+        gemm_tiles<QT, 2>(P.mv, (wave * QC + c) * QT, tok, ENC_YS, v);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < QT; ++mt) {
                 bf16x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (__bf16)(pr[i][0] * v[mt][0][r] + pr[i][1] * v[mt][1][r]);
-                *(bf16x4 *)(obuf + (i * ENC_TA + (lane & 15)) * ENC_OS + (wave * 8 + c * 4 + mt) * 16 + (lane >> 4) * 4) = o;
+                *(bf16x4 *)(obuf + (i * ENC_TA + (lane & 15)) * ENC_OS + ((wave * QC + c) * QT + mt) * 16 + (lane >> 4) * 4) = o;
             }
     }
     __syncthreads();
@@ -646,8 +686,15 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_k
         }
     }
     __syncthreads();
-    feed_forward(P, cat, a0, B, out, (float *)hid);
+    feed_forward<S2R ? ENC_MTF / 2 : ENC_MTF>(P, cat, a0, B, out, (float *)hid);
 }
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+    mha_body<false>(obs, B, P, out);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_s2r_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+    mha_body<true>(obs, B, P, out);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // mean_embed / mlp / no_encoder: one launch
@@ -790,7 +837,7 @@ static size_t lds_mha(void) {
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
 size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 
-// out[B, 512] = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
+// out[B, 512] (ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
     if (!obs || !params || B < 0) { g_enc_error = "bad argument"; return -1; }
     const EncParams &P = *params;
@@ -798,8 +845,8 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         g_enc_error = "bad argument";   // neither the features nor a head output requested, or an incomplete head
         return -1;
     }
-    const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, mha = P.nbr_encoder == ENC_MODEL_MHA;
-    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0 || P.nbr_encoder > ENC_MODEL_MHA ||
+    const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, s2r = P.nbr_encoder == ENC_MODEL_S2R, mha = P.nbr_encoder == ENC_MODEL_MHA || s2r;
+    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0 || P.nbr_encoder > ENC_MODEL_S2R ||
         (att && P.self_dim + P.nbr_dim > 32) || ((P.nbr_encoder == ENC_NBR_MLP || mha) && P.nbr_dim * P.num_nbr > 64) ||
         (mha && (P.num_nbr < 1 || P.obst_dim < 1 || !P.ln_w || !P.ln_b))) {
         g_enc_error = "unsupported encoder shape (inputs wider than 32 - 64 for the mlp neighbour encoder - or more than 8 neighbours)";
@@ -826,6 +873,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
             if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(0)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_s2r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed()) != hipSuccess) {
                 g_enc_error = "cannot raise the dynamic LDS limit";
                 return -2;
@@ -833,7 +881,9 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
             attr_set |= 1ull << dev;
         }
     }
-    if (mha)
+    if (s2r)
+        hipLaunchKernelGGL(qs_encoder_s2r_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);
+    else if (mha)
         hipLaunchKernelGGL(qs_encoder_mha_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);
     else if (att) {
         hipLaunchKernelGGL(qs_encoder_embed_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_embed(), (hipStream_t)stream, obs, B, P);

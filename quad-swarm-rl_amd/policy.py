@@ -64,7 +64,7 @@ def lib():
     return _lib
 
 
-MODELS = ("mean_embed", "attention", "mlp", "no_encoder", "multi_head_attention")   # qs_enc_params.nbr_encoder
+MODELS = ("mean_embed", "attention", "mlp", "no_encoder", "multi_head_attention", "single_head_sim2real")   # qs_enc_params.nbr_encoder
 NBR_ENCODERS = ("mean_embed", "attention", "mlp", "no_encoder")   # --quads_neighbor_encoder_type (quadrotor_params.py:38-40); index = QS_ENC_NBR_*
 
 
@@ -173,8 +173,57 @@ def make_reference_mha_encoder(self_dim=19, nbr_dim=6, num_nbr=2, obst_dim=9, hi
             tokens = self.attention_layer(torch.stack((n, o), dim=1))
             return self.feed_forward(torch.cat((s, tokens.reshape(obs.shape[0], -1)), dim=1))
 
+    if seed is None:   # the Sim2Real subclass: construct (and drop) the parent's layers on the current generator state
+        return QuadMultiHeadAttentionEncoderRef()
     torch.manual_seed(seed)
     return QuadMultiHeadAttentionEncoderRef()
+
+
+def make_reference_sim2real_encoder(self_dim=19, nbr_dim=6, num_nbr=2, obst_dim=9, hidden=HIDDEN, seed=0):
+    """QuadSingleHeadAttentionEncoder_Sim2Real (quad_multi_model.py:199-248, --quads_encoder_type=attention --quads_sim2real=True):
+    one-layer embeddings, OneHeadAttention (attention_layer.py:56-97) over the token pair [neighbour embedding, obstacle
+    embedding], feed forward 3*hidden -> hidden.  Random init in the reference's order: the class first builds everything its
+    parent (QuadMultiHeadAttentionEncoder) builds - consuming the generator - and then replaces the layers."""
+    import torch
+    from torch import nn
+
+    class OneHeadAttentionRef(nn.Module):                                       # attention_layer.py:56-97
+        def __init__(self):
+            super().__init__()
+            self.w_qs = nn.Linear(hidden, hidden, bias=False)
+            self.w_ks = nn.Linear(hidden, hidden, bias=False)
+            self.w_vs = nn.Linear(hidden, hidden, bias=False)
+            self.fc = nn.Linear(hidden, hidden, bias=False)
+            self.layer_norm = nn.LayerNorm(hidden, eps=1e-6)
+
+        def forward(self, x):                                                   # q = k = v = x: [B, L, hidden]
+            q, k, v = self.w_qs(x), self.w_ks(x), self.w_vs(x)
+            attn = torch.softmax(torch.matmul(q / hidden ** 0.5, k.transpose(-1, -2)), dim=-1)   # :83-85
+            return self.layer_norm(self.fc(torch.matmul(attn, v)) + x)
+
+    class QuadSingleHeadAttentionEncoderSim2RealRef(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.self_dim, self.nbr_dim, self.num_nbr, self.obst_dim = self_dim, nbr_dim, num_nbr, obst_dim
+            self.nbr_encoder = "single_head_sim2real"
+            make_reference_mha_encoder(self_dim, nbr_dim, num_nbr, obst_dim, hidden, seed=None)   # the parent's draws (:201)
+            emb = lambda i: nn.Sequential(nn.Linear(i, hidden), nn.Tanh())
+            self.self_encoder = emb(self_dim)                                   # self_embed_layer      :222-225
+            self.neighbor_encoder = emb(nbr_dim * num_nbr)                      # neighbor_embed_layer  :226-229
+            self.obstacle_encoder = emb(obst_dim)                               # obstacle_embed_layer  :231-234
+            self.attention_layer = OneHeadAttentionRef()                        # :237
+            self.feed_forward = nn.Sequential(nn.Linear(3 * hidden, hidden), nn.Tanh())   # :240-242
+
+        def forward(self, obs):                                                 # the parent's forward (:176-196)
+            nb = self.nbr_dim * self.num_nbr
+            s = self.self_encoder(obs[:, :self.self_dim])
+            n = self.neighbor_encoder(obs[:, self.self_dim:self.self_dim + nb])
+            o = self.obstacle_encoder(obs[:, self.self_dim + nb:])
+            tokens = self.attention_layer(torch.stack((n, o), dim=1))
+            return self.feed_forward(torch.cat((s, tokens.reshape(obs.shape[0], -1)), dim=1))
+
+    torch.manual_seed(seed)
+    return QuadSingleHeadAttentionEncoderSim2RealRef()
 
 
 # reference / Sample Factory parameter names -> the names of the restatements above (the encoder sits under "encoder." in an SF
@@ -212,8 +261,8 @@ def encoder_from_state_dict(sd, num_nbr, nbr_dim=6):
     if mha:
         hidden, self_dim = out["self_encoder.0.weight"].shape
         obst_dim = out["obstacle_encoder.0.weight"].shape[1]
-        module = make_reference_mha_encoder(self_dim=self_dim, nbr_dim=nbr_dim, num_nbr=out["neighbor_encoder.0.weight"].shape[1] // nbr_dim,
-                                            obst_dim=obst_dim, hidden=hidden)
+        make = make_reference_mha_encoder if "self_encoder.2.weight" in out else make_reference_sim2real_encoder   # one-layer embeddings: Sim2Real
+        module = make(self_dim=self_dim, nbr_dim=nbr_dim, num_nbr=out["neighbor_encoder.0.weight"].shape[1] // nbr_dim, obst_dim=obst_dim, hidden=hidden)
         out = {k: v for k, v in out.items() if not k.startswith("attention_layer.attention")}
     else:
         hidden, self_dim = out["self_encoder.0.weight"].shape
@@ -254,7 +303,7 @@ def pack_linear(linear, device, cols=None):
 
 
 class FusedQuadEncoder:
-    """forward(obs[B, D] float32 on the GPU) -> [B, 512] float32, one kernel launch."""
+    """forward(obs[B, D] float32 on the GPU) -> [B, 512] float32 ([B, 256] for the Sim2Real encoder), one kernel launch."""
 
     def __init__(self, module, device=0):
         import torch
@@ -272,13 +321,20 @@ class FusedQuadEncoder:
             self._keep += [w, b]
             return EncLayer(w.data_ptr(), b.data_ptr(), M, K)
 
-        P.s1, P.s2 = layer(module.self_encoder[0]), layer(module.self_encoder[2])
-        if module.neighbor_encoder is not None:
-            P.n1, P.n2 = layer(module.neighbor_encoder[0]), layer(module.neighbor_encoder[2])
-        if module.obstacle_encoder is not None:
-            P.o1, P.o2 = layer(module.obstacle_encoder[0]), layer(module.obstacle_encoder[2])
         P.nbr_encoder = MODELS.index(getattr(module, "nbr_encoder", "mean_embed"))
-        if P.nbr_encoder == 4:
+        s2r = P.nbr_encoder == 5   # one-layer embeddings, one head, 256 outputs
+        P.s1 = layer(module.self_encoder[0])
+        if module.neighbor_encoder is not None:
+            P.n1 = layer(module.neighbor_encoder[0])
+        if module.obstacle_encoder is not None:
+            P.o1 = layer(module.obstacle_encoder[0])
+        if not s2r:
+            P.s2 = layer(module.self_encoder[2])
+            if module.neighbor_encoder is not None:
+                P.n2 = layer(module.neighbor_encoder[2])
+            if module.obstacle_encoder is not None:
+                P.o2 = layer(module.obstacle_encoder[2])
+        if P.nbr_encoder in (4, 5):
             if module.nbr_dim * module.num_nbr > 64:
                 raise ValueError("multi-head attention encoder: num_nbr * nbr_dim must fit two 32-wide K steps")
             att = module.attention_layer
@@ -303,10 +359,10 @@ class FusedQuadEncoder:
             P.a3w, P.a3b = a3w.data_ptr(), float(a3.bias.detach().float().item())
         self._scratch_rows = 0
         P.f = layer(module.feed_forward[0])
-        if P.f.M != 2 * HIDDEN or P.s1.M != HIDDEN:
+        self.out_dim = HIDDEN if s2r else 2 * HIDDEN
+        if P.f.M != self.out_dim or P.s1.M != HIDDEN:
             raise ValueError("the fused encoder is built for hidden size 256")
         self.params = P
-        self.out_dim = 2 * HIDDEN
         lib()
 
     def forward(self, obs, out=None):
@@ -328,7 +384,7 @@ class FusedQuadEncoder:
         w = weight.detach().to(self.device, torch.float32).contiguous()
         b = bias.detach().to(self.device, torch.float32).contiguous()
         if w.dim() != 2 or w.shape[1] != self.out_dim or not 1 <= w.shape[0] <= 8 or b.shape != (w.shape[0],):
-            raise ValueError("head: weight [h, 512] with 1 <= h <= 8, bias [h]")
+            raise ValueError(f"head: weight [h, {self.out_dim}] with 1 <= h <= 8, bias [h]")
         self._head = (w, b)
 
     def forward_head(self, obs, head_out=None, features=None):

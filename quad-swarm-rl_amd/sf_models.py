@@ -20,13 +20,12 @@ class QuadEncoder(Encoder):
             num_nbr = cfg.quads_num_agents - 1 if cfg.quads_neighbor_visible_num == -1 else cfg.quads_neighbor_visible_num
         obst_dim = 9 if cfg.quads_use_obstacles else 0
         if cfg.quads_encoder_type == "attention":
-            if getattr(cfg, "quads_sim2real", False):
-                raise NotImplementedError("QuadSingleHeadAttentionEncoder_Sim2Real is not restated here")
-            self.body = policy.make_reference_mha_encoder(self_dim=self_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=cfg.rnn_size)
+            make = policy.make_reference_sim2real_encoder if getattr(cfg, "quads_sim2real", False) else policy.make_reference_mha_encoder   # :358-362
+            self.body = make(self_dim=self_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=cfg.rnn_size)
         else:
             self.body = policy.make_reference_encoder(self_dim=self_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=cfg.rnn_size,
                                                       nbr_encoder=cfg.quads_neighbor_encoder_type)
-        self.encoder_out_size = 2 * cfg.rnn_size
+        self.encoder_out_size = self.body.feed_forward[0].out_features
 
     def forward(self, obs_dict):
         return self.body(obs_dict["obs"])

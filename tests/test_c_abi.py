@@ -123,6 +123,7 @@ def test_encoder_library_exports_and_layout():
     for i, name in enumerate(("MEAN_EMBED", "ATTENTION", "MLP", "NONE")):
         assert f"QS_ENC_NBR_{name} = {i}" in enum and policy.MODELS[i] == policy.NBR_ENCODERS[i]
     assert "QS_ENC_MODEL_MHA = 4" in enum and policy.MODELS[4] == "multi_head_attention"
+    assert "QS_ENC_MODEL_S2R = 5" in enum and policy.MODELS[5] == "single_head_sim2real"
     lib.qs_enc_forward.argtypes = [C.c_void_p, C.c_int32, C.POINTER(policy.EncParams), C.c_void_p, C.c_void_p]
     P = policy.EncParams()
     assert lib.qs_enc_forward(None, 4, C.byref(P), None, None) == -1 and b"bad argument" in lib.qs_enc_last_error()
@@ -149,6 +150,7 @@ def test_reference_encoder_modules_cover_the_flag_choices():
     with pytest.raises(NotImplementedError):
         policy.make_reference_encoder(nbr_encoder="transformer")
     assert policy.make_reference_mha_encoder()(torch.zeros(3, 40)).shape == (3, 512)
+    assert policy.make_reference_sim2real_encoder()(torch.zeros(3, 40)).shape == (3, 256)
 
 
 def test_weight_packing_follows_the_header_formula():

@@ -1,7 +1,7 @@
 """The policy-encoder restatements (quad-swarm-rl_amd/policy.py) and the fused MFMA kernel against the REFERENCE classes' outputs.
 
 tests/golden/encoder_*.npz come from oracle/ref_harness/capture_encoders.py: the reference's QuadMultiEncoder (every neighbour
-encoder type, with / without obstacles) and QuadMultiHeadAttentionEncoder instantiated under a torch seed and run on a fixed
+encoder type, with / without obstacles), QuadMultiHeadAttentionEncoder and QuadSingleHeadAttentionEncoder_Sim2Real instantiated under a torch seed and run on a fixed
 batch.  The restatements create their parameters in the reference's order, so the seed reproduces the reference's weights (the
 fixture's per-tensor checksums prove it on this machine); then
   * CPU: the restatement's output must equal the reference class's output (1e-6; it was 0.0 when captured);
@@ -26,7 +26,7 @@ def build(name):
     if str(g["cls"]) == "multi":
         m = policy.make_reference_encoder(seed=seed, nbr_encoder=str(g["nbr_encoder"]), num_nbr=K, obst_dim=int(g["obst_dim"]), self_dim=int(g["self_dim"]))
     else:
-        m = policy.make_reference_mha_encoder(seed=seed, num_nbr=K)
+        m = (policy.make_reference_mha_encoder if str(g["cls"]) == "mha" else policy.make_reference_sim2real_encoder)(seed=seed, num_nbr=K)
         with torch.no_grad():
             m.attention_layer.layer_norm.weight.copy_(torch.from_numpy(g["ln"][0]))
             m.attention_layer.layer_norm.bias.copy_(torch.from_numpy(g["ln"][1]))
@@ -55,7 +55,7 @@ def reference_names(module):
 
 
 def test_fixtures_present():
-    assert len(NAMES) >= 9 and {"attention", "mean_embed", "mlp", "none", "mha"} <= set(NAMES)
+    assert len(NAMES) >= 11 and {"attention", "mean_embed", "mlp", "none", "mha", "sim2real"} <= set(NAMES)
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -13,7 +13,7 @@ def bf16_emulation(module, obs):
 
     def mlp(seq, x):
         x = torch.tanh(r(x) @ r(seq[0].weight).T + seq[0].bias)
-        return torch.tanh(r(x) @ r(seq[2].weight).T + seq[2].bias)
+        return torch.tanh(r(x) @ r(seq[2].weight).T + seq[2].bias) if len(seq) > 2 else x   # the Sim2Real class has one-layer embeddings
 
     B = obs.shape[0]
     emb = [r(mlp(module.self_encoder, obs[:, :module.self_dim]))]
@@ -139,15 +139,16 @@ def mha_bf16_emulation(module, obs):
 
     def mlp(seq, x):
         x = torch.tanh(r(x) @ r(seq[0].weight).T + seq[0].bias)
-        return torch.tanh(r(x) @ r(seq[2].weight).T + seq[2].bias)
+        return torch.tanh(r(x) @ r(seq[2].weight).T + seq[2].bias) if len(seq) > 2 else x   # the Sim2Real class has one-layer embeddings
 
     B, nb = obs.shape[0], module.nbr_dim * module.num_nbr
     s = mlp(module.self_encoder, obs[:, :module.self_dim])
     x = torch.stack((mlp(module.neighbor_encoder, obs[:, module.self_dim:module.self_dim + nb]), mlp(module.obstacle_encoder, obs[:, module.self_dim + nb:])), dim=1)
     a = module.attention_layer
-    q = (r(x) @ r(a.w_qs.weight).T).view(B, 2, 4, 256).transpose(1, 2)
-    k = (r(x) @ r(a.w_ks.weight).T).view(B, 2, 4, 256).transpose(1, 2)
-    v = (r(x) @ r(a.w_vs.weight).T).view(B, 2, 4, 256).transpose(1, 2)
+    H = a.w_qs.weight.shape[0] // 256   # heads: 4, or 1 (OneHeadAttention)
+    q = (r(x) @ r(a.w_qs.weight).T).view(B, 2, H, 256).transpose(1, 2)
+    k = (r(x) @ r(a.w_ks.weight).T).view(B, 2, H, 256).transpose(1, 2)
+    v = (r(x) @ r(a.w_vs.weight).T).view(B, 2, H, 256).transpose(1, 2)
     p = torch.softmax(torch.matmul(q, k.transpose(2, 3)) / 16.0, dim=-1)
     o = torch.matmul(p, v).transpose(1, 2).contiguous().view(B, 2, -1)
     y = a.layer_norm(r(o) @ r(a.fc.weight).T + x)
@@ -157,11 +158,13 @@ def mha_bf16_emulation(module, obs):
 
 @pytest.mark.parametrize("shape", [dict(num_nbr=2), dict(num_nbr=6), dict(num_nbr=8, self_dim=18), dict(num_nbr=1, obst_dim=25)])
 @pytest.mark.parametrize("batch", [1, 16, 77, 8192])
-def test_fused_multi_head_attention_encoder_matches_torch(shape, batch):
-    """QuadMultiHeadAttentionEncoder (--quads_encoder_type=attention; quad_multi_model.py:124-196, attention_layer.py:12-56)."""
+@pytest.mark.parametrize("sim2real", [False, True])
+def test_fused_multi_head_attention_encoder_matches_torch(shape, batch, sim2real):
+    """QuadMultiHeadAttentionEncoder (--quads_encoder_type=attention; quad_multi_model.py:124-196, attention_layer.py:12-56) and
+    its --quads_sim2real subclass QuadSingleHeadAttentionEncoder_Sim2Real (:199-248, attention_layer.py:56-97)."""
     import torch
     from quad_swarm_rl_amd import policy
-    ref = policy.make_reference_mha_encoder(seed=11, **shape).cuda()
+    ref = (policy.make_reference_sim2real_encoder if sim2real else policy.make_reference_mha_encoder)(seed=11, **shape).cuda()
     with torch.no_grad():
         for p in ref.parameters():
             p.mul_(2.0)
@@ -170,7 +173,7 @@ def test_fused_multi_head_attention_encoder_matches_torch(shape, batch):
         a.layer_norm.weight.uniform_(0.5, 1.5)
         a.layer_norm.bias.uniform_(-0.3, 0.3)
     fused = policy.FusedQuadEncoder(ref)
-    assert fused.params.nbr_encoder == 4
+    assert fused.params.nbr_encoder == (5 if sim2real else 4)
     g = torch.Generator(device="cuda").manual_seed(batch + 2000)
     D = fused.params.obs_dim
     obs = (torch.rand((batch, D), device="cuda", generator=g) * 2 - 1) * torch.tensor([3.0] * 3 + [1.0] * (D - 3), device="cuda")
@@ -178,7 +181,7 @@ def test_fused_multi_head_attention_encoder_matches_torch(shape, batch):
         want32, want16 = ref(obs), mha_bf16_emulation(ref, obs)
     got = fused(obs)
     torch.cuda.synchronize()
-    assert got.shape == (batch, 512) and torch.isfinite(got).all()
+    assert got.shape == (batch, 256 if sim2real else 512) and torch.isfinite(got).all()
     assert (got - want32).abs().max().item() < 8e-2, (got - want32).abs().max().item()
     assert (got - want16).abs().max().item() < 2e-2, (got - want16).abs().max().item()
     assert (got - want16).abs().mean().item() < 5e-4, (got - want16).abs().mean().item()
@@ -209,17 +212,18 @@ def test_attention_encoder_is_not_the_per_agent_pairing():
     assert (got - natural).abs().max().item() > 0.2
 
 
-@pytest.mark.parametrize("model", ["attention", "mean_embed", "mha"])
+@pytest.mark.parametrize("model", ["attention", "mean_embed", "mha", "sim2real"])
 @pytest.mark.parametrize("hdim,batch", [(4, 77), (1, 8192), (8, 16)])
 def test_fused_linear_head(model, hdim, batch):
     """Linear head in the encoder's epilogue == the same Linear applied to the features the kernel writes; features optional."""
     import torch
     from quad_swarm_rl_amd import policy
-    ref = (policy.make_reference_mha_encoder(seed=3) if model == "mha" else policy.make_reference_encoder(seed=3, nbr_encoder=model)).cuda()
+    ref = (policy.make_reference_mha_encoder(seed=3) if model == "mha" else policy.make_reference_sim2real_encoder(seed=3) if model == "sim2real"
+           else policy.make_reference_encoder(seed=3, nbr_encoder=model)).cuda()
     fused = policy.FusedQuadEncoder(ref)
     g = torch.Generator(device="cuda").manual_seed(hdim)
     obs = torch.rand((batch, fused.params.obs_dim), device="cuda", generator=g) * 2 - 1
-    W = torch.randn((hdim, 512), device="cuda", generator=g) * 0.1
+    W = torch.randn((hdim, fused.out_dim), device="cuda", generator=g) * 0.1
     b = torch.randn((hdim,), device="cuda", generator=g)
     feats = fused(obs)
     fused.set_head(W, b)

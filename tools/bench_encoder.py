@@ -12,23 +12,26 @@ from quad_swarm_rl_amd import policy
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 ATT = len(sys.argv) > 2 and sys.argv[2] == "attention"
-MHA = len(sys.argv) > 2 and sys.argv[2] == "mha"   # QuadMultiHeadAttentionEncoder on C3's observations (obs 40: self 19, 2 neighbours, 9 SDF cells)
+S2R = len(sys.argv) > 2 and sys.argv[2] == "sim2real"   # QuadSingleHeadAttentionEncoder_Sim2Real, same observations
+MHA = len(sys.argv) > 2 and sys.argv[2] in ("mha", "sim2real")   # QuadMultiHeadAttentionEncoder on C3's observations (obs 40: self 19, 2 neighbours, 9 SDF cells)
 shape = dict(num_nbr=6, obst_dim=0, attention=ATT)
 make = policy.make_reference_encoder
 if MHA:
     shape = dict(num_nbr=2, obst_dim=9, self_dim=19)
-    make = policy.make_reference_mha_encoder
+    make = policy.make_reference_sim2real_encoder if S2R else policy.make_reference_mha_encoder
 ref = make(seed=0, **shape).cuda()
 fused = policy.FusedQuadEncoder(ref)
 D = fused.params.obs_dim
 obs = torch.rand((B, D), device="cuda") * 2 - 1
-out = torch.empty((B, 512), device="cuda")
+out = torch.empty((B, fused.out_dim), device="cuda")
 H = 256
 macs = 18 * H + H * H + shape["num_nbr"] * (6 * H + H * H) + (2 * H) * (2 * H)      # per agent, unpadded
 if ATT:   # embedding on [self | nbr], value MLP, score MLP (e_mean half once per agent)
     macs = 18 * H + H * H + shape["num_nbr"] * ((18 + 6) * H + H * H + 2 * H * H + 2 * H * H + H) + H * H + (2 * H) * (2 * H)
 if MHA:
     macs = (19 + 12 + 9) * H + 3 * H * H + 2 * 3 * H * 4 * H + 2 * 4 * H * H + 2 * 4 * 2 * H + 3 * H * 2 * H
+if S2R:   # one-layer embeddings; q, k, v, fc 256 x 256 on two tokens; 2 x 2 scores and mixes; feed forward 768 -> 256
+    macs = (19 + 12 + 9) * H + 2 * 3 * H * H + 2 * H * H + 2 * 2 * 2 * H + 3 * H * H
 flops = 2.0 * macs * B
 
 
@@ -51,7 +54,7 @@ with torch.no_grad():
     obs16 = obs.to(torch.bfloat16)
     t_bf16 = timeit(lambda: ref16(obs16), 100)
 PEAK = 2500.0   # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
-print(json.dumps({"kernel": "qs_encoder_mha_kernel" if MHA else "qs_encoder_embed_kernel + qs_encoder_attn_kernel" if ATT else "qs_encoder_kernel", "agents": B, "obs_dim": D, "algorithmic_gflop": flops / 1e9,
+print(json.dumps({"kernel": "qs_encoder_s2r_kernel" if S2R else "qs_encoder_mha_kernel" if MHA else "qs_encoder_embed_kernel + qs_encoder_attn_kernel" if ATT else "qs_encoder_kernel", "agents": B, "obs_dim": D, "algorithmic_gflop": flops / 1e9,
                   "fused_us": t_fused * 1e6, "fused_us_one_python_call_per_pass": t_fused_host * 1e6, "fused_tflops": flops / t_fused / 1e12, "frac_of_bf16_mfma_peak": flops / t_fused / 1e12 / PEAK,
                   "torch_fp32_eager_us": t_fp32 * 1e6, "torch_bf16_eager_us": t_bf16 * 1e6,
                   "speedup_vs_torch_fp32": t_fp32 / t_fused, "speedup_vs_torch_bf16": t_bf16 / t_fused}))
