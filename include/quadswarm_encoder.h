@@ -69,6 +69,10 @@ const char *qs_enc_last_error(void);
  * (qs_enc_last_error()). */
 int qs_enc_forward(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream);
 
+/* The mean_embed (and attention) encoders have a second set of kernels with 32 agents per workgroup, taken for batches of at least
+ * this many agents (default 2048; environment QS_ENC_WIDE_MIN; 0 = never).  Returns the previous value; a negative argument only reads. */
+int32_t qs_enc_set_wide_min(int32_t agents);
+
 /* `iters` back-to-back forward passes timed with HIP events on `stream` (no host work in between): average ms per pass. */
 int qs_enc_benchmark(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream, int32_t iters, double *avg_ms);
 

@@ -20,10 +20,14 @@
 // Operand layout verified on hardware by tools/mfma_layout_probe.hip.
 #include <hip/hip_runtime.h>
 #include <mutex>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include <string>
 
+#ifdef ENC_EXP_NO_BARRIER   // timing experiment: no workgroup barriers (results are wrong)
+#define __syncthreads() do { } while (0)
+#endif
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -79,7 +83,9 @@ struct EncParams {
 
 #ifdef ENC_TIMING   // phase stamps of workgroup 0, wave 0 (tools/enc_quick.py prints them)
 __device__ unsigned long long enc_stamps[16];
-#define ENC_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) enc_stamps[k] = clock64(); } while (0)
+__device__ unsigned long long enc_wg_times[2 * 8192];   // start / end of every workgroup on the constant 100 MHz clock
+#define ENC_STAMP(k) do { if (threadIdx.x == 0) { if (blockIdx.x == 0) enc_stamps[k] = clock64(); \
+                                                  if (((k) == 0 || (k) == 9) && blockIdx.x < 8192) enc_wg_times[2 * blockIdx.x + ((k) == 9)] = wall_clock64(); } } while (0)
 #else
 #define ENC_STAMP(k) do { } while (0)
 #endif
@@ -90,8 +96,31 @@ __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1)
 #ifdef ENC_EXP_NO_TANH   // timing experiment
     return x;
 #endif
-    const float e = __expf(2.0f * x);
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x): one multiply, v_exp_f32
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// floor(n / d) for small operands (n * d < 2^32) from m = ceil(2^32 / d), computed once per thread: integer division by a
+// run-time divisor is ~40 instructions, and the staging loops did two per element
+__device__ __forceinline__ uint32_t div_magic(uint32_t d) { return 0xffffffffu / d + 1u; }
+__device__ __forceinline__ uint32_t div_by(uint32_t n, uint32_t magic) { return __umulhi(n, magic); }
+// j mod B for j < 2^24 (the host bounds batch x neighbours): float estimate of the quotient, one correction step
+__device__ __forceinline__ uint32_t mod_batch(uint32_t j, uint32_t B, float invB) {
+    const uint32_t q = (uint32_t)((float)j * invB);
+    int32_t r = (int32_t)(j - q * B);
+    if (r < 0) r += (int32_t)B;
+    else if (r >= (int32_t)B) r -= (int32_t)B;
+    return (uint32_t)r;
+}
+
+// Observation elements through a buffer resource: an invalid element (padding column, row past the batch) gets an out-of-range
+// offset and reads as zero, so the staging loops have no branch around their loads and issue them back to back (a conditional
+// load per iteration is a branch plus s_waitcnt vmcnt(0): the memory latency once per element instead of once per loop).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t obs_rsrc(const float *obs, int B, int D) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)obs, 0, (uint32_t)B * (uint32_t)D * 4u, 0x00020000);
+}
+__device__ __forceinline__ float obs_at(__amdgpu_buffer_rsrc_t rs, bool valid, uint32_t index) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, valid ? index * 4u : 0xffffffffu, 0, 0));
 }
 
 // acc[mt][nt] (+)= W[features of (wave, mt)] x X[rows of tile nt], K-loop over the whole layer.  NT is a compile-time tile count
@@ -126,7 +155,11 @@ __device__ __forceinline__ void gemm_tiles(const EncLayer &L, int mtile0, const 
     const uint32_t voff = lane * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, L.M * L.K * 2, 0x00020000);
 #define ENC_WFRAG(mt, ks) ENC_WLOAD(__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, ((mtile0 + (mt)) * ksteps + (ks)) * 1024, 0)))
+#ifdef ENC_EXP_NO_BREAD   // timing experiment: one activation fragment per row tile and layer instead of one per K-step
+#define ENC_XFRAG(nt, ks) (*(const bf16x8 *)(xrow + (nt) * 16 * xstride + (ks) * 0))
+#else
 #define ENC_XFRAG(nt, ks) (*(const bf16x8 *)(xrow + (nt) * 16 * xstride + (ks) * 32))
+#endif
     if (ksteps & (ENC_PD - 1)) {   // the 32- and 64-wide input layers: one or two K-steps, nothing to pipeline
         for (int ks = 0; ks < ksteps; ++ks) {
             bf16x8 a[MT];
@@ -297,13 +330,14 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     uint16_t *emean = buf_a + ENC_NH * ENC_TA * ENC_YS;               // [16][YS]
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
+    const float invB = 1.0f / (float)B;
+    const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
+#pragma unroll 4
     for (int idx = tid; idx < NB * ENC_TA * 32; idx += 64 * ENC_WAVES) {
         const int row = idx >> 5, c = idx & 31, k = row >> 4, a = row & 15, ga = a0 + a;
-        float v = 0.0f;
-        if (ga < B) {
-            if (c < P.self_dim) v = obs[(size_t)(((size_t)ga * NB + k) % (size_t)B) * D + c];        // self_obs.repeat(K, 1)  (:84)
-            else if (c < P.self_dim + P.nbr_dim) v = obs[(size_t)ga * D + P.self_dim + k * P.nbr_dim + (c - P.self_dim)];
-        }
+        const uint32_t i_self = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB) * (uint32_t)D + c;   // self_obs.repeat(K, 1)  (:84)
+        const uint32_t i_nbr = (uint32_t)ga * (uint32_t)D + P.self_dim + k * P.nbr_dim + (c - P.self_dim);
+        const float v = obs_at(ors, ga < B && c < P.self_dim + P.nbr_dim, c < P.self_dim ? i_self : i_nbr);
         x_in[row * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
     }
     __syncthreads();
@@ -372,7 +406,7 @@ __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int
         const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)P.gbuf, 0, (uint32_t)B * (ENC_H * 4), 0x00020000);
 #pragma unroll
         for (int nt = 0; nt < NTH; ++nt) {
-            const uint32_t j = ((uint32_t)ga * (uint32_t)P.num_nbr + (uint32_t)(t0 + nt)) % (uint32_t)B;
+            const uint32_t j = mod_batch((uint32_t)ga * (uint32_t)P.num_nbr + (uint32_t)(t0 + nt), (uint32_t)B, 1.0f / (float)B);
             const uint32_t off = ga < B ? j * (ENC_H * 4) + (lane >> 4) * 16 : 0xffffffffu;   // padding rows: out of range, reads zero
 #pragma unroll
             for (int mt = 0; mt < ENC_MT; ++mt) {
@@ -452,7 +486,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     for (int idx = tid; idx < 2 * ENC_TA * 32; idx += 64 * ENC_WAVES) {   // self and obstacle columns as bf16, zero padded to K = 32
         const int which = idx >> 9, a = (idx >> 5) & 15, c = idx & 31, ga = a0 + a;
         const int dim = which ? P.obst_dim : P.self_dim, col = which ? P.self_dim + P.nbr_dim * NB : 0;
-        const float v = (ga < B && c < dim) ? obs[(size_t)ga * D + col + c] : 0.0f;
+        const float v = obs_at(obs_rsrc(obs, B, D), ga < B && c < dim, (uint32_t)ga * (uint32_t)D + col + c);
         (which ? x_obst : x_self)[a * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
     }
     __syncthreads();
@@ -562,7 +596,7 @@ __device__ __forceinline__ void mha_body(const float *__restrict__ obs, int B, c
         if (c < 32) { dst = x_self + a * ENC_XS + c; if (c < P.self_dim) col = c; }
         else if (c < 64) { dst = x_obst + a * ENC_XS + (c - 32); if (c - 32 < P.obst_dim) col = P.self_dim + nbw + (c - 32); }
         else { dst = x_nbr + a * ENC_XW + (c - 64); if (c - 64 < nbw) col = P.self_dim + (c - 64); }
-        const float v = (ga < B && col >= 0) ? obs[(size_t)ga * D + col] : 0.0f;
+        const float v = obs_at(obs_rsrc(obs, B, D), ga < B && col >= 0, (uint32_t)ga * (uint32_t)D + col);
         *dst = __builtin_bit_cast(uint16_t, (__bf16)v);
     }
     __syncthreads();
@@ -747,23 +781,25 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
         for (int idx = tid; idx < (2 + ENC_MAX_NBR) * ENC_TA * ENC_XS / 2; idx += 64 * ENC_WAVES) z[idx] = 0;
         constexpr int PER = (ENC_TA * (32 + 32 * ENC_MAX_NBR + 32) + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);   // upper bound on elements per thread
         const int total = ENC_TA * D;
-        const size_t first = (size_t)a0 * D, limit = (size_t)B * D;
+        const size_t first = (size_t)a0 * D;
+        const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
+        const uint32_t mD = div_magic(D), mN = div_magic(P.nbr_dim > 0 ? P.nbr_dim : 1);
         float v[PER];
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
             const int idx = tid + it * 64 * ENC_WAVES;
-            v[it] = (idx < total && first + idx < limit) ? obs[first + idx] : 0.0f;
+            v[it] = obs_at(ors, idx < total, (uint32_t)first + idx);   // rows past the batch: beyond the resource
         }
         __syncthreads();   // zeros are in place
 #pragma unroll
         for (int it = 0; it < PER; ++it) {
             const int idx = tid + it * 64 * ENC_WAVES;
             if (idx < total) {
-                const int a = idx / D, cidx = idx - a * D;
+                const int a = div_by(idx, mD), cidx = idx - a * D;
                 const uint16_t h = __builtin_bit_cast(uint16_t, (__bf16)v[it]);
                 if (cidx < P.self_dim) x_self[a * ENC_XS + cidx] = h;
                 else if (cidx < P.self_dim + P.nbr_dim * NB) {
-                    const int q = cidx - P.self_dim, nb = q / P.nbr_dim, j = q - nb * P.nbr_dim;
+                    const int q = cidx - P.self_dim, nb = div_by(q, mN), j = q - nb * P.nbr_dim;
                     if (mode == ENC_NBR_MLP) x_nbr[a * ENC_XW + q] = h;
                     else x_nbr[(nb * ENC_TA + a) * ENC_XS + j] = h;
                 } else x_obst[a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB)] = h;
@@ -818,6 +854,578 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     ENC_STAMP(9);
 }
 
+
+// ================================================================================================
+// Wide variants: 32 agents per workgroup, one workgroup per CU (batches of >= ENC_WIDE_MIN agents).
+//
+// Phase stamps (tools/enc_stamps.py, profiles/r02_encoder_*): one 16-agent workgroup ALONE on the GPU needs 89 % of the time 512
+// of them need - the kernel is the latency of one workgroup's chain of dependent layers, and a third of that chain is exposed L2
+// latency: every layer starts with a load of its bias and first weight fragments (~650 ticks of a 36 k-tick chain each), a
+// 256-wide layer waits a second time for the K-steps beyond the four-deep ring, the 512-wide feed-forward four times.  Here
+//   * the weight ring holds a whole 256-wide layer (ENC_WPD = 8 K-steps) and is carried ACROSS layers: the slot an MFMA group of
+//     the last ENC_WPD K-steps has consumed is refilled with the NEXT layer's fragment, so those loads fly during the tail of the
+//     K loop, the tanh epilogue and the barrier, and the next layer starts on weights that are already in registers;
+//   * the bias is added after the K loop instead of seeding the accumulators (its load is issued before the loop and first
+//     needed behind it);
+//   * 32 agents per workgroup halve the weight stream per agent and the barriers per agent; the register file of the lone
+//     workgroup (2 waves per SIMD, 256 VGPRs) holds the deeper ring and the wider accumulator tiles.
+// ================================================================================================
+#define ENC_AT 2                    // agent tiles per workgroup
+#define ENC_WA (16 * ENC_AT)        // agents per workgroup
+#define ENC_WPD 8                   // weight ring depth (K-steps)
+#define ENC_WSLOTS (ENC_MAX_NBR + 1)   // neighbour slots in the staging rows: ceil(8 / 3) * 3
+struct WRing { bf16x8 a[ENC_WPD][ENC_MT]; };
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t layer_rsrc(const EncLayer &L) {   // a layer without weights (w == nullptr, M == 0): every load is out of range and returns zero
+    return __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, L.M * L.K * 2, 0x00020000);
+}
+#define ENC_RFRAG(rs, mtile, kst, mt, ks) ENC_WLOAD(__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (((mtile) + (mt)) * (kst) + (ks)) * 1024, 0)))
+
+__device__ __forceinline__ void ring_fill(WRing &R, const EncLayer &L, int mtile0) {
+    const uint32_t voff = (threadIdx.x & 63) * 16;
+    const int kst = L.K >> 5;
+    const __amdgpu_buffer_rsrc_t rs = layer_rsrc(L);
+#pragma unroll
+    for (int s = 0; s < ENC_WPD; ++s)
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rs, mtile0, kst, mt, s);   // K-steps past a short layer: in-range junk nobody multiplies
+}
+
+// acc (+)= L[features of (wave, mt)] x X[row tiles]; the ring holds L's first ENC_WPD K-steps on entry and Ln's on exit.
+// KS = K / 32 of L is a template parameter: a run-time K-step count puts branches and a loop around the loads, behind which the
+// compiler no longer knows how many are in flight and waits for ALL of them (s_waitcnt vmcnt(0)) at the next use of any loaded
+// value - i.e. for the whole prefetched next layer at the end of every layer.
+template <int NT, int KS>
+__device__ __forceinline__ void gemm_ring(WRing &R, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n, const uint16_t *X, int xstride,
+                                          f32x4 (&acc)[ENC_MT][NT]) {
+    const int lane = threadIdx.x & 63, kn = Ln.K >> 5;
+    const uint16_t *xrow = X + (lane & 15) * xstride + 8 * (lane >> 4);
+    const uint32_t voff = lane * 16;
+    const __amdgpu_buffer_rsrc_t rs = layer_rsrc(L), rsn = layer_rsrc(Ln);
+    bf16x8 b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = ENC_XFRAG(nt, 0);
+    if constexpr (KS < ENC_WPD) {   // the 32- and 64-wide input layers
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                mfma_tile<ENC_MT, NT>(R.a[s], b[nt], acc, nt);
+                if (s + 1 < KS) b[nt] = ENC_XFRAG(nt, s + 1);
+            }
+#pragma unroll
+        for (int s = 0; s < ENC_WPD; ++s)
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rsn, mtile0n, kn, mt, s);
+    } else {
+        static_assert(KS % ENC_WPD == 0, "K-steps of a hidden layer: a multiple of the ring depth");
+#pragma unroll
+        for (int ks0 = 0; ks0 + ENC_WPD < KS; ks0 += ENC_WPD) {   // K > 256: the ring is refilled with this layer's next K-steps
+#pragma unroll
+            for (int s = 0; s < ENC_WPD; ++s) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    mfma_tile<ENC_MT, NT>(R.a[s], b[nt], acc, nt);
+                    b[nt] = ENC_XFRAG(nt, ks0 + s + 1);
+                }
+#pragma unroll
+                for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rs, mtile0, KS, mt, ks0 + s + ENC_WPD);
+                __builtin_amdgcn_sched_barrier(0);   // keep the K-steps in program order: hoisted LDS reads of later K-steps cost 4 VGPRs per tile each
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < ENC_WPD; ++s) {   // the last ENC_WPD K-steps: each consumed slot takes the next layer's fragment
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                mfma_tile<ENC_MT, NT>(R.a[s], b[nt], acc, nt);
+                if (s + 1 < ENC_WPD) b[nt] = ENC_XFRAG(nt, KS - ENC_WPD + s + 1);
+            }
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rsn, mtile0n, kn, mt, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+struct Bias { f32x4 v[ENC_MT]; };
+__device__ __forceinline__ Bias load_bias(const EncLayer &L, int mtile0) {
+    Bias b;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) b.v[mt] = *(const f32x4 *)(L.b + (mtile0 + mt) * 16 + (lane >> 4) * 4);
+    return b;
+}
+template <int NT>
+__device__ __forceinline__ void add_bias(f32x4 (&acc)[ENC_MT][NT], const Bias &b) {
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][nt][r] += b.v[mt][r];
+}
+// one layer of the chain: acc = L X + b (fp32, before the non-linearity)
+template <int NT, int KS>
+__device__ __forceinline__ void layer_ring(WRing &R, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n, const uint16_t *X, int xstride,
+                                           f32x4 (&acc)[ENC_MT][NT]) {
+    const Bias b = load_bias(L, mtile0);
+    zero_acc<ENC_MT, NT>(acc);
+    gemm_ring<NT, KS>(R, L, mtile0, Ln, mtile0n, X, xstride, acc);
+    add_bias<NT>(acc, b);
+}
+
+// epilogues of the wide kernels: one row tile at a time (a scheduling fence after each - interleaving a dozen tanh chains costs
+// more registers than it hides latency, and the weight ring has to stay resident through them)
+template <int NT>
+__device__ __forceinline__ void store_tanh_wide(const f32x4 (&acc)[ENC_MT][NT], int mtile0, uint16_t *Y, int ystride, int col0 = 0) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)fast_tanh(acc[mt][nt][r]);
+            *(bf16x4 *)(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// observation rows of the workgroup's ENC_WA agents -> bf16 staging rows (self [WA][XS] | neighbours [(k*WA + a)][XS] | obstacles [WA][XS])
+__device__ __forceinline__ void stage_obs_wide(const float *__restrict__ obs, int B, const EncParams &P, int a0, uint16_t *x_self, uint16_t *x_nbr, uint16_t *x_obst) {
+    const int tid = threadIdx.x, D = P.obs_dim, NB = P.num_nbr;
+    uint32_t *z = (uint32_t *)x_self;   // the three are contiguous: clear the padding first
+    for (int idx = tid; idx < (2 + ENC_WSLOTS) * ENC_WA * ENC_XS / 2; idx += 64 * ENC_WAVES) z[idx] = 0;
+    constexpr int PER = (ENC_WA * (32 + 32 * ENC_MAX_NBR + 32) + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);
+    const int total = ENC_WA * D;
+    const size_t first = (size_t)a0 * D;
+    const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
+    const uint32_t mD = div_magic(D), mN = div_magic(P.nbr_dim > 0 ? P.nbr_dim : 1);
+    float v[PER];
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int idx = tid + it * 64 * ENC_WAVES;
+        v[it] = obs_at(ors, idx < total, (uint32_t)first + idx);   // rows past the batch: beyond the resource
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        const int idx = tid + it * 64 * ENC_WAVES;
+        if (idx < total) {
+            const int a = div_by(idx, mD), cidx = idx - a * D;
+            const uint16_t h = __builtin_bit_cast(uint16_t, (__bf16)v[it]);
+            if (cidx < P.self_dim) x_self[a * ENC_XS + cidx] = h;
+            else if (cidx < P.self_dim + P.nbr_dim * NB) {
+                const int q = cidx - P.self_dim, nb = div_by(q, mN), j = q - nb * P.nbr_dim;
+                x_nbr[(nb * ENC_WA + a) * ENC_XS + j] = h;
+            } else x_obst[a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB)] = h;
+        }
+    }
+}
+
+// feed forward on the ring: the wave's 64 output features as two 32-feature halves over the same `cat` rows
+template <int KS>   // K-steps of the feed-forward layer: 16 ([self | neighbourhood]) or 24 (with obstacles)
+__device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, const uint16_t *cat, int a0, int B, float *__restrict__ out, float *red) {
+    const int wave = wave_id(), lane = threadIdx.x & 63, mf0 = wave * ENC_MTF;
+    const EncLayer none = {nullptr, nullptr, 0, 0};
+    f32x4 acc[2][ENC_MT][ENC_AT];
+    layer_ring<ENC_AT, KS>(R, P.f, mf0, P.f, mf0 + ENC_MT, cat, ENC_CS, acc[0]);
+    layer_ring<ENC_AT, KS>(R, P.f, mf0 + ENC_MT, none, 0, cat, ENC_CS, acc[1]);
+    ENC_STAMP(8);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int h = 0; h < ENC_AT; ++h) {
+                const int ga = a0 + h * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[hf][mt][h][r] = fast_tanh(acc[hf][mt][h][r]);
+                if (out && ga < B) *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + hf * ENC_MT + mt) * 16 + (lane >> 4) * 4) = acc[hf][mt][h];
+            }
+    if (P.head_dim > 0) {   // linear head on the features (see feed_forward): red = [8 waves][8 heads][ENC_WA] floats
+        for (int hd = 0; hd < P.head_dim; ++hd) {
+            float sp[ENC_AT];
+#pragma unroll
+            for (int h = 0; h < ENC_AT; ++h) sp[h] = 0.0f;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int mt = 0; mt < ENC_MT; ++mt) {
+                    const f32x4 w = *(const f32x4 *)(P.head_w + hd * (2 * ENC_H) + (mf0 + hf * ENC_MT + mt) * 16 + (lane >> 4) * 4);
+#pragma unroll
+                    for (int h = 0; h < ENC_AT; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sp[h] += acc[hf][mt][h][r] * w[r];
+                }
+#pragma unroll
+            for (int h = 0; h < ENC_AT; ++h) {
+                const float t = lane_groups_sum(sp[h]);
+                if (lane < 16) red[(wave * 8 + hd) * ENC_WA + h * 16 + lane] = t;
+            }
+        }
+        __syncthreads();
+        const int tid = threadIdx.x, hd = tid / ENC_WA, row = tid % ENC_WA;
+        if (hd < P.head_dim && a0 + row < B) {
+            float t = P.head_b[hd];
+#pragma unroll
+            for (int w = 0; w < ENC_WAVES; ++w) t += red[(w * 8 + hd) * ENC_WA + row];
+            P.head_out[(size_t)(a0 + row) * P.head_dim + hd] = t;
+        }
+    }
+}
+
+// mean_embed, wide: per-neighbour MLP in passes of WNP neighbours (WNP * ENC_AT row tiles, tile = neighbour * ENC_AT + agent half).
+// WNP is a template parameter picked per neighbour count at launch (one pass body, no run-time tile counts); a last pass that
+// runs past the neighbour count works on zero rows and is masked out of the mean.
+template <int WNP>
+__device__ __forceinline__ void mean_pass_wide(WRing &R, const EncParams &P, int t0, const EncLayer &after, int mt_after, const uint16_t *x_nbr, uint16_t *buf_a,
+                                               f32x4 (&mean)[ENC_MT][ENC_AT]) {
+    constexpr int NT = WNP * ENC_AT;
+    const int wave = wave_id(), mt0 = wave * ENC_MT;
+    f32x4 acc[ENC_MT][NT];
+    layer_ring<NT, 1>(R, P.n1, mt0, P.n2, mt0, x_nbr + t0 * ENC_WA * ENC_XS, ENC_XS, acc);
+    ENC_STAMP(4);
+    if (t0) __syncthreads();   // the previous pass's second layer is done reading buf_a
+    store_tanh_wide<NT>(acc, mt0, buf_a, ENC_YS);
+    __syncthreads();
+    ENC_STAMP(5);
+    layer_ring<NT, 8>(R, P.n2, mt0, after, mt_after, buf_a, ENC_YS, acc);
+    ENC_STAMP(6);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float keep = t0 + nt / ENC_AT < P.num_nbr ? 1.0f : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mean[mt][nt % ENC_AT][r] += keep * fast_tanh(acc[mt][nt][r]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int WNP>
+__device__ __forceinline__ void wide_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_self = (uint16_t *)smem;                              // [WA][XS]
+    uint16_t *x_nbr = x_self + ENC_WA * ENC_XS;                       // [WSLOTS*WA][XS]
+    uint16_t *x_obst = x_nbr + ENC_WSLOTS * ENC_WA * ENC_XS;          // [WA][XS]
+    uint16_t *buf_a = x_obst + ENC_WA * ENC_XS;                       // [3*WA][YS]   hidden layer of the neighbour MLP (one pass at a time)
+    uint16_t *buf_b = buf_a + 3 * ENC_WA * ENC_YS;                    // [WA][YS]     hidden layer of the self / obstacle MLPs
+    uint16_t *cat = buf_b + ENC_WA * ENC_YS;                          // [WA][CS]: self | neighbourhood | obstacles
+    const int wave = wave_id(), lane = threadIdx.x & 63, a0 = blockIdx.x * ENC_WA, mt0 = wave * ENC_MT, NB = P.num_nbr;
+    const bool obst = P.obst_dim > 0;
+    const int col_nbr = ENC_H, col_obst = 2 * ENC_H;
+
+    ENC_STAMP(0);
+    WRing R;
+    ring_fill(R, P.s1, mt0);   // in flight while the observations are staged
+    stage_obs_wide(obs, B, P, a0, x_self, x_nbr, x_obst);
+    __syncthreads();
+    ENC_STAMP(1);
+    {
+        f32x4 acc[ENC_MT][ENC_AT];
+        layer_ring<ENC_AT, 1>(R, P.s1, mt0, P.s2, mt0, x_self, ENC_XS, acc);
+        store_tanh_wide<ENC_AT>(acc, mt0, buf_b, ENC_YS);
+        __syncthreads();
+        layer_ring<ENC_AT, 8>(R, P.s2, mt0, obst ? P.o1 : P.n1, mt0, buf_b, ENC_YS, acc);
+        store_tanh_wide<ENC_AT>(acc, mt0, cat, ENC_CS, 0);                                    // self encoder -> cat[:, 0:256]
+        ENC_STAMP(2);
+        if (obst) {
+            layer_ring<ENC_AT, 1>(R, P.o1, mt0, P.o2, mt0, x_obst, ENC_XS, acc);
+            __syncthreads();   // the self encoder's second layer is done reading buf_b
+            store_tanh_wide<ENC_AT>(acc, mt0, buf_b, ENC_YS);
+            __syncthreads();
+            layer_ring<ENC_AT, 8>(R, P.o2, mt0, P.n1, mt0, buf_b, ENC_YS, acc);
+            store_tanh_wide<ENC_AT>(acc, mt0, cat, ENC_CS, col_obst);                         // obstacle encoder -> cat[:, 512:768]
+        }
+    }
+    ENC_STAMP(3);
+    f32x4 mean[ENC_MT][ENC_AT];
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < ENC_AT; ++h) mean[mt][h] = (f32x4){0, 0, 0, 0};
+#pragma unroll 1
+    for (int t0 = 0; t0 < NB; t0 += WNP) {
+        const bool last = t0 + WNP >= NB;
+        mean_pass_wide<WNP>(R, P, t0, last ? P.f : P.n1, last ? wave * ENC_MTF : mt0, x_nbr, buf_a, mean);
+    }
+    const float inv = 1.0f / (float)NB;   // torch.mean(neighbor_embeds, dim=1) (:41-42)
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < ENC_AT; ++h) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(mean[mt][h][r] * inv);
+            *(bf16x4 *)(cat + (h * 16 + (lane & 15)) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+    __syncthreads();
+    ENC_STAMP(7);
+    if (obst) feed_forward_wide<24>(R, P, cat, a0, B, out, (float *)buf_a);
+    else feed_forward_wide<16>(R, P, cat, a0, B, out, (float *)buf_a);
+    ENC_STAMP(9);
+}
+#define ENC_WIDE_KERNEL(n)                                                                                                                          \
+    extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_wide##n##_kernel(const float *__restrict__ obs, int B, EncParams P, \
+                                                                                                 float *__restrict__ out) {                         \
+        wide_body<n>(obs, B, P, out);                                                                                                               \
+    }
+ENC_WIDE_KERNEL(1) ENC_WIDE_KERNEL(2) ENC_WIDE_KERNEL(3)
+
+// ------------------------------------------------------------------------------------------------
+// attention, wide.  Launch 1: e_i -> ebuf, g = W_m e_mean -> gbuf (see qs_encoder_embed_kernel).
+// ------------------------------------------------------------------------------------------------
+template <int WNP>
+__device__ __forceinline__ void embed_wide_body(const float *__restrict__ obs, int B, const EncParams &P) {
+    constexpr int NT = WNP * ENC_AT;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_in = (uint16_t *)smem;                                // [WSLOTS*WA][XS]
+    uint16_t *buf_a = x_in + ENC_WSLOTS * ENC_WA * ENC_XS;            // [3*WA][YS]
+    uint16_t *emean = buf_a + 3 * ENC_WA * ENC_YS;                    // [WA][YS]
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_WA;
+    const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
+    const EncLayer none = {nullptr, nullptr, 0, 0};
+    WRing R;
+    ring_fill(R, P.n1, mt0);
+    {
+        const float invB = 1.0f / (float)B;
+        const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
+#pragma unroll 6
+        for (int idx = tid; idx < ENC_WSLOTS * ENC_WA * 32; idx += 64 * ENC_WAVES) {   // 18 iterations; neighbour slots past NB are zero rows
+            const int row = idx >> 5, c = idx & 31, k = row / ENC_WA, a = row % ENC_WA, ga = a0 + a;
+            const uint32_t i_self = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB) * (uint32_t)D + c;   // self_obs.repeat(K, 1)  (:84)
+            const uint32_t i_nbr = (uint32_t)ga * (uint32_t)D + P.self_dim + k * P.nbr_dim + (c - P.self_dim);
+            const float v = obs_at(ors, ga < B && k < NB && c < P.self_dim + P.nbr_dim, c < P.self_dim ? i_self : i_nbr);
+            x_in[row * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        }
+    }
+    __syncthreads();
+    f32x4 mean[ENC_MT][ENC_AT];
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < ENC_AT; ++h) mean[mt][h] = (f32x4){0, 0, 0, 0};
+#pragma unroll 1
+    for (int t0 = 0; t0 < NB; t0 += WNP) {
+        const bool last = t0 + WNP >= NB;
+        f32x4 acc[ENC_MT][NT];
+        layer_ring<NT, 1>(R, P.n1, mt0, P.n2, mt0, x_in + t0 * ENC_WA * ENC_XS, ENC_XS, acc);
+        if (t0) __syncthreads();   // the previous pass is done reading buf_a
+        store_tanh_wide<NT>(acc, mt0, buf_a, ENC_YS);
+        __syncthreads();
+        layer_ring<NT, 8>(R, P.n2, mt0, last ? P.a1m : P.n1, mt0, buf_a, ENC_YS, acc);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int k = t0 + nt / ENC_AT, ga = a0 + (nt % ENC_AT) * 16 + (lane & 15);
+            const bool live = k < NB;
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = fast_tanh(acc[mt][nt][r]); mean[mt][nt % ENC_AT][r] += live ? e : 0.0f; v[r] = (__bf16)e; }
+                if (live && ga < B) *(bf16x4 *)(P.ebuf + ((size_t)ga * NB + k) * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const float inv = 1.0f / (float)NB;   // e_mean (:90-91), then its half of the score MLP's first layer once per agent
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < ENC_AT; ++h) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(mean[mt][h][r] * inv);
+            *(bf16x4 *)(emean + (h * 16 + (lane & 15)) * ENC_YS + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+    __syncthreads();
+    f32x4 g[ENC_MT][ENC_AT];
+    zero_acc<ENC_MT, ENC_AT>(g);
+    gemm_ring<ENC_AT, 8>(R, P.a1m, mt0, none, 0, emean, ENC_YS, g);
+#pragma unroll
+    for (int h = 0; h < ENC_AT; ++h) {
+        const int ga = a0 + h * 16 + (lane & 15);
+        if (ga < B) {
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt) *(f32x4 *)(P.gbuf + (size_t)ga * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = g[mt][h];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attention, wide.  Launch 2: groups of WNP neighbours (WNP * ENC_AT row tiles): score MLP, value MLP, online softmax (see attn_pass).
+// ------------------------------------------------------------------------------------------------
+struct AttnStateWide { f32x4 o[ENC_MT][ENC_AT]; float mx[ENC_AT], den[ENC_AT]; };
+
+template <int WNP>
+__device__ __forceinline__ void attn_wide_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
+    constexpr int NT = WNP * ENC_AT;
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_self = (uint16_t *)smem;                              // [WA][XS]
+    uint16_t *x_obst = x_self + ENC_WA * ENC_XS;                      // [WA][XS]
+    uint16_t *buf_a = x_obst + ENC_WA * ENC_XS;                       // [3*WA][YS]  e_i of the group
+    uint16_t *buf_h = buf_a + 3 * ENC_WA * ENC_YS;                    // [3*WA][YS]  hidden layers; first the self / obstacle MLPs'
+    uint16_t *cat = buf_h + 3 * ENC_WA * ENC_YS;                      // [WA][CS]: self | neighbourhood | obstacles
+    float *s_alpha = (float *)(cat + ENC_WA * ENC_CS);                // [8 waves][3*AT tiles][16] partial scores of the group
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_WA;
+    const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
+    const bool obst = P.obst_dim > 0;
+    const int col_nbr = ENC_H, col_obst = 2 * ENC_H;
+    const float invB = 1.0f / (float)B;
+
+    WRing R;
+    ring_fill(R, P.s1, mt0);
+    {
+        const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
+#pragma unroll
+        for (int idx = tid; idx < 2 * ENC_WA * 32; idx += 64 * ENC_WAVES) {   // self and obstacle columns as bf16, zero padded to K = 32
+            const int which = idx / (ENC_WA * 32), a = (idx >> 5) % ENC_WA, c = idx & 31, ga = a0 + a;
+            const int dim = which ? P.obst_dim : P.self_dim, col = which ? P.self_dim + P.nbr_dim * NB : 0;
+            const float v = obs_at(ors, ga < B && c < dim, (uint32_t)ga * (uint32_t)D + col + c);
+            (which ? x_obst : x_self)[a * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        }
+    }
+    __syncthreads();
+    {
+        f32x4 acc[ENC_MT][ENC_AT];
+        layer_ring<ENC_AT, 1>(R, P.s1, mt0, P.s2, mt0, x_self, ENC_XS, acc);
+        store_tanh_wide<ENC_AT>(acc, mt0, buf_h, ENC_YS);
+        __syncthreads();
+        layer_ring<ENC_AT, 8>(R, P.s2, mt0, obst ? P.o1 : P.a1e, mt0, buf_h, ENC_YS, acc);
+        store_tanh_wide<ENC_AT>(acc, mt0, cat, ENC_CS, 0);
+        if (obst) {
+            layer_ring<ENC_AT, 1>(R, P.o1, mt0, P.o2, mt0, x_obst, ENC_XS, acc);
+            __syncthreads();   // the self encoder's second layer is done reading buf_h
+            store_tanh_wide<ENC_AT>(acc, mt0, buf_h, ENC_YS);
+            __syncthreads();
+            layer_ring<ENC_AT, 8>(R, P.o2, mt0, P.a1e, mt0, buf_h, ENC_YS, acc);
+            store_tanh_wide<ENC_AT>(acc, mt0, cat, ENC_CS, col_obst);
+        }
+    }
+    AttnStateWide st;
+#pragma unroll
+    for (int h = 0; h < ENC_AT; ++h) {
+        st.mx[h] = -3.0e38f; st.den[h] = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) st.o[mt][h] = (f32x4){0, 0, 0, 0};
+    }
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)P.ebuf, 0, (uint32_t)B * (uint32_t)NB * (ENC_H * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)P.gbuf, 0, (uint32_t)B * (ENC_H * 4), 0x00020000);
+#pragma unroll 1
+    for (int t0 = 0; t0 < NB; t0 += WNP) {
+        const bool last = t0 + WNP >= NB;
+        f32x4 acc[ENC_MT][NT];
+        // score MLP, first layer on [e_i | e_mean.repeat(K, 1)]: W_e e_i + b + g[(a*K + k) mod B]   (:92-94): g seeds the accumulators
+        // (issued first; it has landed by the time the e_i tile has made its round trip through the registers into LDS)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int k = t0 + nt / ENC_AT, ga = a0 + (nt % ENC_AT) * 16 + (lane & 15);
+            const uint32_t j = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB);
+            const uint32_t off = (ga < B && k < NB) ? j * (ENC_H * 4) + (lane >> 4) * 16 : 0xffffffffu;   // padding rows: out of range, reads zero
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt) acc[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, (mt0 + mt) * 64, 0));
+        }
+        {   // e_i rows of the group in 16-byte chunks, coalesced
+            constexpr int PER = NT * 16 * (ENC_H / 8) / (64 * ENC_WAVES);
+            bf16x8 ev[PER];
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {
+                const int idx = tid + it * 64 * ENC_WAVES, row = idx >> 5, ch = idx & 31, k = t0 + row / ENC_WA, ra = a0 + row % ENC_WA;
+                const uint32_t off = (ra < B && k < NB) ? ((uint32_t)ra * (uint32_t)NB + (uint32_t)k) * (ENC_H * 2) + ch * 16 : 0xffffffffu;
+                ev[it] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ers, off, 0, 0));
+            }
+            if (t0) __syncthreads();   // the previous group's value layers are done with buf_a / buf_h
+#pragma unroll
+            for (int it = 0; it < PER; ++it) {
+                const int idx = tid + it * 64 * ENC_WAVES, row = idx >> 5, ch = idx & 31;
+                *(bf16x8 *)(buf_a + row * ENC_YS + ch * 8) = ev[it];
+            }
+        }
+        const Bias b1 = load_bias(P.a1e, mt0);
+        __syncthreads();   // e_i is in buf_a
+        gemm_ring<NT, 8>(R, P.a1e, mt0, P.a2, mt0, buf_a, ENC_YS, acc);
+        add_bias<NT>(acc, b1);
+        store_tanh_wide<NT>(acc, mt0, buf_h, ENC_YS);
+        __syncthreads();
+        layer_ring<NT, 8>(R, P.a2, mt0, P.v1, mt0, buf_h, ENC_YS, acc);
+        // last score layer 256 -> 1 straight from the accumulators (see attn_pass)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float sp = 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt) {
+                const f32x4 w = *(const f32x4 *)(P.a3w + (mt0 + mt) * 16 + (lane >> 4) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sp += fast_tanh(acc[mt][nt][r]) * w[r];
+            }
+            sp = lane_groups_sum(sp);
+            if (lane < 16) s_alpha[(wave * (3 * ENC_AT) + nt) * 16 + lane] = sp;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // partial scores visible; every wave is done reading buf_h (second score layer)
+        layer_ring<NT, 8>(R, P.v1, mt0, P.v2, mt0, buf_a, ENC_YS, acc);
+        store_tanh_wide<NT>(acc, mt0, buf_h, ENC_YS);
+        __syncthreads();
+        layer_ring<NT, 8>(R, P.v2, mt0, last ? P.f : P.a1e, last ? wave * ENC_MTF : mt0, buf_h, ENC_YS, acc);
+        // online softmax over the neighbours of agent (h, lane & 15)   (:95-100)
+#pragma unroll
+        for (int h = 0; h < ENC_AT; ++h) {
+            float al[WNP], mx = st.mx[h];
+#pragma unroll
+            for (int j = 0; j < WNP; ++j) {
+                al[j] = P.a3b;
+#pragma unroll
+                for (int w = 0; w < ENC_WAVES; ++w) al[j] += s_alpha[(w * (3 * ENC_AT) + j * ENC_AT + h) * 16 + (lane & 15)];
+                if (t0 + j >= NB) al[j] = -3.0e38f;   // padded neighbour slot of the last group
+                mx = fmaxf(mx, al[j]);
+            }
+            const float scale = __expf(st.mx[h] - mx);
+            st.den[h] *= scale;
+#pragma unroll
+            for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st.o[mt][h][r] *= scale;
+#pragma unroll
+            for (int j = 0; j < WNP; ++j) {
+                const float e = t0 + j < NB ? __expf(al[j] - mx) : 0.0f;
+                st.den[h] += e;
+#pragma unroll
+                for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st.o[mt][h][r] += e * fast_tanh(acc[mt][j * ENC_AT + h][r]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            st.mx[h] = mx;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < ENC_AT; ++h) {
+        const float rden = 1.0f / st.den[h];
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(st.o[mt][h][r] * rden);
+            *(bf16x4 *)(cat + (h * 16 + (lane & 15)) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+    }
+    __syncthreads();
+    if (obst) feed_forward_wide<24>(R, P, cat, a0, B, out, (float *)buf_a);
+    else feed_forward_wide<16>(R, P, cat, a0, B, out, (float *)buf_a);
+}
+#define ENC_WIDE_ATT_KERNELS(n)                                                                                                                        \
+    extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_embed_wide##n##_kernel(const float *__restrict__ obs, int B, EncParams P) { \
+        embed_wide_body<n>(obs, B, P);                                                                                                                 \
+    }                                                                                                                                                  \
+    extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_attn_wide##n##_kernel(const float *__restrict__ obs, int B, EncParams P,   \
+                                                                                                      float *__restrict__ out) {                       \
+        attn_wide_body<n>(obs, B, P, out);                                                                                                             \
+    }
+ENC_WIDE_ATT_KERNELS(1) ENC_WIDE_ATT_KERNELS(2) ENC_WIDE_ATT_KERNELS(3)
+
+
 // ------------------------------------------------------------------------------------------------
 // C ABI (include/quadswarm_encoder.h)
 // ------------------------------------------------------------------------------------------------
@@ -834,6 +1442,13 @@ static size_t lds_main(int attention) {
 static size_t lds_mha(void) {
     return sizeof(uint16_t) * (2 * ENC_TA * ENC_XS + ENC_TA * ENC_XW + 3 * ENC_TA * ENC_YS + 2 * ENC_TA * ENC_OS + ENC_TA * ENC_CS) + sizeof(float) * (4 * 2 * 4 * 16 + ENC_WAVES * 2 * 2 * 16);
 }
+static size_t lds_wide(void) { return sizeof(uint16_t) * ((2 + ENC_WSLOTS) * ENC_WA * ENC_XS + 3 * ENC_WA * ENC_YS + ENC_WA * ENC_YS + ENC_WA * ENC_CS); }
+// batches from this many agents on take the 32-agent workgroups (mean_embed, attention); 0 = never.  QS_ENC_WIDE_MIN / qs_enc_set_wide_min override
+static size_t lds_embed_wide(void) { return sizeof(uint16_t) * (ENC_WSLOTS * ENC_WA * ENC_XS + 3 * ENC_WA * ENC_YS + ENC_WA * ENC_YS); }
+static size_t lds_attn_wide(void) { return sizeof(uint16_t) * (2 * ENC_WA * ENC_XS + 6 * ENC_WA * ENC_YS + ENC_WA * ENC_CS) + sizeof(float) * ENC_WAVES * 3 * ENC_AT * 16; }
+static int g_wide_min = [] { const char *e = getenv("QS_ENC_WIDE_MIN"); return e ? atoi(e) : 2048; }();
+static int wide_min_agents(void) { return g_wide_min; }
+int32_t qs_enc_set_wide_min(int32_t agents) { const int prev = g_wide_min; if (agents >= 0) g_wide_min = agents; return prev; }
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
 size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 
@@ -855,6 +1470,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
     if (att && !P.a3w) { g_enc_error = "the attention neighbour encoder needs the last score layer's weight row (a3w)"; return -1; }
     if (att && (!P.ebuf || !P.gbuf)) { g_enc_error = "the attention neighbour encoder needs the ebuf / gbuf scratch buffers"; return -1; }
     if (att && (int64_t)B * P.num_nbr * (ENC_H * 2) > 0x7fffffffll) { g_enc_error = "attention: batch x neighbours too large for 32-bit scratch offsets"; return -4; }
+    if ((int64_t)B * P.obs_dim * 4 > 0xffffffffll) { g_enc_error = "batch x obs_dim too large for 32-bit observation offsets"; return -4; }
     if (B == 0) return 0;
     // launch on the device that owns `obs` (a process may drive several GPUs); the > 64 KB dynamic-LDS attribute is per device
     int dev = 0;
@@ -874,6 +1490,15 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
                 hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_s2r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed()) != hipSuccess) {
                 g_enc_error = "cannot raise the dynamic LDS limit";
                 return -2;
@@ -881,7 +1506,30 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
             attr_set |= 1ull << dev;
         }
     }
-    if (s2r)
+    const bool wide = wide_min_agents() > 0 && B >= wide_min_agents() && P.num_nbr > 0 && (P.nbr_encoder == ENC_NBR_MEAN_EMBED || att);
+    if (wide) {
+        // neighbours per pass: the fewest padded neighbour slots, then the fewest passes (1 -> 1; 2, 4 -> 2; 3, 5, 6, 7, 8 -> 3)
+        const dim3 grid((B + ENC_WA - 1) / ENC_WA), block(64 * ENC_WAVES);
+        const int wnp = P.num_nbr == 1 ? 1 : (P.num_nbr == 2 || P.num_nbr == 4) ? 2 : 3;
+        hipStream_t st = (hipStream_t)stream;
+        if (att) {
+            if (wnp == 1) {
+                hipLaunchKernelGGL(qs_encoder_embed_wide1_kernel, grid, block, lds_embed_wide(), st, obs, B, P);
+                hipLaunchKernelGGL(qs_encoder_attn_wide1_kernel, grid, block, lds_attn_wide(), st, obs, B, P, out);
+            } else if (wnp == 2) {
+                hipLaunchKernelGGL(qs_encoder_embed_wide2_kernel, grid, block, lds_embed_wide(), st, obs, B, P);
+                hipLaunchKernelGGL(qs_encoder_attn_wide2_kernel, grid, block, lds_attn_wide(), st, obs, B, P, out);
+            } else {
+                hipLaunchKernelGGL(qs_encoder_embed_wide3_kernel, grid, block, lds_embed_wide(), st, obs, B, P);
+                hipLaunchKernelGGL(qs_encoder_attn_wide3_kernel, grid, block, lds_attn_wide(), st, obs, B, P, out);
+            }
+        } else if (wnp == 1)
+            hipLaunchKernelGGL(qs_encoder_wide1_kernel, grid, block, lds_wide(), st, obs, B, P, out);
+        else if (wnp == 2)
+            hipLaunchKernelGGL(qs_encoder_wide2_kernel, grid, block, lds_wide(), st, obs, B, P, out);
+        else
+            hipLaunchKernelGGL(qs_encoder_wide3_kernel, grid, block, lds_wide(), st, obs, B, P, out);
+    } else if (s2r)
         hipLaunchKernelGGL(qs_encoder_s2r_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);
     else if (mha)
         hipLaunchKernelGGL(qs_encoder_mha_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);
@@ -897,6 +1545,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
 
 #ifdef ENC_TIMING
 int qs_enc_stamps(unsigned long long *out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(enc_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2; }
+int qs_enc_wg_times(unsigned long long *out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(enc_wg_times), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -2; }
 #endif
 // `iters` back-to-back forward passes timed with HIP events on `stream` (no host work in between): average ms per pass
 int qs_enc_benchmark(const float *obs, int32_t B, const EncParams *params, float *out, void *stream, int32_t iters, double *avg_ms) {

@@ -70,6 +70,39 @@ def test_fused_encoder_matches_torch(shape, batch):
 
 
 @pytest.mark.parametrize("shape", [dict(num_nbr=6, obst_dim=0), dict(num_nbr=2, obst_dim=9, self_dim=19), dict(num_nbr=8, obst_dim=0),
+                                   dict(num_nbr=1, obst_dim=0), dict(num_nbr=5, obst_dim=9), dict(num_nbr=3, obst_dim=0), dict(num_nbr=7, obst_dim=9)])
+@pytest.mark.parametrize("batch", [1, 31, 33, 77, 4111, 8192])
+@pytest.mark.parametrize("attention", [False, True])
+def test_wide_workgroup_kernels_match_torch_and_the_narrow_kernels(shape, batch, attention):
+    """The 32-agents-per-workgroup kernels (weight ring carried across layers), forced for every batch size, against the PyTorch
+    module, its bf16 restatement and the 16-agent kernels."""
+    import torch
+    from quad_swarm_rl_amd import policy
+    ref = policy.make_reference_encoder(seed=13, attention=attention, **shape).cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(2.5)
+    fused = policy.FusedQuadEncoder(ref)
+    g = torch.Generator(device="cuda").manual_seed(batch + 77)
+    D = fused.params.obs_dim
+    obs = (torch.rand((batch, D), device="cuda", generator=g) * 2 - 1) * torch.tensor([3.0] * 3 + [1.0] * (D - 3), device="cuda")
+    with torch.no_grad():
+        want32, want16 = ref(obs), bf16_emulation(ref, obs)
+    prev = policy.lib().qs_enc_set_wide_min(1)
+    try:
+        wide = fused(obs).clone()
+        policy.lib().qs_enc_set_wide_min(0)
+        narrow = fused(obs).clone()
+    finally:
+        policy.lib().qs_enc_set_wide_min(prev)
+    torch.cuda.synchronize()
+    assert torch.isfinite(wide).all()
+    assert (wide - want32).abs().max().item() < 8e-2, (wide - want32).abs().max().item()
+    assert (wide - want16).abs().max().item() < (2e-2 if attention else 8e-3), (wide - want16).abs().max().item()
+    assert (wide - narrow).abs().max().item() < (2e-2 if attention else 8e-3), (wide - narrow).abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [dict(num_nbr=6, obst_dim=0), dict(num_nbr=2, obst_dim=9, self_dim=19), dict(num_nbr=8, obst_dim=0),
                                    dict(num_nbr=1, obst_dim=0), dict(num_nbr=5, obst_dim=9)])
 @pytest.mark.parametrize("batch", [1, 16, 77, 8192])
 def test_fused_attention_encoder_matches_torch(shape, batch):
