@@ -1,0 +1,136 @@
+"""The Philox-side draw mappings against the distributions the reference draws from.
+
+Parity with the reference's trajectories runs on its recorded np.random draws (the noise tape: tests/test_oracle_vs_reference.py for
+the oracle, tests/test_hip_vs_reference.py for the HIP kernels).  In production both sides draw from the counter-based Philox stream
+instead, and every draw site maps Philox words to what the reference's call returns: uniform(lo, hi), normal(loc, scale), a
+choice without replacement (partial Fisher-Yates), a rejection loop.  HIP and oracle are compared on that stream bit for bit
+(tests/test_hip_parity.py); this file pins the MAPPINGS themselves, statistically, against the reference's documented calls:
+
+  spawn position   pos = uniform(-box, box, 3) + spawn_point, z >= 0.75               gym_art/quadrotor_multi/quadrotor_single.py:419-423
+  spawn yaw        theta = uniform(-pi, pi) until the heading is within 60 degrees
+                   of the direction to the origin                                      quadrotor_single.py:431-434
+  obstacle map     np.random.choice(cells, M, replace=False), cell centres             quadrotor_multi.py:304-325
+  o_random goals   N distinct FREE cells, z = uniform(1, 3)                            scenarios/obstacles/o_base.py:69-81
+  sensor noise     obs position = true position + normal(0, pos_norm_std)              sensor_noise.py:100-110
+
+The same checks run on the CPU oracle (-m "not gpu", a few thousand environments) and on the HIP kernels (-m gpu, more of them).
+p-value floors are 1e-4: a wrong range, a clamped tail or a biased choice fails by tens of orders of magnitude.
+"""
+import numpy as np
+import pytest
+from scipy import stats
+
+from quad_swarm_rl_amd import config as qcfg
+
+REW = dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0, quadcol_bin=5.0, quadcol_bin_smooth_max=4.0, quadcol_bin_obst=5.0)
+OPEN = dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW,
+            quads_mode="static_same_goal")
+OBST = dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW,
+            use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_random", obs_repr="xyz_vxyz_R_omega_floor")
+P_MIN = 1e-4
+
+
+def oracle_reset(kw, E, seed):
+    """after reset() of E independent oracle environments: pos [E, N, 3], rot [E, N, 9], goal [E, N, 3], obs [E, N, D], obst_pos [E, M, 2]
+    (state row layout: include/quadswarm.h QS_STATE_STRIDE - pos3 vel3 rot9 omega3 ... goal3)"""
+    from oracle import oracle as orc
+    cfg = qcfg.make_config(num_envs=1, seed=seed, **kw)
+    pos, rot, goal, obs, obst = [], [], [], [], []
+    for e in range(E):
+        env = orc.OracleEnv(cfg, env_global_id=e)
+        o = env.reset()
+        s, _ = env.get_state()
+        pos.append(s[:, 0:3].copy()); rot.append(s[:, 6:15].copy()); goal.append(s[:, 32:35].copy()); obs.append(o)
+        info = env.info()
+        obst.append([[info.obst_pos[k][0], info.obst_pos[k][1]] for k in range(cfg.num_obstacles)])
+        env.close()
+    return cfg, np.array(pos), np.array(rot), np.array(goal), np.array(obs), np.array(obst).reshape(E, -1, 2)
+
+
+def hip_reset(kw, E, seed):
+    from quad_swarm_rl_amd import native
+    cfg = qcfg.make_config(num_envs=E, seed=seed, **kw)
+    N = cfg.num_agents
+    st = native.Stepper(cfg)
+    st.reset()
+    soa = lambda a: np.ascontiguousarray(a.reshape(a.shape[0], E, N).transpose(1, 2, 0)).astype(np.float64)
+    pos, rot, goal = soa(st.to_host("pos")), soa(st.to_host("rot")), soa(st.to_host("goal"))
+    obs = st.to_host("obs").reshape(E, N, -1).astype(np.float64)
+    M = cfg.num_obstacles
+    obst = st.to_host("obst_pos").astype(np.float64).reshape(2, E, M).transpose(1, 2, 0) if cfg.use_obstacles else np.zeros((E, 0, 2))   # [2][E*M] on the device
+    st.close()
+    return cfg, pos, rot, goal, obs, obst
+
+
+def check_spawn_and_yaw(cfg, pos, rot, obs, float_eps):
+    box = cfg.spawn_box
+    spawn = np.array([0.0, 0.0, 2.0])                                  # static_same_goal: every goal and spawn point (scenarios/static_same_goal.py)
+    d = pos.reshape(-1, 3) - spawn
+    assert (np.abs(d[:, :2]) <= box + float_eps).all()
+    for ax in range(2):                                                # uniform(-box, box)
+        assert stats.kstest((d[:, ax] + box) / (2 * box), "uniform").pvalue > P_MIN, ax
+    z = pos.reshape(-1, 3)[:, 2]                                       # 2 + uniform(-2, 2), lifted to 0.75 (quadrotor_single.py:421-423)
+    assert (z >= 0.75 - float_eps).all() and (z <= 2 + box + float_eps).all()
+    free = z > 0.75 + 1e-6
+    lo = 0.75 - 2.0                                                    # the clamp cuts the lower tail of uniform(-box, box): what is left is uniform above it
+    assert stats.kstest((d[free, 2] - lo) / (box - lo), "uniform").pvalue > P_MIN
+    assert abs((~free).mean() - (lo + box) / (2 * box)) < 0.02        # and the clamped share is the tail's probability
+    # yaw: heading (first column of R) within 60 degrees of the direction to the origin, uniform inside that arc
+    r = rot.reshape(-1, 9)
+    yaw = np.arctan2(r[:, 3], r[:, 0])
+    to_origin = np.arctan2(-pos.reshape(-1, 3)[:, 1], -pos.reshape(-1, 3)[:, 0])
+    delta = (yaw - to_origin + np.pi) % (2 * np.pi) - np.pi
+    assert (np.cos(delta) >= 0.5 - 1e-6).all()                         # the rejection criterion holds for every drone
+    assert stats.kstest((delta + np.pi / 3) / (2 * np.pi / 3), "uniform").pvalue > P_MIN
+    # planar rotation: R = yaw rotation exactly
+    np.testing.assert_allclose(r[:, [2, 5, 6, 7]], 0.0, atol=1e-7)
+    np.testing.assert_allclose(r[:, 8], 1.0, atol=1e-7)
+    # sensor noise on the observed position: obs[:, 0:3] = (pos - goal) + normal(0, pos_norm_std)   (uniform part off by default)
+    assert cfg.pos_unif_range == 0.0
+    resid = (obs[..., 0:3].reshape(-1, 3) - d).reshape(-1)
+    assert stats.kstest(resid / cfg.pos_norm_std, "norm").pvalue > P_MIN
+    assert abs(resid.std() / cfg.pos_norm_std - 1.0) < 0.03
+
+
+def check_obstacle_draws(cfg, obst, goal_xyz):
+    E, M = obst.shape[0], cfg.num_obstacles
+    L, W = cfg.obst_area[0], cfg.obst_area[1]
+    assert M == int(cfg.obst_density * L * W) or M > 0
+    xs, ys = np.unique(np.round(obst[..., 0], 6)), np.unique(np.round(obst[..., 1], 6))
+    assert len(xs) == L and len(ys) == W                               # every obstacle sits on a cell centre of the L x W grid
+    np.testing.assert_allclose(np.diff(xs), 1.0, atol=1e-6)           # grid pitch = obstacle-area cell size (quadrotor_multi.py:304-310)
+    ix = np.searchsorted(xs, np.round(obst[..., 0], 6)); iy = np.searchsorted(ys, np.round(obst[..., 1], 6))
+    cell = ix * W + iy
+    assert all(len(set(c)) == M for c in cell)                         # replace=False: M distinct cells per environment
+    counts = np.bincount(cell.reshape(-1), minlength=L * W)
+    assert stats.chisquare(counts).pvalue > P_MIN                      # every cell equally likely
+    # first and last pick are each uniform over the cells too (a partial Fisher-Yates that reuses a slot would skew the later picks)
+    for k in (0, M - 1):
+        assert stats.chisquare(np.bincount(cell[:, k], minlength=L * W)).pvalue > P_MIN, k
+    if goal_xyz is not None:                                           # o_random: goals on N distinct free cells, z = uniform(1, 3)
+        g = np.asarray(goal_xyz)
+        N = g.shape[1]
+        gx, gy = np.searchsorted(xs, np.round(g[..., 0], 6)), np.searchsorted(ys, np.round(g[..., 1], 6))
+        np.testing.assert_allclose(xs[np.clip(gx, 0, L - 1)], g[..., 0], atol=1e-5)
+        np.testing.assert_allclose(ys[np.clip(gy, 0, W - 1)], g[..., 1], atol=1e-5)
+        gcell = gx * W + gy
+        for e in range(E):
+            assert len(set(gcell[e])) == N and not (set(gcell[e]) & set(cell[e]))
+        assert stats.kstest((g[..., 2].reshape(-1) - 1.0) / 2.0, "uniform").pvalue > P_MIN
+        free_share = np.bincount(gcell.reshape(-1), minlength=L * W) / np.maximum(E - counts, 1)   # picks per environment in which the cell was free
+        assert free_share.std() / free_share.mean() < 0.15            # uniform over the FREE cells of each map
+
+
+def test_oracle_philox_draws_follow_the_reference_distributions():
+    cfg, pos, rot, _, obs, _ = oracle_reset(OPEN, 1500, seed=21)
+    check_spawn_and_yaw(cfg, pos, rot, obs, 0.0)
+    cfg, pos, rot, goal, obs, obst = oracle_reset(OBST, 2500, seed=22)
+    check_obstacle_draws(cfg, obst, goal)
+
+
+@pytest.mark.gpu
+def test_hip_philox_draws_follow_the_reference_distributions():
+    cfg, pos, rot, _, obs, _ = hip_reset(OPEN, 4096, seed=31)
+    check_spawn_and_yaw(cfg, pos, rot, obs, 1e-6)
+    cfg, pos, rot, goal, obs, obst = hip_reset(OBST, 4096, seed=32)
+    check_obstacle_draws(cfg, obst, goal)
