@@ -12,6 +12,7 @@ choice without replacement (partial Fisher-Yates), a rejection loop.  HIP and or
   obstacle map     np.random.choice(cells, M, replace=False), cell centres             quadrotor_multi.py:304-325
   o_random goals   N distinct FREE cells, z = uniform(1, 3)                            scenarios/obstacles/o_base.py:69-81
   sensor noise     obs position = true position + normal(0, pos_norm_std)              sensor_noise.py:100-110
+  goal shuffle     np.random.shuffle(goals): every drone -> slot assignment equally likely  scenarios/base.py:151 (static_diff_goal.py)
 
 The same checks run on the CPU oracle (-m "not gpu", a few thousand environments) and on the HIP kernels (-m gpu, more of them).
 p-value floors are 1e-4: a wrong range, a clamped tail or a biased choice fails by tens of orders of magnitude.
@@ -27,6 +28,8 @@ OPEN = dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", u
             quads_mode="static_same_goal")
 OBST = dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW,
             use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_random", obs_repr="xyz_vxyz_R_omega_floor")
+DIFF = dict(num_agents=5, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW,
+            quads_mode="static_diff_goal")
 P_MIN = 1e-4
 
 
@@ -121,11 +124,32 @@ def check_obstacle_draws(cfg, obst, goal_xyz):
         assert free_share.std() / free_share.mean() < 0.15            # uniform over the FREE cells of each map
 
 
+def check_goal_shuffle(goal):
+    """static_diff_goal: the formation's points, shuffled over the drones.  Rank the N goals of an environment canonically (by x, y, z):
+    which rank a given drone receives must be uniform, for every drone (N x N contingency table), whatever the formation."""
+    E, N = goal.shape[0], goal.shape[1]
+    table = np.zeros((N, N))
+    used = 0
+    for e in range(E):
+        g = np.round(goal[e], 4)
+        if len({tuple(r) for r in g}) < N:
+            continue                                                   # degenerate formation (coinciding points): ranks are ambiguous
+        order = np.lexsort((g[:, 2], g[:, 1], g[:, 0]))
+        rank = np.empty(N, dtype=int); rank[order] = np.arange(N)
+        table[np.arange(N), rank] += 1
+        used += 1
+    assert used > 0.8 * E
+    assert stats.chi2_contingency(table).pvalue > P_MIN
+    for i in range(N):
+        assert stats.chisquare(table[i]).pvalue > P_MIN, i
+
+
 def test_oracle_philox_draws_follow_the_reference_distributions():
     cfg, pos, rot, _, obs, _ = oracle_reset(OPEN, 1500, seed=21)
     check_spawn_and_yaw(cfg, pos, rot, obs, 0.0)
     cfg, pos, rot, goal, obs, obst = oracle_reset(OBST, 2500, seed=22)
     check_obstacle_draws(cfg, obst, goal)
+    check_goal_shuffle(oracle_reset(DIFF, 3000, seed=23)[3])
 
 
 @pytest.mark.gpu
@@ -134,3 +158,4 @@ def test_hip_philox_draws_follow_the_reference_distributions():
     check_spawn_and_yaw(cfg, pos, rot, obs, 1e-6)
     cfg, pos, rot, goal, obs, obst = hip_reset(OBST, 4096, seed=32)
     check_obstacle_draws(cfg, obst, goal)
+    check_goal_shuffle(hip_reset(DIFF, 8192, seed=33)[3])
