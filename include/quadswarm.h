@@ -146,16 +146,23 @@ typedef struct qs_buffers {
     void *done;           /* uint8 [E*N] */
     void *rew_info;       /* real  [QS_RI_COUNT, E*N] */
     void *actions;        /* real  [E*N, 4] staging buffer callers may fill instead of passing their own */
-    /* state (SoA, component-major) */
-    void *pos, *vel, *omega;  /* real [3, E*N] */
-    void *rot;                /* real [9, E*N] row-major R */
-    void *thrust_rot_damp, *thrust_cmds_damp, *ou_state; /* real [4, E*N] */
-    void *goal;               /* real [3, E*N] */
-    void *flags;              /* uint32 [E*N] bit0 on_floor, bit1 crashed_floor, bit2 crashed_wall,
+    /* state: WAVE-BLOCKED.  Block b holds the drones of the envs_per_block = 64 / N environments one wavefront steps
+       (envs b * envs_per_block ..., lane = local env * N + drone); inside a block every component of every state array is one
+       row of 64 elements, all rows of a block contiguous (state_block_bytes apart from the next block).  Each pointer below is
+       block 0's first row of its array:
+           element (component c, env e, drone i)  =  ptr + (e / envs_per_block) * state_block_bytes
+                                                         + (c * 64 + (e % envs_per_block) * N + i) * sizeof(element)
+       (quad-swarm-rl_amd/native.py: Stepper.to_host / from_host present them as plain [components, E*N] arrays through
+       qs_state_array_copy).  Why: a wave's 42 state rows are one 11 KB chunk of HBM instead of 42 scattered 256-byte pieces. */
+    void *pos, *vel, *omega;  /* real, 3 components */
+    void *rot;                /* real, 9 components: row-major R */
+    void *thrust_rot_damp, *thrust_cmds_damp, *ou_state; /* real, 4 components */
+    void *goal;               /* real, 3 components */
+    void *flags;              /* uint32, 1 component: bit0 on_floor, bit1 crashed_floor, bit2 crashed_wall,
                                  bit3 crashed_ceiling, bit4 prev_new_wall, bit5 prev_new_ceiling,
                                  bit6 prev_new_room, bit7 obst_hit_prev */
     void *obst_hit_idx;       /* int32 [E*N]: first obstacle hit this step, -1 none (obstacles/utils.py:31-43) */
-    void *col_pair_mask;      /* uint64 [E*N]: bit j set <=> pair (d,j), j>d, within collision_threshold */
+    void *col_pair_mask;      /* uint64, 1 component, wave-blocked like the state: bit j set <=> pair (d,j), j>d, within collision_threshold */
     void *new_pair_mask;      /* uint64 [E*N]: pairs new this step (quadrotor_multi.py:437-438) */
     void *unique_col_mask;    /* uint64 [E]: ids of last_step_unique_collisions (quadrotor_multi.py:440) */
     void *obst_new_mask;      /* uint64 [E]: curr_quad_col (quadrotor_multi.py:467) */
@@ -175,6 +182,8 @@ typedef struct qs_buffers {
     void *obst_density_env;   /* real  [E]: obstacle density of the running episode (statistics only) */
     int32_t obs_dim;
     int32_t real_size;        /* 4 or 8 */
+    int32_t state_block_bytes;/* bytes between the wave blocks of the state arrays */
+    int32_t envs_per_block;   /* 64 / N */
 } qs_buffers;
 
 typedef struct qs_handle qs_handle;
@@ -233,6 +242,9 @@ int qs_set_state(qs_handle *h, int32_t env, const double *state_host, int32_t ti
  * runtime binding of their own, e.g. the ctypes stub of INTEGRATION.md).  Synchronous. */
 int qs_memcpy_d2h(qs_handle *h, void *host_dst, const void *dev_src, size_t bytes);
 int qs_memcpy_h2d(qs_handle *h, void *dev_dst, const void *host_src, size_t bytes);
+/* One wave-blocked state array (a qs_buffers pointer: pos ... col_pair_mask) <-> a plain component-major host array
+ * [comps, E*N] of `elem`-byte elements.  Synchronous. */
+int qs_state_array_copy(qs_handle *h, void *host, void *dev_array, int32_t elem, int32_t comps, int32_t to_device);
 
 /* Check the device NaN flag; returns QS_ERR_NAN_REWARD if set (maps to ValueError('QuadEnv: reward is Nan')). */
 int qs_check_errors(qs_handle *h);

@@ -26,7 +26,19 @@ using namespace qs;
 // single buffer resource: `buffer_load/store vdata, voffset(lane), srsrc, soffset(array + component)` needs one SALU add per
 // access where a flat 64-bit address needs three VALU instructions (about 90 accesses per drone-step; the throughput
 // regime of the single-wave kernels is VALU-bound).  The typed pointers below still point into the block.
-struct StateBlk { char *base; uint32_t bytes, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit; };
+// The per-drone state lives in ONE allocation, wave-blocked: block b holds the drones of the `epb` environments one wave steps
+// (epb = 64 / N, lane = local env * N + drone), and inside a block every component of every state array is one row of 64
+// elements - pos x | pos y | pos z | vel x | ... | flags | pair mask - so that the 42 rows a wave loads and stores each step are one
+// contiguous `block_bytes` chunk (11 KB in float32) instead of 42 rows scattered over 42 component-major arrays.  Measured with
+// the traffic-only kernels of tools/ubench_hbm.hip: 113.7 -> 97.6 us for 2^20 drones.  pos .. pair are byte
+// offsets of an array's first row INSIDE a block; the per-step outputs (newpair, reward, done, ohit) stay flat component-major
+// arrays behind the blocks (absolute offsets) - their consumers read them as plain vectors.
+struct StateBlk { char *base; uint32_t bytes, block_bytes, epb, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit; };
+// element (component q of drone i of env e) of a blocked array, for the code outside the step kernels' buffer-resource views
+template <typename TT> __device__ __forceinline__ TT &blk_at(const StateBlk &b, uint32_t arr, int q, int e, int i, int N) {
+    const int blk = e / (int)b.epb, lane = (e - blk * (int)b.epb) * N + i;
+    return *(TT *)(b.base + (size_t)blk * b.block_bytes + arr + ((size_t)q * 64 + lane) * sizeof(TT));
+}
 
 template <typename real> struct Ptrs {
     StateBlk blk;
@@ -63,8 +75,8 @@ template <typename real> struct Ptrs {
     int64_t tape_len;
 };
 
-// One component-major array inside the state block, seen from one lane: element type T, `row_bytes` between components, this
-// lane's element `lane_off` bytes into a row.
+// One array of the state allocation seen from one lane: element type T, `row_bytes` between components, this lane's element
+// `lane_off` bytes into a row; `off` = scalar offset of the array's first row (for a blocked array: of this wave's block too).
 typedef unsigned int qs_u32x2 __attribute__((ext_vector_type(2)));
 template <typename T> struct BufRow {
     __amdgpu_buffer_rsrc_t r;
@@ -80,7 +92,11 @@ template <typename T> struct BufRow {
     }
 };
 #define QS_BUF_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void *)(p).blk.base, 0, (p).blk.bytes, 0x00020000)
-#define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (p).blk.name, (uint32_t)((T) * sizeof(TYPE)), (uint32_t)((g) * sizeof(TYPE))}
+// blocked state array: the workgroup's block (blockIdx.x: one block = the environments of one workgroup), row pitch 64 elements
+// (a compile-time constant: component offsets fold into the instruction's immediate), lane = position inside the wave
+#define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (uint32_t)(blockIdx.x * (p).blk.block_bytes + (p).blk.name), (uint32_t)(64 * sizeof(TYPE)), (uint32_t)((threadIdx.x & 63) * sizeof(TYPE))}
+// flat component-major array (per-step outputs): row pitch T elements, lane offset = global drone index
+#define QS_ROWF(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (p).blk.name, (uint32_t)((T) * sizeof(TYPE)), (uint32_t)((g) * sizeof(TYPE))}
 
 // (neighbour metric, drone index) as one unsigned key whose order is "smaller metric first, lower index first": the IEEE bit
 // pattern of a float is monotone after flipping the sign bit of non-negatives and all bits of negatives
@@ -866,22 +882,26 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
 #endif
     Drone<real> d;
     real goal[3] = {0, 0, 0}, stale_vel[3];
+    const int es = in_range ? e : 0;   // (inactive lanes read drone 0's slot of a valid env, as before)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) stale_vel[q] = p.vel[q * T + g];
-    d.flags = p.flags[g];
+    for (int q = 0; q < 3; ++q) stale_vel[q] = blk_at<real>(p.blk, p.blk.vel, q, es, in_range ? i : 0, N);
+    d.flags = blk_at<uint32_t>(p.blk, p.blk.flags, 0, es, in_range ? i : 0, N);
     if (FULL && in_range) scen_lds_load<real>(p, L, smem, E, e, le, i, N);
     if (FULL) __syncthreads();
     reset_body<real, FULL, false, true>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);   // writes the obs rows itself
     if (FULL) { __syncthreads(); if (do_reset) scen_lds_store<real>(p, L, smem, E, e, le, i, N); }
     if (do_reset) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = d.pos[q]; p.vel[q * T + g] = 0; p.omega[q * T + g] = 0; p.goal[q * T + g] = goal[q]; }
+        for (int q = 0; q < 3; ++q) {
+            blk_at<real>(p.blk, p.blk.pos, q, e, i, N) = d.pos[q]; blk_at<real>(p.blk, p.blk.vel, q, e, i, N) = 0;
+            blk_at<real>(p.blk, p.blk.omega, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.goal, q, e, i, N) = goal[q];
+        }
 #pragma unroll
-        for (int q = 0; q < 9; ++q) p.rot[q * T + g] = d.rot[q];
+        for (int q = 0; q < 9; ++q) blk_at<real>(p.blk, p.blk.rot, q, e, i, N) = d.rot[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { p.rot_damp[q * T + g] = 0; p.cmds_damp[q * T + g] = 0; p.dist_ring[q * T + g] = 0; }
-        p.flags[g] = d.flags;
-        p.pair_mask[g] = 0;
+        for (int q = 0; q < 4; ++q) { blk_at<real>(p.blk, p.blk.rot_damp, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.cmds_damp, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.ring, q, e, i, N) = 0; }
+        blk_at<uint32_t>(p.blk, p.blk.flags, 0, e, i, N) = d.flags;
+        blk_at<uint64_t>(p.blk, p.blk.pair, 0, e, i, N) = 0;
         p.new_pair_mask[g] = 0;
         p.obst_hit_idx[g] = -1;
         if (c.episode_sums) {
@@ -1012,7 +1032,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c,
 // A snapshot = every per-drone / per-env array of one environment (the list of qs_snapshot_*), packed array after array.
 // ------------------------------------------------------------------------------------------------
 #define QS_REPLAY_MAX_ARR 40
-struct ReplayArr { char *base; uint32_t elem, comps, per_env, off; uint64_t comp_stride; };   // strides / counts in elements, off in bytes
+struct ReplayArr { char *base; uint32_t elem, comps, per_env, off; uint64_t comp_stride; uint32_t group, group_stride; };   // strides / counts in elements, off in bytes; group > 0: wave-blocked array (envs per block, bytes between blocks)
 struct ReplayParams {
     ReplayArr arr[QS_REPLAY_MAX_ARR];
     int32_t narr, N, E, use_obstacles, cp_every, grace_ticks, min_gap, obs_arr, tick_arr, ep_len;   // obs_arr / tick_arr: index of that array in arr[]
@@ -1040,7 +1060,8 @@ __device__ __forceinline__ void replay_copy(const ReplayParams &P, int e, char *
         char *sp = snap + A.off;
         for (int idx = lane; idx < total; idx += QS_WAVE) {
             const int cpt = idx / (int)A.per_env, k = idx - cpt * (int)A.per_env;
-            char *live = A.base + ((size_t)cpt * A.comp_stride + (size_t)e * A.per_env + k) * A.elem;
+            const int gb = A.group ? e / (int)A.group : 0, ge = A.group ? e - gb * (int)A.group : e;
+            char *live = A.base + (size_t)gb * A.group_stride + ((size_t)cpt * A.comp_stride + (size_t)ge * A.per_env + k) * A.elem;
             char *sn = sp + (size_t)idx * A.elem;
             if (A.elem == 8) { if (save) *(uint64_t *)sn = *(const uint64_t *)live; else *(uint64_t *)live = *(const uint64_t *)sn; }
             else if (A.elem == 4) { if (save) *(uint32_t *)sn = *(const uint32_t *)live; else *(uint32_t *)live = *(const uint32_t *)sn; }
@@ -1160,26 +1181,28 @@ __global__ void __launch_bounds__(QS_WAVE) qs_replay_kernel(const ReplayParams P
 // state get/set for one env (qs_get_state / qs_set_state)
 template <typename real>
 __global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf, int32_t *tick_io, int set) {
-    const int i = threadIdx.x, T = E * N;
+    const int i = threadIdx.x;
     if (i >= N) return;
-    const int g = env * N + i;
     double *s = buf + (size_t)i * QS_STATE_STRIDE;
+    const StateBlk &B = p.blk;
+#define QS_S(arr, q) blk_at<real>(B, B.arr, q, env, i, N)
     if (!set) {
-        for (int q = 0; q < 3; ++q) { s[q] = p.pos[q * T + g]; s[3 + q] = p.vel[q * T + g]; s[15 + q] = p.omega[q * T + g]; s[32 + q] = p.goal[q * T + g]; }
-        for (int q = 0; q < 9; ++q) s[6 + q] = p.rot[q * T + g];
-        for (int q = 0; q < 4; ++q) { s[18 + q] = p.rot_damp[q * T + g]; s[22 + q] = p.cmds_damp[q * T + g]; s[26 + q] = p.ou[q * T + g]; }
-        uint32_t f = p.flags[g];
+        for (int q = 0; q < 3; ++q) { s[q] = QS_S(pos, q); s[3 + q] = QS_S(vel, q); s[15 + q] = QS_S(omega, q); s[32 + q] = QS_S(goal, q); }
+        for (int q = 0; q < 9; ++q) s[6 + q] = QS_S(rot, q);
+        for (int q = 0; q < 4; ++q) { s[18 + q] = QS_S(rot_damp, q); s[22 + q] = QS_S(cmds_damp, q); s[26 + q] = QS_S(ou, q); }
+        uint32_t f = blk_at<uint32_t>(B, B.flags, 0, env, i, N);
         s[30] = (f & F_ON_FLOOR) ? 1.0 : 0.0;
         s[31] = (double)((f & F_SVD_MASK) >> F_SVD_SHIFT);
         if (i == 0) *tick_io = p.tick[env];
     } else {
-        for (int q = 0; q < 3; ++q) { p.pos[q * T + g] = (real)s[q]; p.vel[q * T + g] = (real)s[3 + q]; p.omega[q * T + g] = (real)s[15 + q]; p.goal[q * T + g] = (real)s[32 + q]; }
-        for (int q = 0; q < 9; ++q) p.rot[q * T + g] = (real)s[6 + q];
-        for (int q = 0; q < 4; ++q) { p.rot_damp[q * T + g] = (real)s[18 + q]; p.cmds_damp[q * T + g] = (real)s[22 + q]; p.ou[q * T + g] = (real)s[26 + q]; }
-        uint32_t f = p.flags[g] & ~(F_ON_FLOOR | F_SVD_MASK);
+        for (int q = 0; q < 3; ++q) { QS_S(pos, q) = (real)s[q]; QS_S(vel, q) = (real)s[3 + q]; QS_S(omega, q) = (real)s[15 + q]; QS_S(goal, q) = (real)s[32 + q]; }
+        for (int q = 0; q < 9; ++q) QS_S(rot, q) = (real)s[6 + q];
+        for (int q = 0; q < 4; ++q) { QS_S(rot_damp, q) = (real)s[18 + q]; QS_S(cmds_damp, q) = (real)s[22 + q]; QS_S(ou, q) = (real)s[26 + q]; }
+        uint32_t f = blk_at<uint32_t>(B, B.flags, 0, env, i, N) & ~(F_ON_FLOOR | F_SVD_MASK);
         if (s[30] != 0.0) f |= F_ON_FLOOR;
         f |= ((uint32_t)s[31] & 0xffu) << F_SVD_SHIFT;
-        p.flags[g] = f;
+        blk_at<uint32_t>(B, B.flags, 0, env, i, N) = f;
+#undef QS_S
         if (i == 0 && *tick_io >= 0) p.tick[env] = *tick_io;
     }
 }

@@ -46,7 +46,7 @@ struct qs_handle {
     int team = 0;          // waves per workgroup of the team kernels (qs_step_team.inc): 4 generic, 8 (or 4) specialised; 0 = single-wave kernels
     // config-specialised code object (qs_spec_kernels.hip), when one is cached / could be built
     // environment snapshots (qs_snapshot_*): `snap_slots` packed copies of one environment's complete state
-    struct SnapArray { char *base; size_t elem, comps, comp_stride, per_env; int kind; };   // strides / counts in elements; kind: 1 = obs, 2 = episode sums
+    struct SnapArray { char *base; size_t elem, comps, comp_stride, per_env; int kind; size_t group, group_stride; };   // strides / counts in elements; kind: 1 = obs, 2 = episode sums; group > 0: wave-blocked (envs per block, bytes between blocks)
     std::vector<SnapArray> snap_arrays;
     size_t snap_bytes = 0;
     char *snap_pool = nullptr;
@@ -328,19 +328,24 @@ template <typename real> static int create_typed(qs_handle *h) {
     memset(&p, 0, sizeof p);
     int rc;
 #define DA(field, count) if ((rc = dalloc(h, &p.field, (count))) != QS_OK) return rc
-    {   // the state block (StateBlk, qs_kernels.h): one allocation, 256-byte aligned sub-arrays, 32-bit offsets
-        size_t off = 0;
-        auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t EPB = QS_WAVE / N, NBLK = (E + EPB - 1) / EPB;   // environments per wave block, blocks
+    {   // the state allocation (StateBlk, qs_kernels.h): wave-blocked state rows, then the flat per-step outputs; 32-bit offsets
         const size_t R = sizeof(real);
-        const size_t o_pos = carve(3 * T * R), o_vel = carve(3 * T * R), o_rot = carve(9 * T * R), o_omega = carve(3 * T * R), o_rd = carve(4 * T * R),
-                     o_cd = carve(4 * T * R), o_ou = carve(4 * T * R), o_goal = carve(3 * T * R), o_ring = carve(4 * T * R), o_sums = carve(3 * T * R),
-                     o_flags = carve(T * 4), o_pair = carve(T * 8), o_newpair = carve(T * 8), o_reward = carve(T * R), o_done = carve(T), o_ohit = carve(T * 4);
+        size_t row = 0;   // inside a block: every component of every state array is one row of 64 elements
+        auto rows = [&](size_t comps, size_t elem) { size_t o = row; row += comps * 64 * elem; return o; };
+        const size_t o_pos = rows(3, R), o_vel = rows(3, R), o_rot = rows(9, R), o_omega = rows(3, R), o_rd = rows(4, R), o_cd = rows(4, R), o_ou = rows(4, R),
+                     o_goal = rows(3, R), o_ring = rows(4, R), o_sums = rows(3, R), o_flags = rows(1, 4), o_pair = rows(1, 8);
+        const size_t block_bytes = row;
+        size_t off = NBLK * block_bytes;
+        auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_newpair = carve(T * 8), o_reward = carve(T * R), o_done = carve(T), o_ohit = carve(T * 4);
         if (off >= ((size_t)1 << 32)) return fail(QS_ERR_UNSUPPORTED, "per-drone state exceeds the 4 GiB a buffer resource addresses: use fewer envs per handle");
         char *blk = nullptr;
         if ((rc = dalloc(h, &blk, off)) != QS_OK) return rc;
-        p.blk = {blk, (uint32_t)off, (uint32_t)o_pos, (uint32_t)o_vel, (uint32_t)o_rot, (uint32_t)o_omega, (uint32_t)o_rd, (uint32_t)o_cd, (uint32_t)o_ou,
-                 (uint32_t)o_goal, (uint32_t)o_ring, (uint32_t)o_sums, (uint32_t)o_flags, (uint32_t)o_pair, (uint32_t)o_newpair, (uint32_t)o_reward,
+        p.blk = {blk, (uint32_t)off, (uint32_t)block_bytes, (uint32_t)EPB, (uint32_t)o_pos, (uint32_t)o_vel, (uint32_t)o_rot, (uint32_t)o_omega, (uint32_t)o_rd, (uint32_t)o_cd,
+                 (uint32_t)o_ou, (uint32_t)o_goal, (uint32_t)o_ring, (uint32_t)o_sums, (uint32_t)o_flags, (uint32_t)o_pair, (uint32_t)o_newpair, (uint32_t)o_reward,
                  (uint32_t)o_done, (uint32_t)o_ohit};
+        // block 0's first row of each blocked array (what qs_buffers hands out; layout in include/quadswarm.h)
         p.pos = (real *)(blk + o_pos); p.vel = (real *)(blk + o_vel); p.rot = (real *)(blk + o_rot); p.omega = (real *)(blk + o_omega);
         p.rot_damp = (real *)(blk + o_rd); p.cmds_damp = (real *)(blk + o_cd); p.ou = (real *)(blk + o_ou); p.goal = (real *)(blk + o_goal);
         p.dist_ring = (real *)(blk + o_ring); p.dist_sums = (real *)(blk + o_sums); p.flags = (uint32_t *)(blk + o_flags);
@@ -399,22 +404,25 @@ template <typename real> static int create_typed(qs_handle *h) {
     b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters; b.run_sums = p.run_sums; b.ep_sums = p.ep_sums;
     b.obst_count = p.obst_count; b.obst_size_env = p.obst_size_env; b.obst_density_env = p.obst_density_env;
     b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
+    b.state_block_bytes = (int32_t)p.blk.block_bytes; b.envs_per_block = (int32_t)EPB;
     // what a deep copy of one reference env carries (quad_experience_replay.py:99-104 deep-copies the whole env): every
     // per-drone and per-env array except the noise-stream position (step_ctr: a restored env draws fresh noise, as the
     // reference's does from the global numpy stream) and the per-step outputs
     auto &sa = h->snap_arrays;
     sa.clear();
-#define SNAP_T(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), T, N, 0})
-#define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1, 0})
-    SNAP_T(pos, 3); SNAP_T(vel, 3); SNAP_T(rot, 9); SNAP_T(omega, 3); SNAP_T(rot_damp, 4); SNAP_T(cmds_damp, 4); SNAP_T(ou, 4); SNAP_T(goal, 3);
-    SNAP_T(flags, 1); SNAP_T(pair_mask, 1); SNAP_T(new_pair_mask, 1); SNAP_T(obst_hit_idx, 1); SNAP_T(dist_ring, 4); SNAP_T(dist_sums, 3);
+#define SNAP_T(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), T, N, 0, 0, 0})
+#define SNAP_B(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), 64, N, 0, EPB, (size_t)p.blk.block_bytes})   /* wave-blocked state array */
+#define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1, 0, 0, 0})
+    SNAP_B(pos, 3); SNAP_B(vel, 3); SNAP_B(rot, 9); SNAP_B(omega, 3); SNAP_B(rot_damp, 4); SNAP_B(cmds_damp, 4); SNAP_B(ou, 4); SNAP_B(goal, 3);
+    SNAP_B(flags, 1); SNAP_B(pair_mask, 1); SNAP_T(new_pair_mask, 1); SNAP_T(obst_hit_idx, 1); SNAP_B(dist_ring, 4); SNAP_B(dist_sums, 3);
     SNAP_T(run_sums, QS_SUM_COUNT); sa.back().kind = 2;
-    sa.push_back({(char *)p.obs, sizeof(real), 1, T * D, N * D, 1});                     // the observation that goes with the state
+    sa.push_back({(char *)p.obs, sizeof(real), 1, T * D, N * D, 1, 0, 0});                     // the observation that goes with the state
     SNAP_E(unique_col, 1); SNAP_E(obst_new, 1); SNAP_E(room_new, 1); SNAP_E(counters, QS_CNT_COUNT); SNAP_E(tick, 1);
     SNAP_E(scen_real, SR_COUNT); SNAP_E(scen_int, SI_COUNT); SNAP_E(scen_omap, 4); SNAP_E(scenario_id, 1);
     SNAP_E(obst_count, 1); SNAP_E(obst_size_env, 1); SNAP_E(obst_density_env, 1);
-    sa.push_back({(char *)p.obst_pos, sizeof(real), 2, E * (M_ ? M_ : 1), (M_ ? M_ : 1), 0});
+    sa.push_back({(char *)p.obst_pos, sizeof(real), 2, E * (M_ ? M_ : 1), (M_ ? M_ : 1), 0, 0, 0});
 #undef SNAP_T
+#undef SNAP_B
 #undef SNAP_E
     h->snap_bytes = 0;
     for (const auto &a : sa) h->snap_bytes += (a.elem * a.comps * a.per_env + 15) & ~(size_t)15;
@@ -782,6 +790,27 @@ int qs_memcpy_h2d(qs_handle *h, void *dev_dst, const void *host_src, size_t byte
     return QS_OK;
 }
 
+int qs_state_array_copy(qs_handle *h, void *host, void *dev_array, int32_t elem, int32_t comps, int32_t to_device) {
+    if (!h || !host || !dev_array || elem < 1 || comps < 1) return fail(QS_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t E = h->cfg.num_envs, N = h->cfg.num_agents, T = E * N, epb = h->bufs.envs_per_block, pitch = h->bufs.state_block_bytes;
+    const size_t full = E / epb, rem = E - full * epb;   // whole blocks, environments of the last partial one
+    for (int32_t c = 0; c < comps; ++c) {
+        char *dev = (char *)dev_array + (size_t)c * 64 * elem, *hst = (char *)host + (size_t)c * T * elem;
+        const size_t width = epb * N * elem;
+        if (full) {
+            if (to_device) HIP_TRY(hipMemcpy2D(dev, pitch, hst, width, width, full, hipMemcpyHostToDevice));
+            else HIP_TRY(hipMemcpy2D(hst, width, dev, pitch, width, full, hipMemcpyDeviceToHost));
+        }
+        if (rem) {
+            if (to_device) HIP_TRY(hipMemcpy(dev + full * pitch, hst + full * width, rem * N * elem, hipMemcpyHostToDevice));
+            else HIP_TRY(hipMemcpy(hst + full * width, dev + full * pitch, rem * N * elem, hipMemcpyDeviceToHost));
+        }
+    }
+    return QS_OK;
+}
+
 /* debug: phase time stamps (shader clock) of workgroup 0; all zero unless built with -DQS_TIMING */
 // ---- environment snapshots: device-side deep copies of single environments (replay wrapper) ----
 int qs_snapshot_pool(qs_handle *h, int32_t slots) {
@@ -802,7 +831,8 @@ static int snapshot_io(qs_handle *h, int32_t env, int32_t slot, bool save, hipSt
     HIP_TRY(hipSetDevice(h->device));
     char *dst = h->snap_pool + h->snap_bytes * (size_t)slot;
     for (const auto &a : h->snap_arrays) {
-        char *src = a.base + a.elem * a.per_env * (size_t)env;
+        const size_t gb = a.group ? (size_t)env / a.group : 0, ge = a.group ? (size_t)env - gb * a.group : (size_t)env;
+        char *src = a.base + gb * a.group_stride + a.elem * a.per_env * ge;
         const size_t width = a.elem * a.per_env, spitch = a.elem * a.comp_stride;
         if (save) HIP_TRY(hipMemcpy2DAsync(dst, width, src, spitch, width, a.comps, hipMemcpyDeviceToDevice, s));
         else HIP_TRY(hipMemcpy2DAsync(src, spitch, dst, width, width, a.comps, hipMemcpyDeviceToDevice, s));
@@ -837,7 +867,7 @@ int qs_replay_enable(qs_handle *h, double sample_prob) {
         if (P.narr == QS_REPLAY_MAX_ARR) return fail(QS_ERR_UNSUPPORTED, "too many snapshot arrays");
         if (a.kind == 1) P.obs_arr = P.narr;
         if (a.base == (char *)h->pf.tick) P.tick_arr = P.narr;
-        P.arr[P.narr++] = {a.base, (uint32_t)a.elem, (uint32_t)a.comps, (uint32_t)a.per_env, off, (uint64_t)a.comp_stride};
+        P.arr[P.narr++] = {a.base, (uint32_t)a.elem, (uint32_t)a.comps, (uint32_t)a.per_env, off, (uint64_t)a.comp_stride, (uint32_t)a.group, (uint32_t)a.group_stride};
         off += (uint32_t)((a.elem * a.comps * a.per_env + 15) & ~(size_t)15);
     }
     P.snap_bytes = off;

@@ -29,7 +29,8 @@ class QsBuffers(C.Structure):
         "obs", "reward", "done", "rew_info", "actions", "pos", "vel", "omega", "rot", "thrust_rot_damp",
         "thrust_cmds_damp", "ou_state", "goal", "flags", "obst_hit_idx", "col_pair_mask", "new_pair_mask",
         "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_pos", "ep_stats",
-        "ep_counters", "error_flag", "scenario_id", "ep_scenario", "run_sums", "ep_sums", "obst_count", "obst_size_env", "obst_density_env")] + [("obs_dim", C.c_int32), ("real_size", C.c_int32)]
+        "ep_counters", "error_flag", "scenario_id", "ep_scenario", "run_sums", "ep_sums", "obst_count", "obst_size_env", "obst_density_env")] + [
+        ("obs_dim", C.c_int32), ("real_size", C.c_int32), ("state_block_bytes", C.c_int32), ("envs_per_block", C.c_int32)]
 
 
 def build(force=False, verbose=False):
@@ -111,6 +112,7 @@ def lib():
         L.qs_set_state.argtypes = [vp, C.c_int32, C.POINTER(C.c_double), C.c_int32]
         L.qs_memcpy_d2h.argtypes = [vp, vp, vp, C.c_size_t]
         L.qs_memcpy_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+        L.qs_state_array_copy.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32]
         L.qs_check_errors.argtypes = [vp]
         L.qs_set_profiling.argtypes = [vp, C.c_int32]
         L.qs_get_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
@@ -134,7 +136,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
                     "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
-                    "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_check_errors", "qs_set_profiling",
+                    "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_state_array_copy", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor",
                     "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
                     "qs_set_noise_tape", "qs_get_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active"]
@@ -324,20 +326,33 @@ class Stepper:
     def ptr(self, name):
         return getattr(self.bufs, name)
 
+    # state arrays the library keeps wave-blocked (include/quadswarm.h, qs_buffers): host code sees them component-major
+    BLOCKED = frozenset(("pos", "vel", "omega", "rot", "thrust_rot_damp", "thrust_cmds_damp", "ou_state", "goal", "flags", "col_pair_mask"))
+
     def to_host(self, name):
         shape, kind = self._shapes[name]
         out = np.empty(shape, dtype=self._dtype(kind))
-        _check(lib().qs_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr(name)), out.nbytes))
+        if name in self.BLOCKED:
+            _check(lib().qs_state_array_copy(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr(name)), out.dtype.itemsize,
+                                             shape[0] if len(shape) == 2 else 1, 0))
+        else:
+            _check(lib().qs_memcpy_d2h(self._h, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr(name)), out.nbytes))
         return out
 
     def from_host(self, name, arr):
         shape, kind = self._shapes[name]
         a = np.ascontiguousarray(arr, dtype=self._dtype(kind)).reshape(shape)
-        _check(lib().qs_memcpy_h2d(self._h, C.c_void_p(self.ptr(name)), a.ctypes.data_as(C.c_void_p), a.nbytes))
+        if name in self.BLOCKED:
+            _check(lib().qs_state_array_copy(self._h, a.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr(name)), a.dtype.itemsize,
+                                             shape[0] if len(shape) == 2 else 1, 1))
+        else:
+            _check(lib().qs_memcpy_h2d(self._h, C.c_void_p(self.ptr(name)), a.ctypes.data_as(C.c_void_p), a.nbytes))
 
     def tensor(self, name):
         """Zero-copy torch view (device tensor) of a library buffer."""
         import torch
+        if name in self.BLOCKED:
+            raise QsError(f"'{name}' is a wave-blocked state array: use to_host / from_host (or qs_get_state)")
         if name not in self._torch_cache:
             shape, kind = self._shapes[name]
             typestr = {"real": "<f8" if self.real_size == 8 else "<f4", "u1": "|u1", "u4": "<u4", "i4": "<i4", "u8": "<u8"}[kind]
