@@ -11,9 +11,10 @@
  * owned by the library and valid until qs_destroy().
  *
  * E environments x N drones are stepped at once.  Drone d of environment e has flat index e*N+d.
- * All per-drone arrays are struct-of-arrays: component c of a field with C components lives at
- * field[c*E*N + e*N + d] (coalesced across lanes).  Observations are the exception: they are what
- * the policy consumes and are stored row-major [E*N, obs_dim] like the reference returns them.
+ * Per-drone arrays are struct-of-arrays (coalesced across lanes).  Outputs and statistics are component-major: component c
+ * of a field with C components lives at field[c*E*N + e*N + d].  The dynamic STATE (pos ... col_pair_mask) is wave-blocked:
+ * see the comment in qs_buffers and qs_state_array_copy.  Observations are what the policy consumes and are stored
+ * row-major [E*N, obs_dim] like the reference returns them.
  *
  * The same `qs_config` / entry-point shapes are mirrored by the CPU oracle (oracle/quadswarm_oracle.h,
  * test infrastructure only) so parity tests drive both through identical calls.
