@@ -73,6 +73,14 @@ int qs_enc_forward(const float *obs, int32_t B, const qs_enc_params *params, flo
  * this many agents (default 2048; environment QS_ENC_WIDE_MIN; 0 = never).  Returns the previous value; a negative argument only reads. */
 int32_t qs_enc_set_wide_min(int32_t agents);
 
+/* Closed-loop glue of a rollout segment (quad-swarm-rl_amd/rollout.py): one launch before the environment step - trajectory copy of
+ * the observations, act_out[A, 4] = mean[A, 4] + exp(log_std[4]) * N(0, 1) (log_std NULL: the mean itself; Philox4x32-10 keyed by
+ * seed, the device counter and the agent) - and one after it - trajectory copies of rewards / dones, counter += 1.  They replace
+ * eight framework kernels per control step (reference side: Sample Factory's sampler loop around env.step, swarm_rl/train.py). */
+int qs_rollout_pre(const float *obs, float *obs_out, int32_t n_obs, const float *mean, const float *log_std, float *act_out, int32_t A, uint64_t seed,
+                   const uint32_t *counter, void *stream);
+int qs_rollout_post(const float *rew, float *rew_out, const uint8_t *done, uint8_t *done_out, int32_t A, uint32_t *counter, void *stream);
+
 /* `iters` back-to-back forward passes timed with HIP events on `stream` (no host work in between): average ms per pass. */
 int qs_enc_benchmark(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream, int32_t iters, double *avg_ms);
 

@@ -24,6 +24,7 @@ class GaussianActionHead:
         self.bias = torch.zeros(4, device=dev)
         self.log_std = torch.full((4,), -0.5, device=dev)
         self.sample = sample
+        self.seed = seed
 
     def __call__(self, features):
         import torch
@@ -56,9 +57,15 @@ class GraphedRollout:
         self.rewards = torch.empty((steps, A), device=dev)
         self.dones = torch.empty((steps, A), device=dev, dtype=torch.uint8)
         self._fused_head = hasattr(head, "from_mean") and hasattr(head, "weight") and hasattr(encoder, "set_head")
+        self._glue = False
         if self._fused_head:   # the Linear runs in the encoder's epilogue: the [A, 512] features are never written
             encoder.set_head(head.weight, head.bias)
             self._mean = torch.empty((A, 4), device=dev)
+            # ... and sampling + the trajectory copies are two launches of the library's glue kernels instead of eight torch kernels
+            self._glue = isinstance(head, GaussianActionHead) and self.dones.dtype == torch.uint8 and self._done.dtype == torch.uint8
+            if self._glue:
+                self._counter = torch.zeros(1, device=dev, dtype=torch.int32)
+                self._seed = int(getattr(head, "seed", 0)) & 0xffffffffffffffff
         else:
             self._feat = torch.empty((A, encoder.out_dim), device=dev)
         self.graph = None
@@ -76,6 +83,24 @@ class GraphedRollout:
 
     def _step(self, t):
         import torch
+        if self._glue:
+            import ctypes as C
+            from . import policy
+            L = policy.lib()
+            stream = C.c_void_p(torch.cuda.current_stream(self._obs.device).cuda_stream)
+            A = self._obs.shape[0]
+            self.encoder.forward_head(self._obs, head_out=self._mean)
+            log_std = C.c_void_p(self.head.log_std.data_ptr()) if self.head.sample else None
+            rc = L.qs_rollout_pre(C.c_void_p(self._obs.data_ptr()), C.c_void_p(self.obs[t].data_ptr()), self._obs.numel(), C.c_void_p(self._mean.data_ptr()), log_std,
+                                  C.c_void_p(self.actions[t].data_ptr()), A, C.c_uint64(self._seed), C.c_void_p(self._counter.data_ptr()), stream)
+            if rc != 0:
+                raise native.QsError(f"qs_rollout_pre failed ({rc})")
+            self.env.stepper.step(self.actions[t].data_ptr(), stream=torch.cuda.current_stream(self._obs.device))
+            rc = L.qs_rollout_post(C.c_void_p(self._rew.data_ptr()), C.c_void_p(self.rewards[t].data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                   C.c_void_p(self.dones[t].data_ptr()), A, C.c_void_p(self._counter.data_ptr()), stream)
+            if rc != 0:
+                raise native.QsError(f"qs_rollout_post failed ({rc})")
+            return
         self.obs[t].copy_(self._obs)
         if self._fused_head:
             self.encoder.forward_head(self._obs, head_out=self._mean)

@@ -72,3 +72,36 @@ def test_reward_coefficient_updates_reach_a_captured_graph():
         torch.cuda.synchronize()
         env.close()
     assert (rewards[1] < rewards[0] - 1e-4).all()             # -dt * 3 * pos * dist  vs  -dt * pos * dist
+
+
+def test_glue_kernels_sample_gaussian_actions_and_copy_the_trajectory():
+    """qs_rollout_pre / qs_rollout_post (the two launches that replace the framework's copy / randn / exp / mul / add kernels):
+    actions = mean + exp(log_std) * N(0, 1) with fresh noise per step and per replay, trajectory rows = the buffers at that step."""
+    import numpy as np
+    import torch
+    from scipy import stats
+    from quad_swarm_rl_amd import policy, rollout
+    from quad_swarm_rl_amd.env import QuadSwarmVecEnv
+    env = QuadSwarmVecEnv(32, seed=5, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0)
+    env.reset()
+    enc = policy.FusedQuadEncoder(policy.make_reference_encoder(seed=2, nbr_encoder="mean_embed").cuda())
+    head = rollout.GaussianActionHead(sample=True, seed=11)
+    with torch.no_grad():
+        head.weight.zero_(); head.bias.copy_(torch.tensor([0.1, -0.2, 0.3, 0.0], device=head.bias.device))
+        head.log_std.copy_(torch.log(torch.tensor([0.5, 0.25, 1.0, 0.1], device=head.bias.device)))
+    seg = rollout.GraphedRollout(env, enc, head, steps=16)
+    assert seg._glue
+    first = {k: v.clone() for k, v in seg.run().items()}
+    second = {k: v.clone() for k, v in seg.run().items()}
+    torch.cuda.synchronize()
+    acts = torch.cat((first["actions"], second["actions"])).cpu().numpy().reshape(-1, 4)   # 32 steps x 256 agents
+    for j, (mu, sd) in enumerate(((0.1, 0.5), (-0.2, 0.25), (0.3, 1.0), (0.0, 0.1))):
+        z = (acts[:, j] - mu) / sd
+        assert stats.kstest(z, "norm").pvalue > 1e-4, j
+        assert abs(z.std() - 1.0) < 0.05
+    assert not np.array_equal(first["actions"][0].cpu().numpy(), first["actions"][1].cpu().numpy())     # new noise every step ...
+    assert not torch.equal(first["actions"], second["actions"])                                         # ... and every replay
+    assert abs(np.corrcoef(acts[:, 0], acts[:, 1])[0, 1]) < 0.05 and abs(np.corrcoef(acts[:-256, 0], acts[256:, 0])[0, 1]) < 0.05
+    assert torch.equal(second["obs"][0], first["last_obs"])            # the trajectory rows are the live buffers at that step
+    assert torch.isfinite(first["rewards"]).all() and first["dones"].dtype == torch.uint8
+    env.close()
