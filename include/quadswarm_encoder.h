@@ -69,8 +69,10 @@ const char *qs_enc_last_error(void);
  * (qs_enc_last_error()). */
 int qs_enc_forward(const float *obs, int32_t B, const qs_enc_params *params, float *out, void *stream);
 
-/* The mean_embed (and attention) encoders have a second set of kernels with 32 agents per workgroup, taken for batches of at least
- * this many agents (default 2048; environment QS_ENC_WIDE_MIN; 0 = never).  Returns the previous value; a negative argument only reads. */
+/* The mean_embed and attention encoders have a second set of kernels with 32 agents per workgroup (half the weight stream per
+ * agent), taken for batches of at least this many agents.  Default (-1): more agents than 16 x (number of CUs), i.e. as soon as
+ * the 16-agent workgroups would have to share CUs (4097 on MI355X); 0 = never; environment QS_ENC_WIDE_MIN.  Returns the previous
+ * value; an argument below -1 only reads. */
 int32_t qs_enc_set_wide_min(int32_t agents);
 
 /* Closed-loop glue of a rollout segment (quad-swarm-rl_amd/rollout.py): one launch before the environment step - trajectory copy of

@@ -1491,12 +1491,21 @@ static size_t lds_mha(void) {
     return sizeof(uint16_t) * (2 * ENC_TA * ENC_XS + ENC_TA * ENC_XW + 3 * ENC_TA * ENC_YS + 2 * ENC_TA * ENC_OS + ENC_TA * ENC_CS) + sizeof(float) * (4 * 2 * 4 * 16 + ENC_WAVES * 2 * 2 * 16);
 }
 static size_t lds_wide(void) { return sizeof(uint16_t) * ((2 + ENC_WSLOTS) * ENC_WA * ENC_XS + 3 * ENC_WA * ENC_YS + ENC_WA * ENC_YS + ENC_WA * ENC_CS); }
-// batches from this many agents on take the 32-agent workgroups (mean_embed, attention); 0 = never.  QS_ENC_WIDE_MIN / qs_enc_set_wide_min override
 static size_t lds_embed_wide(void) { return sizeof(uint16_t) * (ENC_WSLOTS * ENC_WA * ENC_XS + 3 * ENC_WA * ENC_YS + ENC_WA * ENC_YS); }
 static size_t lds_attn_wide(void) { return sizeof(uint16_t) * (2 * ENC_WA * ENC_XS + 6 * ENC_WA * ENC_YS + ENC_WA * ENC_CS) + sizeof(float) * ENC_WAVES * 3 * ENC_AT * 16; }
-static int g_wide_min = [] { const char *e = getenv("QS_ENC_WIDE_MIN"); return e ? atoi(e) : 2048; }();
-static int wide_min_agents(void) { return g_wide_min; }
-int32_t qs_enc_set_wide_min(int32_t agents) { const int prev = g_wide_min; if (agents >= 0) g_wide_min = agents; return prev; }
+// Batches from this many agents on take the 32-agent workgroups (mean_embed, attention).  Default (-1): more agents than one
+// 16-agent workgroup per CU can hold - up to there every 16-agent workgroup has a CU to itself and its shorter chain wins (measured
+// 8192 / 4096 agents, us: mean_embed 28.4 / 18.9 narrow vs 25.0 / 22.3 wide, attention 76.5 / 51.0 vs 70.1 / 68.2;
+// tools/enc_threshold.sh).  0 = never; QS_ENC_WIDE_MIN / qs_enc_set_wide_min override.
+static int g_wide_min = [] { const char *e = getenv("QS_ENC_WIDE_MIN"); return e ? atoi(e) : -1; }();
+static int wide_min_agents(int dev) {
+    if (g_wide_min >= 0) return g_wide_min;
+    static int cus[64] = {0};
+    if (dev < 0 || dev >= 64) return 4097;
+    if (!cus[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; } cus[dev] = n; }
+    return ENC_TA * cus[dev] + 1;
+}
+int32_t qs_enc_set_wide_min(int32_t agents) { const int prev = g_wide_min; if (agents >= -1) g_wide_min = agents; return prev; }   // -1: the default rule; < -1: read only
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
 size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 
@@ -1554,7 +1563,8 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
             attr_set |= 1ull << dev;
         }
     }
-    const bool wide = wide_min_agents() > 0 && B >= wide_min_agents() && P.num_nbr > 0 && (P.nbr_encoder == ENC_NBR_MEAN_EMBED || att);
+    const int wmin = wide_min_agents(dev);
+    const bool wide = wmin > 0 && B >= wmin && P.num_nbr > 0 && (P.nbr_encoder == ENC_NBR_MEAN_EMBED || att);
     if (wide) {
         // neighbours per pass: the fewest padded neighbour slots, then the fewest passes (1 -> 1; 2, 4 -> 2; 3, 5, 6, 7, 8 -> 3)
         const dim3 grid((B + ENC_WA - 1) / ENC_WA), block(64 * ENC_WAVES);
