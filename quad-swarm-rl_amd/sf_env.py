@@ -178,6 +178,84 @@ class RewardShapingWrapper(_Wrapper):
         return obs, rewards, dones, infos
 
 
+def assemble_batched_infos(finished, n, sums, eps, cnt, scen_ids, rs, obst_density, obst_size, approx, keys, use_obstacles, ep_steps, annealed, infos):
+    """infos[i] = {'true_reward', 'episode_extra_stats'} for the agents of the finished envs, from host copies of the device
+    arrays: sums [25, F*n] (reward-term sums and action moments of the finished episodes), eps [6, F*n] / cnt [11, F] (the env's
+    episode statistics), scen_ids [F], rs (qs_replay_stats dict or None).  What the reference's wrapper stack attaches per agent
+    (quadrotor_multi.py:626-718, quad_experience_replay.py:126-138, reward_shaping.py:85-118); everything that is the same for the
+    agents of an env is built once per env and copied (this runs for E*N agents at once when the episodes of a batch end together)."""
+    from . import config as qcfg
+    nkeys = len(keys) if use_obstacles else 15
+    rew_keys = list(keys[:nkeys])
+    i_main, i_quadcol = rew_keys.index("rewraw_main"), (rew_keys.index("rewraw_quadcol") if "rewraw_quadcol" in rew_keys else -1)
+    i_pos, i_crash = rew_keys.index("rew_pos"), rew_keys.index("rew_crash")
+    sums_rows = np.ascontiguousarray(sums[:nkeys].T).tolist()        # per agent: the reward-term sums as Python floats
+    dist_rows = np.ascontiguousarray(eps[:3].T).tolist()
+    for f, e in enumerate(finished):
+        e = int(e)
+        sl = slice(f * n, (f + 1) * n)
+        scenario_name = qcfg.SCENARIO_CLASS_NAMES[int(scen_ids[f])]
+        name = scenario_name[9:]
+        replayed_episode = rs is not None and bool(rs["ep_was_replay"][e])
+        if replayed_episode:
+            base = {"num_collisions_replay": int(cnt[0, f]), "num_collisions_obst_replay": int(cnt[7, f])}
+        else:   # env-level part of assemble_episode_extra_stats (env.py); the per-agent distances are added below
+            ok = np.logical_and(eps[4, sl], eps[5, sl])
+            succ = float(np.sum(np.logical_and(ok, eps[3, sl])) / n)
+            dead = float(np.sum(np.logical_and(ok, 1 - eps[3, sl])) / n)
+            col, ncol, ocol = float(1.0 - np.sum(ok) / n), float(1.0 - np.sum(eps[4, sl]) / n), float(1.0 - np.sum(eps[5, sl]) / n)
+            c = [int(x) for x in cnt[:, f]]
+            base = {"num_collisions": c[0], "num_collisions_with_room": c[3], "num_collisions_with_floor": c[4], "num_collisions_with_wall": c[5],
+                    "num_collisions_with_ceiling": c[6], "num_collisions_after_settle": c[1], f"{name}/num_collisions": c[1],
+                    "num_collisions_final_5_s": c[2], f"{name}/num_collisions_final_5_s": c[2],
+                    "distance_to_goal_1s": 0.0, "distance_to_goal_3s": 0.0, "distance_to_goal_5s": 0.0,
+                    f"{name}/distance_to_goal_1s": 0.0, f"{name}/distance_to_goal_3s": 0.0, f"{name}/distance_to_goal_5s": 0.0,
+                    "metric/agent_success_rate": succ, f"{name}/agent_success_rate": succ, "metric/agent_deadlock_rate": dead, f"{name}/agent_deadlock_rate": dead,
+                    "metric/agent_col_rate": col, f"{name}/agent_col_rate": col, "metric/agent_neighbor_col_rate": ncol, f"{name}/agent_neighbor_col_rate": ncol,
+                    "metric/agent_obst_col_rate": ocol, f"{name}/agent_obst_col_rate": ocol}
+            if use_obstacles:
+                base.update({"num_collisions_obst_quad": c[7], "num_collisions_obst_quad_after_settle": c[8], f"{name}/num_collisions_obst": c[7],
+                             "num_collisions_obst_quad_3_5": c[9], f"{name}/num_collisions_obst_quad_3_5": c[9], "num_collisions_obst_quad_5": c[10],
+                             f"{name}/num_collisions_obst_quad_5": c[10]})
+        if rs is not None:
+            ep, rp, nb = int(rs["episodes"][e]), int(rs["replayed"][e]), int(rs["buffer_len"][e])
+            base.update({"replay/replay_rate": rp / ep, "replay/new_episode_rate": (ep - rp) / ep, "replay/replay_buffer_size": nb,
+                         "replay/avg_replayed": (int(rs["replayed_sum"][e]) / nb) if nb else 0,
+                         "replay/obst_density": float(obst_density[e]), "replay/obst_size": float(obst_size[e])})
+        for key in rew_keys:      # placeholders keep the key order of the reference's dicts: env stats, replay stats, reward sums, z_* keys
+            base[key] = 0.0
+        base["z_approx_total_training_steps"] = approx
+        k_pos, k_crash = f"{scenario_name}/rew_pos", f"{scenario_name}/rew_crash"
+        base[k_pos] = base[k_crash] = 0.0
+        # action moments over agents x steps of the episode (np.mean / np.std of reward_shaping.py:103-108); a replayed episode
+        # starts at its checkpoint's tick and is shorter than ep_len + 1 steps
+        count = float((int(rs["ep_steps"][e]) if rs is not None else ep_steps) * n)
+        a1, a2 = sums[17:21, sl].sum(axis=1) / count, sums[21:25, sl].sum(axis=1) / count
+        a_std = np.sqrt(np.maximum(a2 - a1 * a1, 0.0))
+        for q in range(4):
+            base[f"z_action{q}_mean"], base[f"z_action{q}_std"] = float(a1[q]), float(a_std[q])
+        for key, val in annealed:
+            base[key] = val
+        dist_keys = None if replayed_episode else ("distance_to_goal_1s", "distance_to_goal_3s", "distance_to_goal_5s",
+                                                   f"{name}/distance_to_goal_1s", f"{name}/distance_to_goal_3s", f"{name}/distance_to_goal_5s")
+        for k in range(n):
+            col = f * n + k
+            row = sums_rows[col]
+            true_reward = row[i_main] + (1000 * row[i_quadcol] if i_quadcol >= 0 else 0)
+            extra = dict(base)
+            if dist_keys is not None:
+                d1, d3, d5 = dist_rows[col]
+                extra[dist_keys[0]] = extra[dist_keys[3]] = d1
+                extra[dist_keys[1]] = extra[dist_keys[4]] = d3
+                extra[dist_keys[2]] = extra[dist_keys[5]] = d5
+            extra.update(zip(rew_keys, row))
+            extra["rewraw_main"] = true_reward
+            extra[k_pos], extra[k_crash] = row[i_pos], row[i_crash]
+            info = infos[e * n + k]
+            info["true_reward"] = true_reward
+            info["episode_extra_stats"] = extra
+
+
 class BatchedQuadSwarm:
     """E environments x N drones behind one object with the batched-sampling shape of Sample Factory (num_agents = E*N,
     device tensors in and out) and the semantics of the reference's wrapper stack - ExperienceReplayWrapper
@@ -263,7 +341,7 @@ class BatchedQuadSwarm:
                 self._episode_infos(finished, infos)
             # every environment's tick after this step (a replayed episode starts at its checkpoint's tick): next possible end
             self._steps_to_done = int(self._ep_steps - st.to_host("tick").max())
-        return {"obs": obs}, rew, done.bool(), self._truncated, infos
+        return {"obs": obs}, rew, done.view(torch.bool), self._truncated, infos   # the uint8 0 / 1 buffer reinterpreted: no kernel, no allocation
 
     def _episode_infos(self, finished, infos):
         """What the wrapper stack attaches at an episode end - the env's own episode_extra_stats (quadrotor_multi.py:626-718, or
@@ -286,45 +364,13 @@ class BatchedQuadSwarm:
         if rs is not None:   # what the wrapper calls curr_obst_density / curr_obst_size: the values of the episode that starts now
             obst_density, obst_size = st.to_host("obst_density_env"), st.to_host("obst_size_env")
         approx = self.training_info.get("approx_total_training_steps", 0)
-        for f, e in enumerate(finished):
-            sl = slice(f * n, (f + 1) * n)
-            scenario_name = qcfg.SCENARIO_CLASS_NAMES[int(scen_ids[f])]
-            if rs is not None and rs["ep_was_replay"][e]:
-                env_stats = [{"num_collisions_replay": int(cnt[0, f]), "num_collisions_obst_replay": int(cnt[7, f])} for _ in range(n)]
-            else:
-                env_stats = assemble_episode_extra_stats(eps[:, sl], cnt[:, f], scenario_name[9:], n, bool(self.vec.cfg.use_obstacles))
-            if rs is not None:
-                ep, rp, nb = int(rs["episodes"][e]), int(rs["replayed"][e]), int(rs["buffer_len"][e])
-                replay_stats = {"replay/replay_rate": rp / ep, "replay/new_episode_rate": (ep - rp) / ep, "replay/replay_buffer_size": nb,
-                                "replay/avg_replayed": (int(rs["replayed_sum"][e]) / nb) if nb else 0,
-                                "replay/obst_density": float(obst_density[e]), "replay/obst_size": float(obst_size[e])}
-            # action moments over agents x steps of the episode (np.mean / np.std of reward_shaping.py:103-108); a replayed episode
-            # starts at its checkpoint's tick and is shorter than ep_len + 1 steps
-            count = float((int(rs["ep_steps"][e]) if rs is not None else self._ep_steps) * n)
-            a1, a2 = sums[17:21, sl].sum(axis=1) / count, sums[21:25, sl].sum(axis=1) / count
-            a_std = np.sqrt(np.maximum(a2 - a1 * a1, 0.0))
-            for k in range(n):
-                i, col = e * n + k, f * n + k
-                cum = {key: float(sums[j, col]) for j, key in enumerate(self._keys) if self.vec.cfg.use_obstacles or j < 15}
-                true_reward = cum["rewraw_main"] + 1000 * cum.get("rewraw_quadcol", 0)
-                cum["rewraw_main"] = true_reward
-                extra = dict(env_stats[k])
-                if rs is not None:
-                    extra.update(replay_stats)
-                extra.update(cum)
-                extra["z_approx_total_training_steps"] = approx
-                for rew_key in ("rew_pos", "rew_crash"):
-                    extra[f"{scenario_name}/{rew_key}"] = cum[rew_key]
-                for q in range(4):
-                    extra[f"z_action{q}_mean"], extra[f"z_action{q}_std"] = float(a1[q]), float(a_std[q])
-                infos[i]["true_reward"] = true_reward
-                infos[i]["episode_extra_stats"] = extra
+        annealed = []
         if self.annealing:   # :111-118, once per step on which episodes ended (same values for every agent)
             for sched in self.annealing:
                 self.rew_coeff[sched.coeff_name] = min(sched.final_value * approx / sched.anneal_env_steps, sched.final_value)
-                for e in finished:
-                    for i in range(e * n, (e + 1) * n):
-                        infos[i]["episode_extra_stats"][f"z_anneal_{sched.coeff_name}"] = self.rew_coeff[sched.coeff_name]
+                annealed.append((f"z_anneal_{sched.coeff_name}", self.rew_coeff[sched.coeff_name]))
+        assemble_batched_infos(finished, n, sums, eps, cnt, scen_ids, rs, obst_density if rs is not None else None, obst_size if rs is not None else None,
+                               approx, self._keys, bool(self.vec.cfg.use_obstacles), self._ep_steps, annealed, infos)
 
     def close(self):
         self.vec.close()
