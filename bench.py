@@ -162,6 +162,37 @@ def c5_record(run_training):
         return {"status": "failed", "error": f"{type(exc).__name__}: {exc}"}
 
 
+def closed_loop_record(device):
+    """The device-resident stand-in for config 5's sampling loop: [fused attention encoder -> Gaussian action head -> env step] on the
+    C2 batch, 32 control steps per HIP-graph replay (quad-swarm-rl_amd/rollout.py).  Random-init policy weights of the
+    published architecture (QuadMultiEncoder, attention neighbour encoder, 6 neighbours); no learner."""
+    import torch
+    try:
+        from quad_swarm_rl_amd import policy, rollout
+        from quad_swarm_rl_amd.env import QuadSwarmVecEnv
+        env = QuadSwarmVecEnv(1024, device=device, seed=0, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, use_downwash=True,
+                              collision_falloff_radius=4.0, write_rew_info=False)
+        env.reset()
+        enc = policy.FusedQuadEncoder(policy.make_reference_encoder(seed=0, nbr_encoder="attention").cuda(device), device=device)
+        seg = rollout.GraphedRollout(env, enc, rollout.GaussianActionHead(device=device, sample=True), steps=32)
+        for _ in range(3):
+            seg.run()
+        torch.cuda.synchronize(device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        ev0.record()
+        for _ in range(reps):
+            seg.run()
+        ev1.record()
+        torch.cuda.synchronize(device)
+        us = ev0.elapsed_time(ev1) * 1e3 / (reps * 32)
+        env.close()
+        return {"what": "encoder (attention, bf16 MFMA) -> sampled action -> env step, one HIP graph of 32 control steps, 1024 envs x 8 drones",
+                "us_per_control_step": us, "env_steps_per_s": 1024 * 8 * 2 / (us * 1e-6)}
+    except Exception as exc:   # noqa: BLE001 - an optional extra must not cost the bench line
+        return {"status": "failed", "error": f"{type(exc).__name__}: {exc}"}
+
+
 def pmc_traffic(workload, num_envs, kernel):
     """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC pass (profiles/rNN_pmc_traffic.json, produced by
     tools/pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units and gfx950 corrections of MI355X_MICROARCH.md);
@@ -195,6 +226,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--no-c5-train", action="store_true", help="where sample_factory imports: do not run the C5 training (tools/train_c5.py)")
     ap.add_argument("--no-f64", action="store_true", help="skip the f64 line (same workload through the float64 kernels)")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip config.c5.closed_loop_without_sample_factory (encoder -> action -> step as a HIP graph)")
     ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a workload keyword (python literal)")
     ap.add_argument("--graph", type=int, default=0, help="headline mode: step the timed region as open-loop rollouts of this many steps per "
@@ -371,7 +403,8 @@ def main():
                        "secondary": secondary,
                        "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and not use_gather else "one launch per control step",
                        "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info),
-                       "c5": c5_record(not args.no_c5_train) if world == 1 else None,
+                       "c5": dict(c5_record(not args.no_c5_train), closed_loop_without_sample_factory=closed_loop_record(local_rank)) if world == 1 and not args.no_secondary and not args.no_closed_loop
+                       else (c5_record(not args.no_c5_train) if world == 1 else None),
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(workload, E, kernel_name), "kernel": kernel_name,

@@ -13,6 +13,6 @@ for line in sys.stdin:
 WL=${WL:-c2}; ENVS=${ENVS:-131072}
 for flags in "$@"; do
   if [ "$flags" = default ]; then unset QS_SPEC_EXTRA_FLAGS; else export QS_SPEC_EXTRA_FLAGS="$flags"; fi
-  python bench.py --workload $WL --envs-per-gpu $ENVS --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 2>&1 | python -c "$fmt" "$WL E=$ENVS [$flags]" | tee -a $out
+  python bench.py --workload $WL --envs-per-gpu $ENVS --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 --no-closed-loop 2>&1 | python -c "$fmt" "$WL E=$ENVS [$flags]" | tee -a $out
 done
 unset QS_SPEC_EXTRA_FLAGS

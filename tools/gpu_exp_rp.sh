@@ -14,10 +14,10 @@ for spec in "c2 131072" "c3 131072" "c4 32768"; do
   set -- $spec
   for rp in 16 32 64; do
     export QS_OBS_RP=$rp
-    python bench.py --workload $1 --envs-per-gpu $2 --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 2>&1 | python -c "$fmt" "$1 E=$2 rows_per_pass=$rp" | tee -a $out
+    python bench.py --workload $1 --envs-per-gpu $2 --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 --no-closed-loop 2>&1 | python -c "$fmt" "$1 E=$2 rows_per_pass=$rp" | tee -a $out
   done
   unset QS_OBS_RP
 done
 export QS_SPEC_EXTRA_FLAGS="-DQS_EXP_NOFLUSH"
-python bench.py --workload c2 --envs-per-gpu 131072 --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 2>&1 | python -c "$fmt" "c2 E=131072 rows_per_pass=16 NOFLUSH" | tee -a $out
+python bench.py --workload c2 --envs-per-gpu 131072 --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 --no-closed-loop 2>&1 | python -c "$fmt" "c2 E=131072 rows_per_pass=16 NOFLUSH" | tee -a $out
 unset QS_SPEC_EXTRA_FLAGS

@@ -12,8 +12,8 @@ out=gpurun_out/exp_c4_${tag}.txt; : > $out
 for team in 4 8 0; do for flags in default "-DQS_EXP_NOBIG"; do
   export QS_TEAM=$team; if [ "$flags" = default ]; then unset QS_SPEC_EXTRA_FLAGS; else export QS_SPEC_EXTRA_FLAGS="$flags"; fi
   [ $team = 0 ] && [ "$flags" != default ] && continue
-  python bench.py --workload c4 --cpu-seconds 0 --steps 2000 --warmup 100 --rollout-steps 0 --profile-steps 0 --no-f64 2>&1 | python -c "$fmt" "c4 512 envs QS_TEAM=$team [$flags]" | tee -a $out
+  python bench.py --workload c4 --cpu-seconds 0 --steps 2000 --warmup 100 --rollout-steps 0 --profile-steps 0 --no-f64 --no-closed-loop 2>&1 | python -c "$fmt" "c4 512 envs QS_TEAM=$team [$flags]" | tee -a $out
 done; done
 unset QS_TEAM QS_SPEC_EXTRA_FLAGS
-for team in 8 4 0; do export QS_TEAM=$team; python bench.py --workload c2 --cpu-seconds 0 --steps 2000 --warmup 100 --rollout-steps 0 --profile-steps 0 --no-f64 2>&1 | python -c "$fmt" "c2 1024 envs QS_TEAM=$team" | tee -a $out; done
+for team in 8 4 0; do export QS_TEAM=$team; python bench.py --workload c2 --cpu-seconds 0 --steps 2000 --warmup 100 --rollout-steps 0 --profile-steps 0 --no-f64 --no-closed-loop 2>&1 | python -c "$fmt" "c2 1024 envs QS_TEAM=$team" | tee -a $out; done
 unset QS_TEAM

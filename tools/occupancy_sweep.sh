@@ -15,7 +15,7 @@ for spec in "c2 131072" "c3 131072" "c4 32768"; do
   set -- $spec
   for occ in default 0 3 4 5; do
     if [ $occ = default ]; then unset QS_SPEC_EXTRA_FLAGS; else export QS_SPEC_EXTRA_FLAGS="-DQS_WAVES_PER_EU=$occ"; fi
-    python bench.py --workload $1 --envs-per-gpu $2 --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 2>&1 | python -c "$fmt" "$1 E=$2 waves_per_eu=$occ" | tee -a $out
+    python bench.py --workload $1 --envs-per-gpu $2 --cpu-seconds 0 --steps 200 --warmup 20 --rollout-steps 0 --profile-steps 0 --no-f64 --no-closed-loop 2>&1 | python -c "$fmt" "$1 E=$2 waves_per_eu=$occ" | tee -a $out
   done
 done
 unset QS_SPEC_EXTRA_FLAGS

@@ -2,14 +2,14 @@
 # usage: tools/pmc.sh <tag> <workload> [bench args...]   (run on the GPU box through gpurun)
 # rocprofv3 PMC passes of the step kernel, each in its own run with --kernel-trace only (the node pool refuses PMC together
 # with other trace domains).  Writes gpurun_out/pmc_<tag>_summary.txt and gpurun_out/pmc_<tag>_traffic.json
-# (per-launch means; FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3).  --no-f64: the float64 line of bench.py runs a kernel
+# (per-launch means; FETCH_SIZE / WRITE_SIZE are reported in KiB by rocprofv3).  --no-f64 --no-closed-loop: the float64 line of bench.py runs a kernel
 # of the same name with twice the bytes, which would be averaged into the float32 kernel's counters.
 tag=$1; wl=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for pmc in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   n=$(echo $pmc | cut -c1-14 | tr " " "_")
-  rocprofv3 --kernel-trace --pmc $pmc -d /tmp/rocprof_pmc_${tag}_$n -o p --output-format csv -- python $R/bench.py --workload $wl --steps 200 --warmup 20 --profile-steps 10 --rollout-steps 0 --cpu-seconds 0 --no-f64 "$@" > $R/gpurun_out/pmc_${tag}_$n.out 2> $R/gpurun_out/pmc_${tag}_$n.err
+  rocprofv3 --kernel-trace --pmc $pmc -d /tmp/rocprof_pmc_${tag}_$n -o p --output-format csv -- python $R/bench.py --workload $wl --steps 200 --warmup 20 --profile-steps 10 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop "$@" > $R/gpurun_out/pmc_${tag}_$n.out 2> $R/gpurun_out/pmc_${tag}_$n.err
 done
 python - <<PY
 import csv, collections, glob, json
