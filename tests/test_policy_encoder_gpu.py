@@ -61,9 +61,11 @@ def test_fused_encoder_matches_torch(shape, batch):
     obs = (torch.rand((batch, D), device="cuda", generator=g) * 2 - 1) * torch.tensor([3.0] * 3 + [1.0] * (D - 3), device="cuda")
     with torch.no_grad():
         want32, want16 = ref(obs), bf16_emulation(ref, obs)
-    got = fused(obs)
+    got = fused(obs).clone()
+    again = fused(obs)
     torch.cuda.synchronize()
     assert got.shape == (batch, 512) and torch.isfinite(got).all()
+    assert torch.equal(got, again)                                     # run-to-run identical, also with two workgroups per CU
     # bf16 tolerance against the fp32 module; much tighter against the bf16-rounded restatement of the same arithmetic
     assert (got - want32).abs().max().item() < 6e-2, (got - want32).abs().max().item()
     assert (got - want16).abs().max().item() < 8e-3, (got - want16).abs().max().item()
@@ -91,8 +93,10 @@ def test_wide_workgroup_kernels_match_torch_and_the_narrow_kernels(shape, batch,
     prev = policy.lib().qs_enc_set_wide_min(1)
     try:
         wide = fused(obs).clone()
+        assert torch.equal(fused(obs), wide)                           # run-to-run identical
         policy.lib().qs_enc_set_wide_min(0)
         narrow = fused(obs).clone()
+        assert torch.equal(fused(obs), narrow)
     finally:
         policy.lib().qs_enc_set_wide_min(prev)
     torch.cuda.synchronize()
@@ -212,9 +216,11 @@ def test_fused_multi_head_attention_encoder_matches_torch(shape, batch, sim2real
     obs = (torch.rand((batch, D), device="cuda", generator=g) * 2 - 1) * torch.tensor([3.0] * 3 + [1.0] * (D - 3), device="cuda")
     with torch.no_grad():
         want32, want16 = ref(obs), mha_bf16_emulation(ref, obs)
-    got = fused(obs)
+    got = fused(obs).clone()
+    again = fused(obs)
     torch.cuda.synchronize()
     assert got.shape == (batch, 256 if sim2real else 512) and torch.isfinite(got).all()
+    assert torch.equal(got, again)
     assert (got - want32).abs().max().item() < 8e-2, (got - want32).abs().max().item()
     assert (got - want16).abs().max().item() < 2e-2, (got - want16).abs().max().item()
     assert (got - want16).abs().mean().item() < 5e-4, (got - want16).abs().mean().item()
