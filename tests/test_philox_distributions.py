@@ -13,6 +13,8 @@ choice without replacement (partial Fisher-Yates), a rejection loop.  HIP and or
   o_random goals   N distinct FREE cells, z = uniform(1, 3)                            scenarios/obstacles/o_base.py:69-81
   sensor noise     obs position = true position + normal(0, pos_norm_std)              sensor_noise.py:100-110
   goal shuffle     np.random.shuffle(goals): every drone -> slot assignment equally likely  scenarios/base.py:151 (static_diff_goal.py)
+  domain random    obst_density = choice(arange(min, max, 0.05)), obst_size = choice(arange(min, max, 0.1)) per episode
+                                                                                       swarm_rl/env_wrappers/quad_experience_replay.py:75-88,:106-118
 
 The same checks run on the CPU oracle (-m "not gpu", a few thousand environments) and on the HIP kernels (-m gpu, more of them).
 p-value floors are 1e-4: a wrong range, a clamped tail or a biased choice fails by tens of orders of magnitude.
@@ -30,6 +32,8 @@ OBST = dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", u
             use_obstacles=True, obst_density=0.2, obst_size=0.6, obst_spawn_area=(8.0, 8.0), quads_mode="o_random", obs_repr="xyz_vxyz_R_omega_floor")
 DIFF = dict(num_agents=5, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0, rew_coeff=REW,
             quads_mode="static_diff_goal")
+DRND = dict(OBST, domain_random=True, obst_density_random=True, obst_size_random=True, obst_density_min=0.05, obst_density_max=0.2,
+            obst_size_min=0.3, obst_size_max=0.6)
 P_MIN = 1e-4
 
 
@@ -144,12 +148,32 @@ def check_goal_shuffle(goal):
         assert stats.chisquare(table[i]).pvalue > P_MIN, i
 
 
+def check_domain_random(cfg, counts, sizes=None):
+    """per-episode obstacle count (= int(cells * density) of the drawn density) and size: uniform over the configured choice lists"""
+    nd, ns = cfg.dr_num_density, cfg.dr_num_size
+    allowed = [cfg.dr_obst_count[k] for k in range(nd)]
+    assert nd >= 2 and len(set(allowed)) == nd
+    assert set(np.unique(counts)) == set(allowed)
+    assert stats.chisquare([int((counts == a).sum()) for a in allowed]).pvalue > P_MIN
+    if sizes is not None:
+        choices = np.array([cfg.dr_size[k] for k in range(ns)])
+        idx = np.abs(sizes[:, None] - choices[None, :]).argmin(axis=1)
+        np.testing.assert_allclose(sizes, choices[idx], rtol=1e-6)
+        assert stats.chisquare(np.bincount(idx, minlength=ns)).pvalue > P_MIN
+        table = np.zeros((nd, ns))                                     # the two draws are independent
+        for c_, i_ in zip(counts, idx):
+            table[allowed.index(int(c_)), i_] += 1
+        assert stats.chi2_contingency(table).pvalue > P_MIN
+
+
 def test_oracle_philox_draws_follow_the_reference_distributions():
     cfg, pos, rot, _, obs, _ = oracle_reset(OPEN, 1500, seed=21)
     check_spawn_and_yaw(cfg, pos, rot, obs, 0.0)
     cfg, pos, rot, goal, obs, obst = oracle_reset(OBST, 2500, seed=22)
     check_obstacle_draws(cfg, obst, goal)
     check_goal_shuffle(oracle_reset(DIFF, 3000, seed=23)[3])
+    cfg, _, _, _, _, obst = oracle_reset(DRND, 2000, seed=24)
+    check_domain_random(cfg, (obst[..., 0] < 1e5).sum(axis=1))          # unused obstacle slots are parked at (1e6, 1e6)
 
 
 @pytest.mark.gpu
@@ -159,3 +183,12 @@ def test_hip_philox_draws_follow_the_reference_distributions():
     cfg, pos, rot, goal, obs, obst = hip_reset(OBST, 4096, seed=32)
     check_obstacle_draws(cfg, obst, goal)
     check_goal_shuffle(hip_reset(DIFF, 8192, seed=33)[3])
+    from quad_swarm_rl_amd import native
+    cfg = qcfg.make_config(num_envs=4096, seed=34, **DRND)
+    st = native.Stepper(cfg)
+    st.reset()
+    counts, sizes = st.to_host("obst_count").astype(np.int64), st.to_host("obst_size_env").astype(np.float64)
+    parked = (st.to_host("obst_pos").reshape(2, 4096, cfg.num_obstacles)[0] < 1e5).sum(axis=1)
+    st.close()
+    np.testing.assert_array_equal(parked, counts)
+    check_domain_random(cfg, counts, sizes)
