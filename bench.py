@@ -10,11 +10,15 @@ U(-1,1)^4 actions that are already resident in HBM.
 N = 1 (BASELINE.json configs[1], "C2", the configuration the metric is quoted on): 8 drones x 1024 envs,
 static_same_goal, 6 visible neighbours (obs 54), downwash on, Numba-path semantics, sensor + thrust noise on,
 auto-resets included.
-N > 1 (BASELINE.json configs[3], "C4"): 32 drones x 512 envs PER GPU (4096 envs at 8 GPUs), swarm_vs_swarm, and ONE
-RCCL all-gather of the observations after every step INSIDE the timed region (north_star: "a single RCCL gather of
-observations over xGMI per rollout step"), double-buffered so that gather(t) overlaps step(t+1).  The rate of the same
-shards stepping with no collective is measured right after and reported as config.independent_shards
-(--no-gather makes it the headline; --workload / --envs-per-gpu override the shape).
+N > 1 (BASELINE.json configs[3], "C4"): 32 drones x 512 envs PER GPU (4096 envs at 8 GPUs), swarm_vs_swarm, and the exchange
+of the observation rows after every step INSIDE the timed region (north_star: "a single ... gather of observations over xGMI
+per rollout step"): every rank ends each step with the rows of all ranks.  [step -> exchange] x 64 is ONE captured HIP graph per
+rank (quad-swarm-rl_amd/parallel.py: ObsExchange); exchange(t) runs on a second stream under step(t+1); the wire format is
+bfloat16 (--wire f32 for bit-exact rows).  --transport peer: the library's peer-store exchange over hipIpc-mapped windows
+(include/quadswarm_exchange.h), rccl: RCCL all-gather of the packed rows, auto (default): peer if its start-up self-check against
+the RCCL all-gather passes on every rank, else rccl; torch: round 2's eager per-step all_gather (comparison).  The rate of the
+same shards stepping with no exchange is measured right after and reported as config.secondary (--no-gather makes it the
+headline; --workload / --envs-per-gpu override the shape).
 
 Timing.  W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize.  `value` / `ms_per_step` come from
 HIP events recorded on the launch stream right after the opening synchronize and right after the K-th step (for the
@@ -209,6 +213,44 @@ def pmc_traffic(workload, num_envs, kernel):
     return None
 
 
+def make_exchange(st, world, rank, transport, wire, dist, dev, info):
+    """The observation exchange of this rank (quad-swarm-rl_amd/parallel.py).  auto / peer: the peer-store transport, kept only if
+    EVERY rank could map its peers' windows and passed the start-up self-check (synthetic rows through both window slots); otherwise
+    all ranks fall back to the RCCL all-gather together."""
+    import torch
+    from quad_swarm_rl_amd import parallel
+
+    def all_agree(flag):
+        if world == 1:
+            return flag
+        t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    if transport in ("auto", "peer"):
+        ex, why = None, ""
+        try:
+            ex = parallel.ObsExchange(st, world, rank, transport="peer", wire=wire, hold=False)
+        except Exception as exc:   # noqa: BLE001 - recorded; the fallback is a different transport, not a different result
+            why = f"{type(exc).__name__}: {exc}"
+        attached = all_agree(ex is not None)
+        ok = False
+        if attached:
+            try:
+                ok, why = ex.self_check()
+            except Exception as exc:   # noqa: BLE001
+                ok, why = False, f"{type(exc).__name__}: {exc}"
+            ok = all_agree(ok)
+        info["peer_self_check"] = "passed on every rank" if ok else ("failed" + (f" here: {why}" if why else " on another rank"))
+        if ok:
+            info["transport"] = "peer"
+            return ex
+        if ex is not None:
+            ex.close()
+    info["transport"] = "rccl"
+    return parallel.ObsExchange(st, world, rank, transport="rccl", wire=wire, hold=False)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,7 +265,11 @@ def main():
     ap.add_argument("--gather", action="store_true", help="(default at N>1) ONE RCCL all-gather of the observations after every step inside the timed region")
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL obs all-gather path even at N=1 (exercises the multi-GPU code on a 1-GPU box)")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
-    ap.add_argument("--no-overlap", action="store_true", help="gather on the compute stream instead of overlapping it with the next step")
+    ap.add_argument("--no-overlap", action="store_true", help="--transport torch: gather on the compute stream instead of overlapping it with the next step")
+    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "torch"], help="observation exchange (see the module docstring)")
+    ap.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="wire format of the exchanged rows")
+    ap.add_argument("--segment", type=int, default=64, help="control steps per captured [step -> exchange] graph (0 = eager launches)")
+    ap.add_argument("--no-variants", action="store_true", help="skip config.variants (shaped / rew_info / downwash-off / seeds 1, 2 runs of the same workload)")
     ap.add_argument("--no-c5-train", action="store_true", help="where sample_factory imports: do not run the C5 training (tools/train_c5.py)")
     ap.add_argument("--no-f64", action="store_true", help="skip the f64 line (same workload through the float64 kernels)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip config.c5.closed_loop_without_sample_factory (encoder -> action -> step as a HIP graph)")
@@ -276,10 +322,14 @@ def main():
     actions = (torch.rand((ring, T, 4), device=dev, generator=gen, dtype=torch.float32) * 2.0 - 1.0).contiguous()
     aptr, astride = actions.data_ptr(), T * 4 * 4
     obs = st.tensor("obs")
-    gather_obj = None
+    gather_obj, exchange, xinfo = None, None, {"requested": args.transport, "wire": args.wire}
     if dist is not None and (use_gather or not args.no_secondary):
         from quad_swarm_rl_amd import parallel
-        gather_obj = parallel.ObsGather(obs, overlap=not args.no_overlap)   # ONE RCCL all-gather of the obs per rollout step
+        if args.transport == "torch":   # round 2's transport: eager torch.distributed all_gather of the float32 rows, per step
+            gather_obj = parallel.ObsGather(obs, overlap=not args.no_overlap)
+            xinfo["transport"] = "torch"
+        else:
+            exchange = make_exchange(st, world, rank, args.transport, args.wire, dist, dev, xinfo)
 
     def run(stepper, base_ptr, stride, k, offset=0, gather=None):
         if args.graph > 0 and gather is None:
@@ -299,17 +349,44 @@ def main():
         if gather is not None:
             gather.drain()   # the launch stream waits for the in-flight collectives: the closing event sees them
 
-    def timed(stepper, base_ptr, stride, warmup, k, gather=None):
+    seg = 0
+    if exchange is not None:   # [step -> exchange] x seg as one HIP graph (captured before any timed region; its warm-up steps are untimed)
+        seg = min(args.segment, ring) & ~1
+        if seg >= 2:
+            exchange.capture([aptr + t * astride for t in range(seg)])
+
+    def run_exchange(k):
+        """exactly k control steps, each followed by the exchange of its rows: whole segments as graph replays, the rest eagerly"""
+        done_steps = 0
+        if seg >= 2:
+            while done_steps + seg <= k:
+                exchange.replay()
+                done_steps += seg
+        for t in range(k - done_steps):
+            exchange.step(aptr + (t % ring) * astride)
+        exchange.drain()     # the stepping stream waits for the last exchanges: the closing event sees them
+
+    def timed(stepper, base_ptr, stride, warmup, k, gather=None, xchg=False):
         """W untimed steps, then exactly K steps bracketed by barrier + synchronize; HIP events on the launch stream right inside
         the bracket.  Returns (device-event seconds, host-clock seconds), each the MAX over ranks."""
-        run(stepper, base_ptr, stride, warmup, 0, gather)
+        if xchg:
+            run_exchange(warmup)
+            exchange.align(aptr)            # an even number of steps issued: the timed region can start with a replay
+        else:
+            if exchange is not None:
+                exchange.drain()
+                stepper.set_obs_target(None)
+            run(stepper, base_ptr, stride, warmup, 0, gather)
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(stream)
-        run(stepper, base_ptr, stride, k, warmup, gather)
+        if xchg:
+            run_exchange(k)
+        else:
+            run(stepper, base_ptr, stride, k, warmup, gather)
         ev1.record(stream)
         if dist is not None:
             dist.barrier()
@@ -322,10 +399,20 @@ def main():
             devs, host = (float(x) for x in tmax.tolist())
         return devs, host
 
-    st.reset(stream=stream)
-    head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None)
+    if exchange is not None:
+        exchange.reset()
+    else:
+        st.reset(stream=stream)
+    head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None, xchg=use_gather and exchange is not None)
     st.check_errors()
-    gather_desc = "rccl all_gather_into_tensor of the obs per step" + ("" if args.no_overlap else ", double-buffered: gather(t) overlaps step(t+1)")
+    if exchange is not None:
+        wire_b = 2 if args.wire == "bf16" else 4
+        gather_desc = (f"{xinfo.get('transport')} transport, {args.wire} wire: every rank receives the rows of all ranks after each step; "
+                       + (f"[step -> exchange] x {seg} per captured HIP graph" if seg >= 2 else "eager launches") + ", exchange(t) on a second stream under step(t+1)")
+        xinfo["status"] = exchange.status()
+    else:
+        wire_b = 4
+        gather_desc = "torch.distributed all_gather_into_tensor of the float32 obs per step (eager)" + ("" if args.no_overlap else ", double-buffered: gather(t) overlaps step(t+1)")
 
     # N>1 / --force-gather: the other variant with the same bracketing (independent shards when the gather is the headline, and
     # the other way round); its step-kernel-only region is also where the kernel duration of the roofline comes from
@@ -333,15 +420,20 @@ def main():
     kernel_region_s, kernel_region_steps = (None, 0) if use_gather else (head_dev, args.steps)
     if dist is not None and not args.no_secondary:
         sk = max(args.steps, 50) if use_gather else min(max(args.steps, 50), 1000)
-        sdev, shost = timed(st, aptr, astride, min(args.warmup, 50), sk, None if use_gather else gather_obj)
+        sdev, shost = timed(st, aptr, astride, min(args.warmup, 50), sk, None if use_gather else gather_obj, xchg=(not use_gather) and exchange is not None)
         secondary = {"value": world * T * 2 * sk / sdev, "unit": "env-steps/s", "ms_per_step": 1e3 * sdev / sk, "steps": sk,
                      "host_clock_ms_per_step": 1e3 * shost / sk,
                      "what": "independent shards: no data-path collective in the timed region" if use_gather else gather_desc}
         if use_gather:
             kernel_region_s, kernel_region_steps = sdev, sk
+            secondary["exchange_cost_us_per_step"] = 1e6 * (head_dev / args.steps - sdev / sk)
     if kernel_region_s is None:   # gather headline without secondary: a short step-only region for the roofline
         kernel_region_steps = max(args.steps, 50)
         kernel_region_s, _ = timed(st, aptr, astride, 10, kernel_region_steps, None)
+    if exchange is not None:
+        exchange.drain()
+        torch.cuda.synchronize()
+        st.set_obs_target(None)
 
     # extra: the same workload as open-loop rollouts (pre-generated actions, K control steps per launch)
     rollout = None
@@ -364,7 +456,40 @@ def main():
     kernel_ms, launches = st.kernel_time()
     st.set_profiling(False)
     kernel_name, flavor = st.kernel_name, ("config-specialised, " if st.specialized else "generic, ") + f"{st.waves_per_workgroup} wave{'s' if st.waves_per_workgroup > 1 else ''} per workgroup"
+    specialized = bool(st.specialized)
+    if exchange is not None:
+        exchange.close()
+        exchange = None
     st.close()
+
+    # the same workload as the callers of the boundary run it (seeds 0 / 1 / 2 with the median, downwash off; VERDICT r02:
+    # the reward-shaping sums the Sample Factory env keeps on the device, and the infos['rewards'] matrix), same bracketing, HIP events
+    variants = None
+    if world == 1 and not args.no_variants and args.graph == 0:
+        def quick(seed=0, kw_over=None, extra_bytes=0, **cfg_over):
+            k2 = dict(kw)
+            k2.update(kw_over or {})
+            c2 = qcfg.make_config(num_envs=E, seed=seed, env_id_offset=rank * E, precision="f32", **dict(dict(write_rew_info=args.rew_info), **cfg_over), **k2)
+            s2 = native.Stepper(c2, device=local_rank)
+            s2.reset(stream=stream)
+            n = min(max(args.steps, 200), 2000)
+            d, _ = timed(s2, aptr, astride, 100, n)
+            s2.check_errors()
+            rec = {"value": T * 2 * n / d, "kernel_avg_us": 1e6 * d / n, "steps": n, "specialized": bool(s2.specialized),
+                   "algorithmic_bytes_per_drone_step": ALGO_BYTES_PER_DRONE_STEP[workload] + extra_bytes}
+            rec["achieved_GBs"] = rec["algorithmic_bytes_per_drone_step"] * T / (d / n) / 1e9
+            s2.close()
+            return rec
+        seeds = [T * 2 * args.steps / head_dev, quick(seed=1)["value"], quick(seed=2)["value"]]
+        variants = {
+            "seeds_0_1_2": seeds, "seeds_median": float(np.median(seeds)),
+            # QuadsRewardShapingWrapper on the device (swarm_rl/env_wrappers/reward_shaping.py:69-83): 25 per-episode sums per drone,
+            # read-modify-write = +200 B per drone-step; what sf_env.BatchedQuadSwarm always runs
+            "shaped_episode_sums": quick(episode_sums=True, extra_bytes=200),
+            # + the 17 infos['rewards'] terms of every step (quadrotor_single.py:68-85, quadrotor_multi.py:533-540): +68 B
+            "shaped_episode_sums_and_rew_info": quick(episode_sums=True, write_rew_info=True, extra_bytes=268),
+            "downwash_off": quick(kw_over=dict(use_downwash=False)),
+        }
 
     # the same workload through the float64 instantiation (the one whose free-running flags are bit-exact against the oracle)
     f64 = None
@@ -399,16 +524,17 @@ def main():
                        "host_clock": {"ms_per_step": 1e3 * head_host / args.steps, "value": world * T * 2 * args.steps / head_host,
                                       "note": "perf_counter over the same K steps incl. the closing barrier + synchronize"},
                        "obs_gather": gather_desc if use_gather else ("none: env shards are independent, no data-path collective (--no-gather)" if world > 1 else "none"),
-                       "gather_bytes_per_gpu_per_step": (world - 1) * T * D * 4 if use_gather else 0,
+                       "gather_bytes_per_gpu_per_step": (world - 1) * T * D * wire_b if use_gather else 0,
+                       "exchange": xinfo if (use_gather or secondary) else None,
                        "secondary": secondary,
                        "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and not use_gather else "one launch per control step",
-                       "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info),
+                       "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info), "variants": variants,
                        "c5": dict(c5_record(not args.no_c5_train), closed_loop_without_sample_factory=closed_loop_record(local_rank)) if world == 1 and not args.no_secondary and not args.no_closed_loop
                        else (c5_record(not args.no_c5_train) if world == 1 else None),
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(workload, E, kernel_name), "kernel": kernel_name,
-                         "kernel_flavor": flavor, "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": kernel_region_steps,
+                         "kernel_flavor": flavor, "specialized": specialized, "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": kernel_region_steps,
                          "kernel_avg_us_event_pair_per_launch": kernel_ms * 1e3, "event_pair_launches": launches,
                          "algorithmic_bytes_per_launch": algo * T},
         }

@@ -227,6 +227,15 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
 int qs_sync(qs_handle *h, void *stream);
 int qs_get_buffers(qs_handle *h, qs_buffers *out);
 
+/* Redirect the observation output: qs_step / qs_step_many / qs_reset calls issued after this one write their observation rows
+ * (real [E*N, obs_dim] row-major, as QuadrotorEnvMulti.step returns them, quadrotor_multi.py:598-607) to obs_dev instead of
+ * qs_buffers.obs; NULL restores the default.  Host-side state only (the pointer is a kernel argument of each launch), so
+ * launches captured into a HIP graph keep the target they were recorded with.  Used by the multi-GPU exchange
+ * (quadswarm_exchange.h): consecutive steps alternate between two staging buffers, so that the rows of step t can leave over
+ * xGMI while step t+1 writes the other buffer.  Not available together with the device-side replay wrapper, whose
+ * snapshots hold qs_buffers.obs (QS_ERR_UNSUPPORTED). */
+int qs_set_obs_target(qs_handle *h, void *obs_dev);
+
 /* Push new reward coefficients (the SF reward-shaping wrapper mutates env.rew_coeff,
  * swarm_rl/env_wrappers/reward_shaping.py:57-59,111-118). */
 int qs_set_reward_coeffs(qs_handle *h, const double *coeffs /* [QS_REW_COUNT] */);

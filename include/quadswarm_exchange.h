@@ -1,0 +1,94 @@
+/*
+ * quadswarm_exchange.h - C ABI of the observation exchange between environment shards (BASELINE.json
+ * configs[3]: "sharded across 8xMI355X with ... obs gather").
+ *
+ * The reference (Zhehui-Huang/quad-swarm-rl) has no multi-GPU path and no collective anywhere: there
+ * is no reference interface to replace here.  What this header serves is north_star's sharding of independent environments
+ * over the GPUs of one node, one process per GPU, where after every control step each rank needs the observation rows of all
+ * ranks - the rows `QuadrotorEnvMulti.step()` returns (gym_art/quadrotor_multi/quadrotor_multi.py:413-724), concatenated over
+ * the shards in rank order.
+ *
+ * Transport: PEER STORES.  Every rank owns a receive window (hipMalloc'd, exported with hipIpcGetMemHandle, mapped by the peers
+ * with hipIpcOpenMemHandle); after a step, ONE kernel per rank reads the rank's own rows once and stores them - as float32
+ * or rounded to bfloat16 (round-to-nearest-even; the fused policy encoder rounds its input to bf16 anyway) - into slot
+ * [seq & 1][rank] of EVERY rank's window, over the 7 point-to-point xGMI links of a GPU concurrently, and then raises a
+ * per-source sequence flag in each window.  No collective launch, no host round trip, no staging copy on the receiver; the
+ * kernel runs on its own stream under the next control step.  Flow control is a second flag per consumer ("ack": highest
+ * sequence number the rank has finished reading), so a window slot is never overwritten while a peer still reads it.
+ *
+ * Per-link arithmetic: C4 shard = 16384 drones x 54 columns; 3.54 MB per link and step in float32, 1.77 MB in
+ * bfloat16; at ~77 GB/s per direction and link that is 46 us / 23 us against a ~20 us step.
+ *
+ * Sequence numbers live in device memory and are advanced by the kernels themselves, so that push / wait / release can be
+ * captured into a HIP graph and replayed (an even number of control steps per graph keeps the slot parity).
+ *
+ * All waits are bounded (QS_XCHG_TIMEOUT_MS of the device wall clock): a missing peer raises the status word instead of
+ * hanging the GPU.
+ */
+#ifndef QUADSWARM_EXCHANGE_H
+#define QUADSWARM_EXCHANGE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_XCHG_MAX_RANKS 16
+#define QS_XCHG_HANDLE_BYTES 64      /* sizeof(hipIpcMemHandle_t) */
+#define QS_XCHG_EXPORT_BYTES (2 * QS_XCHG_HANDLE_BYTES + 16)   /* data window handle, flag window handle, pid + device */
+#define QS_XCHG_TIMEOUT_MS 2000
+
+enum { QS_WIRE_F32 = 0, QS_WIRE_BF16 = 1 };
+/* bits of the status word (qs_xchg_status) */
+enum { QS_XCHG_ERR_ACK_TIMEOUT = 1, QS_XCHG_ERR_ARRIVE_TIMEOUT = 2 };
+
+typedef struct qs_xchg qs_xchg;
+
+/* One endpoint: `rows` observation rows of `cols` float32 columns per rank, `world` ranks, this one is `rank`.  Allocates on
+ * HIP device `device`: the receive window [2 slots][world][rows][cols] of the wire type, the flag window, and two float32
+ * staging buffers [rows][cols] the stepper can write its observations to (qs_set_obs_target, quadswarm.h) so that the push of
+ * step t reads a buffer step t+1 does not touch. */
+int qs_xchg_create(int device, int world, int rank, int64_t rows, int32_t cols, int wire, qs_xchg **out);
+int qs_xchg_destroy(qs_xchg *x);
+
+/* Export this endpoint's windows for the other processes: QS_XCHG_EXPORT_BYTES opaque bytes (two hipIpcMemHandle_t + owner
+ * pid / device).  The callers exchange the blobs of all ranks by any means (torch.distributed all_gather, a pipe, a file). */
+int qs_xchg_export(qs_xchg *x, void *blob_out);
+/* Map the peers' windows: blobs = [world][QS_XCHG_EXPORT_BYTES] in rank order (the own entry is ignored).  A blob of the
+ * calling process itself (several endpoints in one process) is rejected: wire those with qs_xchg_attach_local. */
+int qs_xchg_attach(qs_xchg *x, const void *blobs);
+/* In-process wiring: endpoint `peer` (same process, any device with peer access) is rank `peer_rank` of x's group. */
+int qs_xchg_attach_local(qs_xchg *x, int peer_rank, qs_xchg *peer);
+
+/* float32 staging buffer `slot` (0 / 1) [rows][cols], and the gathered rows of slot `slot`: [world*rows][cols] of the wire type. */
+void *qs_xchg_staging(qs_xchg *x, int slot);
+void *qs_xchg_gathered(qs_xchg *x, int slot);
+
+/* Producer side, asynchronous on `stream`: seq = ++(device counter); wait (bounded) until every destination has released what
+ * slot seq & 1 held before; store src[rows][cols] (float32; NULL = staging[seq & 1]) into slot [seq & 1][rank] of every rank's
+ * window in the wire type; raise arrive[seq & 1][rank] = seq in every window. */
+int qs_xchg_push(qs_xchg *x, const void *src_f32, void *stream);
+/* Consumer side: seq = ++(device counter); returns (stream-ordered) once arrive[seq & 1][r] >= seq for every rank r: kernels
+ * behind it on `stream` may read qs_xchg_gathered(x, seq & 1). */
+int qs_xchg_wait(qs_xchg *x, void *stream);
+/* Consumer side, after the last reader of the slot has been enqueued on `stream`: tell every peer that the sequence number of
+ * the last qs_xchg_wait has been consumed (their push of seq + 2 may overwrite the slot). */
+int qs_xchg_release(qs_xchg *x, void *stream);
+/* qs_xchg_wait + qs_xchg_release as ONE launch, for a consumer that does not read the slot in place. */
+int qs_xchg_wait_release(qs_xchg *x, void *stream);
+
+/* Synchronous: out[0] = status bits (0 = ok), out[1] = pushes, out[2] = waits, out[3] = releases so far. */
+int qs_xchg_status(qs_xchg *x, int64_t out[4]);
+
+/* Plain converter on `stream`: n float32 elements -> wire type (the packing step of the RCCL transport, which all-gathers the
+ * packed rows with ncclAllGather; also what the tests compare the peer-store path against). */
+int qs_obs_pack(const void *src_f32, void *dst, int64_t n, int wire, void *stream);
+
+const char *qs_xchg_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUADSWARM_EXCHANGE_H */

@@ -59,6 +59,7 @@ struct qs_handle {
     std::vector<void *> allocs;
     qs_buffers bufs;
     void *d_actions = nullptr;
+    void *obs_target = nullptr;   // qs_set_obs_target: where the next launches write their observation rows (nullptr = bufs.obs)
     double *d_state_buf = nullptr;
     int32_t *d_tick_io = nullptr;
     // cached hipGraph of a K-step rollout (qs_step_many): K identical step-kernel nodes
@@ -593,19 +594,21 @@ static int launch_reset(qs_handle *h, hipStream_t s) {
         if (e != hipSuccess) return fail(QS_ERR_HIP, std::string("tape reset kernel: ") + hipGetErrorString(e));
         return QS_OK;
     }
+    Ptrs<float> pf = h->pf;   // this launch's pointers: the observation rows go to the target of qs_set_obs_target, if one is set
+    if (h->obs_target) pf.obs = (float *)h->obs_target;
     if (h->spec_reset) {
-        Ptrs<double> pd; memcpy(&pd, &h->pf, sizeof pd);
-        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&h->pf, &h->lds, &h->epb};
+        Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
+        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, &h->lds, &h->epb};
         HIP_TRY(hipModuleLaunchKernel(h->spec_reset, h->blocks, 1, 1, QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         return QS_OK;
     }
     if (h->real_size == 8) {
-        Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
+        Ptrs<double> p; memcpy(&p, &pf, sizeof p);
         if (h->full) hipLaunchKernelGGL((qs_reset_kernel<double, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
         else hipLaunchKernelGGL((qs_reset_kernel<double, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
     } else {
-        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<float, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, h->lds, h->epb);
-        else hipLaunchKernelGGL((qs_reset_kernel<float, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, h->pf, h->lds, h->epb);
+        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<float, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, pf, h->lds, h->epb);
+        else hipLaunchKernelGGL((qs_reset_kernel<float, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, pf, h->lds, h->epb);
     }
     HIP_TRY(hipGetLastError());
     return QS_OK;
@@ -645,9 +648,11 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
     }
+    Ptrs<float> pf = h->pf;   // this launch's pointers (qs_set_obs_target)
+    if (h->obs_target) pf.obs = (float *)h->obs_target;
     if (h->spec_step) {
-        Ptrs<double> pd; memcpy(&pd, &h->pf, sizeof pd);
-        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&h->pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
+        Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
+        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
         HIP_TRY(hipModuleLaunchKernel(ksteps == 1 ? h->spec_step : h->spec_rollout, h->blocks, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
@@ -663,10 +668,10 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
             else { if (h->full) QS_LAUNCH(qs_rollout_kernel_full, QS_WAVE, CONSTS, PTRS, TYPE, ksteps); else QS_LAUNCH(qs_rollout_kernel, QS_WAVE, CONSTS, PTRS, TYPE, ksteps); } \
         } } while (0)
     if (h->real_size == 8) {
-        Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
+        Ptrs<double> p; memcpy(&p, &pf, sizeof p);
         QS_LAUNCH_ALL(h->kd, p, double);
     } else {
-        QS_LAUNCH_ALL(h->kf, h->pf, float);
+        QS_LAUNCH_ALL(h->kf, pf, float);
     }
 #undef QS_LAUNCH_ALL
 #undef QS_LAUNCH
@@ -721,6 +726,14 @@ int qs_sync(qs_handle *h, void *stream) {
 int qs_get_buffers(qs_handle *h, qs_buffers *out) {
     if (!h || !out) return fail(QS_ERR_INVALID, "null argument");
     *out = h->bufs;
+    return QS_OK;
+}
+
+int qs_set_obs_target(qs_handle *h, void *obs_dev) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    if (obs_dev && h->replay_on) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_target: the device-side replay wrapper restores observations into qs_buffers.obs");
+    if (obs_dev && h->d_tape) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_target: not available while a noise tape is set");
+    h->obs_target = obs_dev;
     return QS_OK;
 }
 
@@ -854,6 +867,7 @@ int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *str
 int qs_replay_enable(qs_handle *h, double sample_prob) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     if (h->replay_on) return fail(QS_ERR_INVALID, "replay is already enabled on this handle");
+    if (h->obs_target) return fail(QS_ERR_UNSUPPORTED, "qs_replay_enable: the replay wrapper restores observations into qs_buffers.obs (reset qs_set_obs_target first)");
     if (!h->cfg.episode_sums) return fail(QS_ERR_INVALID, "qs_replay_enable needs a handle created with episode_sums = 1 (per-episode crash reward)");
     if (!(sample_prob >= 0.0 && sample_prob <= 1.0)) return fail(QS_ERR_INVALID, "sample_prob must be in [0, 1]");
     HIP_TRY(hipSetDevice(h->device));

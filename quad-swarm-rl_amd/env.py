@@ -79,6 +79,12 @@ class QuadSwarmVecEnv:
         self._pushed_coeff = [self.rew_coeff[k] for k in qcfg.REW_COEFF_KEYS]
         self.scenario = _Scenario(self.cfg, self.stepper)
         self._t = self.stepper.tensor
+        self.exchange = None   # parallel.ObsExchange when this env is one shard of a multi-GPU batch whose rows are exchanged
+
+    def attach_exchange(self, exchange):
+        """From now on every reset / step writes its observation rows into the exchange's staging buffers and sends them to the other
+        shards (parallel.ObsExchange); reset() / step() return this shard's float32 rows, `exchange.latest()` the rows of all shards."""
+        self.exchange = exchange
 
     def _sync_rew_coeff(self):
         cur = [float(self.rew_coeff[k]) for k in qcfg.REW_COEFF_KEYS]
@@ -88,6 +94,11 @@ class QuadSwarmVecEnv:
 
     def reset(self, env_mask=None):
         import torch
+        if self.exchange is not None:
+            if env_mask is not None:
+                raise ValueError("masked resets are not available on a shard whose observations are exchanged")
+            self.exchange.reset()
+            return self.exchange.local_rows()
         self.stepper.reset(env_mask, stream=torch.cuda.current_stream(self.stepper.device))
         return self._t("obs")
 
@@ -96,6 +107,9 @@ class QuadSwarmVecEnv:
         self._sync_rew_coeff()
         assert actions.is_cuda and actions.is_contiguous() and actions.numel() == self.num_agents * 4
         assert actions.element_size() == self.stepper.real_size, "actions dtype must match the stepper precision"
+        if self.exchange is not None:
+            self.exchange.step(actions.data_ptr())
+            return self.exchange.local_rows(), self._t("reward"), self._t("done"), None
         self.stepper.step(actions.data_ptr(), stream=torch.cuda.current_stream(self.stepper.device))
         return self._t("obs"), self._t("reward"), self._t("done"), None
 
@@ -113,6 +127,9 @@ class QuadSwarmVecEnv:
         return self._t("ep_sums")
 
     def close(self):
+        if self.exchange is not None:
+            self.exchange.close()
+            self.exchange = None
         self.stepper.close()
 
 

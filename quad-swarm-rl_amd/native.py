@@ -15,10 +15,11 @@ from . import config as qcfg
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("QS_LIB", os.path.join(CSRC, "libquadswarm_hip.so"))   # QS_LIB: A/B builds (tools only)
-SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_tape_kernels.hip"), os.path.join(CSRC, "qs_kernels.h"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_step_team.inc"),
+SOURCES = [os.path.join(CSRC, "quadswarm_hip.hip"), os.path.join(CSRC, "qs_tape_kernels.hip"), os.path.join(CSRC, "qs_exchange.hip"),
+           os.path.join(CSRC, "qs_kernels.h"), os.path.join(CSRC, "qs_step_kernel.inc"), os.path.join(CSRC, "qs_step_team.inc"),
            os.path.join(CSRC, "qs_device.h"),
            os.path.join(CSRC, "qs_scenarios.h"),
-           os.path.join(os.path.dirname(HERE), "include", "quadswarm.h")]
+           os.path.join(os.path.dirname(HERE), "include", "quadswarm.h"), os.path.join(os.path.dirname(HERE), "include", "quadswarm_exchange.h")]
 
 QS_OK = 0
 QS_ERR_NAN_REWARD = -3
@@ -40,21 +41,22 @@ def build(force=False, verbose=False):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-    objs = [os.path.join(CSRC, "quadswarm_hip.o"), os.path.join(CSRC, "qs_tape_kernels.o")]
+    objs = [os.path.join(CSRC, "quadswarm_hip.o"), os.path.join(CSRC, "qs_tape_kernels.o"), os.path.join(CSRC, "qs_exchange.o")]
     # the noise-tape flavour replays the reference's float64 arithmetic: no FMA contraction there (NumPy has none)
     cmds = [base + ["-c", SOURCES[0], "-o", objs[0]], base + ["-ffp-contract=off", "-c", SOURCES[1], "-o", objs[1]],
+            base + ["-c", SOURCES[2], "-o", objs[2]],
             [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs]
     procs = []
-    for cmd in cmds[:2]:
+    for cmd in cmds[:-1]:
         if verbose:
             print(" ".join(cmd))
         procs.append(subprocess.Popen(cmd))
-    for pr, cmd in zip(procs, cmds[:2]):
+    for pr, cmd in zip(procs, cmds[:-1]):
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     if verbose:
-        print(" ".join(cmds[2]))
-    subprocess.check_call(cmds[2])
+        print(" ".join(cmds[-1]))
+    subprocess.check_call(cmds[-1])
     for o in objs:
         os.remove(o)
     return LIB_PATH
@@ -128,6 +130,24 @@ def lib():
         L.qs_replay_set_active.argtypes = [vp, C.POINTER(C.c_uint8)]
         L.qs_set_noise_tape.argtypes = [vp, C.POINTER(C.c_double), C.c_int64]
         L.qs_get_tape_pos.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.qs_set_obs_target.argtypes = [vp, vp]
+        # observation exchange between env shards (include/quadswarm_exchange.h)
+        L.qs_xchg_last_error.restype = C.c_char_p
+        L.qs_xchg_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int32, C.c_int, C.POINTER(vp)]
+        L.qs_xchg_destroy.argtypes = [vp]
+        L.qs_xchg_export.argtypes = [vp, vp]
+        L.qs_xchg_attach.argtypes = [vp, vp]
+        L.qs_xchg_attach_local.argtypes = [vp, C.c_int, vp]
+        L.qs_xchg_staging.argtypes = [vp, C.c_int]
+        L.qs_xchg_staging.restype = vp
+        L.qs_xchg_gathered.argtypes = [vp, C.c_int]
+        L.qs_xchg_gathered.restype = vp
+        L.qs_xchg_push.argtypes = [vp, vp, vp]
+        L.qs_xchg_wait.argtypes = [vp, vp]
+        L.qs_xchg_release.argtypes = [vp, vp]
+        L.qs_xchg_wait_release.argtypes = [vp, vp]
+        L.qs_xchg_status.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.qs_obs_pack.argtypes = [vp, vp, C.c_int64, C.c_int, vp]
         if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
             raise RuntimeError("qs_config layout mismatch between config.py and libquadswarm_hip.so")
         _lib = L
@@ -139,7 +159,10 @@ EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_defau
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_state_array_copy", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor",
                     "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
-                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active"]
+                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target"]
+# include/quadswarm_exchange.h
+EXCHANGE_SYMBOLS = ["qs_xchg_create", "qs_xchg_destroy", "qs_xchg_export", "qs_xchg_attach", "qs_xchg_attach_local", "qs_xchg_staging",
+                    "qs_xchg_gathered", "qs_xchg_push", "qs_xchg_wait", "qs_xchg_release", "qs_xchg_wait_release", "qs_xchg_status", "qs_obs_pack", "qs_xchg_last_error"]
 
 
 class QsError(RuntimeError):
@@ -238,6 +261,10 @@ class Stepper:
 
     def sync(self, stream=None):
         _check(lib().qs_sync(self._h, self._stream_ptr(stream)))
+
+    def set_obs_target(self, ptr):
+        """Observation rows of the following reset / step launches go to device address `ptr` (None = the library's `obs` buffer)."""
+        _check(lib().qs_set_obs_target(self._h, C.c_void_p(int(ptr)) if ptr else None))
 
     def check_errors(self):
         _check(lib().qs_check_errors(self._h))

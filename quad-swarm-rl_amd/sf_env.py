@@ -82,10 +82,36 @@ def add_quadrotors_env_args(env, parser):
                                                                  "(num_agents = envs x quads) instead of the single-env facade")
     p.add_argument("--quads_device", default=0, type=int, help="HIP device index")
     p.add_argument("--quads_precision", default="f32", type=str, choices=["f32", "f64"])
+    p.add_argument("--quads_backend", default="hip", type=str, help="'hip': the MI355X stepper.  There is no CPU simulator behind this flag: "
+                                                                    "anything else is rejected")
+    p.add_argument("--quads_num_gpus", default=1, type=int, help="> 1: --quads_num_envs is the GLOBAL batch, sharded over this many processes "
+                                                                 "(one per GPU, launched with torchrun: RANK / LOCAL_RANK / WORLD_SIZE); each steps "
+                                                                 "its contiguous env range on GPU LOCAL_RANK")
+    p.add_argument("--quads_gather_obs", default=False, type=str2bool, help="with --quads_num_gpus > 1: after every step every rank also "
+                                                                            "receives the observation rows of all shards (env.gathered_obs())")
+    p.add_argument("--quads_obs_wire", default="bf16", type=str, choices=["bf16", "f32"], help="wire format of the gathered rows")
 
 
 DEFAULT_QUAD_REWARD_SHAPING = dict(quad_rewards=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0,
                                                      quadcol_bin=0.0, quadcol_bin_smooth_max=0.0, quadcol_bin_obst=0.0))
+
+
+def shard_spec(num_envs, num_gpus, environ):
+    """(envs of this shard, env_id_offset, rank, local_rank) of the calling process for a global batch of `num_envs` environments
+    sharded over `num_gpus` processes, one per GPU (contiguous env ranges; the noise stream is keyed by the global
+    env id, so the shards together are the un-sharded batch).  `environ`: os.environ of a torchrun-launched process."""
+    if num_gpus < 1:
+        raise ValueError("--quads_num_gpus must be >= 1")
+    if num_gpus == 1:
+        return num_envs, 0, 0, None
+    world = int(environ.get("WORLD_SIZE", "1"))
+    if world != num_gpus:
+        raise ValueError(f"--quads_num_gpus={num_gpus} shards the batch over {num_gpus} processes (one per GPU), but WORLD_SIZE={world}: launch with "
+                         f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {num_gpus} --master-addr 127.0.0.1 ...")
+    if num_envs % num_gpus:
+        raise ValueError("--quads_num_envs must be divisible by --quads_num_gpus")
+    rank, per = int(environ.get("RANK", "0")), num_envs // num_gpus
+    return per, rank * per, rank, int(environ.get("LOCAL_RANK", str(rank)))
 
 
 class AnnealSchedule:
@@ -270,12 +296,26 @@ class BatchedQuadSwarm:
     `step(actions) -> (obs_dict, rewards, terminated, truncated, infos)`, torch tensors of leading dimension num_agents; `infos`
     is a list of num_agents dicts on steps where an episode ended (empty dicts for the others) and `[]` otherwise."""
 
-    def __init__(self, num_envs, reward_shaping_scheme=None, annealing=None, device=0, seed=0, replay_buffer_sample_prob=0.0, **env_kwargs):
+    def __init__(self, num_envs, reward_shaping_scheme=None, annealing=None, device=0, seed=0, replay_buffer_sample_prob=0.0,
+                 num_gpus=1, gather_obs=False, obs_wire="bf16", **env_kwargs):
+        """num_gpus > 1: `num_envs` is the global batch; this process (one per GPU under torchrun) steps its contiguous shard on GPU
+        LOCAL_RANK.  gather_obs: the observation rows of all shards are exchanged after every step (parallel.ObsExchange) and available
+        from gathered_obs()."""
+        import os
         import torch
         from . import config as qcfg
         from .env import QuadSwarmVecEnv
         self._torch = torch
-        self.vec = QuadSwarmVecEnv(num_envs, device=device, seed=seed, episode_sums=True, write_rew_info=False, **env_kwargs)
+        self.global_num_envs = num_envs
+        num_envs, env_id_offset, self.rank, local_rank = shard_spec(num_envs, num_gpus, os.environ)
+        self.num_gpus = num_gpus
+        if local_rank is not None:
+            device = local_rank
+        if gather_obs and replay_buffer_sample_prob > 0.0:
+            raise ValueError("--quads_gather_obs is not available together with the device-side replay wrapper (--replay_buffer_sample_prob > 0)")
+        self.vec = QuadSwarmVecEnv(num_envs, device=device, seed=seed, env_id_offset=env_id_offset, episode_sums=True, write_rew_info=False, **env_kwargs)
+        if gather_obs:
+            self.vec.attach_exchange(self._make_exchange(num_gpus, obs_wire))
         self.num_envs, self.agents_per_env = num_envs, self.vec.num_agents_per_env
         self.num_agents = self.vec.num_agents
         self.is_multiagent = True
@@ -294,6 +334,49 @@ class BatchedQuadSwarm:
         self._ep_steps = self.vec.cfg.ep_len + 1          # an episode ends by time: tick > ep_len (quadrotor_single.py:353)
         self._steps_to_done = self._ep_steps              # control steps until the earliest possible episode end
         self._truncated = None
+
+    def _make_exchange(self, world, wire):
+        """peer-store exchange of the observation rows between the shards (include/quadswarm_exchange.h); RCCL all-gather of the
+        packed rows if the peers' windows cannot be mapped or the start-up self-check fails on any rank (same rule as bench.py)"""
+        import torch
+        import torch.distributed as dist
+        from . import parallel
+        st = self.vec.stepper
+        torch.cuda.set_device(st.device)
+        if world > 1 and not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", st.device))
+
+        def all_agree(flag):
+            if world == 1:
+                return flag
+            t = torch.tensor([1 if flag else 0], device=f"cuda:{st.device}", dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        ex = None
+        try:
+            ex = parallel.ObsExchange(st, world, self.rank, transport="peer", wire=wire, hold=True)
+        except Exception:   # noqa: BLE001 - every rank takes the same decision below
+            ex = None
+        ok = all_agree(ex is not None)
+        if ok:
+            try:
+                ok = ex.self_check()[0]
+            except Exception:   # noqa: BLE001
+                ok = False
+            ok = all_agree(ok)
+        if not ok:
+            if ex is not None:
+                ex.close()
+            ex = parallel.ObsExchange(st, world, self.rank, transport="rccl", wire=wire, hold=True)
+        return ex
+
+    def gathered_obs(self):
+        """[global envs * N, obs_dim] observation rows of ALL shards after the most recent step (rank order = global env order), in the
+        wire format (--quads_obs_wire); valid until the next step().  Needs gather_obs=True."""
+        if self.vec.exchange is None:
+            raise RuntimeError("create the env with gather_obs=True (--quads_gather_obs=True)")
+        return self.vec.exchange.latest()
 
     @property
     def unwrapped(self):
@@ -451,6 +534,7 @@ def make_quadrotor_env_batched(cfg, **kwargs):
     return BatchedQuadSwarm(
         cfg.quads_num_envs, reward_shaping_scheme=reward_shaping, annealing=annealing,
         replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0),
+        num_gpus=getattr(cfg, "quads_num_gpus", 1), gather_obs=getattr(cfg, "quads_gather_obs", False), obs_wire=getattr(cfg, "quads_obs_wire", "bf16"),
         device=getattr(cfg, "quads_device", 0), seed=getattr(cfg, "quads_seed", 0), precision=getattr(cfg, "quads_precision", "f32"),
         num_agents=cfg.quads_num_agents, ep_time=cfg.quads_episode_duration, rew_coeff=dict(DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]),
         obs_repr=cfg.quads_obs_repr, neighbor_visible_num=cfg.quads_neighbor_visible_num, neighbor_obs_type=cfg.quads_neighbor_obs_type,
@@ -463,6 +547,11 @@ def make_quadrotor_env_batched(cfg, **kwargs):
 
 def make_quadrotor_env(env_name, cfg=None, _env_config=None, render_mode=None, **kwargs):
     if env_name == "quadrotor_multi":
+        backend = getattr(cfg, "quads_backend", "hip")
+        if backend != "hip":
+            raise NotImplementedError(f"--quads_backend={backend!r}: this package only has the MI355X HIP stepper (no CPU simulator to fall back to)")
+        if getattr(cfg, "quads_num_gpus", 1) > 1 and getattr(cfg, "quads_num_envs", 1) <= 1:
+            raise ValueError("--quads_num_gpus > 1 shards the batched env: set --quads_num_envs to the global number of environments")
         if getattr(cfg, "quads_num_envs", 1) > 1:
             return make_quadrotor_env_batched(cfg, **kwargs)
         return make_quadrotor_env_multi(cfg, render_mode, **kwargs)

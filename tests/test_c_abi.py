@@ -26,6 +26,20 @@ def test_library_exports_every_declared_symbol():
     assert sorted(native.EXPORTED_SYMBOLS) == declared
 
 
+def test_library_exports_every_symbol_of_the_exchange_header():
+    native.build()
+    lib = C.CDLL(native.LIB_PATH)
+    text = open(os.path.join(REPO, "include", "quadswarm_exchange.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int|void \*|const char \*)\s*\*?(qs_\w+)\(", text, flags=re.M)))
+    assert len(declared) >= 12, declared
+    for sym in declared:
+        assert hasattr(lib, sym), f"{sym} declared in include/quadswarm_exchange.h but not exported"
+    assert sorted(native.EXCHANGE_SYMBOLS) == declared
+    from quad_swarm_rl_amd import parallel
+    m = re.search(r"#define QS_XCHG_EXPORT_BYTES \(2 \* QS_XCHG_HANDLE_BYTES \+ (\d+)\)", text)
+    assert parallel.EXPORT_BYTES == 2 * int(re.search(r"#define QS_XCHG_HANDLE_BYTES (\d+)", text).group(1)) + int(m.group(1))
+
+
 def test_config_struct_layout_matches():
     L = native.lib()
     assert L.qs_sizeof_config() == C.sizeof(qcfg.QsConfig)

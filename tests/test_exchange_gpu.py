@@ -1,0 +1,203 @@
+"""Observation exchange between env shards (include/quadswarm_exchange.h, quad-swarm-rl_amd/parallel.py): the rows every rank ends
+up with equal the un-sharded stepper's rows - bit for bit on the float32 wire, equal to the round-to-nearest-even bfloat16 of them
+on the bf16 wire - with two PROCESSES sharing the one GPU of the test box (hipIpc-mapped windows), with two endpoints in one
+process, eager and as a captured HIP graph; the float32 -> bf16 converter equals torch's; bounded waits report instead of hanging."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(REPO, "tests", "xchg_worker.py")
+
+
+def _expected_rows(total_envs, wire, action_batches):
+    """rows of the un-sharded stepper after the reset and after each action batch (an int t = batch t of the global action set)"""
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import xchg_worker as xw
+    cfg = qcfg.make_config(num_envs=total_envs, seed=7, precision="f32", write_rew_info=False, **xw.KW)
+    st = native.Stepper(cfg, device=0)
+    acts = torch.as_tensor(xw.global_actions(max(action_batches) + 1 if action_batches else 1, total_envs, cfg.num_agents)).cuda()
+    obs = st.tensor("obs")
+
+    def rows():
+        torch.cuda.synchronize()
+        r = obs.to(torch.bfloat16).float() if wire == "bf16" else obs.clone()
+        return r.cpu().numpy()
+
+    st.reset()
+    out = [rows()]
+    for t in action_batches:
+        st.step(acts[t].data_ptr())
+        out.append(rows())
+    st.close()
+    return out
+
+
+def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout=300):
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    with tempfile.TemporaryDirectory() as td:
+        port = 29600 + (os.getpid() % 300)
+        procs, outs = [], []
+        for r in (range(world) if mode == "proc" else [0]):
+            out = os.path.join(td, f"r{r}.npz")
+            outs.append(out)
+            cmd = [sys.executable, WORKER, "--mode", mode, "--rank", str(r), "--world", str(world), "--port", str(port), "--wire", wire, "--envs", str(envs),
+                   "--steps", str(steps), "--graph", str(graph), "--replays", str(replays), "--out", out]
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        logs = []
+        for p in procs:
+            try:
+                log, _ = p.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+            logs.append(log)
+        for p, log in zip(procs, logs):
+            assert p.returncode == 0, log[-3000:]
+        return [dict(np.load(o)) for o in outs]
+
+
+def _check(results, mode, world, wire, graph, steps, replays, envs=16):
+    warm = int(results[0]["warm"])
+    if graph:   # reset, `warm` eager steps on action batch 0, then `replays` x the captured batches 0..graph-1; rows recorded after each replay
+        seq = [0] * warm + list(range(graph)) * replays
+        exp = _expected_rows(envs, wire, seq)
+        picks = [0] + [warm + graph * (i + 1) for i in range(replays)]
+    else:
+        exp = _expected_rows(envs, wire, list(range(steps)))
+        picks = list(range(steps + 1))
+    ranks = range(world)
+    for res in results:
+        for r in ranks:
+            if f"rows{r}" not in res:
+                continue
+            assert int(res[f"err{r}"]) == 0, f"exchange status of rank {r}: {int(res[f'err{r}'])}"
+            got = res[f"rows{r}"]
+            assert got.shape[0] == len(picks)
+            for i, k in enumerate(picks):
+                assert got[i].shape == exp[k].shape
+                assert np.array_equal(got[i], exp[k]), f"{mode} wire={wire} graph={graph}: rank {r}, record {i} differs (max {np.abs(got[i] - exp[k]).max()})"
+
+
+@pytest.mark.parametrize("wire", ["f32", "bf16"])
+@pytest.mark.parametrize("graph", [0, 6])
+def test_two_processes_on_one_gpu_gather_equals_unsharded(wire, graph):
+    """north_star's sharding with one process per rank: both processes map each other's windows with hipIpcOpenMemHandle."""
+    res = _run_workers("proc", 2, wire, graph)
+    _check(res, "proc", 2, wire, graph, 10, 3)
+
+
+@pytest.mark.parametrize("wire,graph", [("f32", 0), ("bf16", 4)])
+def test_two_endpoints_in_one_process(wire, graph):
+    res = _run_workers("local", 2, wire, graph)
+    _check(res, "local", 2, wire, graph, 10, 3)
+
+
+def test_four_ranks_in_one_process_bf16():
+    res = _run_workers("local", 4, "bf16", 0, steps=6)
+    _check(res, "local", 4, "bf16", 0, 6, 0)
+
+
+def test_pack_bf16_equals_torch_rounding():
+    import torch
+    from quad_swarm_rl_amd import parallel
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(100003, device="cuda", generator=g) * 37.0
+    bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (50000,), device="cuda", generator=g, dtype=torch.int64).to(torch.int32)
+    special = torch.tensor([0.0, -0.0, 1.0, 1.00390625, 1.01171875, float("inf"), -float("inf"), 3.3895314e38, 1e-40, -1e-45, 65504.0], device="cuda")
+    src = torch.cat([x, bits.view(torch.float32), special]).contiguous()
+    src = src[torch.isfinite(src) | torch.isinf(src)]   # NaN payloads are not part of the contract (obs are finite: NaN rewards raise)
+    src = src.contiguous()
+    for dt in (torch.bfloat16, torch.float32):
+        dst = torch.empty(src.shape, dtype=dt, device="cuda")
+        parallel.pack_rows(src, dst)
+        torch.cuda.synchronize()
+        want = src.to(dt)
+        assert torch.equal(dst.view(torch.int16 if dt == torch.bfloat16 else torch.int32), want.view(torch.int16 if dt == torch.bfloat16 else torch.int32))
+    odd = src[1:4098]                                    # an address that is not 16-byte aligned takes the element-wise path
+    dst = torch.empty(odd.shape, dtype=torch.bfloat16, device="cuda")
+    parallel.pack_rows(odd, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.view(torch.int16), odd.to(torch.bfloat16).view(torch.int16))
+
+
+@pytest.mark.parametrize("transport", ["peer", "rccl"])
+def test_world1_graph_capture_matches_plain_stepping(transport):
+    """world size 1 (what bench.py --force-gather runs on a 1-GPU box): [step -> exchange] x 8 as one HIP graph, replayed, equals
+    the plain stepper on the same actions; the redirected observation output leaves qs_buffers.obs untouched."""
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native, parallel
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import xchg_worker as xw
+    E, G = 12, 8
+    cfg = qcfg.make_config(num_envs=E, seed=7, precision="f32", write_rew_info=False, **xw.KW)
+    acts = torch.as_tensor(xw.global_actions(G, E, cfg.num_agents)).cuda()
+    stride = acts[0].numel() * 4
+    ref = native.Stepper(cfg, device=0)
+    st = native.Stepper(cfg, device=0)
+    ex = parallel.ObsExchange(st, 1, 0, transport=transport, wire="bf16")
+    ex.reset()
+    ref.reset()
+    untouched = st.tensor("obs").clone()
+    ex.capture([acts.data_ptr() + t * stride for t in range(G)])
+    warm = ex.k - 1
+    for _ in range(warm):
+        ref.step(acts[0].data_ptr())
+    for rep in range(3):
+        ex.replay()
+        for t in range(G):
+            ref.step(acts[t].data_ptr())
+        torch.cuda.synchronize()
+        want = ref.tensor("obs")
+        assert torch.equal(ex.latest(), want.to(torch.bfloat16)), (transport, rep)
+        assert torch.equal(ex.local_rows(), want)
+    assert ex.status()["error"] == 0
+    assert torch.equal(st.tensor("obs"), untouched)
+    ex.close()
+    st.close()
+    ref.close()
+
+
+def test_missing_peer_times_out_and_reports():
+    """a rank whose peer never pushes: the bounded wait raises the status word instead of hanging the GPU"""
+    import torch
+    from quad_swarm_rl_amd import parallel
+    os.environ["QS_XCHG_TIMEOUT_MS"] = "50"
+    try:
+        a = parallel.PeerExchange(64, 8, 2, 0, wire="f32")
+        b = parallel.PeerExchange(64, 8, 2, 1, wire="f32")
+    finally:
+        del os.environ["QS_XCHG_TIMEOUT_MS"]
+    a.attach_local(b)
+    b.attach_local(a)
+    a.staging(0).fill_(1.0)
+    torch.cuda.synchronize()
+    a.push(a.staging_ptr(0))
+    a.wait()            # rank 1 never pushed
+    torch.cuda.synchronize()
+    assert a.status()["error"] & 2
+    assert a.status()["pushes"] == 1 and a.status()["waits"] == 1
+    assert torch.equal(b.gathered(1)[:64], a.staging(0))    # the rows themselves did arrive in rank 1's window
+    a.close()
+    b.close()
+
+
+def test_obs_target_is_refused_with_device_replay():
+    from quad_swarm_rl_amd import config as qcfg, native
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import xchg_worker as xw
+    cfg = qcfg.make_config(num_envs=4, seed=1, precision="f32", episode_sums=True, **xw.KW)
+    st = native.Stepper(cfg, device=0)
+    st.replay_enable(0.5)
+    with pytest.raises(native.QsError):
+        st.set_obs_target(st.ptr("rew_info"))
+    st.close()

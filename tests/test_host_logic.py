@@ -103,3 +103,33 @@ def test_bench_workloads_follow_the_baseline_and_the_cpu_leg_runs():
     assert bench.HBM_PEAK_GBS == 8000.0
     rec = bench.cpu_baseline("c1", 0.2)
     assert rec["kind"] == "port" and rec["unit"] == "env-steps/s" and rec["value"] > 0 and rec["cores"] >= 1 and "C oracle" in rec["sample"]
+
+
+def test_shard_spec_of_a_torchrun_process():
+    """--quads_num_gpus: contiguous env ranges per rank, GPU = LOCAL_RANK, and a clear error when the launch does not match"""
+    from quad_swarm_rl_amd import sf_env
+    assert sf_env.shard_spec(1024, 1, {}) == (1024, 0, 0, None)
+    env = dict(WORLD_SIZE="8", RANK="3", LOCAL_RANK="3")
+    assert sf_env.shard_spec(4096, 8, env) == (512, 1536, 3, 3)
+    covered = []
+    for r in range(8):
+        per, off, rank, lr = sf_env.shard_spec(4096, 8, dict(WORLD_SIZE="8", RANK=str(r), LOCAL_RANK=str(r)))
+        covered += list(range(off, off + per))
+    assert covered == list(range(4096))
+    with pytest.raises(ValueError, match="torch.distributed.run"):
+        sf_env.shard_spec(4096, 8, {})
+    with pytest.raises(ValueError, match="divisible"):
+        sf_env.shard_spec(1001, 8, env)
+
+
+def test_backend_flag_has_no_cpu_fallback():
+    import argparse
+    from quad_swarm_rl_amd import sf_env
+    p = argparse.ArgumentParser()
+    sf_env.add_quadrotors_env_args(None, p)
+    cfg = p.parse_args(["--quads_backend=cpu"])
+    with pytest.raises(NotImplementedError, match="no CPU simulator"):
+        sf_env.make_quadrotor_env("quadrotor_multi", cfg)
+    cfg = p.parse_args(["--quads_num_gpus=2"])
+    with pytest.raises(ValueError, match="quads_num_envs"):
+        sf_env.make_quadrotor_env("quadrotor_multi", cfg)
