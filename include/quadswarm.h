@@ -330,9 +330,13 @@ int qs_replay_set_active(qs_handle *h, const uint8_t *active_host /* [num_envs] 
  * QS_SPEC_CACHE or <library dir>/spec_cache), =cache (use only if cached), =off (generic kernels).
  * Results are identical either way.  qs_spec_build() creates the cache entry ahead of time, without a GPU
  * (team: 1 = 4-wave kernels, 0 = single-wave, -1 = what qs_create picks on a 256-CU device).
+ * The fallback to the generic kernels is loud: a warning on stderr, the reason from qs_spec_status(), and QS_SPEC=require makes
+ * qs_create() fail instead (bench.py and the full-size tests assert that the specialised object is what ran).
  */
 int qs_spec_build(const qs_config *cfg, int team, char *path_out, int cap);
 int qs_is_specialized(qs_handle *h);
+/* 1 = config-specialised kernels, 0 = generic kernels with the reason written to why_out (NUL-terminated, at most cap bytes). */
+int qs_spec_status(qs_handle *h, char *why_out, int cap);
 /* which step kernel the handle launches: bit 0 = config-specialised, bit 1 = team kernels, bit 2 = full scenario set,
  * bits 8..15 = waves per workgroup (1, 4 or 8) */
 int qs_kernel_flavor(qs_handle *h);

@@ -242,6 +242,11 @@ template <typename real> struct Consts {
     real arm_r;
 };
 
+// c.cube_fd by value: a pointer INTO the constant block handed to a function that is not inlined would pin the whole block in memory
+// (and every literal of a config-specialised kernel with it); the two ints travel in a temporary instead
+struct CubeFd { int v[2]; __device__ __forceinline__ operator const int *() const { return v; } };
+#define QS_CUBE_FD(c) (CubeFd{{(c).cube_fd[0], (c).cube_fd[1]}})
+
 // per-drone dynamic state held in registers
 template <typename real> struct Drone {
     real pos[3], vel[3], rot[9], omega[3];

@@ -105,6 +105,36 @@ __device__ __forceinline__ unsigned long long nbr_key(float m, int idx) {
     return ((unsigned long long)o << 32) | (uint32_t)idx;
 }
 
+// neighbour metric of neighborhood_indices (quadrotor_multi.py:247-274) for the relative position rp / velocity rv of a partner:
+// max(|rp|, 0.01) + rp.rv / that.  Symmetric in the pair - (-rp).(-rv) = rp.rv and |-rp| = |rp| exactly in IEEE arithmetic - which is
+// what lets the team kernels evaluate every unordered pair once.  ONE definition for every site that ranks neighbours.
+template <typename real> __device__ __forceinline__ real nbr_metric(const real rp[3], const real rv[3]) {
+    const real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
+    return rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) * M<real>::rcp(rd);
+}
+// (metric, index) with the order "smaller metric first, lower index first" = position in the stable argsort
+template <typename real> struct NbrKey;
+template <> struct NbrKey<float> {
+    unsigned long long k;
+    static __device__ __forceinline__ NbrKey make(float m, int j) { return {nbr_key(m, j)}; }
+    __device__ __forceinline__ bool less(const NbrKey &o) const { return k < o.k; }
+    __device__ __forceinline__ int idx() const { return (int)(uint32_t)k; }
+    // LDS list entry `slot` of lane tid: keys [slots][B]
+    static __device__ __forceinline__ void st(unsigned char *base, int slots, int slot, int B, int tid, const NbrKey &v) { ((unsigned long long *)base)[slot * B + tid] = v.k; }
+    static __device__ __forceinline__ NbrKey ld(const unsigned char *base, int slots, int slot, int B, int tid) { return {((const unsigned long long *)base)[slot * B + tid]}; }
+};
+template <> struct NbrKey<double> {
+    double m; int j;
+    static __device__ __forceinline__ NbrKey make(double m, int j) { return {m, j}; }
+    __device__ __forceinline__ bool less(const NbrKey &o) const { return (m < o.m) | ((m == o.m) & (j < o.j)); }
+    __device__ __forceinline__ int idx() const { return j; }
+    // metrics [slots][B] doubles, then indices [slots][B] ints
+    static __device__ __forceinline__ void st(unsigned char *base, int slots, int slot, int B, int tid, const NbrKey &v) {
+        ((double *)base)[slot * B + tid] = v.m; ((int *)(base + (size_t)slots * B * 8))[slot * B + tid] = v.j; }
+    static __device__ __forceinline__ NbrKey ld(const unsigned char *base, int slots, int slot, int B, int tid) {
+        return {((const double *)base)[slot * B + tid], ((const int *)(base + (size_t)slots * B * 8))[slot * B + tid]}; }
+};
+
 #ifdef QS_TIMING
 #define QS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.timing[k] = clock64(); } while (0)
 // helper waves of the team kernels: stamp k of wave w (1..3) lands in timing[32*w + k]
@@ -116,6 +146,7 @@ __device__ __forceinline__ unsigned long long nbr_key(float m, int idx) {
 
 struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
                    int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit;
+                   int off_t_near, off_topk, off_t_redo;   // team kernels, N > 8 (pair-once scan): proximity masks, per-wave top-8 lists, per-env "velocities changed" flags
                    int off_self, off_rows, rows_per_pass, scr_cap;   // single-wave kernels: observation output (see obs_copy_rows)
                    int off_cur; };   // QS_TAPE kernels: per-env tape cursor
 #define QS_NV_MAX 57   // neighbour + SDF columns a lane can keep in registers between the row passes (K <= 8)   // single-wave kernels: observation columns staged per pass (see obs_flush)
@@ -170,6 +201,12 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
         L.off_t_goal = o; o += real_size * 3 * B;
         L.off_t_prox = o; o += real_size * (team - 1) * B;
         L.off_t_ohit = o; o += 4 * B;
+        L.off_t_near = o; o += 8 * B;
+        L.off_t_redo = o; o += 4 * ((epb + 3) & ~3);
+        o = (o + 15) & ~15;
+        // N > 8 with K <= 8: every ranking wave (all but wave 0) publishes the top-8 of its candidates, compacted by local rank:
+        // float32: one 64-bit (metric, index) key per entry; float64: metric + index
+        L.off_topk = o; o += (N > 8 && K > 0 && K < N - 1 && K <= 8) ? (team - 1) * 8 * (real_size + 4) * B : 0;
         o = (o + 15) & ~15;
         L.rows_per_pass = B;
         L.off_obs = o; L.off_self = o; L.off_rows = o + real_size * self_dim * B;   // complete rows [B][D]; the reset kernel sees them as
@@ -596,6 +633,66 @@ __device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, cons
     for (int q = 0; q < 3; ++q) { vel[q] = d.vel[q]; omega[q] = d.omega[q]; }
 }
 
+// Team kernels, more than 8 drones, K <= 8 (qs_step_team.inc, pair-once): wave wv >= 1 ranks ITS candidates j = (wv-1), (wv-1) + (W-1), ...
+// of drone i's row of the metric matrix by counting inside the stripe (all keys in registers; every compare feeds two ranks), and
+// publishes the 8 nearest of them compacted by local rank: s_topk slot (wv-1)*8 + rank.  recompute: the metrics are evaluated from the
+// current positions / velocities instead of read from the matrix (environments whose velocities changed after the pair scan).
+// (the candidate count is a literal in a config-specialised object: register arrays sized for 64 drones there keep the compiler from
+// promoting the kernel's constant block out of scratch memory)
+#ifdef QS_SPEC_N
+#define QS_TEAM_NMAX QS_SPEC_N
+#else
+#define QS_TEAM_NMAX QS_MAX_AGENTS
+#endif
+template <typename real, int W>
+__device__ __forceinline__ void team_rank_local(int N, int i, int base, int B, int tid, int wv, const real *s_pos, const real *s_vel,
+                                                const real *s_metric, unsigned char *s_topk, bool recompute) {
+    constexpr int RW = W - 1, CMAX = (QS_TEAM_NMAX + RW - 1) / RW, SL = RW * 8;
+    const int C = (N + RW - 1) / RW;
+    NbrKey<real> key[CMAX];
+    int lr[CMAX];
+    real mp[3] = {0, 0, 0}, mv[3] = {0, 0, 0};
+    if (recompute) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { mp[q] = s_pos[q * B + tid]; mv[q] = s_vel[q * B + tid]; }
+    }
+#pragma unroll
+    for (int u = 0; u < CMAX; ++u) {
+        lr[u] = 0;
+        if (u < C) {
+            const int j = (wv - 1) + RW * u, jc = j < N ? j : N - 1;
+            const bool valid = (j < N) & (j != i);
+            real m;
+            if (recompute) {
+                const real rp[3] = {s_pos[0 * B + base + jc] - mp[0], s_pos[1 * B + base + jc] - mp[1], s_pos[2 * B + base + jc] - mp[2]};
+                const real rv[3] = {s_vel[0 * B + base + jc] - mv[0], s_vel[1 * B + base + jc] - mv[1], s_vel[2 * B + base + jc] - mv[2]};
+                m = nbr_metric<real>(rp, rv);
+            } else {
+                m = s_metric[jc * B + tid];
+            }
+            key[u] = NbrKey<real>::make(valid ? m : (real)3.4e38, valid ? j : 0x7fffff00 + u);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CMAX; ++u) {
+#pragma unroll
+        for (int k = u + 1; k < CMAX; ++k) {
+            if (k < C) {   // keys are distinct (the index breaks ties): exactly one of the two is the smaller
+                const int lt = (int)key[u].less(key[k]);
+                lr[k] += lt; lr[u] += 1 - lt;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < CMAX; ++u) {
+        if (u < C && lr[u] < 8) NbrKey<real>::st(s_topk, SL, (wv - 1) * 8 + lr[u], B, tid, key[u]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        if (q >= C) NbrKey<real>::st(s_topk, SL, (wv - 1) * 8 + q, B, tid, NbrKey<real>::make((real)3.4e38, 0x7fffff00 + q));   // fewer candidates than slots
+    }
+}
+
 // full-scenario kernels: per-env scenario state HBM <-> LDS (each drone of the env moves a strided part)
 template <typename real>
 __device__ __forceinline__ void scen_lds_load(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
@@ -785,7 +882,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
                 if (M<real>::fabs(df) < F.lo) { real sg = (real)((df > 0) - (df < 0)); c2[ax] = sg * F.lo + c1[ax]; }
             }
             for (int q = 0; q < 3; ++q) { p.scen_real[q * E + e] = c1[q]; p.scen_real[(3 + q) * E + e] = c2[q]; }
-            svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, false, goals);
+            svs_create_formations<real>(key, F, N, QS_CUBE_FD(c), c1, c2, false, goals);
         }
         s_envflag[le] = have_spawn;
 #ifdef QS_TAPE

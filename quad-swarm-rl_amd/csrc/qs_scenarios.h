@@ -272,7 +272,7 @@ __device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, co
             if (M<real>::fabs(df) < F.lo) { real sg = (real)((df > 0) - (df < 0)); c2[ax] = sg * F.lo + c1[ax]; }
         }
         for (int q = 0; q < 3; ++q) { x.sr[SR_C1 + q] = c1[q]; x.sr[SR_C2 + q] = c2[q]; }
-        svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, false, x.goals);
+        svs_create_formations<real>(key, F, N, QS_CUBE_FD(c), c1, c2, false, x.goals);
     }
     x.sr[SR_METRIC] = (sc == QS_SCENARIO_O_STATIC_SAME_GOAL || sc == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || sc == QS_SCENARIO_O_SWAP_GOALS ||
                        sc == QS_SCENARIO_O_EP_RAND_BEZIER) ? (real)1 : (real)0.5;
@@ -297,7 +297,7 @@ __device__ void scenario_step_serial(const Consts<real> &c, const RngKey &key, c
         for (int q = 0; q < 3; ++q) { x.sr[SR_C1 + q] = c1[q]; x.sr[SR_C2 + q] = c2[q]; }
         update_formation<real>(sc, key, 32, N, F);
         store_formation<real>(x, F);
-        svs_create_formations<real>(key, F, N, c.cube_fd, c1, c2, true, x.goals);
+        svs_create_formations<real>(key, F, N, QS_CUBE_FD(c), c1, c2, true, x.goals);
     } else if (sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL) {   // dynamic_diff_goal.py:8-34
         load_formation<real>(x, F);
         real box = c.spawn_box, xy[2];

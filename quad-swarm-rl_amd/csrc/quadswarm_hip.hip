@@ -53,6 +53,7 @@ struct qs_handle {
     int32_t snap_slots = 0;
     hipModule_t spec_mod = nullptr;
     hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr;
+    std::string spec_note;   // why the handle runs the generic kernels (empty when it runs a config-specialised code object)
     Consts<float> kf;    // kernel constants, passed by value in the kernarg segment
     Consts<double> kd;
     Ptrs<float> pf;     // same field layout for float/double: only the pointee type differs
@@ -166,8 +167,8 @@ static std::string spec_header_text(const qs_config *cfg, int team) {
            w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
     std::string o = "// generated by quadswarm_hip (spec_header_text): configuration constants as literals\n";
     char t[256];
-    snprintf(t, sizeof t, "#define QS_SPEC_PRECISION %d\n#define QS_SPEC_TEAM %d\n#define QS_SPEC_FULL %d\n#define QS_SPEC_EPB %d\n", rs, team,
-             scenario_is_full(cfg->scenario) ? 1 : 0, epb);
+    snprintf(t, sizeof t, "#define QS_SPEC_PRECISION %d\n#define QS_SPEC_TEAM %d\n#define QS_SPEC_FULL %d\n#define QS_SPEC_EPB %d\n#define QS_SPEC_N %d\n", rs, team,
+             scenario_is_full(cfg->scenario) ? 1 : 0, epb, cfg->num_agents);
     o += t;
     snprintf(t, sizeof t, "struct QsSpecCW { uint32_t w[%zu]; };\n", w.size()); o += t;
     o += "static constexpr QsSpecCW qs_spec_cw = {{";
@@ -515,8 +516,11 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         const int spec_team = h->team ? ((tv && tv[0] == '4') ? 4 : ((tv && tv[0] == '8') ? 8 : spec_team_waves(cfg->num_agents))) : 0;
         const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, spec_team, scenario_is_full(cfg->scenario), cfg->scenario,
                                            spec_rows_per_pass(cfg, spec_team));
-        if (mode != "off" && mode != "0" && sl.total <= 64 * 1024) {
-            const std::string path = spec_ensure(cfg, spec_team, mode == "jit");
+        const bool require = mode == "require";
+        if (mode == "off" || mode == "0") h->spec_note = "QS_SPEC=off";
+        else if (sl.total > 64 * 1024) h->spec_note = "LDS layout above the 64 KiB a module-loaded kernel gets";
+        else {
+            const std::string path = spec_ensure(cfg, spec_team, mode == "jit" || require);
             if (!path.empty()) {
                 if (hipModuleLoad(&h->spec_mod, path.c_str()) == hipSuccess &&
                     hipModuleGetFunction(&h->spec_step, h->spec_mod, "qs_spec_step") == hipSuccess &&
@@ -527,11 +531,17 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
                     (void)hipGetLastError();
                     if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
                     h->spec_step = h->spec_rollout = h->spec_reset = nullptr;
-                    fprintf(stderr, "quadswarm_hip: cannot load %s, using the generic kernels\n", path.c_str());
+                    h->spec_note = "cannot load " + path;
                 }
-            } else if (mode == "jit") {
-                fprintf(stderr, "quadswarm_hip: %s; using the generic kernels\n", g_last_error.c_str());
+            } else {
+                h->spec_note = g_last_error;
             }
+        }
+        // The fallback is LOUD: one line on stderr, the reason kept for qs_spec_status(), and QS_SPEC=require turns it into an error
+        // (the generic kernels give the same results - tests/test_fp32_parity_gpu.py - at ~1.3x the step time).
+        if (!h->spec_step && mode != "off" && mode != "0") {
+            if (require && sl.total <= 64 * 1024) { const std::string why = h->spec_note; delete h; return fail(QS_ERR_UNSUPPORTED, "QS_SPEC=require: no config-specialised kernels: " + why); }
+            fprintf(stderr, "quadswarm_hip: WARNING: running the GENERIC step kernels (%s)\n", h->spec_note.c_str());
         }
     }
     h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team, scenario_is_full(cfg->scenario), cfg->scenario,
@@ -566,6 +576,11 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
 
 // 1 if the handle runs config-specialised kernels, 0 if the generic ones
 int qs_is_specialized(qs_handle *h) { return (h && h->spec_step) ? 1 : 0; }
+int qs_spec_status(qs_handle *h, char *why_out, int cap) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    if (why_out && cap > 0) { snprintf(why_out, (size_t)cap, "%s", h->spec_note.c_str()); }
+    return h->spec_step ? 1 : 0;
+}
 // bit 0: config-specialised code object, bit 1: team kernels, bit 2: full scenario set, bits 8..15: waves per workgroup
 int qs_kernel_flavor(qs_handle *h) { return h ? ((h->spec_step ? 1 : 0) | (h->team ? 2 : 0) | (h->full ? 4 : 0) | ((h->team ? h->team : 1) << 8)) : 0; }
 

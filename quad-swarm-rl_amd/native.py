@@ -120,6 +120,7 @@ def lib():
         L.qs_get_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.qs_spec_build.argtypes = [C.POINTER(qcfg.QsConfig), C.c_int, C.c_char_p, C.c_int]
         L.qs_is_specialized.argtypes = [vp]
+        L.qs_spec_status.argtypes = [vp, C.c_char_p, C.c_int]
         L.qs_kernel_flavor.argtypes = [vp]
         L.qs_snapshot_pool.argtypes = [vp, C.c_int32]
         L.qs_snapshot_save.argtypes = [vp, C.c_int32, C.c_int32, vp]
@@ -157,7 +158,7 @@ def lib():
 EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
                     "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_state_array_copy", "qs_check_errors", "qs_set_profiling",
-                    "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_kernel_flavor",
+                    "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_spec_status", "qs_kernel_flavor",
                     "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
                     "qs_set_noise_tape", "qs_get_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target"]
 # include/quadswarm_exchange.h
@@ -322,6 +323,13 @@ class Stepper:
     def specialized(self):
         """True when the handle runs a config-specialised code object (QS_SPEC, include/quadswarm.h)."""
         return bool(lib().qs_is_specialized(self._h))
+
+    @property
+    def spec_note(self):
+        """why the handle runs the generic kernels ('' when it runs the config-specialised object)"""
+        buf = C.create_string_buffer(1024)
+        lib().qs_spec_status(self._h, buf, len(buf))
+        return buf.value.decode()
 
     @property
     def team(self):

@@ -72,39 +72,52 @@ MODELS = ("mean_embed", "attention", "mlp", "no_encoder", "multi_head_attention"
 NBR_ENCODERS = ("mean_embed", "attention", "mlp", "no_encoder")   # --quads_neighbor_encoder_type (quadrotor_params.py:38-40); index = QS_ENC_NBR_*
 
 
-def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden=HIDDEN, seed=0, attention=False, nbr_encoder=None):
+NONLINEARITIES = ("tanh", "elu", "relu")   # sample_factory.model.model_utils.nonlinearity(cfg): --nonlinearity
+
+
+def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden=HIDDEN, seed=0, attention=False, nbr_encoder=None,
+                           nbr_hidden=None, obst_hidden=None, nonlinearity="tanh"):
     """QuadMultiEncoder as a torch module; random init (there are no checkpoints in this image).
-    nbr_encoder: one of NBR_ENCODERS (default mean_embed; attention=True is shorthand for "attention")."""
+    nbr_encoder: one of NBR_ENCODERS (default mean_embed; attention=True is shorthand for "attention").
+    hidden = cfg.rnn_size (self encoder, feed forward), nbr_hidden = cfg.quads_neighbor_hidden_size (every layer of the neighbour
+    encoder, :29-34,:52-75,:110-117), obst_hidden = cfg.quads_obst_hidden_size (:315-322); both default to `hidden`, which is what
+    the published runs use.  nonlinearity: what SF's nonlinearity(cfg) returns; the feed-forward layer is always tanh (:329-332)."""
     nbr_encoder = nbr_encoder or ("attention" if attention else "mean_embed")
     if nbr_encoder not in NBR_ENCODERS:
         raise NotImplementedError(nbr_encoder)                                  # :292-293
+    if nonlinearity not in NONLINEARITIES:
+        raise NotImplementedError(f"nonlinearity {nonlinearity!r}")
     import torch
     from torch import nn
+    nh = hidden if nbr_hidden is None else nbr_hidden
+    oh = hidden if obst_hidden is None else obst_hidden
+    act = {"tanh": nn.Tanh, "elu": lambda: nn.ELU(inplace=True), "relu": lambda: nn.ReLU(inplace=True)}[nonlinearity]
 
     class QuadMultiEncoderRef(nn.Module):
         def __init__(self):
             super().__init__()
             self.self_dim, self.nbr_dim, self.num_nbr, self.obst_dim = self_dim, nbr_dim, num_nbr, obst_dim
-            mlp = lambda i: nn.Sequential(nn.Linear(i, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
+            self.hidden, self.nbr_hidden, self.obst_hidden, self.nonlinearity = hidden, nh, oh, nonlinearity
+            mlp = lambda i, h=hidden: nn.Sequential(nn.Linear(i, h), act(), nn.Linear(h, h), act())
             # Parameters are created in the reference's order (neighbour encoder :279-293, self encoder :300-309, obstacle encoder
             # :313-322, feed forward :329-332), so that the same torch seed gives the same weights as the reference class - that is
             # what lets tests/golden/encoder_*.npz hold a seed instead of megabytes of weights.
             self.nbr_encoder = nbr_encoder if num_nbr > 0 else "no_encoder"
             self.attention = self.nbr_encoder == "attention"
             if self.nbr_encoder == "mlp":                                       # :110-117
-                self.neighbor_encoder = nn.Sequential(nn.Linear(nbr_dim * num_nbr, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
-                                                      nn.Linear(hidden, hidden), nn.Tanh())
+                self.neighbor_encoder = nn.Sequential(nn.Linear(nbr_dim * num_nbr, nh), act(), nn.Linear(nh, nh), act(),
+                                                      nn.Linear(nh, nh), act())
             elif self.nbr_encoder == "no_encoder":                              # :289-291 "blind agent"
                 self.neighbor_encoder = None
             else:                                                               # :29-34 / :52-57
-                self.neighbor_encoder = mlp(self_dim + nbr_dim if self.attention else nbr_dim)
+                self.neighbor_encoder = mlp(self_dim + nbr_dim if self.attention else nbr_dim, nh)
             if self.attention:
-                self.neighbor_value_mlp = mlp(hidden)                           # :60-65
-                self.attention_mlp = nn.Sequential(nn.Linear(2 * hidden, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh(),
-                                                   nn.Linear(hidden, 1))        # :68-75
+                self.neighbor_value_mlp = mlp(nh, nh)                           # :60-65
+                self.attention_mlp = nn.Sequential(nn.Linear(2 * nh, nh), act(), nn.Linear(nh, nh), act(),
+                                                   nn.Linear(nh, 1))            # :68-75
             self.self_encoder = mlp(self_dim)                                   # :303-309
-            self.obstacle_encoder = mlp(obst_dim) if obst_dim > 0 else None     # :315-322
-            total = hidden * (1 + (self.neighbor_encoder is not None) + (obst_dim > 0))
+            self.obstacle_encoder = mlp(obst_dim, oh) if obst_dim > 0 else None # :315-322
+            total = hidden + (nh if self.neighbor_encoder is not None else 0) + (oh if obst_dim > 0 else 0)   # :324
             self.feed_forward = nn.Sequential(nn.Linear(total, 2 * hidden), nn.Tanh())   # :329-332
 
         def forward(self, obs):
@@ -129,7 +142,8 @@ def make_reference_encoder(self_dim=18, nbr_dim=6, num_nbr=6, obst_dim=0, hidden
                 emb.append(self.obstacle_encoder(obs[:, self.self_dim + nb:]))
             return self.feed_forward(torch.cat(emb, dim=1))                     # :334-350
 
-    torch.manual_seed(seed)
+    if seed is not None:   # None: the caller's generator state (Sample Factory seeds once, globally)
+        torch.manual_seed(seed)
     return QuadMultiEncoderRef()
 
 
@@ -226,8 +240,37 @@ def make_reference_sim2real_encoder(self_dim=19, nbr_dim=6, num_nbr=2, obst_dim=
             tokens = self.attention_layer(torch.stack((n, o), dim=1))
             return self.feed_forward(torch.cat((s, tokens.reshape(obs.shape[0], -1)), dim=1))
 
-    torch.manual_seed(seed)
+    if seed is not None:
+        torch.manual_seed(seed)
     return QuadSingleHeadAttentionEncoderSim2RealRef()
+
+
+OBS_REPR_DIMS = {"xyz_vxyz_R_omega": 18, "xyz_vxyz_R_omega_floor": 19, "xyz_vxyz_R_omega_wall": 24}   # quad_utils.py:30-34
+
+
+def encoder_from_cfg(cfg, seed=None):
+    """The module swarm_rl/models/quad_multi_model.py:355-370 `make_quadmulti_encoder(cfg, obs_space)` builds, from the same flags:
+    --quads_encoder_type / --quads_sim2real pick the class, --rnn_size / --quads_neighbor_hidden_size / --quads_obst_hidden_size the
+    widths, --nonlinearity the activation of QuadMultiEncoder's MLPs.  Combinations the reference itself cannot run raise here
+    instead of silently building something else.  seed=None: the current torch generator state (what SF does)."""
+    import torch
+    self_dim = OBS_REPR_DIMS[cfg.quads_obs_repr]
+    if cfg.quads_neighbor_obs_type == "none":
+        num_nbr = 0
+    else:
+        num_nbr = cfg.quads_num_agents - 1 if cfg.quads_neighbor_visible_num == -1 else cfg.quads_neighbor_visible_num
+    hidden = cfg.rnn_size
+    if cfg.quads_encoder_type == "attention":                                   # :356-362
+        # QuadMultiHeadAttentionEncoder (:124-196) always embeds 6*K neighbour columns and 9 obstacle columns with rnn_size-wide tanh
+        # layers, whatever the other flags say
+        if not cfg.quads_use_obstacles or num_nbr == 0:
+            raise NotImplementedError("--quads_encoder_type=attention needs neighbour and obstacle observations: the reference's "
+                                      "QuadMultiHeadAttentionEncoder slices both out of the observation row (quad_multi_model.py:176-196)")
+        make = make_reference_sim2real_encoder if getattr(cfg, "quads_sim2real", False) else make_reference_mha_encoder
+        return make(self_dim=self_dim, num_nbr=num_nbr, obst_dim=9, hidden=hidden, seed=seed)
+    return make_reference_encoder(seed=seed, self_dim=self_dim, num_nbr=num_nbr, obst_dim=9 if cfg.quads_use_obstacles else 0, hidden=hidden,
+                                  nbr_encoder=cfg.quads_neighbor_encoder_type, nbr_hidden=getattr(cfg, "quads_neighbor_hidden_size", hidden),
+                                  obst_hidden=getattr(cfg, "quads_obst_hidden_size", hidden), nonlinearity=getattr(cfg, "nonlinearity", "tanh"))
 
 
 # reference / Sample Factory parameter names -> the names of the restatements above (the encoder sits under "encoder." in an SF
@@ -316,6 +359,12 @@ class FusedQuadEncoder:
         if not torch.cuda.is_available():
             raise native.QsError("FusedQuadEncoder needs a GPU: there is no CPU fallback")
         self._keep = []
+        # the kernels are built for the published architecture: every hidden width 256, tanh (HIDDEN); a module with other widths or
+        # another --nonlinearity runs as the torch module it is (sf_models.QuadEncoder), not here
+        widths = {getattr(module, a, HIDDEN) for a in ("hidden", "nbr_hidden", "obst_hidden")} | {module.self_encoder[0].out_features}
+        if widths != {HIDDEN} or getattr(module, "nonlinearity", "tanh") != "tanh":
+            raise NotImplementedError(f"the fused encoder kernels cover rnn_size = neighbor / obstacle hidden size = {HIDDEN} with tanh; got widths "
+                                      f"{sorted(widths)}, nonlinearity {getattr(module, 'nonlinearity', 'tanh')!r}")
         P = EncParams()
         P.self_dim, P.nbr_dim, P.num_nbr, P.obst_dim = module.self_dim, module.nbr_dim, module.num_nbr, module.obst_dim
         P.obs_dim = module.self_dim + module.nbr_dim * module.num_nbr + module.obst_dim

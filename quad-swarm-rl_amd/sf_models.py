@@ -7,24 +7,11 @@ from sample_factory.model.encoder import Encoder
 
 from . import policy
 
-OBS_REPR = {"xyz_vxyz_R_omega": 18, "xyz_vxyz_R_omega_floor": 19, "xyz_vxyz_R_omega_wall": 24}   # quad_utils.py:30-34
-
-
 class QuadEncoder(Encoder):
     def __init__(self, cfg, obs_space):
         super().__init__(cfg)
-        self_dim = OBS_REPR[cfg.quads_obs_repr]
-        if cfg.quads_neighbor_obs_type == "none":
-            num_nbr = 0
-        else:
-            num_nbr = cfg.quads_num_agents - 1 if cfg.quads_neighbor_visible_num == -1 else cfg.quads_neighbor_visible_num
-        obst_dim = 9 if cfg.quads_use_obstacles else 0
-        if cfg.quads_encoder_type == "attention":
-            make = policy.make_reference_sim2real_encoder if getattr(cfg, "quads_sim2real", False) else policy.make_reference_mha_encoder   # :358-362
-            self.body = make(self_dim=self_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=cfg.rnn_size)
-        else:
-            self.body = policy.make_reference_encoder(self_dim=self_dim, num_nbr=num_nbr, obst_dim=obst_dim, hidden=cfg.rnn_size,
-                                                      nbr_encoder=cfg.quads_neighbor_encoder_type)
+        # the reference's factory, flag for flag (widths, nonlinearity, encoder class): quad_multi_model.py:250-370
+        self.body = policy.encoder_from_cfg(cfg)
         self.encoder_out_size = self.body.feed_forward[0].out_features
 
     def forward(self, obs_dict):

@@ -20,8 +20,7 @@ def _expected_rows(total_envs, wire, action_batches):
     """rows of the un-sharded stepper after the reset and after each action batch (an int t = batch t of the global action set)"""
     import torch
     from quad_swarm_rl_amd import config as qcfg, native
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    import xchg_worker as xw
+    from tests import xchg_worker as xw
     cfg = qcfg.make_config(num_envs=total_envs, seed=7, precision="f32", write_rew_info=False, **xw.KW)
     st = native.Stepper(cfg, device=0)
     acts = torch.as_tensor(xw.global_actions(max(action_batches) + 1 if action_batches else 1, total_envs, cfg.num_agents)).cuda()
@@ -136,8 +135,7 @@ def test_world1_graph_capture_matches_plain_stepping(transport):
     the plain stepper on the same actions; the redirected observation output leaves qs_buffers.obs untouched."""
     import torch
     from quad_swarm_rl_amd import config as qcfg, native, parallel
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    import xchg_worker as xw
+    from tests import xchg_worker as xw
     E, G = 12, 8
     cfg = qcfg.make_config(num_envs=E, seed=7, precision="f32", write_rew_info=False, **xw.KW)
     acts = torch.as_tensor(xw.global_actions(G, E, cfg.num_agents)).cuda()
@@ -193,8 +191,7 @@ def test_missing_peer_times_out_and_reports():
 
 def test_obs_target_is_refused_with_device_replay():
     from quad_swarm_rl_amd import config as qcfg, native
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    import xchg_worker as xw
+    from tests import xchg_worker as xw
     cfg = qcfg.make_config(num_envs=4, seed=1, precision="f32", episode_sums=True, **xw.KW)
     st = native.Stepper(cfg, device=0)
     st.replay_enable(0.5)
