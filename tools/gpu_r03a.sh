@@ -26,7 +26,7 @@ done; done
 unset QS_TEAM QS_SPEC_EXTRA_FLAGS
 timeout 300 python bench.py --workload c3 --steps 2000 --warmup 100 $Q 2>>gpurun_out/${tag}_err.txt | python -c "$fmt" "c3" | tee -a $out
 # the exchange at world size 1: captured graph (peer / rccl), eager (segment 0), round 2's torch gather; f32 and bf16 wire
-for wl in c2 c4; do
+for wl in c2; do
   for tr in peer rccl torch; do
     timeout 300 python bench.py --workload $wl --force-gather --transport $tr --steps 2048 --warmup 128 $Q > gpurun_out/${tag}_bench_${wl}_gather_$tr.json 2>>gpurun_out/${tag}_err.txt
     python -c "$fmt" "$wl force-gather $tr bf16 graph" < gpurun_out/${tag}_bench_${wl}_gather_$tr.json | tee -a $out
@@ -34,6 +34,7 @@ for wl in c2 c4; do
   timeout 300 python bench.py --workload $wl --force-gather --transport peer --segment 0 --steps 2048 --warmup 128 $Q 2>>gpurun_out/${tag}_err.txt | python -c "$fmt" "$wl force-gather peer bf16 eager" | tee -a $out
   timeout 300 python bench.py --workload $wl --force-gather --transport peer --wire f32 --steps 2048 --warmup 128 $Q 2>>gpurun_out/${tag}_err.txt | python -c "$fmt" "$wl force-gather peer f32 graph" | tee -a $out
 done
+timeout 300 python bench.py --workload c4 --force-gather --transport peer --steps 2048 --warmup 128 $Q 2>>gpurun_out/${tag}_err.txt | python -c "$fmt" "c4 force-gather peer bf16 graph" | tee -a $out
 timeout 300 python bench.py --force-gather --steps 20 --warmup 5 $Q 2>>gpurun_out/${tag}_err.txt | python -c "$fmt" "c2 force-gather auto steps=20" | tee -a $out
 # phase timing of the C4 team kernel (new and old scan)
 timeout 300 python tools/phase_timing.py c4 > gpurun_out/${tag}_phase_c4.txt 2>&1
@@ -41,3 +42,4 @@ QS_TIMING_EXTRA="-DQS_PAIR_ONCE=0" timeout 300 python tools/phase_timing.py c4 >
 timeout 300 python tools/phase_timing.py c2 > gpurun_out/${tag}_phase_c2.txt 2>&1
 head -20 gpurun_out/${tag}_phase_c4.txt
 tail -3 gpurun_out/${tag}_err.txt
+timeout 200 tools/ubench_hbm > gpurun_out/${tag}_ubench_hbm.txt 2>&1; grep BEST gpurun_out/${tag}_ubench_hbm.txt

@@ -24,6 +24,50 @@ __global__ void k_mix16(const float4 *src, float4 *dst, size_t n4) {
         dst[o] = v; v.x += 1.f; dst[o + 1] = v; v.y += 1.f; dst[o + 2] = v; v.z += 1.f; dst[o + 3] = v;
     }
 }
+// ---- the copy ceiling, swept: size x grid x unroll x cache policy.  /opt/skills/guides/MI355X_MICROARCH.md quotes 6.29 TB/s for a float4
+// copy; the naive loop above reaches 4.6-4.8 TB/s at 1 GiB.  What separates the two is looked for here, not assumed. ----
+typedef float vf4 __attribute__((ext_vector_type(4)));   // (the nontemporal builtins take clang vectors, not HIP's float4 struct)
+template <int NT> __device__ __forceinline__ vf4 ld4(const vf4 *p) { if (NT & 1) return __builtin_nontemporal_load(p); return *p; }
+template <int NT> __device__ __forceinline__ void st4(vf4 *p, vf4 v) { if (NT & 2) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int U, int NT>
+__global__ void __launch_bounds__(256) k_copy_sweep(const float4 *__restrict__ src_, float4 *__restrict__ dst_, size_t n4) {
+    const vf4 *__restrict__ src = (const vf4 *)src_; vf4 *__restrict__ dst = (vf4 *)dst_;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        vf4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = ld4<NT>(&src[i + u * stride]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) st4<NT>(&dst[i + u * stride], v[u]);
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+template <int U, int NT>
+__global__ void __launch_bounds__(256) k_write_sweep(float4 *__restrict__ dst_, size_t n4) {
+    vf4 *__restrict__ dst = (vf4 *)dst_;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const vf4 v = {1.f, 2.f, 3.f, (float)i};
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) st4<NT>(&dst[i + u * stride], v);
+    }
+    for (; i < n4; i += stride) dst[i] = v;
+}
+template <int U, int NT>
+__global__ void __launch_bounds__(256) k_read_sweep(const float4 *__restrict__ src_, float4 *__restrict__ sink, size_t n4) {
+    const vf4 *__restrict__ src = (const vf4 *)src_;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    vf4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += ld4<NT>(&src[i + u * stride]);
+    }
+    if (acc.x == 123.456f) *(vf4 *)sink = acc;   // never true: keeps the loads
+}
+
 // one wave per block of 64 "drones": RC components read, WC components written, component-major (SoA: component c of drone g
 // at base[c*T + g], 4 B per lane) or wave-blocked (AoSoA: the wave's RC/WC rows contiguous)
 template <int RC, int WC, bool BLOCKED>
@@ -66,6 +110,34 @@ int main() {
         CK(hipEventElapsedTime(&ms, e0, e1)); snprintf(nm, sizeof nm, "copy (50:50), 16 B/lane, %d blocks", blocks); report(nm, 2.0 * bytes, ms);
         CK(hipEventRecord(e0)); for (int r = 0; r < reps; ++r) k_mix16<<<blocks, 256>>>(a, b, n4 / 4); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); snprintf(nm, sizeof nm, "20:80 read:write, 16 B/lane, %d blocks", blocks); report(nm, 1.25 * bytes, ms);
+    }
+    {   // ---- sweep: bytes per buffer x blocks x unroll x policy (bit 0 = nt loads, bit 1 = nt stores); best line per size printed last ----
+        const size_t cap = 4ull << 30;
+        float4 *s2 = nullptr, *d2 = nullptr;
+        if (hipMalloc(&s2, cap) == hipSuccess && hipMalloc(&d2, cap) == hipSuccess) {
+            CK(hipMemset(s2, 1, cap)); CK(hipMemset(d2, 0, cap));
+            printf("# copy / write / read sweep: GB/s of bytes moved (copy counts read + written); 256 threads per block\n");
+            for (size_t mb : {64, 256, 1024, 4096}) {
+                const size_t nb = mb << 20, m4 = nb / 16;
+                double best_copy = 0, best_write = 0, best_read = 0; char bc[96] = "", bw[96] = "", br[96] = "";
+                for (int blocks : {1024, 2048, 4096, 8192, 16384}) {
+#define SWEEP(U, NT) do { \
+                    float t; char nm[96]; \
+                    k_copy_sweep<U, NT><<<blocks, 256>>>(s2, d2, m4); CK(hipDeviceSynchronize()); \
+                    CK(hipEventRecord(e0)); for (int r = 0; r < reps; ++r) k_copy_sweep<U, NT><<<blocks, 256>>>(s2, d2, m4); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+                    CK(hipEventElapsedTime(&t, e0, e1)); { double g = 2.0 * nb * reps / (t * 1e-3) / 1e9; snprintf(nm, sizeof nm, "%d blocks, unroll %d, policy %d", blocks, U, NT); \
+                        printf("  copy  %5zu MiB %-40s %8.1f GB/s\n", mb, nm, g); if (g > best_copy) { best_copy = g; snprintf(bc, sizeof bc, "%s", nm); } } \
+                    if (((NT) & 1) == 0) { CK(hipEventRecord(e0)); for (int r = 0; r < reps; ++r) k_write_sweep<U, NT><<<blocks, 256>>>(d2, m4); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+                        CK(hipEventElapsedTime(&t, e0, e1)); double g = 1.0 * nb * reps / (t * 1e-3) / 1e9; if (g > best_write) { best_write = g; snprintf(bw, sizeof bw, "%s", nm); } } \
+                    if (((NT) & 2) == 0) { CK(hipEventRecord(e0)); for (int r = 0; r < reps; ++r) k_read_sweep<U, NT><<<blocks, 256>>>(s2, d2, m4); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
+                        CK(hipEventElapsedTime(&t, e0, e1)); double g = 1.0 * nb * reps / (t * 1e-3) / 1e9; if (g > best_read) { best_read = g; snprintf(br, sizeof br, "%s", nm); } } } while (0)
+                    SWEEP(1, 0); SWEEP(4, 0); SWEEP(8, 0); SWEEP(4, 1); SWEEP(4, 2); SWEEP(4, 3); SWEEP(8, 3);
+#undef SWEEP
+                }
+                printf("BEST %5zu MiB per buffer: copy %8.1f GB/s [%s] | write-only %8.1f GB/s [%s] | read-only %8.1f GB/s [%s]\n", mb, best_copy, bc, best_write, bw, best_read, br);
+            }
+            CK(hipFree(s2)); CK(hipFree(d2));
+        } else { (void)hipGetLastError(); printf("# sweep skipped: cannot allocate 2 x 4 GiB\n"); }
     }
     const size_t T = 1u << 20;   // 2^20 drones = the 131072-env C2 batch
     const float *src = (const float *)a; float *dst = (float *)b;
