@@ -350,15 +350,17 @@ def main():
             gather.drain()   # the launch stream waits for the in-flight collectives: the closing event sees them
 
     seg = 0
-    if exchange is not None:   # [step -> exchange] x seg as one HIP graph (captured before any timed region; its warm-up steps are untimed)
-        seg = min(args.segment, ring) & ~1
+    if exchange is not None:   # reset (its rows are exchanged like a step's), then [step -> exchange] x seg as one HIP graph, captured before
+        exchange.reset()       # any timed region (the eager steps capture() takes first are untimed)
+        seg = min(args.segment, ring, max(args.steps, 2)) & ~1   # (a whole number of segments fits the timed region also at --steps 20)
         if seg >= 2:
             exchange.capture([aptr + t * astride for t in range(seg)])
 
     def run_exchange(k):
         """exactly k control steps, each followed by the exchange of its rows: whole segments as graph replays, the rest eagerly"""
         done_steps = 0
-        if seg >= 2:
+        if seg >= 2 and k >= seg:
+            exchange.align(aptr)   # (an even number of steps issued before a replay; a no-op inside the timed region, see timed())
             while done_steps + seg <= k:
                 exchange.replay()
                 done_steps += seg
@@ -399,9 +401,7 @@ def main():
             devs, host = (float(x) for x in tmax.tolist())
         return devs, host
 
-    if exchange is not None:
-        exchange.reset()
-    else:
+    if exchange is None:
         st.reset(stream=stream)
     head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None, xchg=use_gather and exchange is not None)
     st.check_errors()

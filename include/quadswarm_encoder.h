@@ -63,6 +63,9 @@ typedef struct qs_enc_params {
 
 size_t qs_enc_sizeof_params(void);
 size_t qs_enc_lds_bytes(void);
+/* dynamic LDS the kernel of `model` (QS_ENC_NBR_* / QS_ENC_MODEL_*) requests.  QS_ENC_MODEL_MHA / _S2R: more than half of a CU's
+ * 160 KiB, i.e. one workgroup per CU by construction. */
+size_t qs_enc_lds_bytes_of(int32_t model);
 const char *qs_enc_last_error(void);
 
 /* out[B, 512] (QS_ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]) on `stream` (out may be NULL when params->head_dim > 0).  0 on success, < 0 on error
@@ -78,7 +81,8 @@ int32_t qs_enc_set_wide_min(int32_t agents);
 /* Closed-loop glue of a rollout segment (quad-swarm-rl_amd/rollout.py): one launch before the environment step - trajectory copy of
  * the observations, act_out[A, 4] = mean[A, 4] + exp(log_std[4]) * N(0, 1) (log_std NULL: the mean itself; Philox4x32-10 keyed by
  * seed, the device counter and the agent) - and one after it - trajectory copies of rewards / dones, counter += 1.  They replace
- * eight framework kernels per control step (reference side: Sample Factory's sampler loop around env.step, swarm_rl/train.py). */
+ * eight framework kernels per control step (reference side: Sample Factory's sampler loop around env.step, swarm_rl/train.py).
+ * Alignment: any 4-byte aligned pointers work; 16-byte aligned obs / obs_out (and mean / act_out) take the 16-byte path. */
 int qs_rollout_pre(const float *obs, float *obs_out, int32_t n_obs, const float *mean, const float *log_std, float *act_out, int32_t A, uint64_t seed,
                    const uint32_t *counter, void *stream);
 int qs_rollout_post(const float *rew, float *rew_out, const uint8_t *done, uint8_t *done_out, int32_t A, uint32_t *counter, void *stream);

@@ -139,9 +139,14 @@ template <> struct NbrKey<double> {
 #define QS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.timing[k] = clock64(); } while (0)
 // helper waves of the team kernels: stamp k of wave w (1..3) lands in timing[32*w + k]
 #define QS_STAMPW(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x >= 64) p.timing[32 * (threadIdx.x >> 6) + (k)] = clock64(); } while (0)
+// start / end of EVERY workgroup (wave 0; s_memtime and the constant 100 MHz wall clock) and where it ran: HW_ID (gfx9: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and XCC_ID
+#define QS_STAMP_WG(k) do { if (threadIdx.x == 0) { p.timing[128 + 6 * blockIdx.x + (k)] = clock64(); p.timing[128 + 6 * blockIdx.x + 4 + (k)] = wall_clock64(); \
+        if ((k) == 0) { p.timing[128 + 6 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); \
+                        p.timing[128 + 6 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); } } } while (0)
 #else
 #define QS_STAMP(k) do { } while (0)
 #define QS_STAMPW(k) do { } while (0)
+#define QS_STAMP_WG(k) do { } while (0)
 #endif
 
 struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
@@ -372,6 +377,17 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
 // consecutive words: every store instruction is one contiguous run.  rowmask (bit = row within the block) selects the rows to
 // write (an auto-reset rewrites only the rows of the finished environments).  Whole wave, between barriers.
 // ------------------------------------------------------------------------------------------------
+// QS_NT_OBS: cache policy of the observation rows' stores.  They are write-once per step and not read again by the stepper (42 % of a
+// step's bytes): 1 = non-temporal (`nt`: do not keep the lines in the Infinity Cache, which then holds the state the next step re-reads).
+#ifndef QS_NT_OBS
+#define QS_NT_OBS 0
+#endif
+typedef float qs_f32x2 __attribute__((ext_vector_type(2)));
+typedef float qs_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void obs_st2(float *dst, qs_f32x2 v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, (qs_f32x2 *)dst); else *(qs_f32x2 *)dst = v; }
+__device__ __forceinline__ void obs_st4(float *dst, qs_f32x4 v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, (qs_f32x4 *)dst); else *(qs_f32x4 *)dst = v; }
+template <typename real> __device__ __forceinline__ void obs_st1(real *dst, real v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, dst); else *dst = v; }
+
 template <typename real>
 __device__ __forceinline__ void obs_copy_rows(real *__restrict__ dst_block, const real *s_self, const real *s_rows, int S, int D, int r0, int nr, uint64_t rowmask, int tid) {
 #ifdef QS_EXP_NOFLUSH   // experiment: how much of the step is the observation output path
@@ -384,14 +400,14 @@ __device__ __forceinline__ void obs_copy_rows(real *__restrict__ dst_block, cons
         for (int idx = tid; idx < total; idx += QS_WAVE) {
             const int row = idx / half, c2 = 2 * (idx - row * half);
             const float *src = (c2 < S) ? (const float *)s_self + (r0 + row) * S + c2 : (const float *)s_rows + row * X + (c2 - S);
-            if ((rowmask >> (r0 + row)) & 1) *(float2 *)((float *)dst + 2 * idx) = *(const float2 *)src;
+            if ((rowmask >> (r0 + row)) & 1) obs_st2((float *)dst + 2 * idx, *(const qs_f32x2 *)src);
         }
     } else {
         const int total = nr * D;
         for (int idx = tid; idx < total; idx += QS_WAVE) {
             const int row = idx / D, cc = idx - row * D;
             const real v = (cc < S) ? s_self[(r0 + row) * S + cc] : s_rows[row * X + (cc - S)];
-            if ((rowmask >> (r0 + row)) & 1) dst[idx] = v;
+            if ((rowmask >> (r0 + row)) & 1) obs_st1<real>(dst + idx, v);
         }
     }
 }
@@ -1140,6 +1156,7 @@ struct ReplayParams {
     const uint8_t *done; const int32_t *tick; const uint32_t *step_ctr; const uint64_t *unique_col, *obst_new;
     int32_t *counters;                           // [QS_CNT_COUNT][E]
     const void *ep_sums; int32_t real_size, T;   // per-episode crash reward of drone 0: ep_sums[QS_RI_REW_CRASH][e*N]
+    const void *run_sums;                        // the running episode's sums (an explicit reset records the crash reward so far)
     // per-env wrapper state
     uint8_t *active, *saved, *ep_saved;          // ep_saved: was the episode that just ended a replayed one (quadrotor_multi.py:629-633)
     float *crash_hist; int32_t *crash_n, *crash_pos;    // deque(maxlen=100) of crashes_last_episode
@@ -1167,6 +1184,34 @@ __device__ __forceinline__ void replay_copy(const ReplayParams &P, int e, char *
     }
 }
 
+// QuadrotorEnvMulti.reset's replay-buffer lines (quadrotor_multi.py:356-359, can_drones_fly :284-287): until the buffer is active, every
+// reset files crashes_last_episode in a 100-entry history and activates the buffer once >= 10 episodes average above -1
+__device__ __forceinline__ void replay_record_reset(const ReplayParams &P, int e, float crashes) {
+    if (P.active[e]) return;
+    const int E = P.E;
+    int n = P.crash_n[e], pos = P.crash_pos[e];
+    P.crash_hist[(size_t)pos * E + e] = crashes;
+    pos = (pos + 1) % 100; n = n < 100 ? n + 1 : 100;
+    P.crash_n[e] = n; P.crash_pos[e] = pos;
+    float sum = 0;
+    for (int q = 0; q < n; ++q) sum += P.crash_hist[(size_t)q * E + e];
+    if (fabsf(sum / (float)n) < 1.0f && n >= 10) P.active[e] = 1;
+}
+
+// An EXPLICIT reset (qs_reset) of environments whose replay wrapper is running - what ExperienceReplayWrapper.reset() ->
+// QuadrotorEnvMulti.reset() does to the wrapper's bookkeeping (quad_experience_replay.py:106-118): the crash reward the running episode
+// has collected so far goes into the history (the reference appends crashes_last_episode on every reset), and the new episode starts
+// at tick 0 (start_tick feeds the per-episode step count of the action statistics).  Like the reference, the checkpoint deque and the
+// tick of the last filed event are NOT cleared by a reset - only by an episode end (new_episode, :167-209).  Launched by qs_reset
+// before the reset kernel, one lane per environment.
+__global__ void __launch_bounds__(QS_WAVE) qs_replay_reset_kernel(const ReplayParams P, const uint8_t *reset_mask) {
+    const int e = blockIdx.x * QS_WAVE + threadIdx.x;
+    if (e >= P.E || !reset_mask[e]) return;
+    const size_t at = (size_t)QS_RI_REW_CRASH * P.T + (size_t)e * P.N;
+    replay_record_reset(P, e, P.real_size == 8 ? (float)((const double *)P.run_sums)[at] : ((const float *)P.run_sums)[at]);
+    P.start_tick[e] = 0;
+}
+
 __global__ void __launch_bounds__(QS_WAVE) qs_replay_kernel(const ReplayParams P) {
     __shared__ int s_act[4];   // action, source slot, destination slot, flags
     const int e = blockIdx.x, lane = threadIdx.x, E = P.E, SLOTS = QS_REPLAY_RING + QS_REPLAY_EVENTS;
@@ -1176,16 +1221,7 @@ __global__ void __launch_bounds__(QS_WAVE) qs_replay_kernel(const ReplayParams P
         const bool done = P.done[(size_t)e * P.N] != 0;
         const int tick = P.tick[e];
         RngKey key = {P.seed_lo, P.seed_hi, (uint32_t)(P.env_id_offset + e), P.step_ctr[e]};
-        auto record_reset = [&](float crashes) {   // QuadrotorEnvMulti.reset, quadrotor_multi.py:356-359 (+ can_drones_fly :284-287)
-            if (P.active[e]) return;
-            int n = P.crash_n[e], pos = P.crash_pos[e];
-            P.crash_hist[(size_t)pos * E + e] = crashes;
-            pos = (pos + 1) % 100; n = n < 100 ? n + 1 : 100;
-            P.crash_n[e] = n; P.crash_pos[e] = pos;
-            float sum = 0;
-            for (int q = 0; q < n; ++q) sum += P.crash_hist[(size_t)q * E + e];
-            if (fabsf(sum / (float)n) < 1.0f && n >= 10) P.active[e] = 1;
-        };
+        auto record_reset = [&](float crashes) { replay_record_reset(P, e, crashes); };
         if (done) {   // ExperienceReplayWrapper.new_episode, quad_experience_replay.py:167-209
             const float crashes = P.real_size == 8 ? (float)((const double *)P.ep_sums)[(size_t)QS_RI_REW_CRASH * P.T + (size_t)e * P.N]
                                                    : ((const float *)P.ep_sums)[(size_t)QS_RI_REW_CRASH * P.T + (size_t)e * P.N];

@@ -1447,11 +1447,15 @@ extern "C" __global__ void __launch_bounds__(256) qs_rollout_pre_kernel(const fl
                                                                         const float *__restrict__ log_std, float *__restrict__ act_out, int A, uint32_t seed_lo,
                                                                         uint32_t seed_hi, const uint32_t *__restrict__ counter) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    const int n4 = n_obs >> 2;
+    // 16-byte copies when both rows are 16-byte aligned (a trajectory slot obs[t] of A * D floats is only when A * D % 4 == 0)
+    const int n4 = (((size_t)obs | (size_t)obs_out) & 15) == 0 ? n_obs >> 2 : 0;
     for (int i = tid; i < n4; i += nthreads) ((f32x4 *)obs_out)[i] = ((const f32x4 *)obs)[i];
     for (int i = (n4 << 2) + tid; i < n_obs; i += nthreads) obs_out[i] = obs[i];
+    const bool act16 = ((((size_t)mean | (size_t)act_out)) & 15) == 0;
     for (int a = tid; a < A; a += nthreads) {
-        f32x4 m = *(const f32x4 *)(mean + (size_t)a * 4);
+        f32x4 m;
+        if (act16) m = *(const f32x4 *)(mean + (size_t)a * 4);
+        else { m[0] = mean[(size_t)a * 4]; m[1] = mean[(size_t)a * 4 + 1]; m[2] = mean[(size_t)a * 4 + 2]; m[3] = mean[(size_t)a * 4 + 3]; }
         if (log_std) {   // action = mean + exp(log_std) * N(0, 1): two Box-Muller pairs from one Philox group
             uint32_t w[4];
             glue_philox((uint32_t)a, *counter, 0x51u, 0u, seed_lo, seed_hi, w);
@@ -1464,7 +1468,8 @@ extern "C" __global__ void __launch_bounds__(256) qs_rollout_pre_kernel(const fl
             m[0] += __expf(log_std[0]) * r0 * c0; m[1] += __expf(log_std[1]) * r0 * s0;
             m[2] += __expf(log_std[2]) * r1 * c1; m[3] += __expf(log_std[3]) * r1 * s1;
         }
-        *(f32x4 *)(act_out + (size_t)a * 4) = m;
+        if (act16) *(f32x4 *)(act_out + (size_t)a * 4) = m;
+        else { act_out[(size_t)a * 4] = m[0]; act_out[(size_t)a * 4 + 1] = m[1]; act_out[(size_t)a * 4 + 2] = m[2]; act_out[(size_t)a * 4 + 3] = m[3]; }
     }
 }
 extern "C" __global__ void __launch_bounds__(256) qs_rollout_post_kernel(const float *__restrict__ rew, float *__restrict__ rew_out, const uint8_t *__restrict__ done,
@@ -1508,6 +1513,14 @@ static int wide_min_agents(int dev) {
 int32_t qs_enc_set_wide_min(int32_t agents) { const int prev = g_wide_min; if (agents >= -1) g_wide_min = agents; return prev; }   // -1: the default rule; < -1: read only
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
 size_t qs_enc_lds_bytes(void) { return lds_main(0); }
+// LDS request of the kernel that serves `model` (QS_ENC_NBR_* / QS_ENC_MODEL_*): the multi-head and Sim2Real kernels ask for more than
+// half of a CU's 160 KiB ON PURPOSE - one workgroup per CU by construction (an experiment with two co-resident
+// workgroups of this body was not run-to-run deterministic and was never shipped); tests/test_c_abi.py pins that.
+size_t qs_enc_lds_bytes_of(int32_t model) {
+    if (model == ENC_MODEL_MHA || model == ENC_MODEL_S2R) return lds_mha();
+    if (model == ENC_NBR_ATTENTION) return lds_embed() > lds_main(0) ? lds_embed() : lds_main(0);
+    return lds_main(0);
+}
 
 // out[B, 512] (ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {

@@ -71,6 +71,7 @@ struct qs_handle {
     uint8_t *h_mask = nullptr;   // pinned staging for qs_reset masks
     // batched experience replay (qs_replay_enable)
     bool replay_on = false;
+    bool replay_stepped = false;   // a step was taken since qs_replay_enable: an explicit reset from now on is recorded by the wrapper state
     ReplayParams rp;
     // noise tape (qs_set_noise_tape): device copy [E][tape_len] + per-env cursor; while set, reset / step run the tape kernels
     double *d_tape = nullptr;
@@ -377,7 +378,7 @@ template <typename real> static int create_typed(qs_handle *h) {
         HIP_TRY(hipMemcpy(p.obst_density_env, dn.data(), E * sizeof(real), hipMemcpyHostToDevice));
     }
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
-    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128);
+    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128 + 6 * NBLK);   // QS_TIMING builds: phase stamps of workgroup 0, then {start, end, HW_ID, XCC_ID, wall start, wall end} of every workgroup
 #undef DA
     {   // run-time reward coefficients (+ proximity slope), read by every launch
         real *rw = nullptr;
@@ -636,6 +637,11 @@ int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream) {
     const int E = h->cfg.num_envs;
     for (int e = 0; e < E; ++e) h->h_mask[e] = env_mask_host ? (env_mask_host[e] ? 1 : 0) : 1;
     HIP_TRY(hipMemcpyAsync(h->pf.reset_mask, h->h_mask, (size_t)E, hipMemcpyHostToDevice, s));
+    if (h->replay_on && h->replay_stepped) {   // the replay wrapper's bookkeeping of an explicit reset (before the reset kernel zeroes the running
+        // sums); the reset that starts the very first episode is already in the history (qs_replay_enable)
+        hipLaunchKernelGGL(qs_replay_reset_kernel, dim3((E + QS_WAVE - 1) / QS_WAVE), dim3(QS_WAVE), 0, s, h->rp, (const uint8_t *)h->pf.reset_mask);
+        HIP_TRY(hipGetLastError());
+    }
     int rc = launch_reset(h, s);
     if (rc != QS_OK) return rc;
     HIP_TRY(hipStreamSynchronize(s));   // h_mask is reused by the next call
@@ -706,7 +712,7 @@ int qs_step(qs_handle *h, const void *actions_dev, void *stream) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     int rc = launch_step(h, actions_dev ? actions_dev : h->d_actions, (hipStream_t)stream);
-    if (rc == QS_OK && h->replay_on) rc = launch_replay(h, (hipStream_t)stream);
+    if (rc == QS_OK && h->replay_on) { rc = launch_replay(h, (hipStream_t)stream); h->replay_stepped = true; }
     return rc;
 }
 
@@ -717,7 +723,7 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
     if (h->profiling || h->replay_on) {   // per-step HIP events / the replay kernel behind every step: one launch per control step
         for (int32_t t = 0; t < k; ++t) {
             int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream, 1);
-            if (rc == QS_OK && h->replay_on) rc = launch_replay(h, (hipStream_t)stream);
+            if (rc == QS_OK && h->replay_on) { rc = launch_replay(h, (hipStream_t)stream); h->replay_stepped = true; }
             if (rc != QS_OK) return rc;
         }
         return QS_OK;
@@ -910,7 +916,7 @@ int qs_replay_enable(qs_handle *h, double sample_prob) {
     P.env_id_offset = h->cfg.env_id_offset;
     P.sample_prob = (float)sample_prob;
     P.done = h->pf.done; P.tick = h->pf.tick; P.step_ctr = h->pf.step_ctr; P.unique_col = h->pf.unique_col; P.obst_new = h->pf.obst_new;
-    P.counters = h->pf.counters; P.ep_sums = h->pf.ep_sums; P.real_size = h->real_size; P.T = (int32_t)(E * h->cfg.num_agents);
+    P.counters = h->pf.counters; P.ep_sums = h->pf.ep_sums; P.run_sums = h->pf.run_sums; P.real_size = h->real_size; P.T = (int32_t)(E * h->cfg.num_agents);
     int rc;
     if ((rc = dalloc(h, &P.pool, (size_t)P.snap_bytes * (QS_REPLAY_RING + QS_REPLAY_EVENTS) * E)) != QS_OK) return rc;
     if ((rc = dalloc(h, &P.active, E)) != QS_OK || (rc = dalloc(h, &P.saved, E)) != QS_OK || (rc = dalloc(h, &P.ep_saved, E)) != QS_OK || (rc = dalloc(h, &P.crash_hist, 100 * E)) != QS_OK ||
@@ -1009,6 +1015,14 @@ int qs_debug_lds_bytes(const qs_config *cfg, int team, int spec) {
                       scenario_is_full(cfg->scenario), cfg->scenario, spec ? spec_rows_per_pass(cfg, team) : QS_WAVE).total;
 }
 
+int qs_debug_wg_times(qs_handle *h, unsigned long long *out, int32_t max_blocks) {   // [blocks][6]: start, end (s_memtime), HW_ID, XCC_ID, start, end (100 MHz wall clock) of wave 0 of every workgroup
+    if (!h || !out) return fail(QS_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int n = h->blocks < max_blocks ? h->blocks : max_blocks;
+    HIP_TRY(hipMemcpy(out, h->pf.timing + 128, (size_t)n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return n;
+}
 int qs_debug_timing(qs_handle *h, unsigned long long *out128) {   // [4 waves][32 stamps] of workgroup 0 (QS_TIMING builds)
     if (!h || !out128) return fail(QS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));

@@ -57,6 +57,23 @@ class _SingleView:
         return self._multi.control_freq
 
 
+class _RewCoeff(dict):
+    """env.rew_coeff: the reward-shaping wrapper assigns into it from outside (swarm_rl/env_wrappers/reward_shaping.py:57-59,111-118);
+    every write raises `dirty`, so that a step pushes the coefficients to the device only when one changed - no per-step comparison."""
+    dirty = True
+
+    def __setitem__(self, k, v):
+        dict.__setitem__(self, k, v)
+        self.dirty = True
+
+    def update(self, *a, **k):
+        dict.update(self, *a, **k)
+        self.dirty = True
+
+    def __deepcopy__(self, memo):
+        return _RewCoeff(self)
+
+
 class QuadSwarmVecEnv:
     """Batched env: all E*N agents stepped by one kernel launch; observations are born in HBM.
 
@@ -74,11 +91,16 @@ class QuadSwarmVecEnv:
         low, high = qcfg.obs_bounds(self.cfg)
         self.observation_space = _Box(low, high, dtype=np.float32)
         self.action_space = _Box(-np.ones(4), np.ones(4), dtype=np.float32)   # quadrotor_control.py:37-49
-        self.rew_coeff = dict(qcfg.REW_COEFF_DEFAULT)
+        self.rew_coeff = _RewCoeff(qcfg.REW_COEFF_DEFAULT)
         self.rew_coeff.update({k: self.cfg.rew_coeff[i] for i, k in enumerate(qcfg.REW_COEFF_KEYS)})
         self._pushed_coeff = [self.rew_coeff[k] for k in qcfg.REW_COEFF_KEYS]
+        self.rew_coeff.dirty = False
         self.scenario = _Scenario(self.cfg, self.stepper)
         self._t = self.stepper.tensor
+        # the per-step call path, resolved once: the library entry point, the handle, the stream getter, the output views
+        self._qs_step, self._h = native.lib().qs_step, self.stepper._h
+        self._n_act, self._act_bytes = self.num_agents * 4, self.stepper.real_size
+        self._views = None
         self.exchange = None   # parallel.ObsExchange when this env is one shard of a multi-GPU batch whose rows are exchanged
 
     def attach_exchange(self, exchange):
@@ -91,6 +113,7 @@ class QuadSwarmVecEnv:
         if cur != self._pushed_coeff:   # the SF wrapper mutates env.rew_coeff in place (reward_shaping.py:57-59)
             self.stepper.set_reward_coeffs(cur)
             self._pushed_coeff = cur
+        self.rew_coeff.dirty = False
 
     def reset(self, env_mask=None):
         import torch
@@ -103,15 +126,24 @@ class QuadSwarmVecEnv:
         return self._t("obs")
 
     def step(self, actions):
-        import torch
-        self._sync_rew_coeff()
-        assert actions.is_cuda and actions.is_contiguous() and actions.numel() == self.num_agents * 4
-        assert actions.element_size() == self.stepper.real_size, "actions dtype must match the stepper precision"
+        """One control step.  The returned tensors are VIEWS of the library's buffers (no copy, no allocation): the next step()
+        overwrites them - a caller that keeps one across steps copies it."""
+        if self.rew_coeff.dirty:
+            self._sync_rew_coeff()
+        if not (actions.is_cuda and actions.is_contiguous() and actions.numel() == self._n_act and actions.element_size() == self._act_bytes):
+            raise ValueError("actions: contiguous device tensor [E*N, 4] of the stepper's precision")
+        if self._views is None:
+            import torch
+            self._views = (self._t("obs"), self._t("reward"), self._t("done"))
+            self._cur_stream, self._dev = torch.cuda.current_stream, self.stepper.device
         if self.exchange is not None:
             self.exchange.step(actions.data_ptr())
-            return self.exchange.local_rows(), self._t("reward"), self._t("done"), None
-        self.stepper.step(actions.data_ptr(), stream=torch.cuda.current_stream(self.stepper.device))
-        return self._t("obs"), self._t("reward"), self._t("done"), None
+            return self.exchange.local_rows(), self._views[1], self._views[2], None
+        rc = self._qs_step(self._h, actions.data_ptr(), self._cur_stream(self._dev).cuda_stream)
+        if rc:
+            native._check(rc)
+        v = self._views
+        return v[0], v[1], v[2], None
 
     def reward_info(self):
         """[17, E*N] device tensor of the `infos[i]['rewards']` terms (row order: config.REW_INFO_KEYS)."""

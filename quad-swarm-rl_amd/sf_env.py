@@ -2,17 +2,18 @@
 
   quad_utils.py:20-117        make_quadrotor_env_multi / make_quadrotor_env   -> make_quadrotor_env (same signature)
   quadrotor_params.py:4-120   quadrotors_override_defaults / add_quadrotors_env_args (same flag names and defaults)
-  reward_shaping.py:52-123    QuadsRewardShapingWrapper   -> RewardShapingWrapper (same bookkeeping, no SF import needed)
-  compatibility.py:21-50      QuadEnvCompatibility        -> Compatibility (gymnasium 5-tuple, seed ignored)
+  reward_shaping.py:52-123    QuadsRewardShapingWrapper   -> BatchedQuadSwarm: the per-episode sums run in the step kernel (episode_sums),
+                                                             the host keeps the shaping scheme, the annealing schedule and the assembly
+                                                             of the episode-end `infos` (EpisodeInfoBuilder)
+  compatibility.py:21-50      QuadEnvCompatibility        -> the 5-tuple / `reset(seed, options)` surface of BatchedQuadSwarm and of
+                                                             SingleQuadSwarm (one environment, lists / numpy in and out)
   swarm_rl/train.py:16-19     register_swarm_components
 
-The env underneath is the HIP stepper (env.QuadrotorEnvMulti); nothing here falls back to a CPU simulator.
+The env underneath is always the HIP stepper - one environment is a batch of one; nothing here falls back to a CPU simulator.
 """
 import copy
 
 import numpy as np
-
-from .env import QuadrotorEnvMulti
 
 
 def str2bool(v):
@@ -119,118 +120,54 @@ class AnnealSchedule:
         self.coeff_name, self.final_value, self.anneal_env_steps = coeff_name, final_value, anneal_env_steps
 
 
-class _Wrapper:
-    def __init__(self, env):
-        self.env = env
+class EpisodeInfoBuilder:
+    """Per-agent `infos` of a batch of finished episodes - {'true_reward', 'episode_extra_stats'} as the reference's wrapper stack
+    attaches them (quadrotor_multi.py:626-718, quad_experience_replay.py:126-138, reward_shaping.py:85-118) - from host copies of the
+    device arrays: sums [25, F*n] (reward-term sums and action moments of the finished episodes), eps [6, F*n] / cnt [11, F] (the env's
+    episode statistics), scen_ids [F], rs (qs_replay_stats dict or None).  Everything that can be computed for all finished
+    environments at once is (a handful of numpy reductions in the constructor); `env_dicts(f)` then builds the n dicts of ONE finished
+    environment - on demand, so a step on which 1024 environments finish does not build 8192 dicts before anybody asks for one."""
 
-    def __getattr__(self, name):
-        return getattr(self.env, name)
+    def __init__(self, finished, n, sums, eps, cnt, scen_ids, rs, obst_density, obst_size, approx, keys, use_obstacles, ep_steps, annealed, cur_scen_ids=None):
+        from . import config as qcfg
+        F = len(finished)
+        self.finished, self.n, self.rs, self.approx, self.annealed, self.use_obstacles = finished, n, rs, approx, annealed, use_obstacles
+        nkeys = len(keys) if use_obstacles else 15
+        self.rew_keys = list(keys[:nkeys])
+        self.i_main = self.rew_keys.index("rewraw_main")
+        self.i_quadcol = self.rew_keys.index("rewraw_quadcol") if "rewraw_quadcol" in self.rew_keys else -1
+        self.i_pos, self.i_crash = self.rew_keys.index("rew_pos"), self.rew_keys.index("rew_crash")
+        self.sums_rows = np.ascontiguousarray(sums[:nkeys].T).reshape(F, n, nkeys)       # per agent: the reward-term sums
+        self.dist = np.ascontiguousarray(eps[:3].T).reshape(F, n, 3)
+        e3 = eps[3:6].reshape(3, F, n)
+        ok = np.logical_and(e3[1], e3[2])
+        self.succ = np.sum(np.logical_and(ok, e3[0]), axis=1) / n
+        self.dead = np.sum(np.logical_and(ok, 1 - e3[0]), axis=1) / n
+        self.col, self.ncol, self.ocol = 1.0 - np.sum(ok, axis=1) / n, 1.0 - np.sum(e3[1], axis=1) / n, 1.0 - np.sum(e3[2], axis=1) / n
+        self.cnt = np.asarray(cnt)
+        self.names = [qcfg.SCENARIO_CLASS_NAMES[int(x)] for x in scen_ids]
+        # The shaping wrapper names its two per-scenario keys AFTER env.step() returned (reward_shaping.py:95-98), i.e. after the
+        # auto-reset: under `mix` that is the scenario of the episode that STARTS, not of the one the sums belong to.  Reproduced.
+        self.cur_names = self.names if cur_scen_ids is None else [qcfg.SCENARIO_CLASS_NAMES[int(x)] for x in cur_scen_ids]
+        # action moments over agents x steps of the episode (np.mean / np.std of reward_shaping.py:103-108); a replayed episode starts at
+        # its checkpoint's tick and is shorter than ep_len + 1 steps
+        steps = np.asarray(rs["ep_steps"])[np.asarray(finished, dtype=np.int64)] if rs is not None else np.full(F, ep_steps)
+        count = steps.astype(np.float64) * n
+        a1 = sums[17:21].reshape(4, F, n).sum(axis=2) / count
+        a2 = sums[21:25].reshape(4, F, n).sum(axis=2) / count
+        self.a_mean, self.a_std = a1, np.sqrt(np.maximum(a2 - a1 * a1, 0.0))
+        self.obst_density, self.obst_size = obst_density, obst_size
 
-    @property
-    def unwrapped(self):
-        return self.env.unwrapped
-
-
-class RewardShapingWrapper(_Wrapper):
-    """reward_shaping.py:22-123: pushes the shaping scheme into env.rew_coeff, accumulates the rew_* terms per agent,
-    reports true_reward / episode stats at episode end, anneals the collision coefficients."""
-
-    def __init__(self, env, reward_shaping_scheme=None, annealing=None, with_pbt=False):
-        super().__init__(env)
-        self.reward_shaping_scheme = reward_shaping_scheme
-        self.cumulative_rewards = None
-        self.episode_actions = None
-        self.num_agents = env.num_agents if hasattr(env, "num_agents") else 1
-        self.reward_shaping_updated = True
-        self.annealing = annealing
-        self.training_info = {}
-
-    def set_training_info(self, training_info):
-        self.training_info = training_info
-
-    # Sample Factory's RewardShapingInterface as the reference implements it (reward_shaping.py:36-47)
-    def get_default_reward_shaping(self):
-        return dict(quad_rewards=dict())
-
-    def get_current_reward_shaping(self, agent_idx):
-        return dict(quad_rewards=dict())
-
-    def set_reward_shaping(self, reward_shaping, unused_agent_idx):
-        self.reward_shaping_scheme = dict(quad_rewards=dict())
-        self.reward_shaping_updated = True
-
-    def reset(self):
-        obs = self.env.reset()
-        self.cumulative_rewards = [dict() for _ in range(self.num_agents)]
-        self.episode_actions = []
-        return obs
-
-    def step(self, action):
-        self.episode_actions.append(action)
-        if self.reward_shaping_updated:
-            env_reward_shaping = self.env.unwrapped.rew_coeff
-            for key, weight in self.reward_shaping_scheme["quad_rewards"].items():
-                if key in env_reward_shaping:
-                    env_reward_shaping[key] = weight
-            self.reward_shaping_updated = False
-        obs, rewards, dones, infos = self.env.step(action)
-        for i, info in enumerate(infos):
-            for key, value in info["rewards"].items():
-                if key.startswith("rew"):
-                    self.cumulative_rewards[i][key] = self.cumulative_rewards[i].get(key, 0) + value
-            if dones[i]:
-                true_reward = self.cumulative_rewards[i]["rewraw_main"] + 1000 * self.cumulative_rewards[i].get("rewraw_quadcol", 0)
-                info["true_reward"] = true_reward
-                self.cumulative_rewards[i]["rewraw_main"] = true_reward
-                extra_stats = info.setdefault("episode_extra_stats", dict())
-                extra_stats.update(self.cumulative_rewards[i])
-                approx = self.training_info.get("approx_total_training_steps", 0)
-                extra_stats["z_approx_total_training_steps"] = approx
-                scenario_name = self.env.unwrapped.scenario.name()
-                for rew_key in ("rew_pos", "rew_crash"):
-                    extra_stats[f"{scenario_name}/{rew_key}"] = self.cumulative_rewards[i][rew_key]
-                episode_actions = np.array(self.episode_actions).transpose()
-                for action_idx in range(episode_actions.shape[0]):
-                    extra_stats[f"z_action{action_idx}_mean"] = np.mean(episode_actions[action_idx])
-                    extra_stats[f"z_action{action_idx}_std"] = np.std(episode_actions[action_idx])
-                self.cumulative_rewards[i] = dict()
-                if self.annealing:
-                    env_reward_shaping = self.env.unwrapped.rew_coeff
-                    for sched in self.annealing:
-                        env_reward_shaping[sched.coeff_name] = min(sched.final_value * approx / sched.anneal_env_steps, sched.final_value)
-                        extra_stats[f"z_anneal_{sched.coeff_name}"] = env_reward_shaping[sched.coeff_name]
-        if any(dones):
-            self.episode_actions = []
-        return obs, rewards, dones, infos
-
-
-def assemble_batched_infos(finished, n, sums, eps, cnt, scen_ids, rs, obst_density, obst_size, approx, keys, use_obstacles, ep_steps, annealed, infos):
-    """infos[i] = {'true_reward', 'episode_extra_stats'} for the agents of the finished envs, from host copies of the device
-    arrays: sums [25, F*n] (reward-term sums and action moments of the finished episodes), eps [6, F*n] / cnt [11, F] (the env's
-    episode statistics), scen_ids [F], rs (qs_replay_stats dict or None).  What the reference's wrapper stack attaches per agent
-    (quadrotor_multi.py:626-718, quad_experience_replay.py:126-138, reward_shaping.py:85-118); everything that is the same for the
-    agents of an env is built once per env and copied (this runs for E*N agents at once when the episodes of a batch end together)."""
-    from . import config as qcfg
-    nkeys = len(keys) if use_obstacles else 15
-    rew_keys = list(keys[:nkeys])
-    i_main, i_quadcol = rew_keys.index("rewraw_main"), (rew_keys.index("rewraw_quadcol") if "rewraw_quadcol" in rew_keys else -1)
-    i_pos, i_crash = rew_keys.index("rew_pos"), rew_keys.index("rew_crash")
-    sums_rows = np.ascontiguousarray(sums[:nkeys].T).tolist()        # per agent: the reward-term sums as Python floats
-    dist_rows = np.ascontiguousarray(eps[:3].T).tolist()
-    for f, e in enumerate(finished):
-        e = int(e)
-        sl = slice(f * n, (f + 1) * n)
-        scenario_name = qcfg.SCENARIO_CLASS_NAMES[int(scen_ids[f])]
+    def env_dicts(self, f):
+        e, n, rs = int(self.finished[f]), self.n, self.rs
+        scenario_name = self.names[f]
         name = scenario_name[9:]
         replayed_episode = rs is not None and bool(rs["ep_was_replay"][e])
+        c = [int(x) for x in self.cnt[:, f]]
         if replayed_episode:
-            base = {"num_collisions_replay": int(cnt[0, f]), "num_collisions_obst_replay": int(cnt[7, f])}
+            base = {"num_collisions_replay": c[0], "num_collisions_obst_replay": c[7]}
         else:   # env-level part of assemble_episode_extra_stats (env.py); the per-agent distances are added below
-            ok = np.logical_and(eps[4, sl], eps[5, sl])
-            succ = float(np.sum(np.logical_and(ok, eps[3, sl])) / n)
-            dead = float(np.sum(np.logical_and(ok, 1 - eps[3, sl])) / n)
-            col, ncol, ocol = float(1.0 - np.sum(ok) / n), float(1.0 - np.sum(eps[4, sl]) / n), float(1.0 - np.sum(eps[5, sl]) / n)
-            c = [int(x) for x in cnt[:, f]]
+            succ, dead, col, ncol, ocol = float(self.succ[f]), float(self.dead[f]), float(self.col[f]), float(self.ncol[f]), float(self.ocol[f])
             base = {"num_collisions": c[0], "num_collisions_with_room": c[3], "num_collisions_with_floor": c[4], "num_collisions_with_wall": c[5],
                     "num_collisions_with_ceiling": c[6], "num_collisions_after_settle": c[1], f"{name}/num_collisions": c[1],
                     "num_collisions_final_5_s": c[2], f"{name}/num_collisions_final_5_s": c[2],
@@ -239,7 +176,7 @@ def assemble_batched_infos(finished, n, sums, eps, cnt, scen_ids, rs, obst_densi
                     "metric/agent_success_rate": succ, f"{name}/agent_success_rate": succ, "metric/agent_deadlock_rate": dead, f"{name}/agent_deadlock_rate": dead,
                     "metric/agent_col_rate": col, f"{name}/agent_col_rate": col, "metric/agent_neighbor_col_rate": ncol, f"{name}/agent_neighbor_col_rate": ncol,
                     "metric/agent_obst_col_rate": ocol, f"{name}/agent_obst_col_rate": ocol}
-            if use_obstacles:
+            if self.use_obstacles:
                 base.update({"num_collisions_obst_quad": c[7], "num_collisions_obst_quad_after_settle": c[8], f"{name}/num_collisions_obst": c[7],
                              "num_collisions_obst_quad_3_5": c[9], f"{name}/num_collisions_obst_quad_3_5": c[9], "num_collisions_obst_quad_5": c[10],
                              f"{name}/num_collisions_obst_quad_5": c[10]})
@@ -247,39 +184,117 @@ def assemble_batched_infos(finished, n, sums, eps, cnt, scen_ids, rs, obst_densi
             ep, rp, nb = int(rs["episodes"][e]), int(rs["replayed"][e]), int(rs["buffer_len"][e])
             base.update({"replay/replay_rate": rp / ep, "replay/new_episode_rate": (ep - rp) / ep, "replay/replay_buffer_size": nb,
                          "replay/avg_replayed": (int(rs["replayed_sum"][e]) / nb) if nb else 0,
-                         "replay/obst_density": float(obst_density[e]), "replay/obst_size": float(obst_size[e])})
+                         "replay/obst_density": float(self.obst_density[e]), "replay/obst_size": float(self.obst_size[e])})
+        rew_keys = self.rew_keys
         for key in rew_keys:      # placeholders keep the key order of the reference's dicts: env stats, replay stats, reward sums, z_* keys
             base[key] = 0.0
-        base["z_approx_total_training_steps"] = approx
-        k_pos, k_crash = f"{scenario_name}/rew_pos", f"{scenario_name}/rew_crash"
+        base["z_approx_total_training_steps"] = self.approx
+        k_pos, k_crash = f"{self.cur_names[f]}/rew_pos", f"{self.cur_names[f]}/rew_crash"
         base[k_pos] = base[k_crash] = 0.0
-        # action moments over agents x steps of the episode (np.mean / np.std of reward_shaping.py:103-108); a replayed episode
-        # starts at its checkpoint's tick and is shorter than ep_len + 1 steps
-        count = float((int(rs["ep_steps"][e]) if rs is not None else ep_steps) * n)
-        a1, a2 = sums[17:21, sl].sum(axis=1) / count, sums[21:25, sl].sum(axis=1) / count
-        a_std = np.sqrt(np.maximum(a2 - a1 * a1, 0.0))
         for q in range(4):
-            base[f"z_action{q}_mean"], base[f"z_action{q}_std"] = float(a1[q]), float(a_std[q])
-        for key, val in annealed:
+            base[f"z_action{q}_mean"], base[f"z_action{q}_std"] = float(self.a_mean[q, f]), float(self.a_std[q, f])
+        for key, val in self.annealed:
             base[key] = val
         dist_keys = None if replayed_episode else ("distance_to_goal_1s", "distance_to_goal_3s", "distance_to_goal_5s",
                                                    f"{name}/distance_to_goal_1s", f"{name}/distance_to_goal_3s", f"{name}/distance_to_goal_5s")
+        rows, dist = self.sums_rows[f].tolist(), self.dist[f].tolist()
+        i_main, i_quadcol, i_pos, i_crash = self.i_main, self.i_quadcol, self.i_pos, self.i_crash
+        out = []
         for k in range(n):
-            col = f * n + k
-            row = sums_rows[col]
+            row = rows[k]
             true_reward = row[i_main] + (1000 * row[i_quadcol] if i_quadcol >= 0 else 0)
             extra = dict(base)
             if dist_keys is not None:
-                d1, d3, d5 = dist_rows[col]
+                d1, d3, d5 = dist[k]
                 extra[dist_keys[0]] = extra[dist_keys[3]] = d1
                 extra[dist_keys[1]] = extra[dist_keys[4]] = d3
                 extra[dist_keys[2]] = extra[dist_keys[5]] = d5
             extra.update(zip(rew_keys, row))
             extra["rewraw_main"] = true_reward
             extra[k_pos], extra[k_crash] = row[i_pos], row[i_crash]
-            info = infos[e * n + k]
-            info["true_reward"] = true_reward
-            info["episode_extra_stats"] = extra
+            out.append({"true_reward": true_reward, "episode_extra_stats": extra})
+        return out
+
+
+def assemble_batched_infos(finished, n, sums, eps, cnt, scen_ids, rs, obst_density, obst_size, approx, keys, use_obstacles, ep_steps, annealed, infos):
+    """eager form of EpisodeInfoBuilder: fills infos[e * n + k] for every agent of every finished environment"""
+    b = EpisodeInfoBuilder(finished, n, sums, eps, cnt, scen_ids, rs, obst_density, obst_size, approx, keys, use_obstacles, ep_steps, annealed)
+    for f, e in enumerate(finished):
+        for k, d in enumerate(b.env_dicts(f)):
+            infos[int(e) * n + k].update(d)
+
+
+class EpisodeInfos(list):
+    """What BatchedQuadSwarm.step returns as `infos` on a step where episodes ended: a list with one entry per agent, {} for the agents
+    still flying, {'true_reward', 'episode_extra_stats'} for those whose episode ended.  The dicts of a finished environment are built
+    when one of its agents is first asked for (indexing or iterating) - a sampler that looks at the finished agents pays for exactly
+    those, nobody pays 60-120 ms on the step where all 8192 agents of a batch finish together.  The underlying list storage is only
+    filled by `materialize()` (copying / pickling the object calls it)."""
+
+    def __init__(self, num_agents, n, builder):
+        super().__init__()
+        self._num, self._n, self._b = num_agents, n, builder
+        self._slot = {int(e): f for f, e in enumerate(builder.finished)}
+        self._built = {}
+
+    def _env(self, e):
+        f = self._slot.get(e)
+        if f is None:
+            return None
+        d = self._built.get(f)
+        if d is None:
+            d = self._built[f] = self._b.env_dicts(f)
+        return d
+
+    def __len__(self):
+        return self._num
+
+    def __bool__(self):
+        return self._num > 0
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._num))]
+        if i < 0:
+            i += self._num
+        if not 0 <= i < self._num:
+            raise IndexError("list index out of range")
+        e, k = divmod(i, self._n)
+        d = self._env(e)
+        return {} if d is None else d[k]
+
+    def __iter__(self):
+        n = self._n
+        for e in range(self._num // n):
+            d = self._env(e)
+            if d is None:
+                for _ in range(n):
+                    yield {}
+            else:
+                yield from d
+
+    def __eq__(self, other):
+        return list(self) == other
+
+    def __ne__(self, other):
+        return not self == other
+
+    __hash__ = None
+
+    def finished_agents(self):
+        """indices of the agents whose episode ended on this step"""
+        n = self._n
+        return [e * n + k for e in sorted(self._slot) for k in range(n)]
+
+    def materialize(self):
+        """a plain list of dicts (everything built)"""
+        return list(self)
+
+    def __reduce__(self):
+        return (list, (self.materialize(),))
+
+    def __repr__(self):
+        return f"EpisodeInfos({self._num} agents, {len(self._slot)} finished envs, {len(self._built)} built)"
 
 
 class BatchedQuadSwarm:
@@ -297,7 +312,7 @@ class BatchedQuadSwarm:
     is a list of num_agents dicts on steps where an episode ended (empty dicts for the others) and `[]` otherwise."""
 
     def __init__(self, num_envs, reward_shaping_scheme=None, annealing=None, device=0, seed=0, replay_buffer_sample_prob=0.0,
-                 num_gpus=1, gather_obs=False, obs_wire="bf16", **env_kwargs):
+                 num_gpus=1, gather_obs=False, obs_wire="bf16", write_rew_info=False, _vec=None, **env_kwargs):
         """num_gpus > 1: `num_envs` is the global batch; this process (one per GPU under torchrun) steps its contiguous shard on GPU
         LOCAL_RANK.  gather_obs: the observation rows of all shards are exchanged after every step (parallel.ObsExchange) and available
         from gathered_obs()."""
@@ -313,7 +328,9 @@ class BatchedQuadSwarm:
             device = local_rank
         if gather_obs and replay_buffer_sample_prob > 0.0:
             raise ValueError("--quads_gather_obs is not available together with the device-side replay wrapper (--replay_buffer_sample_prob > 0)")
-        self.vec = QuadSwarmVecEnv(num_envs, device=device, seed=seed, env_id_offset=env_id_offset, episode_sums=True, write_rew_info=False, **env_kwargs)
+        # (_vec: a ready-made vec env - the CPU test of the shaping / annealing / infos logic drives this class over a scripted stand-in)
+        self.vec = _vec if _vec is not None else QuadSwarmVecEnv(num_envs, device=device, seed=seed, env_id_offset=env_id_offset, episode_sums=True,
+                                                                 write_rew_info=write_rew_info, **env_kwargs)
         if gather_obs:
             self.vec.attach_exchange(self._make_exchange(num_gpus, obs_wire))
         self.num_envs, self.agents_per_env = num_envs, self.vec.num_agents_per_env
@@ -414,19 +431,20 @@ class BatchedQuadSwarm:
         obs, rew, done, _ = self.vec.step(actions)
         if self._truncated is None:
             self._truncated = torch.zeros_like(done, dtype=torch.bool)
+            self._terminated = done.view(torch.bool)   # the uint8 0 / 1 buffer reinterpreted: no kernel, no allocation - and, like `obs`
+                                                       # and `rew`, a view of the live buffer that the next step() overwrites
         infos = []
         self._steps_to_done -= 1
         if self._steps_to_done <= 0:      # the only steps on which the host looks at the device
             st, n = self.vec.stepper, self.agents_per_env
             finished = np.nonzero(st.to_host("done").reshape(self.num_envs, n)[:, 0])[0]
             if len(finished):
-                infos = [{} for _ in range(self.num_agents)]
-                self._episode_infos(finished, infos)
+                infos = self._episode_infos(finished)
             # every environment's tick after this step (a replayed episode starts at its checkpoint's tick): next possible end
             self._steps_to_done = int(self._ep_steps - st.to_host("tick").max())
-        return {"obs": obs}, rew, done.view(torch.bool), self._truncated, infos   # the uint8 0 / 1 buffer reinterpreted: no kernel, no allocation
+        return {"obs": obs}, rew, self._terminated, self._truncated, infos
 
-    def _episode_infos(self, finished, infos):
+    def _episode_infos(self, finished):
         """What the wrapper stack attaches at an episode end - the env's own episode_extra_stats (quadrotor_multi.py:626-718, or
         the two `*_replay` counters of a replayed episode, :629-633), the replay wrapper's statistics
         (quad_experience_replay.py:126-138), the reward-shaping wrapper's sums / action moments / annealed coefficients
@@ -443,6 +461,7 @@ class BatchedQuadSwarm:
         eps = st.tensor("ep_stats").index_select(1, agent_idx).double().cpu().numpy()
         cnt = st.tensor("ep_counters").index_select(1, env_idx).cpu().numpy()
         scen_ids = st.tensor("ep_scenario").index_select(0, env_idx).cpu().numpy()
+        cur_scen = st.tensor("scenario_id").index_select(0, env_idx).cpu().numpy()   # after the auto-reset (and a replay restore)
         rs = st.replay_stats() if self.use_replay_buffer else None
         if rs is not None:   # what the wrapper calls curr_obst_density / curr_obst_size: the values of the episode that starts now
             obst_density, obst_size = st.to_host("obst_density_env"), st.to_host("obst_size_env")
@@ -452,23 +471,12 @@ class BatchedQuadSwarm:
             for sched in self.annealing:
                 self.rew_coeff[sched.coeff_name] = min(sched.final_value * approx / sched.anneal_env_steps, sched.final_value)
                 annealed.append((f"z_anneal_{sched.coeff_name}", self.rew_coeff[sched.coeff_name]))
-        assemble_batched_infos(finished, n, sums, eps, cnt, scen_ids, rs, obst_density if rs is not None else None, obst_size if rs is not None else None,
-                               approx, self._keys, bool(self.vec.cfg.use_obstacles), self._ep_steps, annealed, infos)
+        builder = EpisodeInfoBuilder(finished, n, sums, eps, cnt, scen_ids, rs, obst_density if rs is not None else None, obst_size if rs is not None else None,
+                                     approx, self._keys, bool(self.vec.cfg.use_obstacles), self._ep_steps, annealed, cur_scen_ids=cur_scen)
+        return EpisodeInfos(self.num_agents, n, builder)
 
     def close(self):
         self.vec.close()
-
-
-class Compatibility(_Wrapper):
-    """compatibility.py:21-50: old 4-tuple step -> gymnasium 5-tuple; reset(seed, options) ignores the seed."""
-
-    def reset(self, seed=None, options=None):
-        return self.env.reset(), {}
-
-    def step(self, action):
-        obs, reward, done, info = self.env.step(action)
-        done = np.array(done)
-        return obs, reward, done, np.zeros_like(done, dtype=bool), info
 
 
 def _domain_random_kwargs(cfg, use_replay_buffer):
@@ -483,58 +491,27 @@ def _domain_random_kwargs(cfg, use_replay_buffer):
                 obst_size_min=cfg.quads_obst_size_min, obst_size_max=cfg.quads_obst_size_max)
 
 
-def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
-    """quad_utils.py:20-110 on the HIP stepper (the experience-replay wrapper of :67-70 is the device-side replay of the stepper)."""
+def _shaping_from_cfg(cfg):
+    """reward-shaping scheme and annealing schedule of quad_utils.py:72-107"""
+    reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
+    reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
+    reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty
+    reward_shaping["quad_rewards"]["quadcol_bin_obst"] = cfg.quads_obst_collision_reward
+    annealing = None
+    if cfg.anneal_collision_steps > 0:
+        for k in ("quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"):
+            reward_shaping["quad_rewards"][k] = 0.0
+        annealing = [AnnealSchedule("quadcol_bin", cfg.quads_collision_reward, cfg.anneal_collision_steps),
+                     AnnealSchedule("quadcol_bin_smooth_max", cfg.quads_collision_smooth_max_penalty, cfg.anneal_collision_steps),
+                     AnnealSchedule("quadcol_bin_obst", cfg.quads_obst_collision_reward, cfg.anneal_collision_steps)]
+    return reward_shaping, annealing
+
+
+def _env_kwargs_from_cfg(cfg):
+    """QuadrotorEnvMulti's constructor arguments as make_quadrotor_env_multi derives them from the flags (quad_utils.py:20-65)"""
     use_replay_buffer = getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0
-    rew_coeff = DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]
-    env = QuadrotorEnvMulti(
-        num_agents=cfg.quads_num_agents, ep_time=cfg.quads_episode_duration,
-        rew_coeff=dict(rew_coeff),
-        obs_repr=cfg.quads_obs_repr,
-        neighbor_visible_num=cfg.quads_neighbor_visible_num, neighbor_obs_type=cfg.quads_neighbor_obs_type,
-        collision_hitbox_radius=cfg.quads_collision_hitbox_radius, collision_falloff_radius=cfg.quads_collision_falloff_radius,
-        use_obstacles=cfg.quads_use_obstacles, obst_density=cfg.quads_obst_density, obst_size=cfg.quads_obst_size,
-        obst_spawn_area=cfg.quads_obst_spawn_area, use_downwash=cfg.quads_use_downwash, use_numba=cfg.quads_use_numba,
-        quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims, use_replay_buffer=use_replay_buffer,
-        quads_view_mode=getattr(cfg, "quads_view_mode", None), quads_render=getattr(cfg, "quads_render", False),
-        dynamics_params="Crazyflie", raw_control=True, raw_control_zero_middle=True, dynamics_randomize_every=None,
-        dynamics_change=dict(noise=dict(thrust_noise_ratio=0.05), damp=dict(vel=0, omega_quadratic=0)), dyn_sampler_1=None,
-        sense_noise="default", init_random_state=False, render_mode=render_mode,
-        seed=getattr(cfg, "quads_seed", 0), device=getattr(cfg, "quads_device", 0), precision=getattr(cfg, "quads_precision", "f32"),
-        replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0),   # the replay wrapper of quad_utils.py:67-70 runs on the device
-        **_domain_random_kwargs(cfg, use_replay_buffer))
-    reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
-    reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
-    reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty
-    reward_shaping["quad_rewards"]["quadcol_bin_obst"] = cfg.quads_obst_collision_reward
-    annealing = None
-    if cfg.anneal_collision_steps > 0:
-        for k in ("quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"):
-            reward_shaping["quad_rewards"][k] = 0.0
-        annealing = [AnnealSchedule("quadcol_bin", cfg.quads_collision_reward, cfg.anneal_collision_steps),
-                     AnnealSchedule("quadcol_bin_smooth_max", cfg.quads_collision_smooth_max_penalty, cfg.anneal_collision_steps),
-                     AnnealSchedule("quadcol_bin_obst", cfg.quads_obst_collision_reward, cfg.anneal_collision_steps)]
-    env = RewardShapingWrapper(env, reward_shaping_scheme=reward_shaping, annealing=annealing, with_pbt=getattr(cfg, "with_pbt", False))
-    return Compatibility(env)
-
-
-def make_quadrotor_env_batched(cfg, **kwargs):
-    """`--quads_num_envs E` > 1: the device-resident batched env (E*N agents) with the same flags and shaping schedule."""
-    reward_shaping = copy.deepcopy(DEFAULT_QUAD_REWARD_SHAPING)
-    reward_shaping["quad_rewards"]["quadcol_bin"] = cfg.quads_collision_reward
-    reward_shaping["quad_rewards"]["quadcol_bin_smooth_max"] = cfg.quads_collision_smooth_max_penalty
-    reward_shaping["quad_rewards"]["quadcol_bin_obst"] = cfg.quads_obst_collision_reward
-    annealing = None
-    if cfg.anneal_collision_steps > 0:
-        for k in ("quadcol_bin", "quadcol_bin_smooth_max", "quadcol_bin_obst"):
-            reward_shaping["quad_rewards"][k] = 0.0
-        annealing = [AnnealSchedule("quadcol_bin", cfg.quads_collision_reward, cfg.anneal_collision_steps),
-                     AnnealSchedule("quadcol_bin_smooth_max", cfg.quads_collision_smooth_max_penalty, cfg.anneal_collision_steps),
-                     AnnealSchedule("quadcol_bin_obst", cfg.quads_obst_collision_reward, cfg.anneal_collision_steps)]
-    return BatchedQuadSwarm(
-        cfg.quads_num_envs, reward_shaping_scheme=reward_shaping, annealing=annealing,
+    return dict(
         replay_buffer_sample_prob=getattr(cfg, "replay_buffer_sample_prob", 0.0),
-        num_gpus=getattr(cfg, "quads_num_gpus", 1), gather_obs=getattr(cfg, "quads_gather_obs", False), obs_wire=getattr(cfg, "quads_obs_wire", "bf16"),
         device=getattr(cfg, "quads_device", 0), seed=getattr(cfg, "quads_seed", 0), precision=getattr(cfg, "quads_precision", "f32"),
         num_agents=cfg.quads_num_agents, ep_time=cfg.quads_episode_duration, rew_coeff=dict(DEFAULT_QUAD_REWARD_SHAPING["quad_rewards"]),
         obs_repr=cfg.quads_obs_repr, neighbor_visible_num=cfg.quads_neighbor_visible_num, neighbor_obs_type=cfg.quads_neighbor_obs_type,
@@ -542,7 +519,98 @@ def make_quadrotor_env_batched(cfg, **kwargs):
         use_obstacles=cfg.quads_use_obstacles, obst_density=cfg.quads_obst_density, obst_size=cfg.quads_obst_size,
         obst_spawn_area=cfg.quads_obst_spawn_area, use_downwash=cfg.quads_use_downwash, use_numba=cfg.quads_use_numba,
         quads_mode=cfg.quads_mode, room_dims=cfg.quads_room_dims,
-        **_domain_random_kwargs(cfg, getattr(cfg, "replay_buffer_sample_prob", 0.0) > 0.0))
+        **_domain_random_kwargs(cfg, use_replay_buffer))
+
+
+class SingleQuadSwarm:
+    """`make_quadrotor_env_multi`'s product for ONE environment: the call protocol of the reference's wrapper stack
+    (QuadrotorEnvMulti -> ExperienceReplayWrapper -> QuadsRewardShapingWrapper -> QuadEnvCompatibility, quad_utils.py:20-110) - lists /
+    numpy arrays in and out, per-step infos[i]['rewards'], `true_reward` and `episode_extra_stats` at an episode end - over a
+    BatchedQuadSwarm of one environment: the same kernels, the same on-device episode sums, the same host-side assembly as the
+    batched env (tests/test_facade_gpu.py compares the two).  A compatibility path: every step copies actions in and observations,
+    rewards and reward terms out."""
+
+    is_multiagent = True
+
+    def __init__(self, batched):
+        from . import config as qcfg
+        self._b, self._vec = batched, batched.vec
+        self.num_agents = batched.agents_per_env
+        self.observation_space, self.action_space = batched.observation_space, batched.action_space
+        self.rew_coeff, self.scenario = batched.rew_coeff, batched.scenario
+        self.use_replay_buffer = batched.use_replay_buffer
+        self.use_obstacles = bool(self._vec.cfg.use_obstacles)
+        self.control_freq = 1.0 / (self._vec.cfg.dt * self._vec.cfg.sim_steps)
+        self._keys = qcfg.REW_INFO_KEYS if self.use_obstacles else qcfg.REW_INFO_KEYS[:15]
+        self.envs = [self]                                   # `env.envs[0].tick` of the reference (the replay wrapper reads it)
+
+    # what the reference's wrappers and tests reach for on the inner env
+    @property
+    def unwrapped(self):
+        return self
+
+    @property
+    def tick(self):
+        return int(self._vec.stepper.to_host("tick")[0])
+
+    @property
+    def activate_replay_buffer(self):
+        return bool(self.use_replay_buffer and self._vec.stepper.replay_stats()["active"][0])
+
+    @activate_replay_buffer.setter
+    def activate_replay_buffer(self, value):
+        self._vec.stepper.replay_set_active([1 if value else 0])
+
+    def set_training_info(self, training_info):
+        self._b.set_training_info(training_info)
+
+    def get_default_reward_shaping(self):
+        return self._b.get_default_reward_shaping()
+
+    def get_current_reward_shaping(self, agent_idx):
+        return self._b.get_current_reward_shaping(agent_idx)
+
+    def set_reward_shaping(self, reward_shaping, agent_idx):
+        self._b.set_reward_shaping(reward_shaping, agent_idx)
+
+    def render(self, *a, **k):
+        return None
+
+    def reset(self, seed=None, options=None):
+        obs, info = self._b.reset()
+        return obs["obs"].double().cpu().numpy(), info
+
+    def step(self, actions):
+        import torch
+        st = self._vec.stepper
+        a = torch.as_tensor(np.ascontiguousarray(np.asarray(actions, dtype=st.np_real).reshape(self.num_agents, 4)), device=f"cuda:{st.device}")
+        obs, rew, term, trunc, ep_infos = self._b.step(a)
+        st.sync(stream=torch.cuda.current_stream(st.device))
+        st.check_errors()                                    # ValueError('QuadEnv: reward is Nan'), quadrotor_single.py:87-90
+        ri = st.to_host("rew_info")                          # [17, N]: the infos[i]['rewards'] terms of this step (quadrotor_single.py:68-85)
+        infos = [{"rewards": {k: float(ri[j, i]) for j, k in enumerate(self._keys)}} for i in range(self.num_agents)]
+        for i, d in enumerate(ep_infos):
+            infos[i].update(d)
+        done = term.cpu().numpy().copy()
+        return obs["obs"].double().cpu().numpy(), [float(r) for r in rew.cpu().numpy()], done, np.zeros_like(done, dtype=bool), infos
+
+    def close(self):
+        self._b.close()
+
+
+def make_quadrotor_env_multi(cfg, render_mode=None, **kwargs):
+    """quad_utils.py:20-110 for one environment: a batch of one behind the reference's list / numpy protocol"""
+    reward_shaping, annealing = _shaping_from_cfg(cfg)
+    return SingleQuadSwarm(BatchedQuadSwarm(1, reward_shaping_scheme=reward_shaping, annealing=annealing, write_rew_info=True, **_env_kwargs_from_cfg(cfg)))
+
+
+def make_quadrotor_env_batched(cfg, **kwargs):
+    """`--quads_num_envs E` > 1: the device-resident batched env (E*N agents) with the same flags and shaping schedule."""
+    reward_shaping, annealing = _shaping_from_cfg(cfg)
+    return BatchedQuadSwarm(
+        cfg.quads_num_envs, reward_shaping_scheme=reward_shaping, annealing=annealing,
+        num_gpus=getattr(cfg, "quads_num_gpus", 1), gather_obs=getattr(cfg, "quads_gather_obs", False), obs_wire=getattr(cfg, "quads_obs_wire", "bf16"),
+        **_env_kwargs_from_cfg(cfg))
 
 
 def make_quadrotor_env(env_name, cfg=None, _env_config=None, render_mode=None, **kwargs):

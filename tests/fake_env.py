@@ -55,6 +55,96 @@ class FakeQuadEnv:
         return self._obs(), rewards, [done] * self.num_agents, infos
 
 
+class FakeVec:
+    """What sf_env.BatchedQuadSwarm needs from env.QuadSwarmVecEnv, over ONE FakeQuadEnv and with CPU torch tensors where the real one has
+    device tensors: step() keeps the per-episode sums of the reward terms and the action moments the way the step kernel does
+    (`episode_sums`), the "stepper" hands them out.  Lets the CPU suite drive the host side of the batched env - shaping scheme, annealing,
+    episode-end infos - over the script the reference wrapper was recorded on."""
+
+    def __init__(self, env):
+        import types
+        import torch
+        from quad_swarm_rl_amd import config as qcfg
+        self.env, self._torch = env, torch
+        n = env.num_agents
+        self.num_agents_per_env = self.num_agents = n
+        self.observation_space = self.action_space = None
+        self.rew_coeff, self.scenario = env.rew_coeff, env.scenario
+        self.cfg = types.SimpleNamespace(ep_len=env.ep_len - 1, use_obstacles=0)
+        self.exchange = None
+        self._scen_id = lambda: qcfg.SCENARIOS[env.scenario.name()]
+        self.run = np.zeros((25, n))
+        self.bufs = {"ep_sums": torch.zeros((25, n), dtype=torch.float64), "ep_stats": torch.zeros((6, n), dtype=torch.float64),
+                     "ep_counters": torch.zeros((11, 1), dtype=torch.int32), "ep_scenario": torch.zeros(1, dtype=torch.int32),
+                     "scenario_id": torch.zeros(1, dtype=torch.int32), "done": torch.zeros(n, dtype=torch.uint8), "tick": torch.zeros(1, dtype=torch.int32)}
+        vec = self
+
+        class Stepper:
+            device = "cpu"
+
+            @staticmethod
+            def tensor(name):
+                return vec.bufs[name]
+
+            @staticmethod
+            def to_host(name):
+                return vec.bufs[name].numpy().copy()
+
+        self.stepper = Stepper()
+
+    def reset(self, env_mask=None):
+        self.bufs["scenario_id"][0] = self._scen_id()
+        return self._torch.as_tensor(np.stack(self.env.reset()))
+
+    def step(self, actions):
+        torch = self._torch
+        a = np.asarray(actions, dtype=np.float64)
+        scen_before = self._scen_id()
+        obs, rewards, dones, infos = self.env.step([a[i] for i in range(self.num_agents)])
+        for i, info in enumerate(infos):
+            self.run[:15, i] += [info["rewards"][k] for k in REW_KEYS]
+            self.run[17:21, i] += a[i]
+            self.run[21:25, i] += a[i] ** 2
+        self.env_infos = infos
+        done = bool(dones[0])
+        self.bufs["done"][:] = int(done)
+        self.bufs["tick"][0] = 0 if done else self.env.t % self.env.ep_len
+        self.bufs["scenario_id"][0] = self._scen_id()
+        if done:
+            self.bufs["ep_sums"].copy_(torch.as_tensor(self.run))
+            self.bufs["ep_scenario"][0] = scen_before
+            self.run[:] = 0
+        return torch.as_tensor(np.stack(obs)), torch.as_tensor(np.array(rewards)), self.bufs["done"], None
+
+    def close(self):
+        pass
+
+
+def drive_batched(batched, vec, env, steps=30, seed=0):
+    """drive()'s script through sf_env.BatchedQuadSwarm over a FakeVec; the record keeps what the shaping wrapper adds (the env's own
+    episode statistics - zeros here - are dropped, the scenario prefix of the class names is stripped: the scripted env's scenarios
+    are called by their bare names)"""
+    import torch
+    rng = np.random.RandomState(seed + 555)
+    batched.reset()
+    rec = []
+    for t in range(steps):
+        batched.set_training_info({"approx_total_training_steps": 40000 * t})
+        actions = np.stack([rng.uniform(-1, 1, 4) for _ in range(env.num_agents)])
+        _, rewards, term, _, infos = batched.step(torch.as_tensor(actions))
+        extra = [None] * env.num_agents
+        if len(infos):
+            for i in range(env.num_agents):
+                ex = infos[i]["episode_extra_stats"]
+                # drop what only the env's own statistics contribute (neither a reward sum, nor a z_* key, nor a per-scenario reward key)
+                extra[i] = {k.replace("Scenario_", ""): float(v) for k, v in sorted(ex.items())
+                            if k.startswith(("rew", "z_")) or k.endswith(("/rew_pos", "/rew_crash"))}
+        rec.append({"rewards": [float(r) for r in rewards], "dones": [bool(d) for d in term],
+                    "true_reward": [float(infos[i]["true_reward"]) if len(infos) else None for i in range(env.num_agents)],
+                    "extra": extra, "rew_coeff": {k: float(v) for k, v in sorted(env.rew_coeff.items())}})
+    return {"steps": rec, "coeff_seen_by_env": [{k: float(v) for k, v in sorted(c.items())} for c in env.coeff_log]}
+
+
 def drive(wrapper, env, steps=30, seed=0):
     """The fixed script both sides run; returns a JSON-able record of everything the wrapper adds or changes."""
     rng = np.random.RandomState(seed + 555)

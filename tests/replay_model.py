@@ -76,6 +76,11 @@ class ReplayModel:
                     acts.append(("file", src, dst))
         return acts
 
+    def explicit_reset(self, crash_sum_so_far):
+        """ExperienceReplayWrapper.reset() -> QuadrotorEnvMulti.reset() in the middle of an episode (quad_experience_replay.py:106-118,
+        quadrotor_multi.py:356-359): the crash reward collected so far goes into the history; checkpoints and last_added stay."""
+        self._record_reset(crash_sum_so_far)
+
     def stats(self):
         return dict(episodes=self.episodes, replayed=self.replayed, buffer_len=len(self.ev_slot), replayed_sum=sum(self.ev_replayed),
                     active=int(self.active), checkpoints=len(self.ck), errors=self.errors)

@@ -4,6 +4,7 @@ tests/test_facade_gpu.py compares with the reference's dict keys."""
 import time
 
 import numpy as np
+import pytest
 
 
 def naive(finished, n, sums, eps, cnt, scen_ids, rs, obst_density, obst_size, approx, keys, use_obstacles, ep_steps, annealed, infos):
@@ -90,3 +91,33 @@ def test_batched_infos_cost_for_a_full_batch():
     dt_naive = time.perf_counter() - t0
     print(f"assemble_batched_infos: {dt * 1e3:.0f} ms for 8192 agents (per-agent construction: {dt_naive * 1e3:.0f} ms)")
     assert dt < 1.0
+
+
+def test_lazy_episode_infos_equal_the_eager_list_and_cost_nothing_until_read():
+    """sf_env.EpisodeInfos (what BatchedQuadSwarm.step returns): same dicts as the eager assembly, built per finished environment on
+    first access; creating it for a full 1024 x 8 batch takes milliseconds (the eager list cost 60-120 ms on that step)."""
+    import copy
+    import pickle
+    from quad_swarm_rl_amd import sf_env
+    args = synthetic(64, 8, 40, True, True, seed=11)
+    eager = [{} for _ in range(64 * 8)]
+    sf_env.assemble_batched_infos(*args, eager)
+    lazy = sf_env.EpisodeInfos(64 * 8, 8, sf_env.EpisodeInfoBuilder(*args))
+    assert isinstance(lazy, list) and len(lazy) == 512 and bool(lazy)
+    e0 = int(args[0][0])
+    assert lazy[e0 * 8 + 3] == eager[e0 * 8 + 3] and len(lazy._built) == 1          # one environment built, on demand
+    assert lazy[-1] == eager[-1] and lazy[5:9] == eager[5:9]
+    assert lazy == eager and list(lazy) == eager and [d for d in lazy] == eager
+    assert pickle.loads(pickle.dumps(lazy)) == eager and copy.deepcopy(lazy) == eager
+    assert lazy.finished_agents() == [i for i, d in enumerate(eager) if d]
+    with pytest.raises(IndexError):
+        lazy[512]
+    args = synthetic(1024, 8, 1024, False, True, seed=9)
+    t0 = time.perf_counter()
+    lazy = sf_env.EpisodeInfos(8192, 8, sf_env.EpisodeInfoBuilder(*args))
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    one = lazy[4097]
+    dt_one = time.perf_counter() - t0
+    print(f"EpisodeInfos for 8192 finished agents: {dt * 1e3:.2f} ms to create, {dt_one * 1e6:.0f} us for the first dict of an environment")
+    assert dt < 0.010 and "episode_extra_stats" in one

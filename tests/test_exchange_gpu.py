@@ -95,8 +95,10 @@ def test_two_processes_on_one_gpu_gather_equals_unsharded(wire, graph):
     _check(res, "proc", 2, wire, graph, 10, 3)
 
 
-@pytest.mark.parametrize("wire,graph", [("f32", 0), ("bf16", 4)])
+@pytest.mark.parametrize("wire,graph", [("f32", 0), ("bf16", 0)])
 def test_two_endpoints_in_one_process(wire, graph):
+    """(eager launches only: two captured graphs of ONE process that poll each other's flags are not guaranteed to run concurrently -
+    the graph form is covered with one process per rank above, which is the deployment)"""
     res = _run_workers("local", 2, wire, graph)
     _check(res, "local", 2, wire, graph, 10, 3)
 

@@ -194,8 +194,10 @@ def test_episode_sums_on_device_match_host_accumulation():
 
 
 def test_batched_env_matches_the_single_env_wrapper_stack():
-    """BatchedQuadSwarm (E envs, device tensors, on-device sums) reports at episode end what the reference-shaped stack
-    QuadrotorEnvMulti -> RewardShapingWrapper -> Compatibility reports for the same env, seed and actions."""
+    """BatchedQuadSwarm (E envs, device tensors, on-device sums) and the one-environment stack of make_quadrotor_env (SingleQuadSwarm:
+    lists / numpy in and out, per-step infos[i]['rewards']) report the same for the same env, seed and actions - and what they report
+    at an episode end is what accumulating the per-step infos[i]['rewards'] on the host gives (reward_shaping.py:78-94: cumulative
+    rew_* terms, true_reward = rewraw_main + 1000 * rewraw_quadcol)."""
     import torch
     from quad_swarm_rl_amd import sf_env
     argv = ["--quads_num_agents=4", "--quads_neighbor_visible_num=2", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
@@ -211,9 +213,13 @@ def test_batched_env_matches_the_single_env_wrapper_stack():
     np.testing.assert_allclose(obs_b["obs"][:4].cpu().numpy(), obs_s, atol=1e-12)
     rng = np.random.RandomState(4)
     saw = 0
+    acc = [dict() for _ in range(4)]
     for t in range(45):
         a = rng.uniform(-1, 1, size=(12, 4))
         o_s, r_s, term_s, _, inf_s = single.step([a[i] for i in range(4)])
+        for i in range(4):
+            for k, v in inf_s[i]["rewards"].items():
+                acc[i][k] = acc[i].get(k, 0.0) + v
         o_b, r_b, term_b, trunc_b, inf_b = batched.step(torch.as_tensor(a, device="cuda:0", dtype=torch.float64))
         np.testing.assert_allclose(o_b["obs"][:4].cpu().numpy(), o_s, atol=1e-10)
         np.testing.assert_allclose(r_b[:4].cpu().numpy(), r_s, atol=1e-12)
@@ -223,6 +229,11 @@ def test_batched_env_matches_the_single_env_wrapper_stack():
             assert len(inf_b) == 12
             for i in range(4):
                 assert inf_b[i]["true_reward"] == pytest.approx(inf_s[i]["true_reward"], abs=1e-9)
+                assert inf_s[i]["true_reward"] == pytest.approx(acc[i]["rewraw_main"] + 1000 * acc[i]["rewraw_quadcol"], abs=1e-9)
+                for k, v in acc[i].items():
+                    if k != "rewraw_main":   # (the wrapper overwrites that entry with true_reward, reward_shaping.py:88)
+                        assert inf_s[i]["episode_extra_stats"][k] == pytest.approx(v, abs=1e-9), k
+                acc[i] = dict()
                 es, eb = inf_s[i]["episode_extra_stats"], inf_b[i]["episode_extra_stats"]
                 assert set(eb) == set(es), sorted(set(eb) ^ set(es))   # incl. the env's own episode_extra_stats (quadrotor_multi.py:637-718)
                 for k, v in eb.items():
@@ -300,7 +311,7 @@ def test_experience_replay_through_the_facade():
     cfg = parse(["--quads_num_agents=4", "--quads_neighbor_visible_num=2", "--quads_neighbor_obs_type=pos_vel", "--quads_use_numba=True",
                  "--quads_episode_duration=3.0", "--replay_buffer_sample_prob=1.0", "--quads_precision=f64", "--quads_seed=2"])
     env = sf_env.make_quadrotor_env("quadrotor_multi", cfg=cfg)
-    quad = env.unwrapped                                # Compatibility -> RewardShaping -> QuadrotorEnvMulti (replay on the device)
+    quad = env.unwrapped                                # SingleQuadSwarm over a batch of one (replay on the device)
     assert quad.use_replay_buffer and not quad.activate_replay_buffer
     env.reset()
     quad.activate_replay_buffer = True                 # (the reference switches it on after 10 episodes without crashes, :280-287)

@@ -5,8 +5,8 @@
   (b) float32 FREE-RUNNING against the float64 oracle over event-free windows (the method of the reference's
       gym_art/quadrotor_multi/tests/test_numba_opt.py:59-119: two implementations, identical injected noise, compare trajectories):
       hover-ish actions from the spawn, up to 100 control steps, the window of an environment ends at its first event (collision,
-      floor / wall / ceiling contact, obstacle hit, proximity, downwash, episode end) - inside it: 1e-4 on state / obs / reward,
-      flags and counters exact;
+      floor / wall / ceiling contact, obstacle hit, proximity, episode end, or a near-tie in the neighbour ranking that float32 cannot
+      resolve) - inside it: 1e-4 on state / obs / reward, flags and counters exact;
   (c) float32 vs float64 kernels over one FULL episode of BASELINE configs[1] at full size (8 x 1024, same seeds => same noise):
       the episode statistics the reference reports (quadrotor_multi.py:626-718) agree as distributions - means within a stated
       confidence interval;
@@ -44,6 +44,22 @@ def _event_free(info, n, t, ep_len):
             and not any(info.col_pair_mask[:n]) and not any(info.counters) and info.tick < ep_len)
 
 
+def _ranking_margin(s, K):
+    """smallest gap between consecutive neighbour metrics among every drone's K + 1 nearest (quadrotor_multi.py:247-274): below the
+    float32 resolution of the metric the SELECTION (which drone fills which observation slot) is decided by rounding - a discrete
+    event like a contact, and the end of an environment's window"""
+    pos, vel = s[:, 0:3], s[:, 3:6]
+    n = pos.shape[0]
+    if K <= 0 or K >= n - 1:
+        return np.inf
+    dp, dv = pos[None, :, :] - pos[:, None, :], vel[None, :, :] - vel[:, None, :]
+    rd = np.maximum(np.linalg.norm(dp, axis=2), 0.01)
+    m = rd + (dp * dv).sum(axis=2) / rd
+    m[np.arange(n), np.arange(n)] = np.inf
+    top = np.sort(m, axis=1)[:, :K + 1]
+    return float(np.diff(top, axis=1).min())
+
+
 FREE_CASES = [("c1_single", None, None), ("c2_n8_dw", None, None), ("c2_n8_dw", "0", None), ("c2_n8_dw", None, "off"),
               ("c3_n8_obst", None, None), ("c4_n32_svs", None, None), ("c4_n32_svs", "0", None), ("x_no_noise", None, None)]
 
@@ -72,6 +88,7 @@ def test_free_running_f32_event_free_windows(case, team, spec, monkeypatch):
             info = oe.info()
             # proximity (a continuous penalty inside 4 arm lengths) and downwash are interactions too: they show in rew_info / flags
             quiet = _event_free(info, N, t, pr.cfg.ep_len) and not np.any(o[3][e][:, 13] != 0.0)
+            quiet = quiet and _ranking_margin(oe.get_state()[0], pr.cfg.num_neighbors) > 2e-4
             if alive[e] and not quiet:
                 alive[e] = False
             if not alive[e]:

@@ -226,6 +226,24 @@ def test_fused_multi_head_attention_encoder_matches_torch(shape, batch, sim2real
     assert (got - want16).abs().mean().item() < 5e-4, (got - want16).abs().mean().item()
 
 
+@pytest.mark.parametrize("sim2real", [False, True])
+@pytest.mark.parametrize("batch", [4112, 16384])
+def test_multi_head_kernels_are_run_to_run_identical_above_one_workgroup_per_cu(batch, sim2real):
+    """The multi-head / Sim2Real kernel body is one workgroup per CU by construction (its LDS request is more than half a CU's LDS,
+    tests/test_c_abi.py).  From 4097 agents on a CU runs several workgroups one after the other: five forwards of the same batch must be
+    bit-identical (a two-workgroups-per-CU experiment of this body was not, and was never shipped)."""
+    import torch
+    from quad_swarm_rl_amd import policy
+    ref = (policy.make_reference_sim2real_encoder if sim2real else policy.make_reference_mha_encoder)(seed=5, num_nbr=6).cuda()
+    fused = policy.FusedQuadEncoder(ref)
+    g = torch.Generator(device="cuda").manual_seed(batch)
+    obs = torch.rand((batch, fused.params.obs_dim), device="cuda", generator=g) * 2 - 1
+    first = fused(obs).clone()
+    for _ in range(4):
+        assert torch.equal(fused(obs), first)
+    torch.cuda.synchronize()
+
+
 def test_attention_encoder_is_not_the_per_agent_pairing():
     """Guards the quirk: with the 'natural' pairing (row (a,k) with agent a) the result differs measurably for batch > 1."""
     import torch

@@ -110,6 +110,45 @@ def test_replay_kernel_equals_the_model():
     st.close()
 
 
+def test_explicit_reset_feeds_the_crash_history():
+    """qs_reset while the replay wrapper runs: every explicit reset of an environment records the running episode's crash reward, like
+    the reference's reset() does (quadrotor_multi.py:356-359) - ten recorded episodes with a mean above -1 switch the buffer on.  The
+    masked-out environments are untouched, and the action statistics of the next finished episode count its steps from tick 0."""
+    from quad_swarm_rl_amd import config as qcfg, native
+    E, N = 6, 4
+    cfg = qcfg.make_config(num_envs=E, num_agents=N, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, ep_time=0.5, seed=3,
+                           precision="f32", episode_sums=True, write_rew_info=False)
+    st = native.Stepper(cfg, device=0)
+    st.replay_enable(0.5)
+    st.reset()
+    models = [ReplayModel(0.5, control_freq=100) for _ in range(E)]
+    act = np.full((E * N, 4), 0.06, dtype=np.float32)
+    mask = np.array([1, 0, 1, 1, 0, 0], dtype=np.uint8)
+    for rnd in range(9):                                # 1 (first reset) + 9 explicit resets = 10 entries => active
+        for _ in range(5):
+            st.from_host("actions", act)
+            st.step()
+        st.sync()
+        crash = st.to_host("run_sums")[3].reshape(E, N)[:, 0]
+        assert not st.to_host("done").any()
+        st.reset(mask)
+        for e in np.nonzero(mask)[0]:
+            models[e].explicit_reset(float(crash[e]))
+        rs = st.replay_stats()
+        assert rs["active"].tolist() == [int(m.active) for m in models], (rnd, rs["active"].tolist())
+        assert (st.to_host("tick")[mask == 1] == 0).all() and (st.to_host("tick")[mask == 0] == 5 * (rnd + 1)).all()
+    assert rs["active"].tolist() == [1, 0, 1, 1, 0, 0]
+    # the reset environments finish their next episode after ep_len + 1 steps, counted from the reset
+    for _ in range(cfg.ep_len + 1):
+        st.from_host("actions", act)
+        st.step()
+    st.sync()
+    rs = st.replay_stats()
+    done = st.to_host("done").reshape(E, N)[:, 0]
+    assert done[mask == 1].all() and (rs["ep_steps"][mask == 1] == cfg.ep_len + 1).all()
+    st.close()
+
+
 def test_domain_random_through_the_batched_env():
     """--quads_domain_random with the replay wrapper (quad_experience_replay.py:75-88,:106-118,:191-206): every new episode of every
     environment draws its obstacle density and size; the wrapper's statistics report them."""

@@ -1,14 +1,16 @@
 """(The experience-replay wrapper is pinned in tests/test_replay_model_vs_reference.py + tests/test_replay_gpu.py.)
-sf_env.RewardShapingWrapper against the reference's QuadsRewardShapingWrapper (swarm_rl/env_wrappers/reward_shaping.py:19-123).
-tests/golden/wrapper_reward_shaping.json holds what the reference wrapper produced over the scripted env of tests/fake_env.py
-(oracle/ref_harness/capture_wrappers.py, build container); here the repo's wrapper runs over the same script.  CPU only."""
+The host side of sf_env.BatchedQuadSwarm - shaping scheme pushed into env.rew_coeff, collision-coefficient annealing, `true_reward` and the
+episode-end `episode_extra_stats` assembled from per-episode sums - against the reference's QuadsRewardShapingWrapper
+(swarm_rl/env_wrappers/reward_shaping.py:19-123).  tests/golden/wrapper_reward_shaping.json holds what the reference wrapper produced
+over the scripted env of tests/fake_env.py (oracle/ref_harness/capture_wrappers.py, build container); here BatchedQuadSwarm runs over
+the same script through tests/fake_env.FakeVec, which keeps the sums the way the step kernel does.  CPU only."""
 import json
 import os
 
 import pytest
 
 from quad_swarm_rl_amd import sf_env
-from tests.fake_env import FakeQuadEnv, drive
+from tests.fake_env import FakeQuadEnv, FakeVec, drive_batched
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wrapper_reward_shaping.json")
 
@@ -32,12 +34,15 @@ def test_reward_shaping_wrapper_equals_reference(case, seed):
     scheme = dict(quad_rewards=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0,
                                     quadcol_bin=0.0 if annealing else 5.0, quadcol_bin_smooth_max=0.0 if annealing else 10.0, quadcol_bin_obst=5.0))
     env = FakeQuadEnv(seed=seed)
-    got = drive(sf_env.RewardShapingWrapper(env, reward_shaping_scheme=scheme, annealing=annealing), env, steps=30, seed=seed)
+    vec = FakeVec(env)
+    got = drive_batched(sf_env.BatchedQuadSwarm(1, reward_shaping_scheme=scheme, annealing=annealing, _vec=vec), vec, env, steps=30, seed=seed)
     assert len(got["steps"]) == len(want["steps"]) == 30
     for t, (g, w) in enumerate(zip(got["steps"], want["steps"])):
         for key in ("rewards", "dones", "true_reward", "rew_coeff"):
             assert close(g[key], w[key]), (t, key, g[key], w[key])
-        assert close(g["extra"], w["extra"]), (t, "episode_extra_stats", g["extra"], w["extra"])
+        # (the scripted env's own {"num_collisions": k} of agent 0 stays in place in the reference's dict: not part of what the wrapper adds)
+        w_extra = [None if e is None else {k: v for k, v in e.items() if k != "num_collisions"} for e in w["extra"]]
+        assert close(g["extra"], w_extra), (t, "episode_extra_stats", g["extra"], w_extra)
     assert close(got["coeff_seen_by_env"], want["coeff_seen_by_env"])
     # the script crosses four episode ends; the annealed coefficients grow and saturate at their final values
     ends = [s for s in want["steps"] if s["dones"][0]]

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Where and when every workgroup of the step kernel ran (-DQS_TIMING build): start / end of wave 0 of each workgroup on the shader clock
+(s_memtime) and on the constant 100 MHz wall clock, plus HW_ID / XCC_ID.  Answers: do all workgroups of a 256-workgroup launch run at
+once, one per CU?  how long does a workgroup take compared with the kernel?  what does a shader-clock tick last?
+usage (GPU box): python tools/wg_times.py c4 [KEY=VALUE ...]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+os.environ["QS_SPEC_EXTRA_FLAGS"] = "-DQS_TIMING " + os.environ.get("QS_TIMING_EXTRA", "")
+os.environ.setdefault("QS_SPEC", "jit")
+import bench
+from quad_swarm_rl_amd import config as qcfg, native
+import ast
+args = sys.argv[1:]
+wl = args[0] if args else "c4"
+kw = dict(bench.WORKLOADS[wl]["kw"])
+E = bench.WORKLOADS[wl]["num_envs"]
+for item in args[1:]:
+    k, v = item.split("=", 1)
+    if k == "num_envs":
+        E = int(v)
+    else:
+        kw[k] = ast.literal_eval(v)
+cfg = qcfg.make_config(num_envs=E, seed=0, write_rew_info=False, **kw)
+st = native.Stepper(cfg)
+assert st.specialized
+L = native.lib()
+L.qs_debug_wg_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int32]
+st.reset()
+rng = np.random.RandomState(0)
+blocks = (E + (64 // cfg.num_agents) - 1) // (64 // cfg.num_agents)
+rows = []
+for t in range(40):
+    st.from_host("actions", rng.uniform(-1, 1, size=(st.T, 4)))
+    st.step()
+    st.sync()
+    buf = (C.c_ulonglong * (6 * blocks))()
+    n = L.qs_debug_wg_times(st._h, buf, blocks)
+    a = np.array(buf[:6 * n], dtype=np.uint64).reshape(n, 6).astype(np.int64)
+    if t >= 10:
+        rows.append(a)
+a = rows[-1]
+dur = np.stack([r[:, 1] - r[:, 0] for r in rows]).astype(np.float64)           # shader-clock ticks per workgroup
+wall = np.stack([r[:, 5] - r[:, 4] for r in rows]).astype(np.float64) * 10.0   # ns per workgroup (100 MHz)
+start_spread = np.stack([(r[:, 4] - r[:, 4].min()) for r in rows]).astype(np.float64) * 10.0
+span = np.array([(r[:, 5].max() - r[:, 4].min()) * 10.0 for r in rows])
+hw, xcc = a[:, 2], a[:, 3] & 0xf
+cu_key = (xcc << 16) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)
+uniq, counts = np.unique(cu_key, return_counts=True)
+print(f"workload {wl} {args[1:]}: {n} workgroups x {st.waves_per_workgroup} waves, kernel {st.kernel_name}")
+print(f"  workgroup duration: shader clock ticks median {np.median(dur):.0f} (min {dur.min():.0f}, max {dur.max():.0f}); wall median {np.median(wall) / 1e3:.2f} us "
+      f"(min {wall.min() / 1e3:.2f}, max {wall.max() / 1e3:.2f}) => {np.median(dur) / np.median(wall):.2f} ticks per ns")
+print(f"  first start -> last end: median {np.median(span) / 1e3:.2f} us; start of the last workgroup after the first: median {np.median(start_spread.max(axis=1)) / 1e3:.2f} us")
+print(f"  placement (last step): {len(uniq)} distinct (xcc, se, sh, cu) for {n} workgroups; workgroups per CU histogram: "
+      f"{dict(zip(*np.unique(counts, return_counts=True)))}; per XCC: {dict(zip(*np.unique(xcc, return_counts=True)))}")
+slow = np.argsort(-wall[-1])[:8]
+print("  slowest workgroups (last step):", [(int(b), f"{wall[-1][b] / 1e3:.2f} us", f"xcc {int(xcc[b])} cu {int((hw[b] >> 8) & 15)} se {int((hw[b] >> 13) & 7)}", int(counts[list(uniq).index(cu_key[b])])) for b in slow])
