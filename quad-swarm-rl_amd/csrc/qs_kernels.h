@@ -140,17 +140,22 @@ template <> struct NbrKey<double> {
 // helper waves of the team kernels: stamp k of wave w (1..3) lands in timing[32*w + k]
 #define QS_STAMPW(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x >= 64) p.timing[32 * (threadIdx.x >> 6) + (k)] = clock64(); } while (0)
 // start / end of EVERY workgroup (wave 0; s_memtime and the constant 100 MHz wall clock) and where it ran: HW_ID (gfx9: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and XCC_ID
-#define QS_STAMP_WG(k) do { if (threadIdx.x == 0) { p.timing[128 + 6 * blockIdx.x + (k)] = clock64(); p.timing[128 + 6 * blockIdx.x + 4 + (k)] = wall_clock64(); \
-        if ((k) == 0) { p.timing[128 + 6 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); \
-                        p.timing[128 + 6 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); } } } while (0)
+#define QS_WG_STRIDE 16
+#define QS_STAMP_WG(k) do { if (threadIdx.x == 0) { p.timing[128 + QS_WG_STRIDE * blockIdx.x + (k)] = clock64(); p.timing[128 + QS_WG_STRIDE * blockIdx.x + 4 + (k)] = wall_clock64(); \
+        if ((k) == 0) { p.timing[128 + QS_WG_STRIDE * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); \
+                        p.timing[128 + QS_WG_STRIDE * blockIdx.x + 3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); } } } while (0)
+// phase boundaries of EVERY workgroup's wave 0 (slots 6..15): which phase makes the slowest workgroup of a launch slow
+#define QS_STAMP_WGK(k) do { if (threadIdx.x == 0) p.timing[128 + QS_WG_STRIDE * blockIdx.x + (k)] = clock64(); } while (0)
 #else
 #define QS_STAMP(k) do { } while (0)
 #define QS_STAMPW(k) do { } while (0)
 #define QS_STAMP_WG(k) do { } while (0)
+#define QS_STAMP_WGK(k) do { } while (0)
 #endif
 
 struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
                    int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit;
+                   int off_t_ri;                            // team kernels: the step's 17 reward terms + the done flag, for the wave that keeps the episode sums
                    int off_t_near, off_topk, off_t_redo;   // team kernels, N > 8 (pair-once scan): proximity masks, per-wave top-8 lists, per-env "velocities changed" flags
                    int off_self, off_rows, rows_per_pass, scr_cap;   // single-wave kernels: observation output (see obs_copy_rows)
                    int off_cur; };   // QS_TAPE kernels: per-env tape cursor
@@ -207,6 +212,7 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
         L.off_t_prox = o; o += real_size * (team - 1) * B;
         L.off_t_ohit = o; o += 4 * B;
         L.off_t_near = o; o += 8 * B;
+        L.off_t_ri = o; o += real_size * (QS_RI_COUNT + 1) * B;
         L.off_t_redo = o; o += 4 * ((epb + 3) & ~3);
         o = (o + 15) & ~15;
         // N > 8 with K <= 8: every ranking wave (all but wave 0) publishes the top-8 of its candidates, compacted by local rank:
@@ -378,9 +384,11 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
 // write (an auto-reset rewrites only the rows of the finished environments).  Whole wave, between barriers.
 // ------------------------------------------------------------------------------------------------
 // QS_NT_OBS: cache policy of the observation rows' stores.  They are write-once per step and not read again by the stepper (42 % of a
-// step's bytes): 1 = non-temporal (`nt`: do not keep the lines in the Infinity Cache, which then holds the state the next step re-reads).
+// step's bytes): 1 = non-temporal (`nt`), so that they do not displace the state rows - which the next step re-reads - from the 256 MiB
+// Infinity Cache.  Measured on MI355X, C2 shape at 131072 envs (539 MB per step): 132.2 -> 107.0 us per step, 0.50 -> 0.61 of 8 TB/s, same
+// FETCH_SIZE / WRITE_SIZE (profiles/r03b_nt_obs_E131072.txt).
 #ifndef QS_NT_OBS
-#define QS_NT_OBS 0
+#define QS_NT_OBS 1
 #endif
 typedef float qs_f32x2 __attribute__((ext_vector_type(2)));
 typedef float qs_f32x4 __attribute__((ext_vector_type(4)));

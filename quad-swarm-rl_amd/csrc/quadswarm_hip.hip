@@ -378,7 +378,7 @@ template <typename real> static int create_typed(qs_handle *h) {
         HIP_TRY(hipMemcpy(p.obst_density_env, dn.data(), E * sizeof(real), hipMemcpyHostToDevice));
     }
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
-    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128 + 6 * NBLK);   // QS_TIMING builds: phase stamps of workgroup 0, then {start, end, HW_ID, XCC_ID, wall start, wall end} of every workgroup
+    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128 + 16 * NBLK);   // QS_TIMING builds: phase stamps of workgroup 0, then {start, end, HW_ID, XCC_ID, wall start, wall end} of every workgroup
 #undef DA
     {   // run-time reward coefficients (+ proximity slope), read by every launch
         real *rw = nullptr;
@@ -1015,12 +1015,12 @@ int qs_debug_lds_bytes(const qs_config *cfg, int team, int spec) {
                       scenario_is_full(cfg->scenario), cfg->scenario, spec ? spec_rows_per_pass(cfg, team) : QS_WAVE).total;
 }
 
-int qs_debug_wg_times(qs_handle *h, unsigned long long *out, int32_t max_blocks) {   // [blocks][6]: start, end (s_memtime), HW_ID, XCC_ID, start, end (100 MHz wall clock) of wave 0 of every workgroup
+int qs_debug_wg_times(qs_handle *h, unsigned long long *out, int32_t max_blocks) {   // [blocks][16]: start, end (s_memtime), HW_ID, XCC_ID, start, end (100 MHz wall clock), then s_memtime at 10 phase boundaries of wave 0 of every workgroup
     if (!h || !out) return fail(QS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     const int n = h->blocks < max_blocks ? h->blocks : max_blocks;
-    HIP_TRY(hipMemcpy(out, h->pf.timing + 128, (size_t)n * 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, h->pf.timing + 128, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return n;
 }
 int qs_debug_timing(qs_handle *h, unsigned long long *out128) {   // [4 waves][32 stamps] of workgroup 0 (QS_TIMING builds)

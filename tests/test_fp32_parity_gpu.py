@@ -88,13 +88,16 @@ def test_free_running_f32_event_free_windows(case, team, spec, monkeypatch):
             info = oe.info()
             # proximity (a continuous penalty inside 4 arm lengths) and downwash are interactions too: they show in rew_info / flags
             quiet = _event_free(info, N, t, pr.cfg.ep_len) and not np.any(o[3][e][:, 13] != 0.0)
-            quiet = quiet and _ranking_margin(oe.get_state()[0], pr.cfg.num_neighbors) > 2e-4
+            # a near-tie in the neighbour ranking is a transient: WHICH drone fills WHICH observation slot is then decided by rounding, but the
+            # selection does not feed back into the dynamics - on such a step only the self columns of the row are compared
+            tie = _ranking_margin(oe.get_state()[0], pr.cfg.num_neighbors) < 5e-5
             if alive[e] and not quiet:
                 alive[e] = False
             if not alive[e]:
                 continue
             window[e] = t + 1
-            for nm, a, b in (("obs", o[0][e], h[0][e]), ("reward", o[1][e], h[1][e]), ("rew_info", o[3][e], h[3][e])):
+            sd = pr.D - 6 * pr.cfg.num_neighbors - (9 if pr.cfg.use_obstacles else 0)
+            for nm, a, b in (("obs", o[0][e][:, :sd] if tie else o[0][e], h[0][e][:, :sd] if tie else h[0][e]), ("reward", o[1][e], h[1][e]), ("rew_info", o[3][e], h[3][e])):
                 err = np.abs(a - b).max()
                 worst = max(worst, err / (1.0 + np.abs(a).max()))
                 assert err <= tol * (1.0 + np.abs(a).max()), f"{case}: {nm} env {e} step {t}: {err}"

@@ -32,14 +32,22 @@ L.qs_debug_wg_times.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int32]
 st.reset()
 rng = np.random.RandomState(0)
 blocks = (E + (64 // cfg.num_agents) - 1) // (64 // cfg.num_agents)
+warm = int(os.environ.get("QS_WG_WARM", "0"))          # control steps before the measured ones (steady state of a random-action rollout: ~1000)
+if warm:
+    import torch
+    acts = (torch.rand((64, st.T, 4), device="cuda") * 2 - 1).contiguous()
+    for t in range(warm):
+        st.step(acts.data_ptr() + (t % 64) * st.T * 16)
+    st.sync()
 rows = []
-for t in range(40):
+S = 16
+for t in range(60):
     st.from_host("actions", rng.uniform(-1, 1, size=(st.T, 4)))
     st.step()
     st.sync()
-    buf = (C.c_ulonglong * (6 * blocks))()
+    buf = (C.c_ulonglong * (S * blocks))()
     n = L.qs_debug_wg_times(st._h, buf, blocks)
-    a = np.array(buf[:6 * n], dtype=np.uint64).reshape(n, 6).astype(np.int64)
+    a = np.array(buf[:S * n], dtype=np.uint64).reshape(n, S).astype(np.int64)
     if t >= 10:
         rows.append(a)
 a = rows[-1]
@@ -57,4 +65,17 @@ print(f"  first start -> last end: median {np.median(span) / 1e3:.2f} us; start 
 print(f"  placement (last step): {len(uniq)} distinct (xcc, se, sh, cu) for {n} workgroups; workgroups per CU histogram: "
       f"{dict(zip(*np.unique(counts, return_counts=True)))}; per XCC: {dict(zip(*np.unique(xcc, return_counts=True)))}")
 slow = np.argsort(-wall[-1])[:8]
+# phases of wave 0 (shader clock ticks): start | sub-steps done | barrier 1 | barrier 2 | bookkeeping | responses | barrier 3 | barrier 4 | barrier 5 | reset | copy-out | end
+names = ["loads+substeps", "publish+b1", "pair scan+b2", "bookkeeping", "downwash+responses+scenario", "publish vel+b3", "metrics+b4", "rank/rows+b5", "reset check/tail", "b6+copy-out", "outputs+stores"]
+idx = [0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 1]
+ph_med = np.zeros(len(names)); ph_slow = np.zeros(len(names)); ph_max = np.zeros(len(names))
+for r in rows:
+    ph = np.diff(r[:, idx].astype(np.float64), axis=1)            # [blocks, phases]
+    ph_med += np.median(ph, axis=0); ph_max += ph.max(axis=0)
+    ph_slow += ph[np.argmax(r[:, 1] - r[:, 0])]
+k = len(rows)
+print(f"  phases of wave 0, shader clock ticks (mean over {k} steps): median workgroup | the step's slowest workgroup | per-phase maximum over workgroups")
+for nm, a1, a2, a3 in zip(names, ph_med / k, ph_slow / k, ph_max / k):
+    print(f"    {nm:32s} {a1:8.0f} {a2:8.0f} {a3:8.0f}")
+print(f"    {'total':32s} {ph_med.sum() / k:8.0f} {ph_slow.sum() / k:8.0f}")
 print("  slowest workgroups (last step):", [(int(b), f"{wall[-1][b] / 1e3:.2f} us", f"xcc {int(xcc[b])} cu {int((hw[b] >> 8) & 15)} se {int((hw[b] >> 13) & 7)}", int(counts[list(uniq).index(cu_key[b])])) for b in slow])
