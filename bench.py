@@ -14,9 +14,10 @@ N > 1 (BASELINE.json configs[3], "C4"): 32 drones x 512 envs PER GPU (4096 envs 
 of the observation rows after every step INSIDE the timed region (north_star: "a single ... gather of observations over xGMI
 per rollout step"): every rank ends each step with the rows of all ranks.  [step -> exchange] x 64 is ONE captured HIP graph per
 rank (quad-swarm-rl_amd/parallel.py: ObsExchange); exchange(t) runs on a second stream under step(t+1); the wire format is
-bfloat16 (--wire f32 for bit-exact rows).  --transport peer: the library's peer-store exchange over hipIpc-mapped windows
-(include/quadswarm_exchange.h), rccl: RCCL all-gather of the packed rows, auto (default): peer if its start-up self-check against
-the RCCL all-gather passes on every rank, else rccl; torch: round 2's eager per-step all_gather (comparison).  The rate of the
+bfloat16 (--wire f32 for bit-exact rows).  --transport fused: the step kernel itself stores its rows into every rank's hipIpc-mapped
+receive window (include/quadswarm_exchange.h; no launch besides the step), peer: the same windows filled by a push kernel on a second
+stream, rccl: RCCL all-gather of the packed rows, auto (default): fused (peer for batches that run the single-wave kernels) if every
+rank could map its peers' windows and passed the start-up self-check, else rccl; torch: round 2's eager per-step all_gather.  The rate of the
 same shards stepping with no exchange is measured right after and reported as config.secondary (--no-gather makes it the
 headline; --workload / --envs-per-gpu override the shape).
 
@@ -227,10 +228,11 @@ def make_exchange(st, world, rank, transport, wire, dist, dev, info):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
-    if transport in ("auto", "peer"):
+    if transport in ("auto", "peer", "fused"):
         ex, why = None, ""
+        kind = "peer" if transport == "peer" or not st.team else "fused"   # fused: the step kernel pushes its own rows (team kernels)
         try:
-            ex = parallel.ObsExchange(st, world, rank, transport="peer", wire=wire, hold=False)
+            ex = parallel.ObsExchange(st, world, rank, transport=kind, wire=wire, hold=False)
         except Exception as exc:   # noqa: BLE001 - recorded; the fallback is a different transport, not a different result
             why = f"{type(exc).__name__}: {exc}"
         attached = all_agree(ex is not None)
@@ -243,7 +245,7 @@ def make_exchange(st, world, rank, transport, wire, dist, dev, info):
             ok = all_agree(ok)
         info["peer_self_check"] = "passed on every rank" if ok else ("failed" + (f" here: {why}" if why else " on another rank"))
         if ok:
-            info["transport"] = "peer"
+            info["transport"] = kind
             return ex
         if ex is not None:
             ex.close()
@@ -266,7 +268,7 @@ def main():
     ap.add_argument("--force-gather", action="store_true", help="run the RCCL obs all-gather path even at N=1 (exercises the multi-GPU code on a 1-GPU box)")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
     ap.add_argument("--no-overlap", action="store_true", help="--transport torch: gather on the compute stream instead of overlapping it with the next step")
-    ap.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "torch"], help="observation exchange (see the module docstring)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "fused", "peer", "rccl", "torch"], help="observation exchange (see the module docstring)")
     ap.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="wire format of the exchanged rows")
     ap.add_argument("--segment", type=int, default=64, help="control steps per captured [step -> exchange] graph (0 = eager launches)")
     ap.add_argument("--no-variants", action="store_true", help="skip config.variants (shaped / rew_info / downwash-off / seeds 1, 2 runs of the same workload)")

@@ -236,6 +236,15 @@ int qs_get_buffers(qs_handle *h, qs_buffers *out);
  * snapshots hold qs_buffers.obs (QS_ERR_UNSUPPORTED). */
 int qs_set_obs_target(qs_handle *h, void *obs_dev);
 
+/* Fused observation exchange (quadswarm_exchange.h): from now on every qs_step launch also stores its observation rows, in the wire
+ * type of endpoint `xchg` (a qs_xchg*, fully attached), into slot [seq & 1][rank] of every rank's receive window and raises the
+ * sequence flags - the multi-GPU "gather of observations per rollout step" with no launch of its own.  auto_ack != 0: the launch also
+ * acts as the consumer (for callers that do not read the gathered rows in place).  xchg = NULL switches it off.  Needs the float32
+ * team kernels (batches up to ~8 waves per CU, see qs_kernel_flavor) and rows * cols of the endpoint = E*N * obs_dim;
+ * QS_ERR_UNSUPPORTED otherwise (large batches use qs_xchg_push on the rows instead). */
+struct qs_xchg;
+int qs_set_obs_exchange(qs_handle *h, struct qs_xchg *xchg, int32_t auto_ack);
+
 /* Push new reward coefficients (the SF reward-shaping wrapper mutates env.rew_coeff,
  * swarm_rl/env_wrappers/reward_shaping.py:57-59,111-118). */
 int qs_set_reward_coeffs(qs_handle *h, const double *coeffs /* [QS_REW_COUNT] */);

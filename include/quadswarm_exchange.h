@@ -79,6 +79,13 @@ int qs_xchg_release(qs_xchg *x, void *stream);
 /* qs_xchg_wait + qs_xchg_release as ONE launch, for a consumer that does not read the slot in place. */
 int qs_xchg_wait_release(qs_xchg *x, void *stream);
 
+/* The FUSED form: after qs_set_obs_exchange(handle, x, auto_ack) (quadswarm.h) every qs_step launch of that stepper stores its
+ * observation rows into all windows itself, from the workgroups' LDS stage - no push launch at all; with auto_ack the same launch
+ * also plays the consumer (waits for the rows of every rank, releases the slot), otherwise the consumer calls qs_xchg_wait /
+ * qs_xchg_release around its reads.  qs_xchg_fused_desc is the library-internal hand-over (device descriptor for `blocks`
+ * workgroups per launch); callers use qs_set_obs_exchange. */
+void *qs_xchg_fused_desc(qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *n_out);
+
 /* Synchronous: out[0] = status bits (0 = ok), out[1] = pushes, out[2] = waits, out[3] = releases so far. */
 int qs_xchg_status(qs_xchg *x, int64_t out[4]);
 

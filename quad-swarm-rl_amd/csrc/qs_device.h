@@ -810,4 +810,97 @@ __device__ void svs_create_formations(const RngKey &key, const Formation<real> &
     if (do_shuffle) shuffle_rows<real>(key, goals + r1 * 3, 3, r2, 256);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same two formations + shuffles (Scenario_swarm_vs_swarm.create_formations / update_goals, swarm_vs_swarm.py:52-69) built by the
+// WAVE: lane i of the environment makes goal row i.  The serial form above costs one lane ~25 k cycles (32 rows of sin / cos or
+// double-precision sphere points, 30 serial Fisher-Yates draws); with 512 environments that swap goals every 4-6 s, some environment
+// of the batch does so on EVERY control step, and that one workgroup set the duration of the whole C4 launch (8.5 us median
+// workgroup, 21.8 us kernel: profiles/r03c_wg_c4_steady_*.txt).  Same arithmetic per row, same summation order of the means, the same
+// draws (QS_SITE_SCEN_SHUFFLE slots) - results are bit-identical to the serial form.
+//   goals: LDS rows [>= 2N][3] of the environment (first N rows = result), scr: N ints of LDS scratch of the environment.
+//   Must be called by all lanes of the wave with `on` uniform per environment; needs N / 2 >= 3 (every formation has as many rows as drones).
+// ------------------------------------------------------------------------------------------------
+template <typename real>
+__device__ __forceinline__ void goal_row(const Formation<real> &F, int n, int fd, const real center[3], int i, real g[3], bool &needs_mean) {
+    const int f = F.f, per = F.per_layer;
+    const real size = F.size;
+    needs_mean = false;
+    if (f_is_circle(f)) {
+        const int layer = i / per, cur = (n <= per) ? n : ((layer < n / per) ? per : n % per);
+        real deg = (real)2 * (real)QS_PI_D * (real)(i % cur) / (real)cur, sn, cs;
+        M<real>::sincos(deg, &sn, &cs);
+        goal_by_formation<real>(f, size * cs, size * sn, (real)layer * F.layer_dist, g);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g[q] = g[q] + center[q];
+    } else if (f == 3) {   // (double throughout, like generate_goals)
+        const int m = n < 3 ? 3 : n;
+        const double x = 0.1 + 1.2 * m, start = -1.0 + 1.0 / (m - 1.0), inc = (2.0 - 2.0 / (m - 1.0)) / (m - 1.0);
+        const double sj = start + i * inc, sg = (double)((sj > 0) - (sj < 0));
+        const double xx = sj * x, yy = (QS_PI_D / 2.) * sg * (1.0 - ::sqrt(1.0 - ::fabs(sj)));
+        const double sx = ::sin(xx), cx = ::cos(xx), sy = ::sin(yy), cy = ::cos(yy);
+        g[0] = (real)((double)size * (cx * cy) + (double)center[0]);
+        g[1] = (real)((double)size * (sx * cy) + (double)center[1]);
+        g[2] = (real)((double)size * sy + (double)center[2]);
+    } else if (f_is_grid(f)) {
+        const int layer = i / per, cnt = (n <= per) ? n : ((layer < n / per) ? per : n % per);
+        int d1, d2;
+        grid_dim(cnt, &d1, &d2);
+        goal_by_formation<real>(f, size * (real)(i % d2), size * (real)((i / d2) % d1), (real)layer * F.layer_dist, g);
+        needs_mean = true;
+    } else {
+        g[0] = center[2] + size * (real)(i / (fd * fd)); g[1] = size * (real)((i / fd) % fd); g[2] = size * (real)(i % fd);
+        needs_mean = true;
+    }
+}
+
+template <typename real>
+__device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, const Formation<real> &F, int N, int fd0, int fd1, const real c1[3], const real c2[3],
+                                                           bool do_shuffle, real *goals, int *scr, int i, bool on) {
+    const int n1 = N / 2, n2 = N - N / 2;
+    const bool second = i >= n1;
+    const int n = second ? n2 : n1, li = second ? i - n1 : i, r0 = second ? n1 : 0;   // this lane's formation: rows, local row, first row
+    real g[3] = {0, 0, 0};
+    bool needs_mean = false;
+    if (on) {
+        goal_row<real>(F, n, second ? fd1 : fd0, second ? c2 : c1, li, g, needs_mean);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) goals[i * 3 + q] = g[q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (on && needs_mean) {   // grid / cube: centre the formation; the mean is summed in row order like the serial loop
+        real mean[3] = {0, 0, 0};
+        for (int k = 0; k < n; ++k)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) mean[q] += goals[(r0 + k) * 3 + q];
+        const real *cen = second ? c2 : c1;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { mean[q] /= (real)n; g[q] = g[q] - mean[q] + cen[q]; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (every lane has read the uncentred rows)
+    if (on && needs_mean) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) goals[i * 3 + q] = g[q];
+    }
+    if (!do_shuffle) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
+    // np.random.shuffle of each formation's rows: Fisher-Yates from the top, swap (k, j_k) with j_k = randint(k + 1), k = n-1 .. 1.  Lane
+    // li draws j_li; the row that ends at position li is found by sending li back through the swaps in reverse order.
+    if (on) scr[i] = li >= 1 ? rng_index<real>(key, QS_SITE_SCEN_SHUFFLE, (second ? 256 : 0) + li, li + 1) : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (on) {
+        int pos = li;
+        for (int k = 1; k < n; ++k) {
+            const int j = scr[r0 + k];
+            pos = (pos == k) ? j : ((pos == j) ? k : pos);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) g[q] = goals[(r0 + pos) * 3 + q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (every lane has read its source row)
+    if (on) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) goals[i * 3 + q] = g[q];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 }  // namespace qs

@@ -19,53 +19,15 @@
 #include <string>
 #include <unistd.h>
 
-#include "../../include/quadswarm_exchange.h"
+#include "qs_xchg_dev.h"
+
+using namespace qsx;
 
 namespace {
 
 thread_local std::string g_err;
 int fail(int code, const std::string &m) { g_err = m; return code; }
 #define XTRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
-
-struct FlagWin {
-    unsigned long long arrive[2][QS_XCHG_MAX_RANKS];   // written by rank s: arrive[slot][s] = seq of the rows now in slot
-    unsigned long long ack[QS_XCHG_MAX_RANKS];         // written by rank c: ack[c] = last seq rank c has finished reading
-};
-struct Local {   // device memory of the owning rank only
-    unsigned long long push_seq, wait_seq, release_seq;
-    unsigned int ticket[QS_XCHG_MAX_RANKS], ticket_all, status;
-};
-struct PushArgs {
-    const float *src, *staging[2];
-    char *data_win[QS_XCHG_MAX_RANKS];
-    FlagWin *flag_win[QS_XCHG_MAX_RANKS];
-    FlagWin *mine;
-    Local *loc;
-    long long n;                // elements per rank (rows * cols)
-    long long slot_bytes;       // bytes of one slot of a data window = world * n * wire size
-    int world, rank, wire;
-    unsigned long long timeout_ticks;
-};
-
-__device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;   // NaN (what torch's conversion produces)
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-
-// bounded poll: true when *p >= want before the deadline
-__device__ __forceinline__ bool poll_ge(const unsigned long long *p, unsigned long long want, unsigned long long timeout_ticks) {
-    if (ld_sys(p) >= want) return true;
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < timeout_ticks) {
-        if (ld_sys(p) >= want) return true;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return ld_sys(p) >= want;
-}
 
 // copy / convert this workgroup's share (part of parts) of src[0, n) into dst (wire type).  Vector path: groups of 8 floats
 // (two 16-byte loads, one or two 16-byte stores per lane); pointers that are not 16-byte aligned (a row count that is not a
@@ -182,6 +144,7 @@ struct qs_xchg {
     char *peer_data[QS_XCHG_MAX_RANKS] = {};
     FlagWin *peer_flags[QS_XCHG_MAX_RANKS] = {};
     bool opened[QS_XCHG_MAX_RANKS] = {};   // mapped with hipIpcOpenMemHandle (to be closed)
+    XchgDev *desc = nullptr;               // device copy of what a step kernel needs for the fused push (qs_xchg_fused_desc)
     unsigned long long timeout_ticks = 0;
 };
 
@@ -237,6 +200,7 @@ int qs_xchg_destroy(qs_xchg *x) {
     if (x->flags) (void)hipFree(x->flags);
     if (x->loc) (void)hipFree(x->loc);
     if (x->staging[0]) (void)hipFree(x->staging[0]);
+    if (x->desc) (void)hipFree(x->desc);
     delete x;
     return 0;
 }
@@ -340,6 +304,24 @@ int qs_xchg_release(qs_xchg *x, void *stream) {
     hipLaunchKernelGGL(qs_xchg_release_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     XTRY(hipGetLastError());
     return 0;
+}
+
+// Device-resident descriptor for the FUSED form (quadswarm.h: qs_set_obs_exchange): the team step kernels store their rows into every
+// rank's window themselves.  blocks = workgroups of one step launch; auto_ack: that launch also waits for the rows of all ranks and
+// releases the slot.  Returns the device pointer (owned by the endpoint), or NULL (qs_xchg_last_error()).
+void *qs_xchg_fused_desc(qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *n_out) {
+    if (!x || blocks < 1) { g_err = "qs_xchg_fused_desc: bad argument"; return nullptr; }
+    if (check_wired(x)) return nullptr;
+    if (hipSetDevice(x->device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    XchgDev d;
+    memset(&d, 0, sizeof d);
+    for (int r = 0; r < x->world; ++r) { d.data_win[r] = x->peer_data[r]; d.flag_win[r] = x->peer_flags[r]; }
+    d.mine = x->flags; d.loc = x->loc; d.n = x->n; d.slot_bytes = (long long)x->slot_bytes; d.world = x->world; d.rank = x->rank; d.wire = x->wire;
+    d.auto_ack = auto_ack ? 1 : 0; d.blocks = (unsigned int)blocks; d.timeout_ticks = x->timeout_ticks;
+    if (!x->desc && hipMalloc((void **)&x->desc, sizeof d) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(x->desc, &d, sizeof d, hipMemcpyHostToDevice) != hipSuccess) { g_err = "descriptor upload failed"; return nullptr; }
+    if (n_out) *n_out = x->n;
+    return x->desc;
 }
 
 int qs_xchg_status(qs_xchg *x, int64_t out[4]) {

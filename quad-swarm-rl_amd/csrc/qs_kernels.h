@@ -7,6 +7,7 @@
 
 #include "qs_device.h"
 #include "qs_scenarios.h"
+#include "qs_xchg_dev.h"
 
 using namespace qs;
 
@@ -69,6 +70,7 @@ template <typename real> struct Ptrs {
     uint8_t *reset_mask;   // [E] nonzero => reset kernel re-initialises this env
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
     const real *rew_rt;   // [QS_REW_COUNT + 1] run-time reward coefficients + proximity slope (qs_set_reward_coeffs)
+    const qsx::XchgDev *xchg;   // qs_set_obs_exchange: the team step kernels also store their observation rows into every rank's window
     // noise tape (qs_set_noise_tape; consumed by the QS_TAPE kernels only): [E][tape_len] reference draws, per-env cursor
     const double *tape;
     int32_t *tape_pos;

@@ -758,6 +758,22 @@ int qs_set_obs_target(qs_handle *h, void *obs_dev) {
     return QS_OK;
 }
 
+extern "C" void *qs_xchg_fused_desc(struct qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *n_out);
+extern "C" const char *qs_xchg_last_error(void);
+int qs_set_obs_exchange(qs_handle *h, struct qs_xchg *xchg, int32_t auto_ack) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    if (!xchg) { h->pf.xchg = nullptr; return QS_OK; }
+    if (!h->team || h->real_size != 4) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_exchange: the fused exchange lives in the float32 team kernels (small batches); use qs_xchg_push for this handle");
+    if (h->d_tape) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_exchange: not available while a noise tape is set");
+    HIP_TRY(hipSetDevice(h->device));
+    int64_t n = 0;
+    void *desc = qs_xchg_fused_desc(xchg, h->blocks, auto_ack, &n);
+    if (!desc) return fail(QS_ERR_INVALID, std::string("qs_set_obs_exchange: ") + qs_xchg_last_error());
+    if (n != (int64_t)h->cfg.num_envs * h->cfg.num_agents * h->obs_dim) return fail(QS_ERR_INVALID, "qs_set_obs_exchange: the endpoint's rows * cols must be E*N * obs_dim");
+    h->pf.xchg = (const qsx::XchgDev *)desc;
+    return QS_OK;
+}
+
 int qs_set_reward_coeffs(qs_handle *h, const double *coeffs) {
     if (!h || !coeffs) return fail(QS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));

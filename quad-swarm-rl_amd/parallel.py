@@ -6,7 +6,11 @@ Environments are fully independent (no cross-env term in quadrotor_multi.py), so
 union of the shards is bit-identical to one un-sharded run (tests/test_hip_parity.py::test_determinism_and_sharding_invariance).
 xGMI is point-to-point (7 links / GPU): the only traffic is each rank's observation shard going to its peers, no reduction.
 
-Two transports, same result (`ObsExchange(transport=...)`):
+Three transports, same result (`ObsExchange(transport=...)`):
+
+  "fused" the step kernel itself stores its rows into every rank's receive window, straight from the workgroups' LDS stage, and the
+          last workgroup raises the sequence flags (qs_set_obs_exchange): no launch besides the step.  Team kernels (batches up to
+          ~8 waves per CU: the BASELINE shards); measured at world size 1: + 0.x us per step (profiles/r03*).
 
   "peer"  (default) the library's own exchange (include/quadswarm_exchange.h, csrc/qs_exchange.hip): every rank's receive window is
           mapped into its peers (hipIpc); ONE kernel per rank and step stores the rank's rows into all windows over the
@@ -158,16 +162,19 @@ class ObsExchange:
     def __init__(self, stepper, world, rank, transport="peer", wire="bf16", group=None, peers=None, hold=True):
         if stepper.real_size != 4:
             raise ValueError("the exchange moves float32 observation rows (production precision)")
-        if transport not in ("peer", "rccl"):
-            raise ValueError("transport must be 'peer' or 'rccl'")
+        if transport not in ("fused", "peer", "rccl"):
+            raise ValueError("transport must be 'fused', 'peer' or 'rccl'")
+        if transport == "fused" and not stepper.team:
+            raise native.QsError("the fused exchange lives in the team step kernels (small batches): use transport='peer' for this batch size")
         self.st, self.world, self.rank, self.transport, self.wire, self.group = stepper, world, rank, transport, wire, group
         self.device = torch.device("cuda", stepper.device)
         self.main = torch.cuda.current_stream(self.device)
         self.comm = torch.cuda.Stream(device=self.device)
         T, D = stepper.T, stepper.obs_dim
         # the endpoint also owns the two staging buffers; under "rccl" it is used for those (and its converter) only
-        self.x = PeerExchange(T, D, world if transport == "peer" else 1, rank if transport == "peer" else 0, device=stepper.device, wire=wire)
-        if transport == "peer":
+        windows = transport in ("peer", "fused")
+        self.x = PeerExchange(T, D, world if windows else 1, rank if windows else 0, device=stepper.device, wire=wire)
+        if windows:
             if peers is not None:          # in-process wiring (tests, one process driving several shards)
                 for p in peers:
                     if p is not None and p.rank != rank:
@@ -178,6 +185,7 @@ class ObsExchange:
             dt = torch.bfloat16 if wire == "bf16" else torch.float32
             self._packed = [torch.empty((T, D), dtype=dt, device=self.device) for _ in range(2)]
             self._out = [torch.empty((world * T, D), dtype=dt, device=self.device) for _ in range(2)]
+        self.fused_on = False
         self.hold = bool(hold)
         self._pending_release = False                                 # hold: the slot of the last exchange is still ours
         self.k = 0                                                    # control steps issued so far (= pushes)
@@ -191,8 +199,11 @@ class ObsExchange:
     def _release_pending(self):
         """hold mode: hand back the slot the caller may have been reading since the previous step (readers on the stepping stream first)"""
         if self._pending_release:
-            self.comm.wait_stream(self.main)
-            self.x.release(stream=self.comm)
+            if self.transport == "fused":
+                self.x.release(stream=self.main)
+            else:
+                self.comm.wait_stream(self.main)
+                self.x.release(stream=self.comm)
             self._pending_release = False
 
     def _exchange(self, buf, keep=False):
@@ -210,7 +221,22 @@ class ObsExchange:
                 else:
                     self._out[buf].copy_(self._packed[buf])
 
+    def _fuse(self):
+        """switch the stepper to the fused push (after the windows are wired and, in bench.py, self-checked through the push kernel)"""
+        if not self.fused_on:
+            self.drain()
+            torch.cuda.synchronize(self.device)
+            self.st.set_obs_target(None)
+            self.st.set_obs_exchange(self.x._x, auto_ack=not self.hold)
+            self.fused_on = True
+
     def _one(self, actions_ptr, buf, keep=False):
+        if self.transport == "fused":   # the step launch is the exchange
+            self._fuse()
+            self.st.step(actions_ptr, stream=self.main)
+            if self.hold:
+                self.x.wait(stream=self.main)        # (reader mode: the slot stays ours until _release_pending())
+            return
         if self._used[buf]:
             self.main.wait_event(self._done[buf])                    # the push that read staging[buf] two steps ago has finished
         self.st.set_obs_target(self.x.staging_ptr(buf))
@@ -225,7 +251,7 @@ class ObsExchange:
         """control step k (eager): observations -> staging[k & 1]; exchange(k) on the side stream under step k+1"""
         self._release_pending()
         self._one(actions_ptr, self.k & 1, keep=self.hold)
-        self._pending_release = self.hold and self.transport == "peer"
+        self._pending_release = self.hold and self.transport in ("peer", "fused")
         self.k += 1
 
     def align(self, actions_ptr):
@@ -237,6 +263,17 @@ class ObsExchange:
         """reset all envs; the first observation rows are exchanged like a step's"""
         self._release_pending()
         self.drain()
+        if self.transport == "fused":   # the reset kernel has no epilogue: its rows go out through the push kernel, from the library's own buffer
+            self._fuse()
+            self.st.reset(stream=self.main)
+            self.x.push(self.st.ptr("obs"), stream=self.main)
+            if self.hold:
+                self.x.wait(stream=self.main)
+            else:
+                self.x.wait_release(stream=self.main)
+            self._pending_release = self.hold
+            self.k += 1
+            return
         buf = self.k & 1
         self.st.set_obs_target(self.x.staging_ptr(buf))
         self.st.reset(stream=self.main)
@@ -269,13 +306,20 @@ class ObsExchange:
             saved, self.main = self.main, cap
             try:
                 for t in range(n):
+                    if self.transport == "fused" and self.hold:   # reader mode inside a segment: every slot but the last is released at once
+                        self.st.step(action_ptrs[t], stream=self.main)
+                        self.x.wait(stream=self.main)
+                        if t < n - 1:
+                            self.x.release(stream=self.main)
+                        continue
                     self._one(action_ptrs[t], t & 1, keep=self.hold and t == n - 1)   # hold: the last slot of a segment stays ours
                 cap.wait_stream(self.comm)                             # join: the graph ends when its last exchange has
             finally:
                 self.main = saved
         self._used = [False, False]                                    # everything recorded is ordered by the graph launch itself
         self._graph_steps = n
-        self.st.set_obs_target(self.x.staging_ptr(self.k & 1))
+        if self.transport != "fused":
+            self.st.set_obs_target(self.x.staging_ptr(self.k & 1))
         return self
 
     def _capture_stream(self):
@@ -293,7 +337,7 @@ class ObsExchange:
             self._used[b] = False
         with torch.cuda.stream(self.main):
             self.graph.replay()
-        self._pending_release = self.hold and self.transport == "peer"
+        self._pending_release = self.hold and self.transport in ("peer", "fused")
         self.k += self._graph_steps
 
     # ---- start-up self-check of the peer-store transport ----
@@ -301,8 +345,8 @@ class ObsExchange:
         """Exchange `rounds` (even) synthetic row sets whose content every rank can compute for every rank, and compare what arrived
         with it: exercises both window slots, the flow control and - on a multi-GPU node - the visibility of remote stores to local
         readers, with no collective involved.  Returns (ok, reason).  Call it on every rank at the same point."""
-        if self.transport != "peer":
-            return True, "not the peer transport"
+        if self.transport == "rccl":
+            return True, "no windows to check"
         if rounds % 2:
             rounds += 1
         self._release_pending()
@@ -340,19 +384,24 @@ class ObsExchange:
     def latest(self):
         """gathered rows [world*T, D] (wire dtype) of the most recent step, valid on the stepping stream"""
         self.drain()
-        slot = self.k & 1 if self.transport == "peer" else (self.k - 1) & 1   # peer: slot = push sequence number & 1 (1-based)
-        return self.x.gathered(slot) if self.transport == "peer" else self._out[slot]
+        slot = self.k & 1 if self.transport != "rccl" else (self.k - 1) & 1   # windows: slot = push sequence number & 1 (1-based)
+        return self.x.gathered(slot) if self.transport != "rccl" else self._out[slot]
 
     def local_rows(self):
-        """this rank's float32 rows of the most recent step (the staging buffer the stepper wrote)"""
+        """this rank's float32 rows of the most recent step (the staging buffer the stepper wrote; fused: the library's own `obs`)"""
+        if self.transport == "fused":
+            return self.st.tensor("obs")
         return self.x.staging((self.k - 1) & 1)
 
     def status(self):
-        return self.x.status() if self.transport == "peer" else dict(error=0, pushes=self.k, waits=self.k, releases=self.k)
+        return self.x.status() if self.transport != "rccl" else dict(error=0, pushes=self.k, waits=self.k, releases=self.k)
 
     def close(self):
         torch.cuda.synchronize(self.device)
         self.st.set_obs_target(None)
+        if self.fused_on:
+            self.st.set_obs_exchange(None)
+            self.fused_on = False
         self.graph = None
         self.x.close()
 

@@ -40,7 +40,7 @@ def _expected_rows(total_envs, wire, action_batches):
     return out
 
 
-def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout=300):
+def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout=300, transport="peer", hold=1):
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     with tempfile.TemporaryDirectory() as td:
         port = 29600 + (os.getpid() % 300)
@@ -49,7 +49,7 @@ def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout
             out = os.path.join(td, f"r{r}.npz")
             outs.append(out)
             cmd = [sys.executable, WORKER, "--mode", mode, "--rank", str(r), "--world", str(world), "--port", str(port), "--wire", wire, "--envs", str(envs),
-                   "--steps", str(steps), "--graph", str(graph), "--replays", str(replays), "--out", out]
+                   "--steps", str(steps), "--graph", str(graph), "--replays", str(replays), "--transport", transport, "--hold", str(hold), "--out", out]
             procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         logs = []
         for p in procs:
@@ -95,6 +95,14 @@ def test_two_processes_on_one_gpu_gather_equals_unsharded(wire, graph):
     _check(res, "proc", 2, wire, graph, 10, 3)
 
 
+@pytest.mark.parametrize("wire,graph,hold", [("f32", 0, 1), ("bf16", 6, 1), ("bf16", 0, 0), ("f32", 6, 0)])
+def test_two_processes_fused_push_from_the_step_kernel(wire, graph, hold):
+    """the FUSED transport (qs_set_obs_exchange): the team step kernels store their rows into both processes' windows themselves;
+    hold = 1: reader mode (wait / release launches around the reads), hold = 0: the step launch acknowledges on its own"""
+    res = _run_workers("proc", 2, wire, graph, transport="fused", hold=hold)
+    _check(res, "proc-fused", 2, wire, graph, 10, 3)
+
+
 @pytest.mark.parametrize("wire,graph", [("f32", 0), ("bf16", 0)])
 def test_two_endpoints_in_one_process(wire, graph):
     """(eager launches only: two captured graphs of ONE process that poll each other's flags are not guaranteed to run concurrently -
@@ -131,7 +139,7 @@ def test_pack_bf16_equals_torch_rounding():
     assert torch.equal(dst.view(torch.int16), odd.to(torch.bfloat16).view(torch.int16))
 
 
-@pytest.mark.parametrize("transport", ["peer", "rccl"])
+@pytest.mark.parametrize("transport", ["fused", "peer", "rccl"])
 def test_world1_graph_capture_matches_plain_stepping(transport):
     """world size 1 (what bench.py --force-gather runs on a 1-GPU box): [step -> exchange] x 8 as one HIP graph, replayed, equals
     the plain stepper on the same actions; the redirected observation output leaves qs_buffers.obs untouched."""
@@ -161,7 +169,8 @@ def test_world1_graph_capture_matches_plain_stepping(transport):
         assert torch.equal(ex.latest(), want.to(torch.bfloat16)), (transport, rep)
         assert torch.equal(ex.local_rows(), want)
     assert ex.status()["error"] == 0
-    assert torch.equal(st.tensor("obs"), untouched)
+    if transport != "fused":   # (the fused transport leaves the rows where the library puts them)
+        assert torch.equal(st.tensor("obs"), untouched)
     ex.close()
     st.close()
     ref.close()

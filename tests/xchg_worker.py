@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="steps per captured graph (0 = eager)")
     ap.add_argument("--replays", type=int, default=3)
     ap.add_argument("--hold", type=int, default=1)
+    ap.add_argument("--transport", default="peer", choices=["peer", "fused"])
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -58,10 +59,10 @@ def main():
         act_dev[r] = torch.as_tensor(acts[:, r * E * N:(r + 1) * E * N]).cuda().contiguous()
     if args.mode == "proc":
         r = args.rank
-        exs[r] = parallel.ObsExchange(steppers[r], W, r, transport="peer", wire=args.wire, hold=bool(args.hold))
+        exs[r] = parallel.ObsExchange(steppers[r], W, r, transport=args.transport, wire=args.wire, hold=bool(args.hold))
     else:
         for r in ranks:   # every ObsExchange builds its own endpoint: create them all first, then wire each to the others
-            exs[r] = parallel.ObsExchange(steppers[r], W, r, transport="peer", wire=args.wire, hold=bool(args.hold), peers=[])
+            exs[r] = parallel.ObsExchange(steppers[r], W, r, transport=args.transport, wire=args.wire, hold=bool(args.hold), peers=[])
         for r in ranks:
             for q in ranks:
                 if q != r:
