@@ -378,8 +378,7 @@ def main():
             exchange.align(aptr)            # an even number of steps issued: the timed region can start with a replay
         else:
             if exchange is not None:
-                exchange.drain()
-                stepper.set_obs_target(None)
+                exchange.pause()
             run(stepper, base_ptr, stride, warmup, 0, gather)
         if dist is not None:
             dist.barrier()
@@ -433,9 +432,8 @@ def main():
         kernel_region_steps = max(args.steps, 50)
         kernel_region_s, _ = timed(st, aptr, astride, 10, kernel_region_steps, None)
     if exchange is not None:
-        exchange.drain()
+        exchange.pause()
         torch.cuda.synchronize()
-        st.set_obs_target(None)
 
     # extra: the same workload as open-loop rollouts (pre-generated actions, K control steps per launch)
     rollout = None

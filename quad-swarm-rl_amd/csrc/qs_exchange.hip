@@ -36,8 +36,8 @@ __device__ __forceinline__ void copy_range(const float *__restrict__ src, char *
     const bool vec = ((((size_t)src) | ((size_t)dst)) & 15) == 0;
     if (!vec) {
         const long long per = (n + parts - 1) / parts, k0 = per * part, k1 = (k0 + per < n) ? k0 + per : n;
-        if (wire == QS_WIRE_BF16) { unsigned short *d2 = (unsigned short *)dst; for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) d2[k] = (unsigned short)f32_to_bf16_rne(src[k]); }
-        else { float *d1 = (float *)dst; for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) d1[k] = src[k]; }
+        if (wire == QS_WIRE_BF16) { unsigned short *d2 = (unsigned short *)dst; for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) st2_wt(d2 + k, f32_to_bf16_rne(src[k])); }
+        else { float *d1 = (float *)dst; for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) st4_wt(d1 + k, __float_as_uint(src[k])); }
         return;
     }
     const long long nvec = n >> 3;                                   // groups of 8 floats
@@ -47,21 +47,25 @@ __device__ __forceinline__ void copy_range(const float *__restrict__ src, char *
         uint4 *d4 = (uint4 *)dst;
         for (long long v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
             const float4 a = s4[2 * v], b = s4[2 * v + 1];
-            uint4 o;
+            u32x4_t o;
             o.x = f32_to_bf16_rne(a.x) | (f32_to_bf16_rne(a.y) << 16); o.y = f32_to_bf16_rne(a.z) | (f32_to_bf16_rne(a.w) << 16);
             o.z = f32_to_bf16_rne(b.x) | (f32_to_bf16_rne(b.y) << 16); o.w = f32_to_bf16_rne(b.z) | (f32_to_bf16_rne(b.w) << 16);
-            d4[v] = o;
+            st16_wt(d4 + v, o);
         }
         if (part == 0) {
             unsigned short *d2 = (unsigned short *)dst;
-            for (long long k = (nvec << 3) + threadIdx.x; k < n; k += blockDim.x) d2[k] = (unsigned short)f32_to_bf16_rne(src[k]);
+            for (long long k = (nvec << 3) + threadIdx.x; k < n; k += blockDim.x) st2_wt(d2 + k, f32_to_bf16_rne(src[k]));
         }
     } else {
         float4 *d4 = (float4 *)dst;
-        for (long long v = v0 + threadIdx.x; v < v1; v += blockDim.x) { const float4 a = s4[2 * v], b = s4[2 * v + 1]; d4[2 * v] = a; d4[2 * v + 1] = b; }
+        for (long long v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
+            const float4 a = s4[2 * v], b = s4[2 * v + 1];
+            st16_wt(d4 + 2 * v, u32x4_t{__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w)});
+            st16_wt(d4 + 2 * v + 1, u32x4_t{__float_as_uint(b.x), __float_as_uint(b.y), __float_as_uint(b.z), __float_as_uint(b.w)});
+        }
         if (part == 0) {
             float *d1 = (float *)dst;
-            for (long long k = (nvec << 3) + threadIdx.x; k < n; k += blockDim.x) d1[k] = src[k];
+            for (long long k = (nvec << 3) + threadIdx.x; k < n; k += blockDim.x) st4_wt(d1 + k, __float_as_uint(src[k]));
         }
     }
 }
@@ -80,7 +84,7 @@ __global__ void __launch_bounds__(256) qs_xchg_push_kernel(PushArgs a) {
     const size_t wsz = a.wire == QS_WIRE_BF16 ? 2 : 4;
     char *dst = a.data_win[d] + (size_t)slot * a.slot_bytes + (size_t)a.rank * a.n * wsz;
     copy_range(src, dst, a.n, a.wire, blockIdx.x, gridDim.x);
-    __threadfence_system();                                           // this thread's rows are visible system-wide ...
+    wt_drain();                                                       // this thread's (write-through) rows have reached their window ...
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned int t = atomicAdd(&a.loc->ticket[d], 1u);
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(64) qs_xchg_release_kernel(ReleaseArgs a) {
     if (r == 0) a.loc->release_seq = seq;
 }
 
-__global__ void __launch_bounds__(256) qs_obs_pack_kernel(const float *src, char *dst, long long n, int wire) { copy_range(src, dst, n, wire, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(256) qs_obs_pack_kernel(const float *src, char *dst, long long n, int wire) { copy_range(src, dst, n, wire, blockIdx.x, gridDim.x); wt_drain(); }
 
 struct Blob { hipIpcMemHandle_t data, flags; int32_t pid, device; int32_t pad[2]; };
 static_assert(sizeof(hipIpcMemHandle_t) == QS_XCHG_HANDLE_BYTES, "handle size");

@@ -51,6 +51,16 @@ __device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// Write-through stores for the rows that go into a window (own or a peer's): `sc0 sc1` = system scope, the line leaves the L2 at once.
+// With them a workgroup only has to wait for its own stores (s_waitcnt vmcnt(0)) before it takes its ticket - no system-scope release
+// fence per workgroup, which on this part writes the whole L2 back and cost ~20 us per step when 128-256 workgroups each issued one
+// (profiles/r03d_bench_lines.txt: 27.7 us per C2 step with the fences, 7.7 us without any exchange).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_wt(void *p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st4_wt(void *p, unsigned int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st2_wt(void *p, unsigned int v) { asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void wt_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // bounded poll: true when *p >= want before the deadline
 __device__ __forceinline__ bool poll_ge(const unsigned long long *p, unsigned long long want, unsigned long long timeout_ticks) {
     if (ld_sys(p) >= want) return true;

@@ -230,6 +230,15 @@ class ObsExchange:
             self.st.set_obs_exchange(self.x._x, auto_ack=not self.hold)
             self.fused_on = True
 
+    def pause(self):
+        """steps issued directly on the stepper from now on do not exchange their rows (bench.py: the independent-shards figure)"""
+        self.drain()
+        self.st.set_obs_target(None)
+        if self.fused_on:
+            torch.cuda.synchronize(self.device)
+            self.st.set_obs_exchange(None)
+            self.fused_on = False
+
     def _one(self, actions_ptr, buf, keep=False):
         if self.transport == "fused":   # the step launch is the exchange
             self._fuse()
