@@ -654,6 +654,16 @@ __device__ __forceinline__ void grid_dim(int num, int *d1, int *d2) {  // scenar
     *d1 = a; *d2 = num / a;
 }
 template <typename real> struct Formation { int f, per_layer; real lo, hi, size, layer_dist; };
+// The per-episode scenario code below is cold and big; out of line it keeps the step kernels small, but a kernel that CALLS anything
+// needs a stack (private segment > 0), and waves with a private segment are dispatched more slowly.  QS_INLINE_COLD=1 inlines it.
+#ifndef QS_INLINE_COLD
+#define QS_INLINE_COLD 0
+#endif
+#if QS_INLINE_COLD
+#define QS_COLD __forceinline__
+#else
+#define QS_COLD
+#endif
 
 template <typename real> __device__ __forceinline__ void goal_by_formation(int f, real p0, real p1, real layer, real g[3]) {
     int s = f_suffix(f);
@@ -664,7 +674,7 @@ template <typename real> __device__ __forceinline__ void goal_by_formation(int f
 
 // QuadrotorScenario.generate_goals scenarios/base.py:39-113.  out: [rows][3] with stride `ld` reals per row.
 template <typename real>
-__device__ int generate_goals(const Formation<real> &F, int n, int fd, const real center[3], real *out, int ld) {
+__device__ QS_COLD int generate_goals(const Formation<real> &F, int n, int fd, const real center[3], real *out, int ld) {
     // Opaque n: in a config-specialised build n is a literal and the loops below get fully unrolled + SLP-vectorised; the
     // fp32 grid branch then came out wrong on gfx950 (rows 0 and 2 of the second half-swarm, ROCm 7.2 clang), and this is
     // cold per-episode code where unrolling buys nothing.
@@ -731,7 +741,7 @@ __device__ __forceinline__ void scen_params(int scen, int *nform, float *lo, flo
 template <typename real> __device__ __forceinline__ int rng_index(const RngKey &k, int site, int slot, int n);
 // update_formation_and_relate_param scenarios/base.py:123-135
 template <typename real>
-__device__ void update_formation(int scen, const RngKey &key, int slot, int num_agents, Formation<real> &F) {
+__device__ QS_COLD void update_formation(int scen, const RngKey &key, int slot, int num_agents, Formation<real> &F) {
     int nform; float lof, hif;
     scen_params(scen, &nform, &lof, &hif);
     // 5*0.05 etc. are evaluated in double by the reference; 0.25/0.5/1.0 are exact, 0.4/0.8 need the double literal
@@ -769,7 +779,7 @@ template <typename real> __device__ __forceinline__ int draw_period(const RngKey
 
 // np.random.shuffle on rows [0,n) of buf (stride ld): Fisher-Yates with the QS_SITE_SCEN_SHUFFLE stream
 template <typename real>
-__device__ void shuffle_rows(const RngKey &key, real *buf, int ld, int n, int slot_base) {
+__device__ QS_COLD void shuffle_rows(const RngKey &key, real *buf, int ld, int n, int slot_base) {
 #ifdef QS_TAPE
     if (QS_ON_TAPE(key)) {   // the tape holds the permutation itself: rows[k] = old[perm[k]], applied in place cycle by cycle (n <= 64)
         const double *perm = key.tape + *key.cur;
@@ -801,7 +811,7 @@ __device__ void shuffle_rows(const RngKey &key, real *buf, int ld, int n, int sl
 // Scenario_swarm_vs_swarm.create_formations swarm_vs_swarm.py:52-57 (+ shuffle of update_goals :66-69).
 // goals: [>= 2*N+6][3] scratch rows (stride 3); the first N rows are the drones' goals afterwards.
 template <typename real>
-__device__ void svs_create_formations(const RngKey &key, const Formation<real> &F, int N, const int fd[2], const real c1[3],
+__device__ QS_COLD void svs_create_formations(const RngKey &key, const Formation<real> &F, int N, const int fd[2], const real c1[3],
                                       const real c2[3], bool do_shuffle, real *goals) {
     int n1 = N / 2, n2 = N - N / 2;
     int r1 = generate_goals<real>(F, n1, fd[0], c1, goals, 3);

@@ -90,7 +90,6 @@ __global__ void __launch_bounds__(256) qs_xchg_push_kernel(PushArgs a) {
         const unsigned int t = atomicAdd(&a.loc->ticket[d], 1u);
         if (t == gridDim.x - 1) {                                     // ... and this is the last workgroup of destination d
             a.loc->ticket[d] = 0;
-            __threadfence_system();
             st_sys(&a.flag_win[d]->arrive[slot][a.rank], seq);
             const unsigned int g = atomicAdd(&a.loc->ticket_all, 1u);
             if (g == gridDim.y - 1) { a.loc->ticket_all = 0; __threadfence(); a.loc->push_seq = seq; }
@@ -107,7 +106,6 @@ __global__ void __launch_bounds__(64) qs_xchg_wait_kernel(FlagWin *mine, Release
     bool ok = true;
     if (r < a.world) ok = poll_ge(&mine->arrive[slot][r], seq, timeout_ticks);
     if (__any(!ok) && r == 0) atomicOr(&a.loc->status, (unsigned int)QS_XCHG_ERR_ARRIVE_TIMEOUT);
-    __threadfence_system();
     if (release && r < a.world) st_sys(&a.flag_win[r]->ack[a.rank], seq);
     if (r == 0) { a.loc->wait_seq = seq; if (release) a.loc->release_seq = seq; }
 }
@@ -115,7 +113,6 @@ __global__ void __launch_bounds__(64) qs_xchg_wait_kernel(FlagWin *mine, Release
 __global__ void __launch_bounds__(64) qs_xchg_release_kernel(ReleaseArgs a) {
     const unsigned long long seq = a.loc->wait_seq;
     const int r = threadIdx.x;
-    __threadfence_system();
     if (r < a.world) st_sys(&a.flag_win[r]->ack[a.rank], seq);
     if (r == 0) a.loc->release_seq = seq;
 }

@@ -48,8 +48,12 @@ __device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Flags: relaxed system-scope accesses (they bypass the caches; no fence per access - an acquire / release at system scope invalidates
+// / writes back the whole L2 on this part).  What orders them against the rows: the rows are written through and drained
+// (s_waitcnt vmcnt(0)) before a workgroup takes its ticket, the flag is stored by whoever takes the last ticket; readers of the rows
+// are separate launches behind the wait (kernel-boundary acquire).
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // Write-through stores for the rows that go into a window (own or a peer's): `sc0 sc1` = system scope, the line leaves the L2 at once.
 // With them a workgroup only has to wait for its own stores (s_waitcnt vmcnt(0)) before it takes its ticket - no system-scope release
