@@ -867,16 +867,16 @@ __device__ __forceinline__ void goal_row(const Formation<real> &F, int n, int fd
     }
 }
 
+// One formation (or formation half) of an environment built / shuffled by its lanes: lane (r0 + li) makes row li of the `n` rows that start
+// at row r0.  `build`, `do_shuffle`, `n`, `fd`, `cen`, `r0`, `slot_base` are uniform over the lanes of one formation; `on` is uniform per
+// environment; environments of one wave may differ in all of them (their lanes share no data).
 template <typename real>
-__device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, const Formation<real> &F, int N, int fd0, int fd1, const real c1[3], const real c2[3],
-                                                           bool do_shuffle, real *goals, int *scr, int i, bool on) {
-    const int n1 = N / 2, n2 = N - N / 2;
-    const bool second = i >= n1;
-    const int n = second ? n2 : n1, li = second ? i - n1 : i, r0 = second ? n1 : 0;   // this lane's formation: rows, local row, first row
+__device__ __forceinline__ void formation_rows_wave(const RngKey &key, const Formation<real> &F, bool build, int n, int fd, const real cen[3], int li, int r0,
+                                                    bool do_shuffle, int slot_base, real *goals, int *scr, int i, bool on) {
     real g[3] = {0, 0, 0};
     bool needs_mean = false;
-    if (on) {
-        goal_row<real>(F, n, second ? fd1 : fd0, second ? c2 : c1, li, g, needs_mean);
+    if (on && build) {
+        goal_row<real>(F, n, fd, cen, li, g, needs_mean);
 #pragma unroll
         for (int q = 0; q < 3; ++q) goals[i * 3 + q] = g[q];
     }
@@ -886,7 +886,6 @@ __device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, co
         for (int k = 0; k < n; ++k)
 #pragma unroll
             for (int q = 0; q < 3; ++q) mean[q] += goals[(r0 + k) * 3 + q];
-        const real *cen = second ? c2 : c1;
 #pragma unroll
         for (int q = 0; q < 3; ++q) { mean[q] /= (real)n; g[q] = g[q] - mean[q] + cen[q]; }
     }
@@ -895,12 +894,11 @@ __device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, co
 #pragma unroll
         for (int q = 0; q < 3; ++q) goals[i * 3 + q] = g[q];
     }
-    if (!do_shuffle) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
-    // np.random.shuffle of each formation's rows: Fisher-Yates from the top, swap (k, j_k) with j_k = randint(k + 1), k = n-1 .. 1.  Lane
+    // np.random.shuffle of the formation's rows: Fisher-Yates from the top, swap (k, j_k) with j_k = randint(k + 1), k = n-1 .. 1.  Lane
     // li draws j_li; the row that ends at position li is found by sending li back through the swaps in reverse order.
-    if (on) scr[i] = li >= 1 ? rng_index<real>(key, QS_SITE_SCEN_SHUFFLE, (second ? 256 : 0) + li, li + 1) : 0;
+    if (on && do_shuffle) scr[i] = li >= 1 ? rng_index<real>(key, QS_SITE_SCEN_SHUFFLE, slot_base + li, li + 1) : 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (on) {
+    if (on && do_shuffle) {
         int pos = li;
         for (int k = 1; k < n; ++k) {
             const int j = scr[r0 + k];
@@ -910,11 +908,20 @@ __device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, co
         for (int q = 0; q < 3; ++q) g[q] = goals[(r0 + pos) * 3 + q];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (every lane has read its source row)
-    if (on) {
+    if (on && do_shuffle) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) goals[i * 3 + q] = g[q];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <typename real>
+__device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, const Formation<real> &F, int N, int fd0, int fd1, const real c1[3], const real c2[3],
+                                                           bool do_shuffle, real *goals, int *scr, int i, bool on) {
+    const int n1 = N / 2, n2 = N - N / 2;
+    const bool second = i >= n1;   // this lane's formation: rows, local row, first row
+    formation_rows_wave<real>(key, F, true, second ? n2 : n1, second ? fd1 : fd0, second ? c2 : c1, second ? i - n1 : i, second ? n1 : 0, do_shuffle,
+                              second ? 256 : 0, goals, scr, i, on);
 }
 
 }  // namespace qs

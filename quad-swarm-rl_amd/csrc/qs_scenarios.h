@@ -328,6 +328,60 @@ __device__ void scenario_step_serial(const Consts<real> &c, const RngKey &key, c
     }
 }
 
+// The same rewrites done by the environment's LANES (lane i makes goal row i; formation_rows_wave, qs_device.h) - bit-identical to
+// scenario_step_serial (same arithmetic per row, same summation order, same draws).  Why it exists: dynamic_formations rebuilds all goal
+// rows on EVERY step and the others at their periods, so with a few hundred environments some lane 0 of the batch was doing serial trig /
+// Fisher-Yates on every control step, and the slowest workgroup sets the duration of the launch (`mix`, 1024 x 8: 42 us per step with
+// the serial form against 8 us for the same shape on a static scenario; profiles/r03_final_batched_env_host.json).
+__device__ __forceinline__ bool scen_step_wave_ok(int sc, int N) {
+    return N >= 3 && (sc == QS_SCENARIO_DYNAMIC_FORMATIONS || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS || sc == QS_SCENARIO_O_SWAP_GOALS ||
+                      (sc == QS_SCENARIO_SWARM_VS_SWARM && N / 2 >= 3));
+}
+// Called by all lanes of a wave; `on` (uniform per environment): this environment takes the wave path at this tick.  scr: N ints of LDS.
+template <typename real>
+__device__ __forceinline__ void scenario_step_wave(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int *scr, int i, bool on) {
+    const int N = x.N;
+    Formation<real> F;
+    F.f = 0; F.per_layer = 1; F.lo = F.hi = F.size = F.layer_dist = (real)0;
+    real c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, speed = 0;
+    int inc = 0;
+    bool build = false, shuffle = false;
+    const bool svs = sc == QS_SCENARIO_SWARM_VS_SWARM, ddg = sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL, dyf = sc == QS_SCENARIO_DYNAMIC_FORMATIONS;
+    if (on) {   // every lane of the environment derives the new scenario state (identical keys => identical values)
+        if (svs) {                                         // swarm_vs_swarm.py:59-79
+            for (int q = 0; q < 3; ++q) { c1[q] = x.sr[SR_C2 + q]; c2[q] = x.sr[SR_C1 + q]; }
+            update_formation<real>(sc, key, 32, N, F);
+            build = shuffle = true;
+        } else if (ddg) {                                  // dynamic_diff_goal.py:8-34
+            load_formation<real>(x, F);
+            real box = c.spawn_box, xy[2];
+            rng_uniform<real, 2>(key, QS_SITE_SCEN, 40, 0, 0, -box, box, xy);
+            c1[0] = xy[0]; c1[1] = xy[1]; c1[2] = get_z_value<real>(c, key, F, N, 41);
+            update_formation<real>(sc, key, 32, N, F);
+            build = shuffle = true;
+        } else if (dyf) {                                  // dynamic_formations.py:16-35
+            load_formation<real>(x, F);
+            inc = x.si[SI_INCREASE];
+            speed = x.sr[SR_SPEED];
+            if (F.size <= -F.hi) { inc = 1; speed = rng_uniform1<real>(key, QS_SITE_SCEN, 292, 0, 0, (real)1, (real)3); }
+            else if (F.size >= F.hi) { inc = 0; speed = rng_uniform1<real>(key, QS_SITE_SCEN, 292, 0, 0, (real)1, (real)3); }
+            if (inc) F.size += (real)0.001 * speed; else F.size -= (real)0.001 * speed;
+            for (int q = 0; q < 3; ++q) c1[q] = x.sr[SR_C1 + q];
+            build = true;
+        } else shuffle = true;                             // swap_goals.py:13-24 / o_swap_goals.py:14-25
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every lane has read the old state before lane 0 replaces it
+    if (on && i == 0) {
+        if (svs) { for (int q = 0; q < 3; ++q) { x.sr[SR_C1 + q] = c1[q]; x.sr[SR_C2 + q] = c2[q]; } store_formation<real>(x, F); }
+        else if (ddg) { for (int q = 0; q < 3; ++q) x.sr[SR_C1 + q] = c1[q]; store_formation<real>(x, F); }
+        else if (dyf) { x.si[SI_INCREASE] = inc; x.sr[SR_SPEED] = speed; x.sr[SR_SIZE] = F.size; }
+    }
+    const int n1 = N / 2;
+    const bool second = svs && i >= n1;
+    formation_rows_wave<real>(key, F, build, svs ? (second ? N - n1 : n1) : N, svs ? (second ? c.cube_fd[1] : c.cube_fd[0]) : c.cube_fd_all, second ? c2 : c1,
+                              second ? i - n1 : i, second ? n1 : 0, shuffle, second ? 256 : 0, x.goals, scr, i, on);
+}
+
 // lane-local part of scenario.step(): scenarios whose drones all share one goal, computed redundantly by every drone
 // of the env (identical RNG keys => identical values); `persist` (drone 0) writes the env's state back to LDS.
 template <typename real>
