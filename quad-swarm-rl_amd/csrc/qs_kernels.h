@@ -729,6 +729,38 @@ __device__ __forceinline__ void scen_lds_load(const Ptrs<real> &p, const LdsLayo
     for (int k = i; k < SI_COUNT; k += N) si[k] = p.scen_int[k * E + e];
     for (int k = i; k < 4; k += N) om[k] = p.scen_omap[k * E + e];
 }
+#ifdef QS_SPEC_N
+// The same load in two halves for the latency-bound team kernels: the global loads are issued with the state loads, the LDS writes wait
+// until the sub-steps are done (a write right behind its load makes the wave wait for EVERY load in flight before it has drawn its noise).
+template <typename real> struct ScenRegs {
+    real r[(SR_COUNT + QS_SPEC_N - 1) / QS_SPEC_N];
+    int n[(SI_COUNT + QS_SPEC_N - 1) / QS_SPEC_N];
+    uint64_t o[(4 + QS_SPEC_N - 1) / QS_SPEC_N];
+};
+template <typename real>
+__device__ __forceinline__ void scen_regs_load(const Ptrs<real> &p, int E, int e, int i, ScenRegs<real> &v) {
+    constexpr int N = QS_SPEC_N;
+#pragma unroll
+    for (int j = 0; j < (SR_COUNT + N - 1) / N; ++j) { const int k = i + j * N; v.r[j] = (k < SR_COUNT) ? p.scen_real[k * E + e] : (real)0; }
+#pragma unroll
+    for (int j = 0; j < (SI_COUNT + N - 1) / N; ++j) { const int k = i + j * N; v.n[j] = (k < SI_COUNT) ? p.scen_int[k * E + e] : 0; }
+#pragma unroll
+    for (int j = 0; j < (4 + N - 1) / N; ++j) { const int k = i + j * N; v.o[j] = (k < 4) ? p.scen_omap[k * E + e] : 0ull; }
+}
+template <typename real>
+__device__ __forceinline__ void scen_regs_to_lds(const LdsLayout &L, unsigned char *smem, int le, int i, const ScenRegs<real> &v) {
+    constexpr int N = QS_SPEC_N;
+    real *sr = (real *)(smem + L.off_sr) + le * SR_COUNT;
+    int *si = (int *)(smem + L.off_si) + le * SI_COUNT;
+    uint64_t *om = (uint64_t *)(smem + L.off_omap) + le * 4;
+#pragma unroll
+    for (int j = 0; j < (SR_COUNT + N - 1) / N; ++j) { const int k = i + j * N; if (k < SR_COUNT) sr[k] = v.r[j]; }
+#pragma unroll
+    for (int j = 0; j < (SI_COUNT + N - 1) / N; ++j) { const int k = i + j * N; if (k < SI_COUNT) si[k] = v.n[j]; }
+#pragma unroll
+    for (int j = 0; j < (4 + N - 1) / N; ++j) { const int k = i + j * N; if (k < 4) om[k] = v.o[j]; }
+}
+#endif
 template <typename real>
 __device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
     const real *sr = (const real *)(smem + L.off_sr) + le * SR_COUNT;
@@ -1042,6 +1074,8 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
         }
     }
 }
+
+#include "qs_step_sem.h"   // the step semantics shared by the two step bodies below
 
 #ifdef QS_SPEC
 #if QS_SPEC_PRECISION == 8

@@ -49,7 +49,7 @@ __device__ __forceinline__ int kth_free_cell(const uint64_t *omap, int cells, in
 // held in `tidx/tval`, LDS scratch) + z ~ U(1,3).  out: rows of stride `ld` starting at out[0] (x,y,z consecutive) or the
 // component-major spawn array when `to_spawn`.
 template <typename real>
-__device__ void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *tidx, int *tval, int slot_choice, int slot_z,
+__device__ QS_COLD void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *tidx, int *tval, int slot_choice, int slot_z,
                                bool to_spawn) {
     // free cells = cells not in the obstacle map (the episode's obstacle count varies under --quads_domain_random)
     const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - map_count(x.omap), N = x.N;
@@ -78,7 +78,7 @@ __device__ void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const S
 }
 // Scenario_o_base.generate_pos_obst_map o_base.py:48-67 (no surroundings check): one free cell + z ~ U(0.75,3)
 template <typename real>
-__device__ void pos_obst_map_1(const Consts<real> &c, const RngKey &key, const uint64_t *omap, int slot, real out[3]) {
+__device__ QS_COLD void pos_obst_map_1(const Consts<real> &c, const RngKey &key, const uint64_t *omap, int slot, real out[3]) {
     const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - map_count(omap);
     int idx = rng_index<real>(key, QS_SITE_SCEN, slot, nfree);
     int cell = kth_free_cell(omap, cells, idx), cx = cell / W, cy = cell - cx * W;
@@ -87,7 +87,7 @@ __device__ void pos_obst_map_1(const Consts<real> &c, const RngKey &key, const u
 }
 // Scenario_o_base.max_square_area_center o_base.py:124-153 (two-row dynamic programme in LDS scratch rows)
 template <typename real>
-__device__ void max_square_center(const Consts<real> &c, const RngKey &key, const uint64_t *omap, int *prev_row, int *cur_row, int slot_z, real out[3]) {
+__device__ QS_COLD void max_square_center(const Consts<real> &c, const RngKey &key, const uint64_t *omap, int *prev_row, int *cur_row, int slot_z, real out[3]) {
     const int Lr = c.obst_area[0], W = c.obst_area[1];
     int max_size = 0, cx = 0, cy = 0;
     for (int q = 0; q < W; ++q) prev_row[q] = (int)(omap[q >> 6] >> (q & 63) & 1);
@@ -114,7 +114,7 @@ __device__ void max_square_center(const Consts<real> &c, const RngKey &key, cons
 
 // get_z_value scenarios/utils.py:170-181
 template <typename real>
-__device__ real get_z_value(const Consts<real> &c, const RngKey &key, const Formation<real> &F, int N, int slot) {
+__device__ QS_COLD real get_z_value(const Consts<real> &c, const RngKey &key, const Formation<real> &F, int N, int slot) {
     real box = c.spawn_box;
     real z = rng_uniform1<real>(key, QS_SITE_SCEN, slot, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2, zlb = (real)0.25;
     const int f = F.f;
@@ -125,7 +125,7 @@ __device__ real get_z_value(const Consts<real> &c, const RngKey &key, const Form
 
 // QuadrotorScenario.standard_reset scenarios/base.py:153-167
 template <typename real>
-__device__ void standard_reset(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int scen, const real center[3]) {
+__device__ QS_COLD void standard_reset(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int scen, const real center[3]) {
     Formation<real> F;
     update_formation<real>(scen, key, 0, x.N, F);
     store_formation<real>(x, F);
@@ -153,7 +153,7 @@ __device__ __forceinline__ int mix_pick(int num_agents, bool use_obstacles, doub
 
 // scenario.reset() of every scenario (executed by drone 0 of the env); mirrors oracle/quadswarm_oracle.c:scenario_reset
 template <typename real>
-__device__ void scenario_reset_full(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *scratch) {
+__device__ QS_COLD void scenario_reset_full(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *scratch) {
     const int N = x.N;
     int *tidx = scratch, *tval = scratch + 64, *prev_row = scratch + 128, *cur_row = scratch + 144;
     int sc, constructed;
@@ -288,7 +288,7 @@ __device__ __forceinline__ bool scen_step_serial_needed(int sc, int period, int 
 
 // serial part of scenario.step(): rewrites the env's goal rows in LDS (current goals were published there first)
 template <typename real>
-__device__ void scenario_step_serial(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc) {
+__device__ QS_COLD void scenario_step_serial(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc) {
     const int N = x.N;
     Formation<real> F;
     if (sc == QS_SCENARIO_SWARM_VS_SWARM) {            // swarm_vs_swarm.py:59-79
@@ -378,14 +378,18 @@ __device__ __forceinline__ void scenario_step_wave(const Consts<real> &c, const 
     }
     const int n1 = N / 2;
     const bool second = svs && i >= n1;
-    formation_rows_wave<real>(key, F, build, svs ? (second ? N - n1 : n1) : N, svs ? (second ? c.cube_fd[1] : c.cube_fd[0]) : c.cube_fd_all, second ? c2 : c1,
+    // the three cube sizes by VALUE (a select between their addresses would pin the whole constant block in scratch memory: 552 bytes per
+    // lane and a 22 us step instead of 9, tools/spec_resources.py)
+    int fd0 = c.cube_fd[0], fd1 = c.cube_fd[1], fda = c.cube_fd_all;
+    asm volatile("" : "+v"(fd0), "+v"(fd1), "+v"(fda));
+    formation_rows_wave<real>(key, F, build, svs ? (second ? N - n1 : n1) : N, svs ? (second ? fd1 : fd0) : fda, second ? c2 : c1,
                               second ? i - n1 : i, second ? n1 : 0, shuffle, second ? 256 : 0, x.goals, scr, i, on);
 }
 
 // lane-local part of scenario.step(): scenarios whose drones all share one goal, computed redundantly by every drone
 // of the env (identical RNG keys => identical values); `persist` (drone 0) writes the env's state back to LDS.
 template <typename real>
-__device__ void scenario_step_local(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int period, int tick, bool persist,
+__device__ QS_COLD void scenario_step_local(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int period, int tick, bool persist,
                                     real goal[3]) {
     if (sc == QS_SCENARIO_DYNAMIC_SAME_GOAL) {           // dynamic_same_goal.py:16-29 (formation size 0: every goal = the centre)
         if (period > 0 && tick % period == 0 && tick > 0) {

@@ -39,6 +39,6 @@ for name in names:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / steps
     res[name] = round(us, 2)
-    print(f"{name:24s} {us:8.2f} us per step   {env.stepper.spec_note() if hasattr(env.stepper, 'spec_note') else ''}", flush=True)
+    print(f"{name:24s} {us:8.2f} us per step   {getattr(env.stepper, 'spec_note', '')}", flush=True)
     env.close()
 print(json.dumps({"workload": f"{E} envs x 8 drones, step kernel us per step by scenario", "us_per_step": res}))

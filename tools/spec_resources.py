@@ -15,8 +15,8 @@ import bench
 from quad_swarm_rl_amd import config as qcfg, native
 
 
-def resources(wl="c2", team=-1, extra="", precision="f32", out=None, envs=None):
-    kw = dict(bench.WORKLOADS[wl]["kw"])
+def resources(wl="c2", team=-1, extra="", precision="f32", out=None, envs=None, **overrides):
+    kw = dict(bench.WORKLOADS[wl]["kw"], **overrides)   # e.g. quads_mode="mix": the full-scenario kernels on the workload's shape
     cfg = qcfg.make_config(num_envs=envs or bench.WORKLOADS[wl]["num_envs"], seed=0, write_rew_info=False, precision=precision, **kw)
     if extra:
         os.environ["QS_SPEC_EXTRA_FLAGS"] = extra
