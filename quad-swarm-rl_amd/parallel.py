@@ -173,14 +173,32 @@ class ObsExchange:
         T, D = stepper.T, stepper.obs_dim
         # the endpoint also owns the two staging buffers; under "rccl" it is used for those (and its converter) only
         windows = transport in ("peer", "fused")
-        self.x = PeerExchange(T, D, world if windows else 1, rank if windows else 0, device=stepper.device, wire=wire)
+        if windows and peers is None and world > 1:
+            # Every rank takes part in the handle exchange even if its own endpoint could not be created or exported: a rank that
+            # raised before the collective would leave the others waiting in it.  All ranks then fail (or succeed) together.
+            self.x, blob, err = None, None, None
+            try:
+                self.x = PeerExchange(T, D, world, rank, device=stepper.device, wire=wire)
+                blob = self.x.export()
+            except Exception as exc:   # noqa: BLE001 - re-raised below, after the collective
+                err = exc
+            blobs = [None] * world
+            dist.all_gather_object(blobs, blob, group=group)
+            missing = [r for r, b in enumerate(blobs) if b is None]
+            if err is None and missing:
+                err = native.QsError(f"rank(s) {missing} could not create / export their exchange windows")
+            if err is not None:
+                if self.x is not None:
+                    self.x.close()
+                raise err
+            self.x.attach(blobs)
+        else:
+            self.x = PeerExchange(T, D, world if windows else 1, rank if windows else 0, device=stepper.device, wire=wire)
         if windows:
             if peers is not None:          # in-process wiring (tests, one process driving several shards)
                 for p in peers:
                     if p is not None and p.rank != rank:
                         self.x.attach_local(p)
-            elif world > 1:
-                self.x.connect(group)
         else:
             dt = torch.bfloat16 if wire == "bf16" else torch.float32
             self._packed = [torch.empty((T, D), dtype=dt, device=self.device) for _ in range(2)]
