@@ -59,6 +59,16 @@ typedef struct qs_enc_params {
     const float *head_w, *head_b;   /* fp32 [head_dim, 512], [head_dim] */
     float *head_out;                /* fp32 [B, head_dim] */
     int32_t head_dim;               /* 0: none; <= 8 */
+    /* optional Gaussian sampling on the head's output, for rollout segments (SF's continuous action parameterisation with a
+       state-independent std): act_out[B, head_dim] = head_out + exp(sample_log_std[h]) * N(0, 1).  Philox4x32-10 keyed
+       (seed, *sample_counter + sample_step, agent): the same draws as qs_rollout_pre with that counter value.  `sample_step` is a
+       launch argument (a captured graph gives every step its own), `sample_counter` lives in device memory (advance it once per
+       replay and the graph draws fresh noise).  sample_log_std == NULL: no sampling. */
+    uint32_t sample_step;
+    const float *sample_log_std;    /* fp32 [head_dim] */
+    float *act_out;                 /* fp32 [B, head_dim] */
+    const uint32_t *sample_counter;
+    uint32_t sample_seed_lo, sample_seed_hi;
 } qs_enc_params;
 
 size_t qs_enc_sizeof_params(void);

@@ -79,6 +79,13 @@ struct EncParams {
     const float *head_w, *head_b;   // fp32 [head_dim, 512], [head_dim]
     float *head_out;
     int32_t head_dim;               // 0: no head; <= 8
+    // optional Gaussian sampling on the head's output (rollout segments): act_out[B, head_dim] = head_out + exp(sample_log_std) * N(0, 1),
+    // Philox4x32-10 keyed (seed, *sample_counter + sample_step, agent) - the draws of qs_rollout_pre with that counter value
+    uint32_t sample_step;
+    const float *sample_log_std;    // fp32 [head_dim]; NULL: no sampling
+    float *act_out;                 // fp32 [B, head_dim]
+    const uint32_t *sample_counter;
+    uint32_t sample_seed_lo, sample_seed_hi;
 };
 
 #ifdef ENC_TIMING   // phase stamps of workgroup 0, wave 0 (tools/enc_quick.py prints them)
@@ -89,6 +96,29 @@ __device__ unsigned long long enc_wg_times[2 * 8192];   // start / end of every 
 #else
 #define ENC_STAMP(k) do { } while (0)
 #endif
+
+__device__ __forceinline__ void glue_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0, h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// action = mean + exp(log_std) * N(0, 1) for component h of agent a: Box-Muller on the Philox group (agent, counter, 0x51, h / 4) - the
+// values qs_rollout_pre_kernel draws (one group = two pairs = four components)
+__device__ __forceinline__ float sample_action(const EncParams &P, int a, int h, float mean) {
+    uint32_t w[4];
+    glue_philox((uint32_t)a, *P.sample_counter + P.sample_step, 0x51u, (uint32_t)(h >> 2), P.sample_seed_lo, P.sample_seed_hi, w);
+    const int pr = (h >> 1) & 1;
+    const float ua = ((float)(w[2 * pr] >> 9) + 0.5f) * (1.0f / 8388608.0f), ub = ((float)(w[2 * pr + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);
+    const float r = sqrtf(-2.0f * __logf(ua));
+    float sn, cs;
+    __sincosf(6.283185307179586f * ub, &sn, &cs);
+    return mean + __expf(P.sample_log_std[h]) * r * ((h & 1) ? sn : cs);
+}
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }   // in a scalar register
 
@@ -284,6 +314,7 @@ __device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t 
 #pragma unroll
             for (int w = 0; w < ENC_WAVES; ++w) s += red[(w * 8 + h) * 16 + row];
             P.head_out[(size_t)(a0 + row) * P.head_dim + h] = s;
+            if (P.sample_log_std) P.act_out[(size_t)(a0 + row) * P.head_dim + h] = sample_action(P, a0 + row, h, s);
         }
     }
 }
@@ -1072,6 +1103,7 @@ __device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, 
 #pragma unroll
             for (int w = 0; w < ENC_WAVES; ++w) t += red[(w * 8 + hd) * ENC_WA + row];
             P.head_out[(size_t)(a0 + row) * P.head_dim + hd] = t;
+            if (P.sample_log_std) P.act_out[(size_t)(a0 + row) * P.head_dim + hd] = sample_action(P, a0 + row, hd, t);
         }
     }
 }
@@ -1433,16 +1465,6 @@ ENC_WIDE_ATT_KERNELS(1) ENC_WIDE_ATT_KERNELS(2) ENC_WIDE_ATT_KERNELS(3)
 // copy, copy, copy) at 1.5 - 2 us each inside a HIP graph.  The noise is Philox4x32-10 keyed (seed, launch counter, agent); the
 // counter lives in device memory and is advanced by the second launch, so a captured graph draws fresh noise on every replay.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glue_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0, h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
 extern "C" __global__ void __launch_bounds__(256) qs_rollout_pre_kernel(const float *__restrict__ obs, float *__restrict__ obs_out, int n_obs, const float *__restrict__ mean,
                                                                         const float *__restrict__ log_std, float *__restrict__ act_out, int A, uint32_t seed_lo,
                                                                         uint32_t seed_hi, const uint32_t *__restrict__ counter) {
@@ -1526,7 +1548,8 @@ size_t qs_enc_lds_bytes_of(int32_t model) {
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
     if (!obs || !params || B < 0) { g_enc_error = "bad argument"; return -1; }
     const EncParams &P = *params;
-    if (P.head_dim < 0 || P.head_dim > 8 || (P.head_dim > 0 && (!P.head_w || !P.head_b || !P.head_out)) || (!out && P.head_dim == 0)) {
+    if (P.head_dim < 0 || P.head_dim > 8 || (P.head_dim > 0 && (!P.head_w || !P.head_b || !P.head_out)) || (!out && P.head_dim == 0) ||
+        (P.sample_log_std && (P.head_dim == 0 || !P.act_out || !P.sample_counter))) {
         g_enc_error = "bad argument";   // neither the features nor a head output requested, or an incomplete head
         return -1;
     }
@@ -1617,7 +1640,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
 // rollout glue, see the kernels above: obs[n_obs] -> obs_out, act_out[A, 4] = mean[A, 4] (+ exp(log_std[4]) * N(0, 1) if log_std != NULL)
 int qs_rollout_pre(const float *obs, float *obs_out, int32_t n_obs, const float *mean, const float *log_std, float *act_out, int32_t A, uint64_t seed,
                    const uint32_t *counter, void *stream) {
-    if (!obs || !obs_out || !mean || !act_out || !counter || n_obs < 0 || A < 0) { g_enc_error = "bad argument"; return -1; }
+    if ((n_obs > 0 && (!obs || !obs_out)) || !mean || !act_out || !counter || n_obs < 0 || A < 0) { g_enc_error = "bad argument"; return -1; }
     if (A == 0 && n_obs == 0) return 0;
     const int work = (n_obs >> 2) > A ? (n_obs >> 2) : A, blocks = (work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048;
     hipLaunchKernelGGL(qs_rollout_pre_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, obs, obs_out, n_obs, mean, log_std, act_out, A,

@@ -40,7 +40,9 @@ class EncParams(C.Structure):
                 ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3w", C.c_void_p), ("a3b", C.c_float), ("pad0", C.c_int32),
                 ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer),
                 ("mq", EncLayer), ("mk", EncLayer), ("mv", EncLayer), ("mfc", EncLayer), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
-                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p), ("head_dim", C.c_int32)]
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p), ("head_dim", C.c_int32),
+                ("sample_step", C.c_uint32), ("sample_log_std", C.c_void_p), ("act_out", C.c_void_p), ("sample_counter", C.c_void_p),
+                ("sample_seed_lo", C.c_uint32), ("sample_seed_hi", C.c_uint32)]
 
 
 _lib = None
@@ -440,8 +442,10 @@ class FusedQuadEncoder:
             raise ValueError(f"head: weight [h, {self.out_dim}] with 1 <= h <= 8, bias [h]")
         self._head = (w, b)
 
-    def forward_head(self, obs, head_out=None, features=None):
-        """head(encoder(obs)) -> [B, h] float32; the [B, 512] features are written only if a `features` tensor is passed."""
+    def forward_head(self, obs, head_out=None, features=None, sample=None):
+        """head(encoder(obs)) -> [B, h] float32; the [B, 512] features are written only if a `features` tensor is passed.
+        sample = (log_std [h], act_out [B, h], counter (int32 device tensor), step, seed): the epilogue also writes
+        act_out = head + exp(log_std) * N(0, 1), Philox keyed (seed, counter + step, agent) - qs_enc_params.sample_*."""
         torch = self._torch
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.params.obs_dim
         if getattr(self, "_head", None) is None:
@@ -454,9 +458,15 @@ class FusedQuadEncoder:
         self._scratch(B)
         P = self.params
         P.head_w, P.head_b, P.head_out, P.head_dim = w.data_ptr(), b.data_ptr(), head_out.data_ptr(), w.shape[0]
+        if sample is not None:
+            log_std, act_out, counter, step, seed = sample
+            assert act_out.is_contiguous() and act_out.shape == head_out.shape and act_out.dtype == torch.float32 and log_std.numel() == w.shape[0]
+            P.sample_log_std, P.act_out, P.sample_counter = log_std.data_ptr(), act_out.data_ptr(), counter.data_ptr()
+            P.sample_step, P.sample_seed_lo, P.sample_seed_hi = int(step) & 0xffffffff, int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff
         rc = lib().qs_enc_forward(obs.data_ptr(), B, C.byref(P), C.c_void_p(features.data_ptr() if features is not None else None),
                                   C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
         P.head_dim = 0
+        P.sample_log_std = None
         if rc != 0:
             raise native.QsError(f"qs_enc_forward failed ({rc}): {lib().qs_enc_last_error().decode()}")
         return head_out

@@ -41,7 +41,12 @@ class GaussianActionHead:
 class GraphedRollout:
     def __init__(self, env, encoder, head, steps, graph=True):
         """env: QuadSwarmVecEnv (float32), encoder: policy.FusedQuadEncoder, head: features[A, 512] -> actions[A, 4].
-        Construction runs ONE control step eagerly (library warm-up outside the capture) before recording."""
+        Construction runs ONE control step eagerly (library warm-up outside the capture) before recording.
+
+        With the library's GaussianActionHead the segment has no glue launches at all: the encoder's epilogue evaluates the head AND
+        samples the action into actions[t] (qs_enc_params.sample_*), and the step writes its outputs straight into the trajectory -
+        observation rows to obs[t + 1] (qs_set_obs_target), rewards / done flags to rewards[t] / dones[t] (qs_set_output_target).
+        Per control step that is the encoder's launch(es) + the step, 2 (attention: 3) dependent graph nodes instead of 4 (5)."""
         import torch
         if not torch.cuda.is_available():
             raise native.QsError("GraphedRollout needs a GPU")
@@ -61,46 +66,93 @@ class GraphedRollout:
         if self._fused_head:   # the Linear runs in the encoder's epilogue: the [A, 512] features are never written
             encoder.set_head(head.weight, head.bias)
             self._mean = torch.empty((A, 4), device=dev)
-            # ... and sampling + the trajectory copies are two launches of the library's glue kernels instead of eight torch kernels
+            # ... and with the library's head so do sampling and the trajectory writes (no copy / sampling kernels between the steps)
             self._glue = isinstance(head, GaussianActionHead) and self.dones.dtype == torch.uint8 and self._done.dtype == torch.uint8
+            # (the device-side replay wrapper restores observations into the library's buffer and reads its done flags: a handle with
+            # replay enabled keeps its outputs there, and the segment copies them - the two glue launches of qs_rollout_pre / _post)
+            self._in_place = self._glue and not getattr(st, "replay_on", False)
             if self._glue:
                 self._counter = torch.zeros(1, device=dev, dtype=torch.int32)
                 self._seed = int(getattr(head, "seed", 0)) & 0xffffffffffffffff
         else:
             self._feat = torch.empty((A, encoder.out_dim), device=dev)
         self.graph = None
-        if graph:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                self._step(0)
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                for t in range(steps):
-                    self._step(t)
+        try:
+            if graph:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    self._segment(1)     # one step, eagerly: library warm-up outside the capture
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self._segment(steps)
+        finally:
+            self._restore_targets()
+
+    def warmup(self):
+        """one control step outside any capture (what the constructor does before it records a graph)"""
+        try:
+            self._segment(1)
+        finally:
+            self._restore_targets()
+
+    def _restore_targets(self):
+        """the stepper's output redirections are host-side launch state: an env.step() outside the segment writes the library's buffers"""
+        if self._glue and self._in_place:
+            self.env.stepper.set_obs_target(None)
+            self.env.stepper.set_output_target(None, None)
+
+    def _segment(self, n):
+        """n control steps from the environments' current state"""
+        if self._glue and not self._in_place:
+            for t in range(n):
+                self._step_copying(t)
+            return
+        if self._glue:
+            st, last = self.env.stepper, n - 1
+            self.obs[0].copy_(self._obs)      # the one copy of the segment: the observations the environments are in
+            for t in range(n):
+                if self.head.sample:
+                    self.encoder.forward_head(self.obs[t], head_out=self._mean, sample=(self.head.log_std, self.actions[t], self._counter, t, self._seed))
+                else:   # deterministic policy: the head's output IS the action
+                    self.encoder.forward_head(self.obs[t], head_out=self.actions[t])
+                # step t: observation rows -> obs[t + 1] (the last step: the library's buffer, where the next segment starts),
+                # rewards / done flags -> rewards[t] / dones[t]
+                st.set_obs_target(self.obs[t + 1].data_ptr() if t < last else None)
+                st.set_output_target(self.rewards[t].data_ptr(), self.dones[t].data_ptr())
+                st.step(self.actions[t].data_ptr(), stream=self._torch_stream())
+            self._counter.add_(n)             # the next replay draws fresh noise
+            return
+        for t in range(n):
+            self._step(t)
+
+    def _torch_stream(self):
+        import torch
+        return torch.cuda.current_stream(self._obs.device)
+
+    def _step_copying(self, t):
+        """the segment step of a handle whose outputs stay in the library's buffers: sampling + observation copy in one launch before
+        the step, reward / done copies + counter in one launch behind it"""
+        import ctypes as C
+        from . import policy
+        L = policy.lib()
+        stream = C.c_void_p(self._torch_stream().cuda_stream)
+        A = self._obs.shape[0]
+        self.encoder.forward_head(self._obs, head_out=self._mean)
+        log_std = C.c_void_p(self.head.log_std.data_ptr()) if self.head.sample else None
+        rc = L.qs_rollout_pre(C.c_void_p(self._obs.data_ptr()), C.c_void_p(self.obs[t].data_ptr()), self._obs.numel(), C.c_void_p(self._mean.data_ptr()), log_std,
+                              C.c_void_p(self.actions[t].data_ptr()), A, C.c_uint64(self._seed), C.c_void_p(self._counter.data_ptr()), stream)
+        if rc != 0:
+            raise native.QsError(f"qs_rollout_pre failed ({rc})")
+        self.env.stepper.step(self.actions[t].data_ptr(), stream=self._torch_stream())
+        rc = L.qs_rollout_post(C.c_void_p(self._rew.data_ptr()), C.c_void_p(self.rewards[t].data_ptr()), C.c_void_p(self._done.data_ptr()),
+                               C.c_void_p(self.dones[t].data_ptr()), A, C.c_void_p(self._counter.data_ptr()), stream)
+        if rc != 0:
+            raise native.QsError(f"qs_rollout_post failed ({rc})")
 
     def _step(self, t):
-        import torch
-        if self._glue:
-            import ctypes as C
-            from . import policy
-            L = policy.lib()
-            stream = C.c_void_p(torch.cuda.current_stream(self._obs.device).cuda_stream)
-            A = self._obs.shape[0]
-            self.encoder.forward_head(self._obs, head_out=self._mean)
-            log_std = C.c_void_p(self.head.log_std.data_ptr()) if self.head.sample else None
-            rc = L.qs_rollout_pre(C.c_void_p(self._obs.data_ptr()), C.c_void_p(self.obs[t].data_ptr()), self._obs.numel(), C.c_void_p(self._mean.data_ptr()), log_std,
-                                  C.c_void_p(self.actions[t].data_ptr()), A, C.c_uint64(self._seed), C.c_void_p(self._counter.data_ptr()), stream)
-            if rc != 0:
-                raise native.QsError(f"qs_rollout_pre failed ({rc})")
-            self.env.stepper.step(self.actions[t].data_ptr(), stream=torch.cuda.current_stream(self._obs.device))
-            rc = L.qs_rollout_post(C.c_void_p(self._rew.data_ptr()), C.c_void_p(self.rewards[t].data_ptr()), C.c_void_p(self._done.data_ptr()),
-                                   C.c_void_p(self.dones[t].data_ptr()), A, C.c_void_p(self._counter.data_ptr()), stream)
-            if rc != 0:
-                raise native.QsError(f"qs_rollout_post failed ({rc})")
-            return
         self.obs[t].copy_(self._obs)
         if self._fused_head:
             self.encoder.forward_head(self._obs, head_out=self._mean)
@@ -108,15 +160,18 @@ class GraphedRollout:
         else:
             self.encoder(self._obs, out=self._feat)
             self.actions[t].copy_(self.head(self._feat))
-        self.env.stepper.step(self.actions[t].data_ptr(), stream=torch.cuda.current_stream(self._obs.device))
+        self.env.stepper.step(self.actions[t].data_ptr(), stream=self._torch_stream())
         self.rewards[t].copy_(self._rew)
         self.dones[t].copy_(self._done)
 
     def run(self):
-        """One segment of `steps` control steps from the environments' current state (stream-ordered, asynchronous)."""
+        """One segment of `steps` control steps from the environments' current state (stream-ordered, asynchronous).  The returned
+        tensors are the segment's buffers: the next run() overwrites them."""
         if self.graph is not None:
             self.graph.replay()
         else:
-            for t in range(self.steps):
-                self._step(t)
+            try:
+                self._segment(self.steps)
+            finally:
+                self._restore_targets()
         return {"obs": self.obs, "actions": self.actions, "rewards": self.rewards, "dones": self.dones, "last_obs": self._obs}

@@ -19,7 +19,7 @@ def test_graphed_rollout_equals_the_eager_loop(nbr_encoder):
         env.reset()
         seg = rollout.GraphedRollout(env, enc, head, steps=T, graph=graph)   # graph=True: one eager warm-up step, then the capture
         if not graph:
-            seg._step(0)                                                     # the same warm-up step
+            seg.warmup()                                                     # the same warm-up step
         first = {k: v.clone() for k, v in seg.run().items()}
         second = {k: v.clone() for k, v in seg.run().items()}               # a second segment continues where the first ended
         torch.cuda.synchronize()
@@ -74,9 +74,37 @@ def test_reward_coefficient_updates_reach_a_captured_graph():
     assert (rewards[1] < rewards[0] - 1e-4).all()             # -dt * 3 * pos * dist  vs  -dt * pos * dist
 
 
-def test_glue_kernels_sample_gaussian_actions_and_copy_the_trajectory():
-    """qs_rollout_pre / qs_rollout_post (the two launches that replace the framework's copy / randn / exp / mul / add kernels):
-    actions = mean + exp(log_std) * N(0, 1) with fresh noise per step and per replay, trajectory rows = the buffers at that step."""
+def test_epilogue_sampling_draws_what_the_glue_kernel_draws():
+    """qs_enc_params.sample_*: the encoder's epilogue samples the action itself.  Same Philox key and Box-Muller as qs_rollout_pre (the
+    stand-alone sampling launch of the C ABI) with the counter value *sample_counter + sample_step."""
+    import ctypes as C
+    import torch
+    from quad_swarm_rl_amd import policy
+    for nbr_encoder, B in (("mean_embed", 100), ("attention", 100), ("mean_embed", 5000)):   # 16-agent and 32-agent workgroups
+        enc = policy.FusedQuadEncoder(policy.make_reference_encoder(seed=2, nbr_encoder=nbr_encoder).cuda())
+        g = torch.Generator(device="cuda").manual_seed(1)
+        obs = torch.rand((B, enc.params.obs_dim), device="cuda", generator=g) * 2 - 1
+        w = torch.randn((4, enc.out_dim), device="cuda", generator=g) * 0.05
+        b = torch.tensor([0.1, -0.2, 0.3, 0.0], device="cuda")
+        log_std = torch.log(torch.tensor([0.5, 0.25, 1.0, 0.1], device="cuda"))
+        enc.set_head(w, b)
+        mean, act, act2 = (torch.empty((B, 4), device="cuda") for _ in range(3))
+        counter = torch.tensor([7], device="cuda", dtype=torch.int32)
+        seed = 0x1234567811
+        enc.forward_head(obs, head_out=mean, sample=(log_std, act, counter, 3, seed))
+        assert torch.equal(mean, enc.forward_head(obs))                  # the head output itself is untouched by the sampling
+        c10 = torch.tensor([10], device="cuda", dtype=torch.int32)
+        rc = policy.lib().qs_rollout_pre(None, None, 0, C.c_void_p(mean.data_ptr()), C.c_void_p(log_std.data_ptr()), C.c_void_p(act2.data_ptr()), B, C.c_uint64(seed),
+                                         C.c_void_p(c10.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert (act - act2).abs().max().item() <= 2e-6, nbr_encoder
+        assert (act - mean).abs().max().item() > 0.1
+
+
+def test_rollout_samples_gaussian_actions_and_writes_the_trajectory_in_place():
+    """No launch besides the encoder and the step: actions = mean + exp(log_std) * N(0, 1) from the encoder's epilogue with fresh noise
+    per step and per replay; observation rows, rewards and done flags written by the step kernel into their trajectory slots."""
     import numpy as np
     import torch
     from scipy import stats
@@ -104,4 +132,31 @@ def test_glue_kernels_sample_gaussian_actions_and_copy_the_trajectory():
     assert abs(np.corrcoef(acts[:, 0], acts[:, 1])[0, 1]) < 0.05 and abs(np.corrcoef(acts[:-256, 0], acts[256:, 0])[0, 1]) < 0.05
     assert torch.equal(second["obs"][0], first["last_obs"])            # the trajectory rows are the live buffers at that step
     assert torch.isfinite(first["rewards"]).all() and first["dones"].dtype == torch.uint8
+    # an env.step() outside the segment writes the library's own buffers again (the redirections are launch state of the segment's steps)
+    before = second["rewards"].clone()
+    _, rew, done, _ = env.step(second["actions"][0])
+    torch.cuda.synchronize()
+    assert torch.equal(seg.rewards, before) and torch.isfinite(rew).all() and rew.data_ptr() == env.stepper.tensor("reward").data_ptr()
+    env.close()
+
+
+def test_rollout_over_a_handle_with_the_replay_wrapper_keeps_the_copying_glue():
+    """qs_set_obs_target / qs_set_output_target are refused while the device-side replay wrapper is on (it restores observations into
+    the library's buffer and reads its done flags): the segment then copies the outputs with the two glue launches, as before."""
+    import torch
+    from quad_swarm_rl_amd import native, policy, rollout
+    from quad_swarm_rl_amd.env import QuadSwarmVecEnv
+    env = QuadSwarmVecEnv(8, seed=5, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0)
+    env.stepper.replay_enable(0.75)
+    env.reset()
+    with pytest.raises(native.QsError):
+        env.stepper.set_output_target(env.stepper.ptr("rew_info"), None)
+    enc = policy.FusedQuadEncoder(policy.make_reference_encoder(seed=2, nbr_encoder="mean_embed").cuda())
+    seg = rollout.GraphedRollout(env, enc, rollout.GaussianActionHead(sample=True, seed=3), steps=8)
+    assert seg._glue and not seg._in_place
+    first = {k: v.clone() for k, v in seg.run().items()}
+    second = {k: v.clone() for k, v in seg.run().items()}
+    torch.cuda.synchronize()
+    assert torch.equal(second["obs"][0], first["last_obs"]) and torch.isfinite(second["rewards"]).all()
+    assert not torch.equal(first["actions"], second["actions"])
     env.close()
