@@ -672,8 +672,8 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     }
     Ptrs<float> pf = h->pf;   // this launch's pointers (qs_set_obs_target, qs_set_output_target)
     if (h->obs_target) pf.obs = (float *)h->obs_target;
-    if (h->reward_target) pf.reward = (float *)h->reward_target;
-    if (h->done_target) pf.done = (uint8_t *)h->done_target;
+    pf.reward_out = (float *)h->reward_target;   // (the step kernels store these two through the state block's buffer resource unless told otherwise)
+    pf.done_out = (uint8_t *)h->done_target;
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};

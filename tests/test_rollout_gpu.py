@@ -146,7 +146,8 @@ def test_rollout_over_a_handle_with_the_replay_wrapper_keeps_the_copying_glue():
     import torch
     from quad_swarm_rl_amd import native, policy, rollout
     from quad_swarm_rl_amd.env import QuadSwarmVecEnv
-    env = QuadSwarmVecEnv(8, seed=5, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0)
+    env = QuadSwarmVecEnv(8, seed=5, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0,
+                          episode_sums=True)
     env.stepper.replay_enable(0.75)
     env.reset()
     with pytest.raises(native.QsError):
