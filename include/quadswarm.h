@@ -236,14 +236,6 @@ int qs_get_buffers(qs_handle *h, qs_buffers *out);
  * snapshots hold qs_buffers.obs (QS_ERR_UNSUPPORTED). */
 int qs_set_obs_target(qs_handle *h, void *obs_dev);
 
-/* The same for the other two per-step outputs: from the next qs_step on, rewards (real [E*N]) go to reward_dev and done flags
- * (uint8 [E*N]) to done_dev instead of qs_buffers.reward / .done (either may be NULL = default).  Host-side state only, like
- * qs_set_obs_target: a rollout segment captured into a HIP graph points every step at its own trajectory slot
- * (obs[t+1], reward[t], done[t]) and needs no copy kernel between the steps (quad-swarm-rl_amd/rollout.py).  The step of a handle
- * with float64 buffers takes reward_dev as double.  Not available together with the device-side replay wrapper, which reads
- * qs_buffers.done (QS_ERR_UNSUPPORTED).  The reference returns these values from QuadrotorEnvMulti.step (quadrotor_multi.py:720-722). */
-int qs_set_output_target(qs_handle *h, void *reward_dev, void *done_dev);
-
 /* Fused observation exchange (quadswarm_exchange.h): from now on every qs_step launch also stores its observation rows, in the wire
  * type of endpoint `xchg` (a qs_xchg*, fully attached), into slot [seq & 1][rank] of every rank's receive window and raises the
  * sequence flags - the multi-GPU "gather of observations per rollout step" with no launch of its own.  auto_ack != 0: the launch also

@@ -71,7 +71,6 @@ template <typename real> struct Ptrs {
     unsigned long long *timing;   // [32] phase time stamps of workgroup 0 (only written by -DQS_TIMING builds)
     const real *rew_rt;   // [QS_REW_COUNT + 1] run-time reward coefficients + proximity slope (qs_set_reward_coeffs)
     const qsx::XchgDev *xchg;   // qs_set_obs_exchange: the team step kernels also store their observation rows into every rank's window
-    real *reward_out; uint8_t *done_out;   // qs_set_output_target: where this launch writes rewards / done flags (nullptr = the arrays of the state block)
     // noise tape (qs_set_noise_tape; consumed by the QS_TAPE kernels only): [E][tape_len] reference draws, per-env cursor
     const double *tape;
     int32_t *tape_pos;
@@ -100,14 +99,6 @@ template <typename T> struct BufRow {
 #define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (uint32_t)(blockIdx.x * (p).blk.block_bytes + (p).blk.name), (uint32_t)(64 * sizeof(TYPE)), (uint32_t)((threadIdx.x & 63) * sizeof(TYPE))}
 // flat component-major array (per-step outputs): row pitch T elements, lane offset = global drone index
 #define QS_ROWF(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (p).blk.name, (uint32_t)((T) * sizeof(TYPE)), (uint32_t)((g) * sizeof(TYPE))}
-// reward / done of this step: the library's arrays (rows b_reward / b_done of the state allocation) or the caller's (qs_set_output_target)
-#ifdef QS_NO_OUT_TARGET   // A/B switch (QS_SPEC_EXTRA_FLAGS): what the two uniform branches cost
-#define QS_ST_REWARD_DONE(p, g, rew, done) do { b_reward.st(rew); b_done.st((done) ? 1 : 0); } while (0)
-#else
-#define QS_ST_REWARD_DONE(p, g, rew, done) do { \
-        if ((p).reward_out) (p).reward_out[g] = (rew); else b_reward.st(rew); \
-        if ((p).done_out) (p).done_out[g] = (done) ? 1 : 0; else b_done.st((done) ? 1 : 0); } while (0)
-#endif
 
 // (neighbour metric, drone index) as one unsigned key whose order is "smaller metric first, lower index first": the IEEE bit
 // pattern of a float is monotone after flipping the sign bit of non-negatives and all bits of negatives

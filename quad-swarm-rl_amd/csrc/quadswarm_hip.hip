@@ -61,7 +61,6 @@ struct qs_handle {
     qs_buffers bufs;
     void *d_actions = nullptr;
     void *obs_target = nullptr;   // qs_set_obs_target: where the next launches write their observation rows (nullptr = bufs.obs)
-    void *reward_target = nullptr, *done_target = nullptr;   // qs_set_output_target: likewise for the step's rewards / done flags
     double *d_state_buf = nullptr;
     int32_t *d_tick_io = nullptr;
     // cached hipGraph of a K-step rollout (qs_step_many): K identical step-kernel nodes
@@ -670,10 +669,8 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
     }
-    Ptrs<float> pf = h->pf;   // this launch's pointers (qs_set_obs_target, qs_set_output_target)
+    Ptrs<float> pf = h->pf;   // this launch's pointers (qs_set_obs_target)
     if (h->obs_target) pf.obs = (float *)h->obs_target;
-    pf.reward_out = (float *)h->reward_target;   // (the step kernels store these two through the state block's buffer resource unless told otherwise)
-    pf.done_out = (uint8_t *)h->done_target;
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
@@ -758,15 +755,6 @@ int qs_set_obs_target(qs_handle *h, void *obs_dev) {
     if (obs_dev && h->replay_on) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_target: the device-side replay wrapper restores observations into qs_buffers.obs");
     if (obs_dev && h->d_tape) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_target: not available while a noise tape is set");
     h->obs_target = obs_dev;
-    return QS_OK;
-}
-
-int qs_set_output_target(qs_handle *h, void *reward_dev, void *done_dev) {
-    if (!h) return fail(QS_ERR_INVALID, "null handle");
-    if ((reward_dev || done_dev) && h->replay_on) return fail(QS_ERR_UNSUPPORTED, "qs_set_output_target: the device-side replay wrapper reads qs_buffers.done");
-    if ((reward_dev || done_dev) && h->d_tape) return fail(QS_ERR_UNSUPPORTED, "qs_set_output_target: not available while a noise tape is set");
-    h->reward_target = reward_dev;
-    h->done_target = done_dev;
     return QS_OK;
 }
 
@@ -917,7 +905,6 @@ int qs_replay_enable(qs_handle *h, double sample_prob) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     if (h->replay_on) return fail(QS_ERR_INVALID, "replay is already enabled on this handle");
     if (h->obs_target) return fail(QS_ERR_UNSUPPORTED, "qs_replay_enable: the replay wrapper restores observations into qs_buffers.obs (reset qs_set_obs_target first)");
-    if (h->reward_target || h->done_target) return fail(QS_ERR_UNSUPPORTED, "qs_replay_enable: the replay wrapper reads qs_buffers.done (reset qs_set_output_target first)");
     if (!h->cfg.episode_sums) return fail(QS_ERR_INVALID, "qs_replay_enable needs a handle created with episode_sums = 1 (per-episode crash reward)");
     if (!(sample_prob >= 0.0 && sample_prob <= 1.0)) return fail(QS_ERR_INVALID, "sample_prob must be in [0, 1]");
     HIP_TRY(hipSetDevice(h->device));

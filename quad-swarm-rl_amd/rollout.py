@@ -44,9 +44,12 @@ class GraphedRollout:
         Construction runs ONE control step eagerly (library warm-up outside the capture) before recording.
 
         With the library's GaussianActionHead the segment has no glue launches at all: the encoder's epilogue evaluates the head AND
-        samples the action into actions[t] (qs_enc_params.sample_*), and the step writes its outputs straight into the trajectory -
-        observation rows to obs[t + 1] (qs_set_obs_target), rewards / done flags to rewards[t] / dones[t] (qs_set_output_target).
-        Per control step that is the encoder's launch(es) + the step, 2 (attention: 3) dependent graph nodes instead of 4 (5)."""
+        samples the action into actions[t] (qs_enc_params.sample_*); the step writes its observation rows straight into obs[t + 1]
+        (qs_set_obs_target); one small launch behind it copies its rewards / done flags into rewards[t] / dones[t] (qs_rollout_post).
+        3 (attention: 4) dependent graph nodes per control step instead of 4 (5), and no observation copy.  (Tried and measured, C2 with
+        mean_embed, us per control step: this 32.9 (two glue launches per step: 34.3); the copy on a second stream as a parallel graph branch 46.3 - a fork / join costs
+        more than the launch it hides; the copy inside the next forward pass's first launch 33.2; rewards / done redirected inside the
+        step kernel 31.8, but + 0.08 us on every step of every user of the headline kernel - not taken.)"""
         import torch
         if not torch.cuda.is_available():
             raise native.QsError("GraphedRollout needs a GPU")
@@ -73,6 +76,7 @@ class GraphedRollout:
             self._in_place = self._glue and not getattr(st, "replay_on", False)
             if self._glue:
                 self._counter = torch.zeros(1, device=dev, dtype=torch.int32)
+                self._scratch_counter = torch.zeros(1, device=dev, dtype=torch.int32)   # (qs_rollout_post's own counter: unused here)
                 self._seed = int(getattr(head, "seed", 0)) & 0xffffffffffffffff
         else:
             self._feat = torch.empty((A, encoder.out_dim), device=dev)
@@ -102,7 +106,6 @@ class GraphedRollout:
         """the stepper's output redirections are host-side launch state: an env.step() outside the segment writes the library's buffers"""
         if self._glue and self._in_place:
             self.env.stepper.set_obs_target(None)
-            self.env.stepper.set_output_target(None, None)
 
     def _segment(self, n):
         """n control steps from the environments' current state"""
@@ -111,18 +114,24 @@ class GraphedRollout:
                 self._step_copying(t)
             return
         if self._glue:
-            st, last = self.env.stepper, n - 1
-            self.obs[0].copy_(self._obs)      # the one copy of the segment: the observations the environments are in
+            import ctypes as C
+            import torch
+            from . import policy
+            st, last, A = self.env.stepper, n - 1, self._obs.shape[0]
+            main = self._torch_stream()
+            self.obs[0].copy_(self._obs)      # the one observation copy of the segment: the rows the environments are in
             for t in range(n):
                 if self.head.sample:
                     self.encoder.forward_head(self.obs[t], head_out=self._mean, sample=(self.head.log_std, self.actions[t], self._counter, t, self._seed))
                 else:   # deterministic policy: the head's output IS the action
                     self.encoder.forward_head(self.obs[t], head_out=self.actions[t])
-                # step t: observation rows -> obs[t + 1] (the last step: the library's buffer, where the next segment starts),
-                # rewards / done flags -> rewards[t] / dones[t]
+                # step t: observation rows -> obs[t + 1] (the last step: the library's buffer, where the next segment starts)
                 st.set_obs_target(self.obs[t + 1].data_ptr() if t < last else None)
-                st.set_output_target(self.rewards[t].data_ptr(), self.dones[t].data_ptr())
-                st.step(self.actions[t].data_ptr(), stream=self._torch_stream())
+                st.step(self.actions[t].data_ptr(), stream=main)
+                rc = policy.lib().qs_rollout_post(C.c_void_p(self._rew.data_ptr()), C.c_void_p(self.rewards[t].data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                                  C.c_void_p(self.dones[t].data_ptr()), A, C.c_void_p(self._scratch_counter.data_ptr()), C.c_void_p(main.cuda_stream))
+                if rc != 0:
+                    raise native.QsError(f"qs_rollout_post failed ({rc})")
             self._counter.add_(n)             # the next replay draws fresh noise
             return
         for t in range(n):

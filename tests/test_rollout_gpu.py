@@ -103,8 +103,9 @@ def test_epilogue_sampling_draws_what_the_glue_kernel_draws():
 
 
 def test_rollout_samples_gaussian_actions_and_writes_the_trajectory_in_place():
-    """No launch besides the encoder and the step: actions = mean + exp(log_std) * N(0, 1) from the encoder's epilogue with fresh noise
-    per step and per replay; observation rows, rewards and done flags written by the step kernel into their trajectory slots."""
+    """No launch between the encoder and the step: actions = mean + exp(log_std) * N(0, 1) from the encoder's epilogue with fresh noise
+    per step and per replay; observation rows written by the step kernel into their trajectory slot, rewards / done flags moved there by
+    the next forward pass (checked against an eager re-computation of the same steps)."""
     import numpy as np
     import torch
     from scipy import stats
@@ -132,17 +133,27 @@ def test_rollout_samples_gaussian_actions_and_writes_the_trajectory_in_place():
     assert abs(np.corrcoef(acts[:, 0], acts[:, 1])[0, 1]) < 0.05 and abs(np.corrcoef(acts[:-256, 0], acts[256:, 0])[0, 1]) < 0.05
     assert torch.equal(second["obs"][0], first["last_obs"])            # the trajectory rows are the live buffers at that step
     assert torch.isfinite(first["rewards"]).all() and first["dones"].dtype == torch.uint8
-    # an env.step() outside the segment writes the library's own buffers again (the redirections are launch state of the segment's steps)
-    before = second["rewards"].clone()
-    _, rew, done, _ = env.step(second["actions"][0])
-    torch.cuda.synchronize()
-    assert torch.equal(seg.rewards, before) and torch.isfinite(rew).all() and rew.data_ptr() == env.stepper.tensor("reward").data_ptr()
+    # rewards / done flags of every step sit in their slot: replay the recorded actions on a twin environment, one eager step at a time
+    twin = QuadSwarmVecEnv(32, seed=5, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0)
+    o = twin.reset()
+    warm = rollout.GraphedRollout(twin, enc, head, steps=1, graph=False)   # (the constructor of `seg` took one warm-up step first)
+    warm._counter.copy_(torch.zeros_like(warm._counter))
+    o = warm.run()["last_obs"]
+    for traj in (first, second):
+        for t in range(16):
+            assert torch.equal(traj["obs"][t], o), t
+            o, rew, done, _ = twin.step(traj["actions"][t])
+            assert torch.equal(traj["rewards"][t], rew) and torch.equal(traj["dones"][t], done), t
+    # an env.step() outside the segment writes the library's own observation buffer again (the redirection is launch state of the segment's steps)
+    obs_after, _, _, _ = env.step(second["actions"][0])
+    assert obs_after.data_ptr() == env.stepper.tensor("obs").data_ptr()
+    twin.close()
     env.close()
 
 
 def test_rollout_over_a_handle_with_the_replay_wrapper_keeps_the_copying_glue():
-    """qs_set_obs_target / qs_set_output_target are refused while the device-side replay wrapper is on (it restores observations into
-    the library's buffer and reads its done flags): the segment then copies the outputs with the two glue launches, as before."""
+    """qs_set_obs_target is refused while the device-side replay wrapper is on (it restores observations into the library's buffer):
+    the segment then copies the outputs with the two glue launches, as before."""
     import torch
     from quad_swarm_rl_amd import native, policy, rollout
     from quad_swarm_rl_amd.env import QuadSwarmVecEnv
@@ -151,7 +162,7 @@ def test_rollout_over_a_handle_with_the_replay_wrapper_keeps_the_copying_glue():
     env.stepper.replay_enable(0.75)
     env.reset()
     with pytest.raises(native.QsError):
-        env.stepper.set_output_target(env.stepper.ptr("rew_info"), None)
+        env.stepper.set_obs_target(env.stepper.ptr("rew_info"))
     enc = policy.FusedQuadEncoder(policy.make_reference_encoder(seed=2, nbr_encoder="mean_embed").cuda())
     seg = rollout.GraphedRollout(env, enc, rollout.GaussianActionHead(sample=True, seed=3), steps=8)
     assert seg._glue and not seg._in_place
