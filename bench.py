@@ -490,6 +490,21 @@ def main():
             "shaped_episode_sums_and_rew_info": quick(episode_sums=True, write_rew_info=True, extra_bytes=268),
             "downwash_off": quick(kw_over=dict(use_downwash=False)),
         }
+        if not kw.get("use_obstacles"):
+            # what train_local.sh trains on: --quads_mode=mix (scenarios/mix.py: every env draws one of the non-obstacle scenarios per
+            # episode) with the device-side episode sums - the full-scenario kernels; 700 warm-up steps so that the
+            # periodic goal changes of the dynamic scenarios are inside the timed region
+            def mix_line():
+                c2 = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f32", write_rew_info=False, episode_sums=True, **dict(kw, quads_mode="mix"))
+                s2 = native.Stepper(c2, device=local_rank)
+                s2.reset(stream=stream)
+                n = min(max(args.steps, 200), 2000)
+                d, _ = timed(s2, aptr, astride, 700, n)
+                s2.check_errors()
+                rec = {"value": T * 2 * n / d, "kernel_avg_us": 1e6 * d / n, "steps": n, "specialized": bool(s2.specialized)}
+                s2.close()
+                return rec
+            variants["mix_scenarios_shaped"] = mix_line()
 
     # the same workload through the float64 instantiation (the one whose free-running flags are bit-exact against the oracle)
     f64 = None

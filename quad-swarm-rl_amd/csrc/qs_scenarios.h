@@ -280,7 +280,7 @@ __device__ QS_COLD void scenario_reset_full(const Consts<real> &c, const RngKey 
 
 // Does scenario `sc` need the serial (one lane per env, all goals) part of step() at this tick?
 __device__ __forceinline__ bool scen_step_serial_needed(int sc, int period, int tick) {
-    const bool at_period = period > 0 && tick % period == 0 && tick > 0;
+    const bool at_period = period > 0 && tick > 0 && imod_small(tick, period) == 0;
     return sc == QS_SCENARIO_DYNAMIC_FORMATIONS ||
            (at_period && (sc == QS_SCENARIO_SWARM_VS_SWARM || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS || sc == QS_SCENARIO_O_SWAP_GOALS ||
                           sc == QS_SCENARIO_RUN_AWAY));
@@ -392,7 +392,7 @@ template <typename real>
 __device__ QS_COLD void scenario_step_local(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int period, int tick, bool persist,
                                     real goal[3]) {
     if (sc == QS_SCENARIO_DYNAMIC_SAME_GOAL) {           // dynamic_same_goal.py:16-29 (formation size 0: every goal = the centre)
-        if (period > 0 && tick % period == 0 && tick > 0) {
+        if (period > 0 && tick > 0 && imod_small(tick, period) == 0) {
             real box = c.spawn_box, xy[2];
             rng_uniform<real, 2>(key, QS_SITE_SCEN, 40, 0, 0, -box, box, xy);
             real z = M<real>::fmax((real)0.25, rng_uniform1<real>(key, QS_SITE_SCEN, 41, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2);
@@ -440,7 +440,7 @@ __device__ QS_COLD void scenario_step_local(const Consts<real> &c, const RngKey 
             for (int row = 0; row < 3; ++row) goal[row] = om * om * bez[row] + (real)2 * om * sv * bez[3 + row] + sv * sv * bez[6 + row];
         }
     } else if (sc == QS_SCENARIO_O_DYNAMIC_SAME_GOAL) {  // o_dynamic_same_goal.py:17-28
-        if ((period > 0 && tick % period == 0) || tick == 1) {
+        if ((period > 0 && imod_small(tick, period) == 0) || tick == 1) {
             real endp[3] = {x.sr[SR_END], x.sr[SR_END + 1], x.sr[SR_END + 2]}, ng[3];
             for (int it = 0; it < 100000; ++it) {
                 pos_obst_map_1<real>(c, key, x.omap, 5000 + 2 * it, ng);

@@ -348,6 +348,7 @@ class BatchedQuadSwarm:
         if self.use_replay_buffer:
             self.vec.stepper.replay_enable(self.replay_buffer_sample_prob)
         self._keys = qcfg.REW_INFO_KEYS
+        self._warm = False                                # the torch kernels of the episode-end path are loaded by the first reset()
         self._ep_steps = self.vec.cfg.ep_len + 1          # an episode ends by time: tick > ep_len (quadrotor_single.py:353)
         self._steps_to_done = self._ep_steps              # control steps until the earliest possible episode end
         self._truncated = None
@@ -419,6 +420,13 @@ class BatchedQuadSwarm:
     def reset(self, seed=None, options=None):
         obs = self.vec.reset()
         self._steps_to_done = self._ep_steps
+        if not self._warm:   # load the torch kernels of the episode-end path (gather / cast / copy) now: 35 - 80 ms the first time they
+            self._warm = True   # run, which would otherwise land on the first step on which episodes end (tools/episode_end_probe.py)
+            torch, st = self._torch, self.vec.stepper
+            idx = torch.zeros(1, dtype=torch.long, device=st.tensor("ep_sums").device)
+            for name, dim in (("ep_sums", 1), ("ep_stats", 1), ("ep_counters", 1), ("ep_scenario", 0), ("scenario_id", 0)):
+                st.tensor(name).index_select(dim, idx).double().cpu()
+            (idx[:, None] * self.agents_per_env + torch.arange(self.agents_per_env, device=idx.device)[None, :]).reshape(-1)
         return {"obs": obs}, {}
 
     def step(self, actions):
