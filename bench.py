@@ -355,6 +355,8 @@ def main():
     if exchange is not None:   # reset (its rows are exchanged like a step's), then [step -> exchange] x seg as one HIP graph, captured before
         exchange.reset()       # any timed region (the eager steps capture() takes first are untimed)
         seg = min(args.segment, ring, max(args.steps, 2)) & ~1   # (a whole number of segments fits the timed region also at --steps 20)
+        if seg >= 2 and xinfo.get("transport") == "rccl":
+            seg = 0            # torch's collective must not be recorded into a graph (parallel.ObsExchange.capture): eager steps
         if seg >= 2:
             exchange.capture([aptr + t * astride for t in range(seg)])
 

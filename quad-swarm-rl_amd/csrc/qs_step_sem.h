@@ -378,7 +378,7 @@ template <typename real, typename Sync>
 __device__ __forceinline__ void svs_phase(const Consts<real> &c, const Ptrs<real> &p, const RngKey &key, bool active, int N, int E, int e, int i, int tick, int svs_period,
                                           real *env_goals, int *scr, real goal[3], int *s_cur_env, Sync sync) {
     if (c.scenario != QS_SCENARIO_SWARM_VS_SWARM) return;
-    const bool sw = active && svs_period > 0 && tick > 0 && imod_small(tick, svs_period) == 0;
+    const bool sw = active && svs_period > 0 && tick % svs_period == 0 && tick > 0;
     if (__builtin_expect(__ballot(sw) != 0, 0)) {
 #ifndef QS_TAPE
         if (N / 2 >= 3) {   // the wave builds the two formations: lane i makes goal row i (svs_create_formations_wave, qs_device.h)

@@ -320,6 +320,11 @@ class ObsExchange:
         n = len(action_ptrs)
         if n < 2 or n % 2:
             raise ValueError("capture an even number of steps")
+        if self.transport == "rccl" and dist.is_available() and dist.is_initialized():
+            # torch's ProcessGroupNCCL keeps every collective it issues on its watchdog thread's list, also one recorded under stream
+            # capture; the watchdog's later query of that captured event raises hipErrorCapturedEvent and aborts the process
+            # (seen once in five runs of bench.py --force-gather --transport rccl: profiles/r03x_rccl_capture_abort.txt)
+            raise native.QsError("the rccl transport is not captured into a HIP graph: step it eagerly (ObsExchange.step)")
         self.drain()
         while self.k < 2 or self.k & 1:
             self.step(action_ptrs[0])
