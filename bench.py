@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--prewarm", type=int, default=3000, help="steps of a SCRATCH handle of the same configuration run before anything is measured "
+                    "(device clocks / code caches: a 20-step timed region is 160 us long); the measured handle still takes exactly "
+                    "--warmup untimed steps, then --steps timed ones.  0 = off")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS), help="default: c2 at --gpus 1, c4 (512 envs per GPU) at --gpus N>1")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="override the workload's env count per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample length in total (0 = skip)")
@@ -404,6 +407,13 @@ def main():
             devs, host = (float(x) for x in tmax.tolist())
         return devs, host
 
+    if args.prewarm > 0:   # a scratch handle (its own state and noise streams): the measured one is untouched by it
+        s0 = native.Stepper(cfg, device=local_rank)
+        s0.reset(stream=stream)
+        for t in range(args.prewarm):
+            s0.step(aptr + (t % ring) * astride, stream=stream)
+        torch.cuda.synchronize()
+        s0.close()
     if exchange is None:
         st.reset(stream=stream)
     head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None, xchg=use_gather and exchange is not None)
@@ -545,7 +555,7 @@ def main():
                        "exchange": xinfo if (use_gather or secondary) else None,
                        "secondary": secondary,
                        "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and not use_gather else "one launch per control step",
-                       "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info), "variants": variants,
+                       "device_prewarm_steps_on_a_scratch_handle": args.prewarm, "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info), "variants": variants,
                        "c5": dict(c5_record(not args.no_c5_train), closed_loop_without_sample_factory=closed_loop_record(local_rank)) if world == 1 and not args.no_secondary and not args.no_closed_loop
                        else (c5_record(not args.no_c5_train) if world == 1 else None),
                        "overrides": args.set},
