@@ -63,6 +63,18 @@ def pack_rows(src, dst, stream=None):
     return dst
 
 
+def gather_window_handles(blob, world, group=None):
+    """Every rank contributes the export blob of its endpoint - or None when it could not create / export one - and gets the blobs of all
+    ranks in rank order.  A rank that failed still takes part in the collective (raising before it would leave the others waiting), and
+    if ANY blob is missing every rank raises the same QsError, so that all of them take the fallback together."""
+    blobs = [None] * world
+    dist.all_gather_object(blobs, blob, group=group)
+    missing = [r for r, b in enumerate(blobs) if b is None]
+    if missing:
+        raise native.QsError(f"rank(s) {missing} could not create / export their exchange windows")
+    return blobs
+
+
 class PeerExchange:
     """One endpoint of the peer-store exchange (thin wrapper of the qs_xchg_* C ABI)."""
 
@@ -182,11 +194,11 @@ class ObsExchange:
                 blob = self.x.export()
             except Exception as exc:   # noqa: BLE001 - re-raised below, after the collective
                 err = exc
-            blobs = [None] * world
-            dist.all_gather_object(blobs, blob, group=group)
-            missing = [r for r, b in enumerate(blobs) if b is None]
-            if err is None and missing:
-                err = native.QsError(f"rank(s) {missing} could not create / export their exchange windows")
+            blobs = None
+            try:
+                blobs = gather_window_handles(blob, world, group)
+            except native.QsError as exc:
+                err = err or exc
             if err is not None:
                 if self.x is not None:
                     self.x.close()

@@ -87,3 +87,33 @@ def test_shard_range():
     assert [parallel.shard_range(4096, 8, r) for r in (0, 7)] == [(0, 512), (3584, 4096)]
     with pytest.raises(ValueError):
         parallel.shard_range(10, 4, 0)
+
+
+def _handles_worker(rank, world, port, fail_rank, out_dir):
+    sys.path.insert(0, REPO)
+    from quad_swarm_rl_amd import native, parallel
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blob = None if rank == fail_rank else bytes([rank]) * 8
+    try:
+        got = parallel.gather_window_handles(blob, world)
+        res = ["ok"] + [b.hex() for b in got]
+    except native.QsError as exc:
+        res = ["error", str(exc)]
+    dist.barrier()   # nobody hangs in the collective, whoever failed
+    with open(os.path.join(out_dir, f"handles_{rank}.txt"), "w") as f:
+        f.write("\n".join(res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 0, 1])
+def test_window_handle_exchange_fails_on_every_rank_or_on_none(tmp_path, fail_rank):
+    """The multi-GPU exchange maps its peers' windows at start-up (parallel.ObsExchange).  A rank whose endpoint could not be created must
+    neither hang the others in the handle collective nor leave them on a different transport: every rank raises, naming the rank."""
+    port = _free_port()
+    mp.spawn(_handles_worker, args=(2, port, fail_rank, str(tmp_path)), nprocs=2, join=True)
+    res = [open(os.path.join(str(tmp_path), f"handles_{r}.txt")).read().split("\n") for r in range(2)]
+    if fail_rank < 0:
+        assert res[0] == res[1] == ["ok", "00" * 8, "01" * 8]
+    else:
+        assert res[0][0] == res[1][0] == "error" and res[0][1] == res[1][1] and f"[{fail_rank}]" in res[0][1]
