@@ -202,18 +202,24 @@ static bool read_file(const std::string &path, std::string &out) {
     fclose(f);
     return true;
 }
-static const char *const kSpecSources[] = {"qs_spec_kernels.hip", "qs_kernels.h", "qs_device.h", "qs_scenarios.h", "qs_step_kernel.inc", "qs_step_team.inc"};
+static const char *const kSpecSources[] = {"qs_spec_kernels.hip", "qs_kernels.h", "qs_device.h", "qs_scenarios.h", "qs_step_sem.h", "qs_xchg_dev.h", "qs_step_kernel.inc", "qs_step_team.inc"};
 static const char *const kSpecFlags = "--genco --offload-arch=gfx950 -O3 -std=c++17";
 // fp32 objects only (the production precision, specified to 1e-5): reassociation / finite-math simplifications are worth ~8 %
 // of the step; the SLP vectoriser's v_pk_* pairs cost more register shuffling than they save on this code.  The f64 parity
 // instantiation and the generic library keep strict IEEE semantics.
 static const char *const kSpecFlagsF32 = "-ffast-math -fno-slp-vectorize";
+// team objects only (one wave per SIMD, a budget of 256 - 512 VGPRs it does not need for occupancy): the machine scheduler's max-ILP
+// strategy instead of the occupancy-first default.  Same box, us per step: C4 13.58 -> 12.98, C3 8.39 -> 8.17, C2 7.86 -> 7.84, mix 11.95 ->
+// 11.76; the single-wave throughput kernels lose 1 % with it and keep the default (profiles/r03_sched_max_ilp_ab.txt).  Instruction order
+// only: results are bit-identical.  If the compiler fails on an object with it, the object is built without.
+static const char *const kSpecFlagsTeam = "-mllvm -amdgpu-sched-strategy=max-ilp";
 
 // key = hash(header text, kernel sources, flags); false if the sources are not next to the library
 static bool spec_key(const std::string &header, std::string &key) {
     uint64_t h = fnv1a(14695981039346656037ull, header);
     h = fnv1a(h, kSpecFlags);
     h = fnv1a(h, kSpecFlagsF32);
+    h = fnv1a(h, kSpecFlagsTeam);
     if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools/phase_timing.py
     const std::string dir = lib_dir();
     for (const char *src : kSpecSources) {
@@ -256,9 +262,13 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     }
     const char *cc = getenv("HIPCC");
     const std::string src = lib_dir();
-    std::string cmd = std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src +
-                      "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
-    int rc = system(cmd.c_str());
+    auto command = [&](bool team_flags) {
+        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (team_flags ? kSpecFlagsTeam : "") + " " +
+               (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src + "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
+    };
+    const bool team_obj = team > 0;
+    int rc = system(command(team_obj).c_str());
+    if ((rc != 0 || !file_exists(tmp)) && team_obj) { unlink(tmp.c_str()); rc = system(command(false).c_str()); }
     if (rc != 0 || !file_exists(tmp)) { unlink(tmp.c_str()); g_last_error = "specialised kernel build failed, see " + log; return ""; }
     if (rename(tmp.c_str(), out.c_str()) != 0) { unlink(tmp.c_str()); g_last_error = "cannot move code object into the cache"; return ""; }
     return out;
