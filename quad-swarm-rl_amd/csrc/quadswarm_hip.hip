@@ -227,9 +227,11 @@ static bool spec_key(const std::string &header, std::string &key) {
         if (!read_file(dir + "/" + src, text)) return false;
         h = fnv1a(h, text);
     }
-    std::string pub;
-    if (!read_file(dir + "/../../include/quadswarm.h", pub)) return false;
-    h = fnv1a(h, pub);
+    for (const char *pub_name : {"quadswarm.h", "quadswarm_exchange.h"}) {   // the public headers the device code includes
+        std::string pub;
+        if (!read_file(dir + "/../../include/" + pub_name, pub)) return false;
+        h = fnv1a(h, pub);
+    }
     char t[32];
     snprintf(t, sizeof t, "%016llx", (unsigned long long)h);
     key = t;

@@ -194,3 +194,25 @@ def test_weight_packing_follows_the_header_formula():
         assert torch.equal(b[:m_real], lin.bias.detach()) and (b[m_real:] == 0).all()
     half = policy.pack_linear(torch.nn.Linear(512, 256), "cpu", cols=(256, 512))   # the e_mean half of the attention score layer
     assert half[3] == 256
+
+
+def test_spec_cache_key_covers_every_source_the_specialised_object_includes():
+    """The config-specialised code objects are cached under a hash of their sources (spec_key, quadswarm_hip.hip).  A file that
+    qs_spec_kernels.hip pulls in but the key does not hash would let an edit of that file run stale objects (qs_step_sem.h was such a
+    file for part of round 3)."""
+    import re
+    csrc = os.path.join(REPO, "quad-swarm-rl_amd", "csrc")
+    host = open(os.path.join(csrc, "quadswarm_hip.hip")).read()
+    listed = set(re.findall(r'"([^"]+)"', re.search(r"kSpecSources\[\] = \{([^}]*)\}", host).group(1)))
+    seen, todo = set(), ["qs_spec_kernels.hip"]
+    while todo:
+        name = todo.pop()
+        if name in seen:
+            continue
+        seen.add(name)
+        for inc in re.findall(r'#include "([^"]+)"', open(os.path.join(csrc, name)).read()):
+            if os.path.exists(os.path.join(csrc, inc)):
+                todo.append(inc)
+    listed |= {"../../include/" + n for n in re.findall(r'"(quadswarm[a-z_]*\.h)"', host[host.index("static bool spec_key("):host.index("static std::string spec_cache_dir()")])}
+    missing = {n for n in seen if not n.startswith("spec_cache")} - listed
+    assert not missing, f"not part of the spec cache key: {sorted(missing)}"
