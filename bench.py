@@ -16,12 +16,13 @@ per rollout step"): every rank ends each step with the rows of all ranks.  [step
 rank (quad-swarm-rl_amd/parallel.py: ObsExchange); exchange(t) runs on a second stream under step(t+1); the wire format is
 bfloat16 (--wire f32 for bit-exact rows).  --transport fused: the step kernel itself stores its rows into every rank's hipIpc-mapped
 receive window (include/quadswarm_exchange.h; no launch besides the step), peer: the same windows filled by a push kernel on a second
-stream, rccl: RCCL all-gather of the packed rows, auto (default): fused (peer for batches that run the single-wave kernels) if every
+stream, rccl: RCCL all-gather of the packed rows (stepped eagerly: torch's collective is not recorded into a graph), auto (default): fused (peer for batches that run the single-wave kernels) if every
 rank could map its peers' windows and passed the start-up self-check, else rccl; torch: round 2's eager per-step all_gather.  The rate of the
 same shards stepping with no exchange is measured right after and reported as config.secondary (--no-gather makes it the
 headline; --workload / --envs-per-gpu override the shape).
 
-Timing.  W warm-up steps, barrier + synchronize, K timed steps, barrier + synchronize.  `value` / `ms_per_step` come from
+Timing.  (A scratch handle of the same configuration runs --prewarm steps first: device clocks, code caches.)  W warm-up steps, barrier
++ synchronize, K timed steps, barrier + synchronize.  `value` / `ms_per_step` come from
 HIP events recorded on the launch stream right after the opening synchronize and right after the K-th step (for the
 gather variant: after the last gather has drained into the stream), MAX over ranks: at K = 20 the timed region is a few
 hundred microseconds and the closing host synchronize alone is worth several steps, so the host clock would time the
