@@ -2,7 +2,9 @@
 """bench.py - env-steps/s of the HIP QuadSwarm stepper on BASELINE.json's metric.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N>1: started directly, bench.py launches its own N ranks (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+  127.0.0.1 ... bench.py <same arguments>); started by that launcher (WORLD_SIZE set) it is one rank.  --dry-run: the launch path alone
+  (gloo rendezvous + barrier bracket, no GPU; tests/test_bench_launch.py).
 
 A "step" is one control step (= 2 physics sub-steps) of all environments of the workload on synthetic
 U(-1,1)^4 actions that are already resident in HBM.
@@ -254,6 +256,51 @@ def make_exchange(st, world, rank, transport, wire, dist, dev, info):
     return parallel.ObsExchange(st, world, rank, transport="rccl", wire=wire, hold=False)
 
 
+def self_launch(n):
+    """Re-runs this command line as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>` (what the
+    multi-GPU contract prescribes) and returns its exit code.  A free rendezvous port is picked here; 127.0.0.1 because the container's
+    hostname may not resolve.  HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC (RCCL, hipIpc windows)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """--dry-run: everything of the N-rank launch path that needs no GPU - rendezvous (gloo), the barrier bracket of the timed region around
+    K empty steps, MAX over ranks, ONE JSON line from rank 0 - so that the launch contract is testable on a CPU-only machine."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    seen = dist.get_world_size()
+    workload = args.workload or ("c2" if world == 1 else "c4")
+    if rank == 0:
+        print(json.dumps({"metric": "env-steps/s (drones x envs x sim_steps)", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "dry_run": True,
+                          "config": {"workload": workload, "ranks_seen_by_process_group": seen, "backend": "gloo",
+                                     "bracket_host_seconds_max_over_ranks": float(tmax.item()),
+                                     "launch": "self-launched ranks" if os.environ.get("TORCHELASTIC_RUN_ID") else "single process"}}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,18 +331,30 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="headline mode: step the timed region as open-loop rollouts of this many steps per "
                                                           "launch (qs_step_many: state stays in registers between the steps)")
     ap.add_argument("--rollout-steps", type=int, default=64, help="steps per launch of the extra open-loop measurement (0 = skip)")
+    ap.add_argument("--dry-run", action="store_true", help="launch path only: ranks rendezvous over gloo (no GPU needed), take the barriers of the timed "
+                                                           "bracket around K empty steps, rank 0 prints one JSON line with value null")
     args = ap.parse_args()
 
-    import torch
-    from quad_swarm_rl_amd import config as qcfg, native
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started directly: become the launcher of its own N ranks (one process per GPU); the ranks re-enter
+        # main() with RANK / LOCAL_RANK / WORLD_SIZE set and rank 0 prints the one JSON line on the inherited stdout
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
+    if args.dry_run:
+        return dry_run(args, rank, world)
+
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP stepper has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"--gpus {args.gpus}: rank {rank} wants cuda:{local_rank} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     use_gather = (world > 1 and not args.no_gather) or args.force_gather or (world == 1 and args.gather)
@@ -307,6 +366,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    ranks_seen = dist.get_world_size() if dist is not None else 1
 
     import ast
     workload = args.workload or ("c2" if world == 1 else "c4")
@@ -547,7 +607,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}: {N} drones x {E} envs per GPU ({world * E} envs in total), {kw.get('quads_mode', 'static_same_goal')}, "
                                    f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
-                       "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N,
+                       "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N, "ranks_seen_by_process_group": ranks_seen,
                        "timing": "HIP events on the launch stream inside the barrier+synchronize bracket of the K timed steps, max over ranks",
                        "host_clock": {"ms_per_step": 1e3 * head_host / args.steps, "value": world * T * 2 * args.steps / head_host,
                                       "note": "perf_counter over the same K steps incl. the closing barrier + synchronize"},
