@@ -1,0 +1,62 @@
+#!/bin/bash
+# One entry point for the GPU box (through gpurun): tools/gpu.sh <tag> <task> [task ...]
+#   suite            whole `-m gpu` test suite + smoke                      -> gpurun_out/<tag>_pytest.txt
+#   quick            the parity / facade / exchange tests only (fast gate)   -> gpurun_out/<tag>_pytest_quick.txt
+#   bench            default bench line + the driver's --steps 20 line       -> gpurun_out/<tag>_bench_c2_{default,steps20}.json
+#   lines            bench lines of c2 / c3 / c4 and the three 2^20-drone shapes (no extras) -> gpurun_out/<tag>_bench_lines.txt
+#   kstats           rocprofv3 --kernel-trace --stats of c2 / c3 / c4         -> gpurun_out/kt_<tag>_<wl>_stats.txt
+#   calib            FETCH_SIZE / WRITE_SIZE against known byte counts        -> gpurun_out/pmc_calib_<tag>.{txt,json}
+#   pmc              PMC passes: c2, c3, c4 and their 2^20-drone shapes        -> gpurun_out/pmc_<tag>_*_{summary.txt,traffic.json}
+#   pmc:<wl>[:E]     one PMC pass set (e.g. pmc:c2:131072)
+#   wg:<wl>          per-workgroup timing probe (tools/wg_times.py)           -> gpurun_out/<tag>_wg_<wl>.txt
+#   run:<script.py>  python <script.py>                                       -> gpurun_out/<tag>_<script>.txt
+tag=$1; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$PWD}
+BIG="c2:131072 c3:131072 c4:32768"
+kt() { # rocprofv3 kernel stats of one workload
+  wl=$1
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rocprof_kt_${tag}_$wl -o k -- python $R/bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --prewarm 0 > $R/gpurun_out/kt_${tag}_$wl.json 2> $R/gpurun_out/kt_${tag}_$wl.err )
+  db=$(ls /tmp/rocprof_kt_${tag}_$wl/*.db /tmp/rocprof_kt_${tag}_$wl/*/*.db 2>/dev/null | head -1)
+  [ -n "$db" ] && python $R/tools/rocprof_summary.py $db "rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants" > $R/gpurun_out/kt_${tag}_${wl}_stats.txt
+  head -4 $R/gpurun_out/kt_${tag}_${wl}_stats.txt
+}
+for task in "$@"; do
+  echo "== $task"
+  case $task in
+    suite)
+      ( timeout 1700 python -m pytest tests -m gpu -q --maxfail=20 --timeout=900 -p no:cacheprovider 2>&1 | tail -40 ) > gpurun_out/${tag}_pytest.txt
+      tail -4 gpurun_out/${tag}_pytest.txt
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ;;
+    quick)
+      ( timeout 900 python -m pytest tests/test_hip_parity.py tests/test_fp32_parity_gpu.py tests/test_facade_gpu.py tests/test_exchange_gpu.py tests/test_rollout_gpu.py -m gpu -q -x --timeout=600 -p no:cacheprovider 2>&1 | tail -15 ) > gpurun_out/${tag}_pytest_quick.txt
+      tail -3 gpurun_out/${tag}_pytest_quick.txt ;;
+    bench)
+      timeout 600 python bench.py > gpurun_out/${tag}_bench_c2_default.json 2> gpurun_out/${tag}_bench_c2_default.err; tail -c 700 gpurun_out/${tag}_bench_c2_default.json
+      timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_c2_steps20.json 2>> gpurun_out/${tag}_err.txt ;;
+    lines)
+      : > gpurun_out/${tag}_bench_lines.txt
+      for wl in c2 c3 c4; do timeout 300 python bench.py --workload $wl --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants >> gpurun_out/${tag}_bench_lines.txt 2>> gpurun_out/${tag}_err.txt; done
+      for we in $BIG; do timeout 300 python bench.py --workload ${we%%:*} --envs-per-gpu ${we##*:} --steps 400 --warmup 50 --prewarm 200 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants >> gpurun_out/${tag}_bench_lines.txt 2>> gpurun_out/${tag}_err.txt; done
+      python - <<PY
+import json
+for l in open("gpurun_out/${tag}_bench_lines.txt"):
+    if l.startswith("{"):
+        d = json.loads(l); r = d["roofline"]
+        print(d["config"]["workload"][:40], "| us/step %.3f | frac %.4f | traffic %s" % (1e3 * d["ms_per_step"], r["frac"], r["traffic"]))
+PY
+      ;;
+    kstats) for wl in c2 c3 c4; do kt $wl; done ;;
+    calib) bash tools/pmc_calib.sh $tag | tail -12 ;;
+    pmc)
+      for wl in c2 c3 c4; do bash tools/pmc.sh ${tag}_$wl $wl | tail -1; done
+      for we in $BIG; do bash tools/pmc.sh ${tag}_${we%%:*}_E${we##*:} ${we%%:*} --envs-per-gpu ${we##*:} | tail -1; done ;;
+    pmc:*)
+      IFS=: read -r _ wl E <<< "$task"
+      if [ -n "$E" ]; then bash tools/pmc.sh ${tag}_${wl}_E$E $wl --envs-per-gpu $E | tail -1; else bash tools/pmc.sh ${tag}_$wl $wl | tail -1; fi ;;
+    wg:*) wl=${task#wg:}; timeout 600 python tools/wg_times.py --workload $wl > gpurun_out/${tag}_wg_$wl.txt 2>&1; tail -12 gpurun_out/${tag}_wg_$wl.txt ;;
+    run:*) sc=${task#run:}; timeout 900 python $sc > gpurun_out/${tag}_$(basename $sc .py).txt 2>&1; tail -25 gpurun_out/${tag}_$(basename $sc .py).txt ;;
+    *) echo "unknown task $task" ;;
+  esac
+done

@@ -26,7 +26,10 @@ for k, cs in acc.items():
     for c, v in sorted(cs.items()):
         out.append(f"  {c:24s} launches={len(v):4d} mean={sum(v)/len(v):16.1f}")
     if 'FETCH_SIZE' in cs and 'WRITE_SIZE' in cs:
-        traffic[k] = {"fetch_bytes": 1024 * sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE']), "write_bytes": 1024 * sum(cs['WRITE_SIZE']) / len(cs['WRITE_SIZE'])}
+        # calibration (tools/pmc_calib.sh, profiles/r04_pmc_calibration.txt): on gfx950 FETCH_SIZE counts exactly 1/2 of the bytes read, for the
+        # stepper's 4-byte-per-lane buffer_load rows as for 16-byte streams; WRITE_SIZE is exact (1.000x, plain and nt stores)
+        raw = 1024 * sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE'])
+        traffic[k] = {"fetch_bytes": 2.0 * raw, "fetch_counter_bytes": raw, "fetch_correction": 2.0, "write_bytes": 1024 * sum(cs['WRITE_SIZE']) / len(cs['WRITE_SIZE'])}
 open("$R/gpurun_out/pmc_${tag}_summary.txt", "w").write("\n".join(out) + "\n")
 json.dump(traffic, open("$R/gpurun_out/pmc_${tag}_traffic.json", "w"), indent=1)
 print("\n".join(out)); print(json.dumps(traffic))

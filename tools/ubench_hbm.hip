@@ -3,6 +3,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/ubench_hbm tools/ubench_hbm.hip ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -92,7 +93,67 @@ __global__ void __launch_bounds__(64) k_stepper_like(const float *src, float *ds
     for (int k = (int)lane; k < 54 * 64 / 4; k += 64) obs[w * (54 * 64 / 4) + k] = v;
 }
 
-int main() {
+// ---- counter calibration (`ubench_hbm calib`, run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): kernels that move a KNOWN byte count
+// with the stepper's own access pattern - one wave per block, every instruction one 256-byte row (4 B per lane) of the wave's contiguous
+// block through a buffer resource, exactly what BufRow::ld / st emit - next to 16-byte-per-lane streams (the guide's calibrated case:
+// FETCH_SIZE = 1/2 of the bytes).  Working sets > 512 MB, so nothing is served from the L2 / Infinity Cache of a previous launch. ----
+template <int RC>
+__global__ void __launch_bounds__(64) k_calib_read4(const float *src, float *sink, uint32_t bytes) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, bytes, 0x00020000);
+    const uint32_t blk = blockIdx.x * (uint32_t)(RC * 256), lane = threadIdx.x * 4;
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < RC; ++c) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, lane, blk + (uint32_t)c * 256, 0));
+    if (acc == 123.456f) *sink = acc;
+}
+template <int WC>
+__global__ void __launch_bounds__(64) k_calib_write4(float *dst, uint32_t bytes) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)dst, 0, bytes, 0x00020000);
+    const uint32_t blk = blockIdx.x * (uint32_t)(WC * 256), lane = threadIdx.x * 4;
+#pragma unroll
+    for (int c = 0; c < WC; ++c) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)(blockIdx.x + c), r, lane, blk + (uint32_t)c * 256, 0);
+}
+// the observation rows' store: 16 B per lane, non-temporal, one contiguous 54 x 64 x 4-byte block per wave
+__global__ void __launch_bounds__(64) k_calib_write16nt(float4 *dst) {
+    vf4 v = {1.f, 2.f, 3.f, (float)blockIdx.x};
+    for (int k = threadIdx.x; k < 54 * 64 / 4; k += 64) __builtin_nontemporal_store(v, (vf4 *)dst + (size_t)blockIdx.x * (54 * 64 / 4) + k);
+}
+__global__ void __launch_bounds__(256) k_calib_read16(const float4 *src_, float4 *sink, size_t n4) {
+    const vf4 *src = (const vf4 *)src_;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    vf4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) acc += src[i];
+    if (acc.x == 123.456f) *(vf4 *)sink = acc;
+}
+__global__ void __launch_bounds__(256) k_calib_write16(float4 *dst_, size_t n4) {
+    vf4 *dst = (vf4 *)dst_;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const vf4 v = {1.f, 2.f, 3.f, 4.f};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = v;
+}
+static int calib() {
+    const size_t T = 1u << 22, waves = T / 64;                       // 2^22 "drones" = 65536 waves
+    const size_t rbytes = (size_t)47 * T * 4, wbytes = (size_t)54 * T * 4;   // 47 state rows read / 54 rows written (and the 54-column obs block)
+    float *a, *b; float4 *o;
+    CK(hipMalloc(&a, rbytes)); CK(hipMalloc(&b, wbytes)); CK(hipMalloc(&o, wbytes));
+    CK(hipMemset(a, 1, rbytes)); CK(hipMemset(b, 0, wbytes)); CK(hipMemset(o, 0, wbytes));
+    printf("# known bytes per launch: k_calib_read4<47> %zu | k_calib_read4<8> %zu | k_calib_write4<54> %zu | k_calib_write4<8> %zu | k_calib_write16nt %zu | k_calib_read16 %zu | k_calib_write16 %zu\n",
+           rbytes, (size_t)8 * T * 4, wbytes, (size_t)8 * T * 4, wbytes, rbytes, wbytes);
+    for (int rep = 0; rep < 4; ++rep) {
+        k_calib_read4<47><<<waves, 64>>>(a, b, (uint32_t)rbytes);
+        k_calib_read4<8><<<waves, 64>>>(a, b, (uint32_t)rbytes);    // a short row run per wave (8 rows = 2 KB): partial use of the prefetched lines?
+        k_calib_write4<54><<<waves, 64>>>(b, (uint32_t)wbytes);
+        k_calib_write4<8><<<waves, 64>>>(b, (uint32_t)wbytes);
+        k_calib_write16nt<<<waves, 64>>>(o);
+        k_calib_read16<<<2048, 256>>>((const float4 *)a, o, rbytes / 16);
+        k_calib_write16<<<2048, 256>>>(o, wbytes / 16);
+        CK(hipDeviceSynchronize());
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "calib")) return calib();
     const size_t bytes = 1ull << 30;   // 1 GiB buffers: past the 256 MiB Infinity Cache
     float4 *a, *b;
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, 4 * bytes / 4 + bytes));
