@@ -247,6 +247,20 @@ def make_exchange(st, world, rank, transport, wire, dist, dev, info):
                 ok, why = False, f"{type(exc).__name__}: {exc}"
             ok = all_agree(ok)
         info["peer_self_check"] = "passed on every rank" if ok else ("failed" + (f" here: {why}" if why else " on another rank"))
+        if ok:   # ... and through the real producer of the rows (fused: the step kernels' epilogue is not what self_check exercises): the rows of
+            #      an exchanged reset + two steps against an RCCL gather of the same float32 rows, on every rank
+            try:
+                ex.reset()
+                ok, why = ex.verify()
+                for t in range(2):
+                    if ok:
+                        ex.step(info["_actions_ptr"])
+                        torch.cuda.synchronize()
+                        ok, why = ex.verify()
+            except Exception as exc:   # noqa: BLE001
+                ok, why = False, f"{type(exc).__name__}: {exc}"
+            ok = all_agree(ok)
+            info["verified_against_rccl_gather_before"] = "equal on every rank" if ok else ("differs" + (f" here: {why}" if why else " on another rank"))
         if ok:
             info["transport"] = kind
             return ex
@@ -320,7 +334,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
     ap.add_argument("--no-overlap", action="store_true", help="--transport torch: gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--transport", default="auto", choices=["auto", "fused", "peer", "rccl", "torch"], help="observation exchange (see the module docstring)")
-    ap.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="wire format of the exchanged rows")
+    ap.add_argument("--wire", default="bf16", choices=["q8", "bf16", "f32"], help="wire format of the exchanged rows (q8: bf16 self / SDF columns + 8-bit "
+                                                                                  "fixed-point neighbour block, 72 bytes per C4 row: include/quadswarm_exchange.h)")
     ap.add_argument("--segment", type=int, default=64, help="control steps per captured [step -> exchange] graph (0 = eager launches)")
     ap.add_argument("--no-variants", action="store_true", help="skip config.variants (shaped / rew_info / downwash-off / seeds 1, 2 runs of the same workload)")
     ap.add_argument("--no-c5-train", action="store_true", help="where sample_factory imports: do not run the C5 training (tools/train_c5.py)")
@@ -388,7 +403,7 @@ def main():
     actions = (torch.rand((ring, T, 4), device=dev, generator=gen, dtype=torch.float32) * 2.0 - 1.0).contiguous()
     aptr, astride = actions.data_ptr(), T * 4 * 4
     obs = st.tensor("obs")
-    gather_obj, exchange, xinfo = None, None, {"requested": args.transport, "wire": args.wire}
+    gather_obj, exchange, xinfo = None, None, {"requested": args.transport, "wire": args.wire, "_actions_ptr": aptr}
     if dist is not None and (use_gather or not args.no_secondary):
         from quad_swarm_rl_amd import parallel
         if args.transport == "torch":   # round 2's transport: eager torch.distributed all_gather of the float32 rows, per step
@@ -396,6 +411,7 @@ def main():
             xinfo["transport"] = "torch"
         else:
             exchange = make_exchange(st, world, rank, args.transport, args.wire, dist, dev, xinfo)
+    xinfo.pop("_actions_ptr", None)
 
     def run(stepper, base_ptr, stride, k, offset=0, gather=None):
         if args.graph > 0 and gather is None:
@@ -480,7 +496,19 @@ def main():
     head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None, xchg=use_gather and exchange is not None)
     st.check_errors()
     if exchange is not None:
-        wire_b = 2 if args.wire == "bf16" else 4
+        wire_b = exchange.x.row_bytes / D
+        # what the wire costs on a real node: every rank sends its T rows to each of the world-1 peers over that peer's own xGMI link
+        link_bytes = T * exchange.x.row_bytes
+        xinfo.update(row_bytes=exchange.x.row_bytes, bytes_per_link_per_step=link_bytes,
+                     predicted_link_us_per_step={"at_77_GB_per_s_per_direction": 1e6 * link_bytes / 77e9, "at_100_GB_per_s": 1e6 * link_bytes / 100e9,
+                                                 "note": "per-link time of one step's rows (point-to-point, all 7 links concurrently); the 8-GPU line is link-bound "
+                                                         "when this exceeds the step time printed as secondary.ms_per_step"})
+        try:   # the rows of the LAST timed step against an RCCL gather of the same rows (after the timed region: nothing overwrites the slot)
+            torch.cuda.synchronize()
+            v_ok, v_why = exchange.verify()
+            xinfo["verified_against_rccl_gather_after"] = "equal" if v_ok else f"differs: {v_why}"
+        except Exception as exc:   # noqa: BLE001
+            xinfo["verified_against_rccl_gather_after"] = f"not run: {type(exc).__name__}: {exc}"
         gather_desc = (f"{xinfo.get('transport')} transport, {args.wire} wire: every rank receives the rows of all ranks after each step; "
                        + (f"[step -> exchange] x {seg} per captured HIP graph" if seg >= 2 else "eager launches") + ", exchange(t) on a second stream under step(t+1)")
         xinfo["status"] = exchange.status()
@@ -612,7 +640,7 @@ def main():
                        "host_clock": {"ms_per_step": 1e3 * head_host / args.steps, "value": world * T * 2 * args.steps / head_host,
                                       "note": "perf_counter over the same K steps incl. the closing barrier + synchronize"},
                        "obs_gather": gather_desc if use_gather else ("none: env shards are independent, no data-path collective (--no-gather)" if world > 1 else "none"),
-                       "gather_bytes_per_gpu_per_step": (world - 1) * T * D * wire_b if use_gather else 0,
+                       "gather_bytes_per_gpu_per_step": int((world - 1) * T * D * wire_b) if use_gather else 0,
                        "exchange": xinfo if (use_gather or secondary) else None,
                        "secondary": secondary,
                        "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and not use_gather else "one launch per control step",

@@ -40,7 +40,19 @@ extern "C" {
 #define QS_XCHG_EXPORT_BYTES (2 * QS_XCHG_HANDLE_BYTES + 16)   /* data window handle, flag window handle, pid + device */
 #define QS_XCHG_TIMEOUT_MS 2000
 
-enum { QS_WIRE_F32 = 0, QS_WIRE_BF16 = 1 };
+enum { QS_WIRE_F32 = 0, QS_WIRE_BF16 = 1, QS_WIRE_Q8 = 2 };
+/* QS_WIRE_Q8 - the narrow row (with the bf16 row of 108 bytes the 8-GPU line is link-bound at 3.8 - 4.8x one GPU; >= 6x
+ * needs <= ~80 bytes per row).  The neighbour block of an observation row - columns [q0, q1), 6 per visible neighbour: relative
+ * position clipped to +-clip[0..2] and relative velocity clipped to +-clip[3..5] by the environment itself
+ * (gym_art/quadrotor_multi/quadrotor_single.py:294-295, quadrotor_multi.py:233-245) - travels as 8-bit fixed point
+ *     q = clamp(rint(x * (127 / clip[(col - q0) % 6])), -127, 127)          (round half to even; |error| <= clip / 254)
+ * and every other column (self observation, obstacle SDF cells), in column order, as bfloat16 round-to-nearest-even.  Wire row =
+ * [bf16 x c16][int8 x n8], each section zero-padded to a multiple of 4 bytes: C2 / C4 (54 columns, 36 of them neighbour columns)
+ * 72 bytes instead of 108 (bf16) / 216 (f32); C3 (40 columns, 12 neighbour columns) 68 bytes.  With clip = 10 m / 6 m/s the
+ * quantisation step is 0.079 m / 0.047 m/s (error <= 0.039 m / 0.024 m/s). */
+typedef struct qs_wire_q8 { int32_t q0, q1; float clip[6]; } qs_wire_q8;
+/* bytes of one row of `cols` columns on the wire (layout: QS_WIRE_Q8 only, may be NULL otherwise) */
+int64_t qs_wire_row_bytes(int32_t cols, int wire, const qs_wire_q8 *layout);
 /* bits of the status word (qs_xchg_status) */
 enum { QS_XCHG_ERR_ACK_TIMEOUT = 1, QS_XCHG_ERR_ARRIVE_TIMEOUT = 2 };
 
@@ -51,6 +63,8 @@ typedef struct qs_xchg qs_xchg;
  * staging buffers [rows][cols] the stepper can write its observations to (qs_set_obs_target, quadswarm.h) so that the push of
  * step t reads a buffer step t+1 does not touch. */
 int qs_xchg_create(int device, int world, int rank, int64_t rows, int32_t cols, int wire, qs_xchg **out);
+/* the same with the QS_WIRE_Q8 wire: the receive window holds [2 slots][world][rows][qs_wire_row_bytes] */
+int qs_xchg_create_q8(int device, int world, int rank, int64_t rows, int32_t cols, const qs_wire_q8 *layout, qs_xchg **out);
 int qs_xchg_destroy(qs_xchg *x);
 
 /* Export this endpoint's windows for the other processes: QS_XCHG_EXPORT_BYTES opaque bytes (two hipIpcMemHandle_t + owner
@@ -92,6 +106,10 @@ int qs_xchg_status(qs_xchg *x, int64_t out[4]);
 /* Plain converter on `stream`: n float32 elements -> wire type (the packing step of the RCCL transport, which all-gathers the
  * packed rows with ncclAllGather; also what the tests compare the peer-store path against). */
 int qs_obs_pack(const void *src_f32, void *dst, int64_t n, int wire, void *stream);
+/* the row-structured converters: rows x cols float32 -> wire rows (any wire; layout for QS_WIRE_Q8), and back to float32 (what a
+ * consumer of gathered QS_WIRE_Q8 / bf16 rows calls before a float32 policy; dequantisation q * clip / 127) */
+int qs_obs_pack_rows(const void *src_f32, void *dst, int64_t rows, int32_t cols, int wire, const qs_wire_q8 *layout, void *stream);
+int qs_obs_unpack_rows(const void *src_wire, void *dst_f32, int64_t rows, int32_t cols, int wire, const qs_wire_q8 *layout, void *stream);
 
 const char *qs_xchg_last_error(void);
 

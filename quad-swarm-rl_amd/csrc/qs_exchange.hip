@@ -70,6 +70,30 @@ __device__ __forceinline__ void copy_range(const float *__restrict__ src, char *
     }
 }
 
+// QS_WIRE_Q8: this workgroup's share of `rows` float32 rows [rows][q.D] -> wire rows (q.row_words 4-byte words each), 16 bytes per store
+// where source share and destination are 16-byte aligned (always, for the row counts of whole wavefront blocks)
+__device__ __forceinline__ void copy_rows_q8(const float *__restrict__ src, char *__restrict__ dst, long long rows, const Q8Dev &q, int part, int parts) {
+    const long long words = rows * q.row_words;
+    if ((((size_t)dst) & 15) == 0 && (words & 3) == 0) {
+        const long long nvec = words >> 2, per = (nvec + parts - 1) / parts, v0 = per * part, v1 = (v0 + per < nvec) ? v0 + per : nvec;
+        for (long long v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
+            unsigned int o[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long w = 4 * v + u, r = w / q.row_words;
+                o[u] = q8_row_word(src + r * q.D, q, (int)(w - r * q.row_words));
+            }
+            st16_wt(dst + 16 * v, u32x4_t{o[0], o[1], o[2], o[3]});
+        }
+    } else {
+        const long long per = (words + parts - 1) / parts, w0 = per * part, w1 = (w0 + per < words) ? w0 + per : words;
+        for (long long w = w0 + threadIdx.x; w < w1; w += blockDim.x) {
+            const long long r = w / q.row_words;
+            st4_wt(dst + 4 * w, q8_row_word(src + r * q.D, q, (int)(w - r * q.row_words)));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) qs_xchg_push_kernel(PushArgs a) {
     const int d = blockIdx.y;                                         // destination rank
     const unsigned long long seq = a.loc->push_seq + 1;               // advanced by the very last workgroup of this launch only
@@ -81,9 +105,14 @@ __global__ void __launch_bounds__(256) qs_xchg_push_kernel(PushArgs a) {
     }
     __syncthreads();
     const float *src = a.src ? a.src : a.staging[slot];
-    const size_t wsz = a.wire == QS_WIRE_BF16 ? 2 : 4;
-    char *dst = a.data_win[d] + (size_t)slot * a.slot_bytes + (size_t)a.rank * a.n * wsz;
-    copy_range(src, dst, a.n, a.wire, blockIdx.x, gridDim.x);
+    if (a.wire == QS_WIRE_Q8) {
+        char *dst = a.data_win[d] + (size_t)slot * a.slot_bytes + (size_t)a.rank * (size_t)a.rows * (size_t)a.q8.row_words * 4;
+        copy_rows_q8(src, dst, a.rows, a.q8, blockIdx.x, gridDim.x);
+    } else {
+        const size_t wsz = a.wire == QS_WIRE_BF16 ? 2 : 4;
+        char *dst = a.data_win[d] + (size_t)slot * a.slot_bytes + (size_t)a.rank * a.n * wsz;
+        copy_range(src, dst, a.n, a.wire, blockIdx.x, gridDim.x);
+    }
     wt_drain();                                                       // this thread's (write-through) rows have reached their window ...
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -118,6 +147,29 @@ __global__ void __launch_bounds__(64) qs_xchg_release_kernel(ReleaseArgs a) {
 }
 
 __global__ void __launch_bounds__(256) qs_obs_pack_kernel(const float *src, char *dst, long long n, int wire) { copy_range(src, dst, n, wire, blockIdx.x, gridDim.x); wt_drain(); }
+__global__ void __launch_bounds__(256) qs_obs_pack_q8_kernel(const float *src, char *dst, long long rows, Q8Dev q) { copy_rows_q8(src, dst, rows, q, blockIdx.x, gridDim.x); wt_drain(); }
+// wire rows -> float32 rows (one thread per element)
+__global__ void __launch_bounds__(256) qs_obs_unpack_kernel(const char *src, float *dst, long long rows, int cols, int wire, Q8Dev q) {
+    const long long n = rows * cols;
+    for (long long k = blockIdx.x * (long long)blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+        float v;
+        if (wire == QS_WIRE_F32) v = ((const float *)src)[k];
+        else if (wire == QS_WIRE_BF16) v = __uint_as_float((unsigned int)((const unsigned short *)src)[k] << 16);
+        else {
+            const long long r = k / cols;
+            const int c = (int)(k - r * cols);
+            const char *row = src + r * (long long)q.row_words * 4;
+            if (c >= q.q0 && c < q.q1) {
+                const int mm = c - q.q0;
+                v = (float)((const signed char *)(row + 4 * q.w16))[mm] / q.scale[mm % 6];
+            } else {
+                const int b = c < q.q0 ? c : c - (q.q1 - q.q0);
+                v = __uint_as_float((unsigned int)((const unsigned short *)row)[b] << 16);
+            }
+        }
+        dst[k] = v;
+    }
+}
 
 struct Blob { hipIpcMemHandle_t data, flags; int32_t pid, device; int32_t pad[2]; };
 static_assert(sizeof(hipIpcMemHandle_t) == QS_XCHG_HANDLE_BYTES, "handle size");
@@ -147,14 +199,46 @@ struct qs_xchg {
     bool opened[QS_XCHG_MAX_RANKS] = {};   // mapped with hipIpcOpenMemHandle (to be closed)
     XchgDev *desc = nullptr;               // device copy of what a step kernel needs for the fused push (qs_xchg_fused_desc)
     unsigned long long timeout_ticks = 0;
+    Q8Dev q8 = {};                         // wire == QS_WIRE_Q8
+    size_t rank_bytes = 0;                 // bytes of one rank's rows in a window slot
 };
+
+// device-side form of a QS_WIRE_Q8 layout; false if the layout is not one
+static bool q8_dev(int32_t cols, const qs_wire_q8 *l, Q8Dev &q) {
+    if (!l || cols < 1 || l->q0 < 0 || l->q1 < l->q0 || l->q1 > cols) return false;
+    memset(&q, 0, sizeof q);
+    q.D = cols; q.q0 = l->q0; q.q1 = l->q1;
+    const int c16 = cols - (l->q1 - l->q0), n8 = l->q1 - l->q0;
+    q.w16 = (c16 + 1) / 2;
+    q.row_words = q.w16 + (n8 + 3) / 4;
+    for (int a = 0; a < 6; ++a) { if (!(l->clip[a] > 0.0f)) return false; q.scale[a] = (float)(127.0 / (double)l->clip[a]); }
+    return true;
+}
 
 extern "C" {
 
 const char *qs_xchg_last_error(void) { return g_err.c_str(); }
 
+int64_t qs_wire_row_bytes(int32_t cols, int wire, const qs_wire_q8 *layout) {
+    if (wire == QS_WIRE_F32) return 4LL * cols;
+    if (wire == QS_WIRE_BF16) return 2LL * cols;
+    Q8Dev q;
+    if (wire != QS_WIRE_Q8 || !q8_dev(cols, layout, q)) return -1;
+    return 4LL * q.row_words;
+}
+
+static int xchg_create(int device, int world, int rank, int64_t rows, int32_t cols, int wire, const qs_wire_q8 *layout, qs_xchg **out);
 int qs_xchg_create(int device, int world, int rank, int64_t rows, int32_t cols, int wire, qs_xchg **out) {
-    if (!out || world < 1 || world > QS_XCHG_MAX_RANKS || rank < 0 || rank >= world || rows < 1 || cols < 1 || (wire != QS_WIRE_F32 && wire != QS_WIRE_BF16))
+    if (wire != QS_WIRE_F32 && wire != QS_WIRE_BF16) return fail(-1, "qs_xchg_create: bad argument (QS_WIRE_Q8: qs_xchg_create_q8)");
+    return xchg_create(device, world, rank, rows, cols, wire, nullptr, out);
+}
+int qs_xchg_create_q8(int device, int world, int rank, int64_t rows, int32_t cols, const qs_wire_q8 *layout, qs_xchg **out) {
+    Q8Dev q;
+    if (!q8_dev(cols, layout, q)) return fail(-1, "qs_xchg_create_q8: bad layout");
+    return xchg_create(device, world, rank, rows, cols, QS_WIRE_Q8, layout, out);
+}
+static int xchg_create(int device, int world, int rank, int64_t rows, int32_t cols, int wire, const qs_wire_q8 *layout, qs_xchg **out) {
+    if (!out || world < 1 || world > QS_XCHG_MAX_RANKS || rank < 0 || rank >= world || rows < 1 || cols < 1)
         return fail(-1, "qs_xchg_create: bad argument");
     int ndev = 0;
     XTRY(hipGetDeviceCount(&ndev));
@@ -162,8 +246,9 @@ int qs_xchg_create(int device, int world, int rank, int64_t rows, int32_t cols, 
     XTRY(hipSetDevice(device));
     qs_xchg *x = new qs_xchg();
     x->device = device; x->world = world; x->rank = rank; x->wire = wire; x->rows = rows; x->cols = cols; x->n = (long long)rows * cols;
-    const size_t wsz = wire == QS_WIRE_BF16 ? 2 : 4;
-    x->slot_bytes = ((size_t)world * x->n * wsz + 255) & ~(size_t)255;
+    if (wire == QS_WIRE_Q8) q8_dev(cols, layout, x->q8);
+    x->rank_bytes = (size_t)rows * (size_t)qs_wire_row_bytes(cols, wire, layout);
+    x->slot_bytes = ((size_t)world * x->rank_bytes + 255) & ~(size_t)255;
     x->data_bytes = 2 * x->slot_bytes;
     hipError_t e = hipMalloc((void **)&x->data, x->data_bytes);
     // flags: fine-grained (uncached) device memory when the runtime offers it - remote stores to them are polled, not read once
@@ -242,7 +327,7 @@ int qs_xchg_attach(qs_xchg *x, const void *blobs) {
 
 int qs_xchg_attach_local(qs_xchg *x, int peer_rank, qs_xchg *peer) {
     if (!x || !peer || peer_rank < 0 || peer_rank >= x->world || peer_rank == x->rank) return fail(-1, "qs_xchg_attach_local: bad argument");
-    if (peer->world != x->world || peer->n != x->n || peer->wire != x->wire || peer->rank != peer_rank) return fail(-1, "qs_xchg_attach_local: endpoints do not match");
+    if (peer->world != x->world || peer->n != x->n || peer->wire != x->wire || peer->rank_bytes != x->rank_bytes || peer->rank != peer_rank) return fail(-1, "qs_xchg_attach_local: endpoints do not match");
     if (peer->device != x->device) {
         XTRY(hipSetDevice(x->device));
         hipError_t pe = hipDeviceEnablePeerAccess(peer->device, 0);
@@ -271,7 +356,7 @@ int qs_xchg_push(qs_xchg *x, const void *src_f32, void *stream) {
     a.src = (const float *)src_f32; a.staging[0] = x->staging[0]; a.staging[1] = x->staging[1];
     for (int r = 0; r < x->world; ++r) { a.data_win[r] = x->peer_data[r]; a.flag_win[r] = x->peer_flags[r]; }
     a.mine = x->flags; a.loc = x->loc; a.n = x->n; a.slot_bytes = (long long)x->slot_bytes; a.world = x->world; a.rank = x->rank; a.wire = x->wire;
-    a.timeout_ticks = x->timeout_ticks;
+    a.timeout_ticks = x->timeout_ticks; a.q8 = x->q8; a.rows = x->rows;
     hipLaunchKernelGGL(qs_xchg_push_kernel, dim3(grid_parts(x->n), x->world), dim3(256), 0, (hipStream_t)stream, a);
     XTRY(hipGetLastError());
     return 0;
@@ -318,7 +403,7 @@ void *qs_xchg_fused_desc(qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *
     memset(&d, 0, sizeof d);
     for (int r = 0; r < x->world; ++r) { d.data_win[r] = x->peer_data[r]; d.flag_win[r] = x->peer_flags[r]; }
     d.mine = x->flags; d.loc = x->loc; d.n = x->n; d.slot_bytes = (long long)x->slot_bytes; d.world = x->world; d.rank = x->rank; d.wire = x->wire;
-    d.auto_ack = auto_ack ? 1 : 0; d.blocks = (unsigned int)blocks; d.timeout_ticks = x->timeout_ticks;
+    d.auto_ack = auto_ack ? 1 : 0; d.blocks = (unsigned int)blocks; d.timeout_ticks = x->timeout_ticks; d.q8 = x->q8;
     if (!x->desc && hipMalloc((void **)&x->desc, sizeof d) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(x->desc, &d, sizeof d, hipMemcpyHostToDevice) != hipSuccess) { g_err = "descriptor upload failed"; return nullptr; }
     if (n_out) *n_out = x->n;
@@ -340,6 +425,31 @@ int qs_obs_pack(const void *src_f32, void *dst, int64_t n, int wire, void *strea
     int parts = (int)(((n >> 3) + 1023) / 1024);
     parts = parts < 1 ? 1 : (parts > 1024 ? 1024 : parts);
     hipLaunchKernelGGL(qs_obs_pack_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, (const float *)src_f32, (char *)dst, (long long)n, wire);
+    XTRY(hipGetLastError());
+    return 0;
+}
+
+int qs_obs_pack_rows(const void *src_f32, void *dst, int64_t rows, int32_t cols, int wire, const qs_wire_q8 *layout, void *stream) {
+    if (wire != QS_WIRE_Q8) return qs_obs_pack(src_f32, dst, rows * (int64_t)cols, wire, stream);
+    Q8Dev q;
+    if (!src_f32 || !dst || rows < 0 || !q8_dev(cols, layout, q)) return fail(-1, "qs_obs_pack_rows: bad argument");
+    if (rows == 0) return 0;
+    int parts = (int)((rows * q.row_words / 4 + 1023) / 1024);
+    parts = parts < 1 ? 1 : (parts > 1024 ? 1024 : parts);
+    hipLaunchKernelGGL(qs_obs_pack_q8_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, (const float *)src_f32, (char *)dst, (long long)rows, q);
+    XTRY(hipGetLastError());
+    return 0;
+}
+
+int qs_obs_unpack_rows(const void *src_wire, void *dst_f32, int64_t rows, int32_t cols, int wire, const qs_wire_q8 *layout, void *stream) {
+    Q8Dev q;
+    memset(&q, 0, sizeof q);
+    if (!src_wire || !dst_f32 || rows < 0 || cols < 1 || (wire != QS_WIRE_F32 && wire != QS_WIRE_BF16 && wire != QS_WIRE_Q8) || (wire == QS_WIRE_Q8 && !q8_dev(cols, layout, q)))
+        return fail(-1, "qs_obs_unpack_rows: bad argument");
+    if (rows == 0) return 0;
+    long long parts = (rows * cols + 2047) / 2048;
+    parts = parts < 1 ? 1 : (parts > 2048 ? 2048 : parts);
+    hipLaunchKernelGGL(qs_obs_unpack_kernel, dim3((int)parts), dim3(256), 0, (hipStream_t)stream, (const char *)src_wire, (float *)dst_f32, (long long)rows, (int)cols, wire, q);
     XTRY(hipGetLastError());
     return 0;
 }

@@ -15,6 +15,13 @@ struct Local {   // device memory of the owning rank only
     unsigned long long push_seq, wait_seq, release_seq;
     unsigned int ticket[QS_XCHG_MAX_RANKS], ticket_all, status;
 };
+// QS_WIRE_Q8 row layout on the device (include/quadswarm_exchange.h): [bf16 x c16p][int8 x n8p]
+struct Q8Dev {
+    int D, q0, q1;        // columns; the int8 block
+    int w16, row_words;   // 4-byte words of the bf16 section / of the whole row
+    float scale[6];       // 127 / clip
+};
+
 // The fused form: what a step kernel needs to store its observation rows into every rank's window itself (qs_set_obs_exchange).
 // Lives in device memory, owned by the endpoint.
 struct XchgDev {
@@ -28,6 +35,7 @@ struct XchgDev {
     int auto_ack;               // 1: the launch that pushed sequence number s also waits for s from every rank and releases it (no in-place reader)
     unsigned int blocks;        // workgroups of one step launch (set by qs_set_obs_exchange)
     unsigned long long timeout_ticks;
+    Q8Dev q8;                   // wire == QS_WIRE_Q8
 };
 
 struct PushArgs {
@@ -40,6 +48,8 @@ struct PushArgs {
     long long slot_bytes;       // bytes of one slot of a data window = world * n * wire size
     int world, rank, wire;
     unsigned long long timeout_ticks;
+    Q8Dev q8;
+    long long rows;             // rows per rank (wire == QS_WIRE_Q8: n = rows * q8.D)
 };
 
 __device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
@@ -48,6 +58,33 @@ __device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+// QS_WIRE_Q8: 4-byte word j of the wire row of the float32 row `row` (LDS or global memory)
+__device__ __forceinline__ unsigned int q8_byte(float x, float scale) {
+    const float v = __builtin_rintf(x * scale);                       // round half to even (v_rndne_f32)
+    const int q = (int)__builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);   // (NaN -> -127 by the min / max order: not a value the env produces)
+    return (unsigned int)q & 0xffu;
+}
+__device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8Dev &q, int j) {
+    if (j < q.w16) {
+        const int b0 = 2 * j, b1 = b0 + 1, nq = q.q1 - q.q0;
+        const int c0 = b0 < q.q0 ? b0 : b0 + nq, c1 = b1 < q.q0 ? b1 : b1 + nq;
+        const unsigned int lo = c0 < q.D ? f32_to_bf16_rne(row[c0]) : 0u, hi = c1 < q.D ? f32_to_bf16_rne(row[c1]) : 0u;
+        return lo | (hi << 16);
+    }
+    const int m = 4 * (j - q.w16), nq = q.q1 - q.q0;
+    unsigned int o = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int mm = m + u;
+        if (mm < nq) {
+            const int a = mm % 6;
+            const float sc = a == 0 ? q.scale[0] : a == 1 ? q.scale[1] : a == 2 ? q.scale[2] : a == 3 ? q.scale[3] : a == 4 ? q.scale[4] : q.scale[5];
+            o |= q8_byte(row[q.q0 + mm], sc) << (8 * u);
+        }
+    }
+    return o;
+}
+
 // Flags: relaxed system-scope accesses (they bypass the caches; no fence per access - an acquire / release at system scope invalidates
 // / writes back the whole L2 on this part).  What orders them against the rows: the rows are written through and drained
 // (s_waitcnt vmcnt(0)) before a workgroup takes its ticket, the flag is stored by whoever takes the last ticket; readers of the rows

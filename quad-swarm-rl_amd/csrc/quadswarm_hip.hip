@@ -683,6 +683,9 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     }
     Ptrs<float> pf = h->pf;   // this launch's pointers (qs_set_obs_target)
     if (h->obs_target) pf.obs = (float *)h->obs_target;
+    // the fused exchange epilogue exists in the one-step kernels only: a multi-step launch would advance the environments without sending
+    // their rows and desynchronise push / wait sequence numbers (qs_step_many splits into single steps while an exchange is set)
+    if (pf.xchg != nullptr && ksteps > 1) return fail(QS_ERR_UNSUPPORTED, "multi-step launches do not exchange observation rows: qs_set_obs_exchange is active");
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
@@ -732,7 +735,7 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
     if (!h || !actions_dev || k < 0) return fail(QS_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
     const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * h->real_size;
-    if (h->profiling || h->replay_on) {   // per-step HIP events / the replay kernel behind every step: one launch per control step
+    if (h->profiling || h->replay_on || h->pf.xchg) {   // per-step HIP events / the replay kernel behind every step / the fused exchange epilogue: one launch per control step
         for (int32_t t = 0; t < k; ++t) {
             int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream, 1);
             if (rc == QS_OK && h->replay_on) { rc = launch_replay(h, (hipStream_t)stream); h->replay_stepped = true; }

@@ -70,6 +70,18 @@ class _RewCoeff(dict):
         dict.update(self, *a, **k)
         self.dirty = True
 
+    def setdefault(self, k, default=None):
+        self.dirty = True
+        return dict.setdefault(self, k, default)
+
+    def pop(self, *a):
+        self.dirty = True
+        return dict.pop(self, *a)
+
+    def __delitem__(self, k):
+        dict.__delitem__(self, k)
+        self.dirty = True
+
     def __deepcopy__(self, memo):
         return _RewCoeff(self)
 
@@ -91,10 +103,10 @@ class QuadSwarmVecEnv:
         low, high = qcfg.obs_bounds(self.cfg)
         self.observation_space = _Box(low, high, dtype=np.float32)
         self.action_space = _Box(-np.ones(4), np.ones(4), dtype=np.float32)   # quadrotor_control.py:37-49
-        self.rew_coeff = _RewCoeff(qcfg.REW_COEFF_DEFAULT)
-        self.rew_coeff.update({k: self.cfg.rew_coeff[i] for i, k in enumerate(qcfg.REW_COEFF_KEYS)})
-        self._pushed_coeff = [self.rew_coeff[k] for k in qcfg.REW_COEFF_KEYS]
-        self.rew_coeff.dirty = False
+        self._rew_coeff = _RewCoeff(qcfg.REW_COEFF_DEFAULT)
+        self._rew_coeff.update({k: self.cfg.rew_coeff[i] for i, k in enumerate(qcfg.REW_COEFF_KEYS)})
+        self._pushed_coeff = [self._rew_coeff[k] for k in qcfg.REW_COEFF_KEYS]
+        self._rew_coeff.dirty = False
         self.scenario = _Scenario(self.cfg, self.stepper)
         self._t = self.stepper.tensor
         # the per-step call path, resolved once: the library entry point, the handle, the stream getter, the output views
@@ -102,6 +114,16 @@ class QuadSwarmVecEnv:
         self._n_act, self._act_bytes = self.num_agents * 4, self.stepper.real_size
         self._views = None
         self.exchange = None   # parallel.ObsExchange when this env is one shard of a multi-GPU batch whose rows are exchanged
+
+    @property
+    def rew_coeff(self):
+        return self._rew_coeff
+
+    @rew_coeff.setter
+    def rew_coeff(self, value):
+        """`env.rew_coeff = {...}` from outside: re-wrapped (the dirty flag lives on the wrapper) and pushed by the next step"""
+        self._rew_coeff = value if isinstance(value, _RewCoeff) else _RewCoeff(value)
+        self._rew_coeff.dirty = True
 
     def attach_exchange(self, exchange):
         """From now on every reset / step writes its observation rows into the exchange's staging buffers and sends them to the other

@@ -65,6 +65,23 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+class WireQ8(C.Structure):
+    """qs_wire_q8 (include/quadswarm_exchange.h): the 8-bit fixed-point block [q0, q1) of an observation row and its clip ranges"""
+    _fields_ = [("q0", C.c_int32), ("q1", C.c_int32), ("clip", C.c_float * 6)]
+
+
+def wire_q8_layout(cfg, obs_dim):
+    """The QS_WIRE_Q8 layout of configuration `cfg`: the neighbour block (6 columns per visible neighbour) behind the self observation,
+    clipped by the environment to +-nbr_clip_pos / +-nbr_clip_vel (quadrotor_single.py:294-295)."""
+    self_dim = 18 if cfg.obs_repr == 0 else (19 if cfg.obs_repr == 1 else 24)
+    q = WireQ8()
+    q.q0, q.q1 = self_dim, self_dim + 6 * cfg.num_neighbors
+    assert q.q1 <= obs_dim
+    for a in range(3):
+        q.clip[a], q.clip[3 + a] = cfg.nbr_clip_pos[a], cfg.nbr_clip_vel[a]
+    return q
+
+
 def _preload_torch_hip_runtime():
     """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 (same SONAMEs as /opt/rocm's).  One process
     must run ONE HIP runtime: if this library pulled in the system copy first, a later `import torch` would come up with
@@ -152,6 +169,11 @@ def lib():
         L.qs_xchg_wait_release.argtypes = [vp, vp]
         L.qs_xchg_status.argtypes = [vp, C.POINTER(C.c_int64)]
         L.qs_obs_pack.argtypes = [vp, vp, C.c_int64, C.c_int, vp]
+        L.qs_xchg_create_q8.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int32, C.POINTER(WireQ8), C.POINTER(vp)]
+        L.qs_wire_row_bytes.argtypes = [C.c_int32, C.c_int, C.POINTER(WireQ8)]
+        L.qs_wire_row_bytes.restype = C.c_int64
+        L.qs_obs_pack_rows.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int, C.POINTER(WireQ8), vp]
+        L.qs_obs_unpack_rows.argtypes = [vp, vp, C.c_int64, C.c_int32, C.c_int, C.POINTER(WireQ8), vp]
         if L.qs_sizeof_config() != C.sizeof(qcfg.QsConfig):
             raise RuntimeError("qs_config layout mismatch between config.py and libquadswarm_hip.so")
         _lib = L
@@ -166,7 +188,8 @@ EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_defau
                     "qs_set_noise_tape", "qs_get_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target", "qs_set_obs_exchange"]
 # include/quadswarm_exchange.h
 EXCHANGE_SYMBOLS = ["qs_xchg_create", "qs_xchg_destroy", "qs_xchg_export", "qs_xchg_attach", "qs_xchg_attach_local", "qs_xchg_staging",
-                    "qs_xchg_gathered", "qs_xchg_push", "qs_xchg_wait", "qs_xchg_release", "qs_xchg_wait_release", "qs_xchg_fused_desc", "qs_xchg_status", "qs_obs_pack", "qs_xchg_last_error"]
+                    "qs_xchg_gathered", "qs_xchg_push", "qs_xchg_wait", "qs_xchg_release", "qs_xchg_wait_release", "qs_xchg_fused_desc", "qs_xchg_status", "qs_obs_pack", "qs_xchg_last_error",
+                    "qs_xchg_create_q8", "qs_wire_row_bytes", "qs_obs_pack_rows", "qs_obs_unpack_rows"]
 
 
 class QsError(RuntimeError):

@@ -26,13 +26,14 @@ graph (fork / join between the two streams inside the graph), which removes the 
 """
 import ctypes as C
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import native
 
 EXPORT_BYTES = 144   # QS_XCHG_EXPORT_BYTES
-WIRE = {"f32": 0, "bf16": 1}
+WIRE = {"f32": 0, "bf16": 1, "q8": 2}
 
 
 def shard_range(total_envs, world_size, rank):
@@ -49,18 +50,67 @@ def _xcheck(rc):
 
 
 def _dev_tensor(ptr, shape, wire, device):
-    """zero-copy torch view of library memory: float32 or bfloat16 (exposed as int16 through the CUDA array interface, then viewed)"""
+    """zero-copy torch view of library memory: float32, bfloat16 (exposed as int16 through the CUDA array interface, then viewed) or the
+    raw bytes of QS_WIRE_Q8 rows (uint8 [rows, row_bytes])"""
     if wire == "bf16":
         return torch.as_tensor(native._DevArray(ptr, shape, "<i2"), device=device).view(torch.bfloat16)
+    if wire == "q8":
+        return torch.as_tensor(native._DevArray(ptr, shape, "|u1"), device=device)
     return torch.as_tensor(native._DevArray(ptr, shape, "<f4"), device=device)
 
 
-def pack_rows(src, dst, stream=None):
-    """float32 rows -> dst's dtype (float32 copy or bfloat16 round-to-nearest-even) with the library's converter (qs_obs_pack)."""
-    wire = "bf16" if dst.dtype == torch.bfloat16 else "f32"
+def wire_dtype(wire):
+    return {"f32": torch.float32, "bf16": torch.bfloat16, "q8": torch.uint8}[wire]
+
+
+def wire_row_bytes(cols, wire, q8=None):
+    n = native.lib().qs_wire_row_bytes(cols, WIRE[wire], C.byref(q8) if q8 is not None else None)
+    if n < 0:
+        raise native.QsError("bad wire layout")
+    return int(n)
+
+
+def pack_rows(src, dst, stream=None, q8=None):
+    """float32 rows [R, D] -> dst: float32 copy, bfloat16 round-to-nearest-even, or (dst uint8 [R, row_bytes], q8 = the layout) QS_WIRE_Q8
+    rows, with the library's converter (qs_obs_pack_rows)."""
+    wire = "bf16" if dst.dtype == torch.bfloat16 else ("q8" if dst.dtype == torch.uint8 else "f32")
     s = stream if stream is not None else torch.cuda.current_stream(src.device)
-    _xcheck(native.lib().qs_obs_pack(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel(), WIRE[wire], C.c_void_p(s.cuda_stream)))
+    _xcheck(native.lib().qs_obs_pack_rows(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.shape[0], src.shape[1], WIRE[wire],
+                                          C.byref(q8) if q8 is not None else None, C.c_void_p(s.cuda_stream)))
     return dst
+
+
+def unpack_rows(src, cols, wire, q8=None, out=None, stream=None):
+    """wire rows -> float32 [R, cols] (qs_obs_unpack_rows): what a float32 consumer of gathered bf16 / q8 rows calls"""
+    rows = src.shape[0]
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
+    s = stream if stream is not None else torch.cuda.current_stream(src.device)
+    _xcheck(native.lib().qs_obs_unpack_rows(C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), rows, cols, WIRE[wire],
+                                            C.byref(q8) if q8 is not None else None, C.c_void_p(s.cuda_stream)))
+    return out
+
+
+def quantize_rows_reference(rows, wire, q8=None):
+    """The wire form of float32 rows computed with plain torch ops (any device) - the specification the library's converters, the push
+    kernel and the fused epilogue are tested against.  bf16: torch's round-to-nearest-even; q8: see include/quadswarm_exchange.h."""
+    rows = rows.float()
+    if wire == "f32":
+        return rows.clone()
+    if wire == "bf16":
+        return rows.to(torch.bfloat16)
+    R, D = rows.shape
+    q0, q1 = int(q8.q0), int(q8.q1)
+    nq, c16 = q1 - q0, D - (q1 - q0)
+    w16 = (c16 + 1) // 2
+    out = torch.zeros((R, 4 * (w16 + (nq + 3) // 4)), dtype=torch.uint8, device=rows.device)
+    other = torch.cat([rows[:, :q0], rows[:, q1:]], dim=1).to(torch.bfloat16).contiguous()
+    out[:, :2 * c16] = other.view(torch.uint8).reshape(R, 2 * c16)
+    if nq:
+        scale = torch.tensor([float(np.float32(127.0 / float(q8.clip[a % 6]))) for a in range(nq)], dtype=torch.float32, device=rows.device)
+        q = torch.clamp(torch.round(rows[:, q0:q1] * scale), -127.0, 127.0).to(torch.int8)
+        out[:, 4 * w16:4 * w16 + nq] = q.view(torch.uint8)
+    return out
 
 
 def gather_window_handles(blob, world, group=None):
@@ -78,10 +128,17 @@ def gather_window_handles(blob, world, group=None):
 class PeerExchange:
     """One endpoint of the peer-store exchange (thin wrapper of the qs_xchg_* C ABI)."""
 
-    def __init__(self, rows, cols, world, rank, device=0, wire="bf16"):
-        self.rows, self.cols, self.world, self.rank, self.device, self.wire = rows, cols, world, rank, device, wire
+    def __init__(self, rows, cols, world, rank, device=0, wire="bf16", q8=None):
+        """q8: the native.WireQ8 layout (wire="q8" only; native.wire_q8_layout(cfg, obs_dim))"""
+        self.rows, self.cols, self.world, self.rank, self.device, self.wire, self.q8 = rows, cols, world, rank, device, wire, q8
         self._x = C.c_void_p()
-        _xcheck(native.lib().qs_xchg_create(device, world, rank, rows, cols, WIRE[wire], C.byref(self._x)))
+        if wire == "q8":
+            if q8 is None:
+                raise ValueError("wire='q8' needs the row layout (native.wire_q8_layout)")
+            _xcheck(native.lib().qs_xchg_create_q8(device, world, rank, rows, cols, C.byref(q8), C.byref(self._x)))
+        else:
+            _xcheck(native.lib().qs_xchg_create(device, world, rank, rows, cols, WIRE[wire], C.byref(self._x)))
+        self.row_bytes = wire_row_bytes(cols, wire, q8)
         self._views = {}
 
     def close(self):
@@ -127,10 +184,12 @@ class PeerExchange:
         return self._views[key]
 
     def gathered(self, slot):
-        """[world * rows, cols] rows of all ranks in rank order, wire dtype; slot = seq & 1 of the wait() that returned them"""
+        """[world * rows, cols] rows of all ranks in rank order, wire dtype (q8: uint8 [world * rows, row_bytes], see unpack_rows);
+        slot = seq & 1 of the wait() that returned them"""
         key = ("g", slot & 1)
         if key not in self._views:
-            self._views[key] = _dev_tensor(native.lib().qs_xchg_gathered(self._x, slot), (self.world * self.rows, self.cols), self.wire, f"cuda:{self.device}")
+            shape = (self.world * self.rows, self.row_bytes if self.wire == "q8" else self.cols)
+            self._views[key] = _dev_tensor(native.lib().qs_xchg_gathered(self._x, slot), shape, self.wire, f"cuda:{self.device}")
         return self._views[key]
 
     # ---- protocol (all asynchronous on `stream`) ----
@@ -183,6 +242,7 @@ class ObsExchange:
         self.main = torch.cuda.current_stream(self.device)
         self.comm = torch.cuda.Stream(device=self.device)
         T, D = stepper.T, stepper.obs_dim
+        self.q8 = native.wire_q8_layout(stepper.cfg, D) if wire == "q8" else None
         # the endpoint also owns the two staging buffers; under "rccl" it is used for those (and its converter) only
         windows = transport in ("peer", "fused")
         if windows and peers is None and world > 1:
@@ -190,7 +250,7 @@ class ObsExchange:
             # raised before the collective would leave the others waiting in it.  All ranks then fail (or succeed) together.
             self.x, blob, err = None, None, None
             try:
-                self.x = PeerExchange(T, D, world, rank, device=stepper.device, wire=wire)
+                self.x = PeerExchange(T, D, world, rank, device=stepper.device, wire=wire, q8=self.q8)
                 blob = self.x.export()
             except Exception as exc:   # noqa: BLE001 - re-raised below, after the collective
                 err = exc
@@ -205,16 +265,16 @@ class ObsExchange:
                 raise err
             self.x.attach(blobs)
         else:
-            self.x = PeerExchange(T, D, world if windows else 1, rank if windows else 0, device=stepper.device, wire=wire)
+            self.x = PeerExchange(T, D, world if windows else 1, rank if windows else 0, device=stepper.device, wire=wire, q8=self.q8)
         if windows:
             if peers is not None:          # in-process wiring (tests, one process driving several shards)
                 for p in peers:
                     if p is not None and p.rank != rank:
                         self.x.attach_local(p)
         else:
-            dt = torch.bfloat16 if wire == "bf16" else torch.float32
-            self._packed = [torch.empty((T, D), dtype=dt, device=self.device) for _ in range(2)]
-            self._out = [torch.empty((world * T, D), dtype=dt, device=self.device) for _ in range(2)]
+            dt, wc = wire_dtype(wire), (self.x.row_bytes if wire == "q8" else D)
+            self._packed = [torch.empty((T, wc), dtype=dt, device=self.device) for _ in range(2)]
+            self._out = [torch.empty((world * T, wc), dtype=dt, device=self.device) for _ in range(2)]
         self.fused_on = False
         self.hold = bool(hold)
         self._pending_release = False                                 # hold: the slot of the last exchange is still ours
@@ -224,6 +284,32 @@ class ObsExchange:
         self._used = [False, False]
         self.graph = None
         self._graph_steps = 0
+        self._capturing = False
+        self._failed = None
+
+    def _sync_main(self):
+        """The stepping stream is the caller's CURRENT torch stream, resolved per call like QuadSwarmVecEnv.step without an exchange does
+        (a sampler that runs under torch.cuda.stream(...) gets its steps ordered behind its own action producer and before its readers).
+        A change of stream is ordered behind everything issued on the previous one."""
+        if self._capturing:
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.main:
+            cur.wait_stream(self.main)
+            cur.wait_stream(self.comm)
+            self.main = cur
+
+    def check(self):
+        """Raise if the exchange ever timed out (sticky): a wait that gave up after QS_XCHG_TIMEOUT_MS fell through with the rows of an
+        older step in the slot, an acknowledge that timed out let a peer's slot be overwritten while it may still be read.  Reads the
+        device status word (a blocking copy): call it where the host synchronises anyway (episode ends, drain / close)."""
+        if self._failed is None:
+            st = self.status()
+            if st["error"]:
+                self._failed = (f"observation exchange timed out on rank {self.rank} (status {st['error']}: 1 = a peer did not release a slot, "
+                                f"2 = a peer's rows did not arrive; pushes {st['pushes']}, waits {st['waits']}): rows gathered since are stale")
+        if self._failed is not None:
+            raise native.QsError(self._failed)
 
     # ---- one exchange on the side stream (eager or under capture) ----
     def _release_pending(self):
@@ -245,7 +331,7 @@ class ObsExchange:
                 self.x.wait_release(stream=self.comm)   # one launch
         else:
             with torch.cuda.stream(self.comm):
-                pack_rows(self.x.staging(buf), self._packed[buf], stream=self.comm)
+                pack_rows(self.x.staging(buf), self._packed[buf], stream=self.comm, q8=self.q8)
                 if self.world > 1 or dist.is_initialized():
                     dist.all_gather_into_tensor(self._out[buf], self._packed[buf], group=self.group)
                 else:
@@ -288,6 +374,9 @@ class ObsExchange:
 
     def step(self, actions_ptr):
         """control step k (eager): observations -> staging[k & 1]; exchange(k) on the side stream under step k+1"""
+        if self._failed is not None:
+            raise native.QsError(self._failed)
+        self._sync_main()
         self._release_pending()
         self._one(actions_ptr, self.k & 1, keep=self.hold)
         self._pending_release = self.hold and self.transport in ("peer", "fused")
@@ -300,6 +389,7 @@ class ObsExchange:
 
     def reset(self):
         """reset all envs; the first observation rows are exchanged like a step's"""
+        self._sync_main()
         self._release_pending()
         self.drain()
         if self.transport == "fused":   # the reset kernel has no epilogue: its rows go out through the push kernel, from the library's own buffer
@@ -343,13 +433,18 @@ class ObsExchange:
             self.drain()
         self._release_pending()
         self.drain()
+        if self.transport == "fused":
+            self._fuse()   # outside the capture (it synchronises the device): also when the eager pre-steps above did not run - k already
+                           # even after pause() or self_check() - and the stepper is still on its plain obs target
         self.graph = torch.cuda.CUDAGraph()
         self._used = [False, False]
         with torch.cuda.graph(self.graph, stream=self._capture_stream()):
             cap = torch.cuda.current_stream(self.device)
             saved, self.main = self.main, cap
+            self._capturing = True
             try:
                 for t in range(n):
+                    assert self.transport != "fused" or self.fused_on
                     if self.transport == "fused" and self.hold:   # reader mode inside a segment: every slot but the last is released at once
                         self.st.step(action_ptrs[t], stream=self.main)
                         self.x.wait(stream=self.main)
@@ -360,6 +455,7 @@ class ObsExchange:
                 cap.wait_stream(self.comm)                             # join: the graph ends when its last exchange has
             finally:
                 self.main = saved
+                self._capturing = False
         self._used = [False, False]                                    # everything recorded is ordered by the graph launch itself
         self._graph_steps = n
         if self.transport != "fused":
@@ -375,6 +471,9 @@ class ObsExchange:
         """replay the captured segment on the stepping stream (stream-ordered behind everything issued so far on both streams)"""
         if self.k & 1:
             raise native.QsError("replay() needs an even number of steps issued before it (staging parity)")
+        if self._failed is not None:
+            raise native.QsError(self._failed)
+        self._sync_main()
         self._release_pending()
         self.main.wait_stream(self.comm)
         for b in (0, 1):
@@ -396,8 +495,8 @@ class ObsExchange:
         self._release_pending()
         self.drain()
         T, D, W = self.st.T, self.st.obs_dim, self.world
-        dt = torch.bfloat16 if self.wire == "bf16" else torch.float32
         base = torch.arange(T * D, device=self.device, dtype=torch.float32).reshape(T, D)
+        iv = {"f32": torch.int32, "bf16": torch.int16, "q8": torch.uint8}[self.wire]
         ok, why = True, ""
         for i in range(rounds):
             buf = i & 1
@@ -409,9 +508,9 @@ class ObsExchange:
                 got = self.x.gathered((self.k + i + 1) & 1).clone()
             self.x.release(stream=self.comm)
             self.comm.synchronize()
-            want = torch.cat([(torch.sin(base * (0.37 + 0.01 * r) + float(i)) * (1.0 + r)).to(dt) for r in range(W)])
-            if not torch.equal(got.view(torch.int16 if dt == torch.bfloat16 else torch.int32), want.view(torch.int16 if dt == torch.bfloat16 else torch.int32)):
-                bad = (got.float() != want.float()).reshape(W, -1).any(dim=1).nonzero().flatten().tolist()
+            want = torch.cat([quantize_rows_reference(torch.sin(base * (0.37 + 0.01 * r) + float(i)) * (1.0 + r), self.wire, self.q8) for r in range(W)])
+            if not torch.equal(got.view(iv), want.view(iv)):
+                bad = (got.view(iv) != want.view(iv)).reshape(W, -1).any(dim=1).nonzero().flatten().tolist()
                 ok, why = False, f"round {i}: rows of rank(s) {bad} differ from what they sent"
                 break
         st = self.x.status()
@@ -420,16 +519,50 @@ class ObsExchange:
         self.k += rounds   # pushes so far (even: the staging parity of the steps is unchanged)
         return ok, why
 
+    def verify(self):
+        """Compare the gathered rows of the most recent step with an independent gather of the same rows - every rank's float32 rows,
+        converted to the wire type by the library's converter, through torch.distributed (RCCL) - and return (ok, reason).  Unlike
+        self_check() this goes through whatever produced the rows in the windows: the step kernel's fused epilogue on the real
+        topology included.  Collective: call it on every rank at the same step (needs hold=True, or a quiet exchange: nothing may
+        overwrite the slot meanwhile).  bench.py runs it before and after its timed region, sf_env when a window transport is opted into."""
+        got = self.latest().clone()
+        dt = got.dtype
+        mine = torch.empty((self.st.T, got.shape[1]), dtype=dt, device=self.device)
+        pack_rows(self.local_rows(), mine, stream=self.main, q8=self.q8)
+        if self.world > 1:
+            want = torch.empty_like(got)
+            with torch.cuda.stream(self.main):
+                dist.all_gather_into_tensor(want, mine, group=self.group)
+        else:
+            want = mine
+        self.main.synchronize()
+        iv = {torch.float32: torch.int32, torch.bfloat16: torch.int16, torch.uint8: torch.uint8}[dt]
+        if torch.equal(got.view(iv), want.view(iv)):
+            return True, ""
+        bad = (got.view(iv) != want.view(iv)).reshape(self.world, -1).any(dim=1).nonzero().flatten().tolist()
+        return False, f"gathered rows of rank(s) {bad} differ from what an RCCL all-gather of the same rows delivers (step {self.k})"
+
     # ---- results ----
     def drain(self):
         """the stepping stream waits for every exchange issued so far"""
         self.main.wait_stream(self.comm)
 
-    def latest(self):
-        """gathered rows [world*T, D] (wire dtype) of the most recent step, valid on the stepping stream"""
+    def latest(self, check=False):
+        """gathered rows [world*T, D] (wire dtype) of the most recent step, valid on the stepping stream.  check=True also reads the
+        exchange's status word (a blocking copy) and raises if a wait ever timed out - see check()."""
+        if self._failed is not None:
+            raise native.QsError(self._failed)
         self.drain()
+        if check:
+            self.check()
         slot = self.k & 1 if self.transport != "rccl" else (self.k - 1) & 1   # windows: slot = push sequence number & 1 (1-based)
         return self.x.gathered(slot) if self.transport != "rccl" else self._out[slot]
+
+    def latest_f32(self, out=None):
+        """the gathered rows of the most recent step as float32 [world*T, D] (bf16 widened, q8 dequantised: qs_obs_unpack_rows)"""
+        g = self.latest()
+        with torch.cuda.stream(self.main):
+            return unpack_rows(g, self.st.obs_dim, self.wire, self.q8, out=out, stream=self.main)
 
     def local_rows(self):
         """this rank's float32 rows of the most recent step (the staging buffer the stepper wrote; fused: the library's own `obs`)"""

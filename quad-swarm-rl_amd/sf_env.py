@@ -90,7 +90,11 @@ def add_quadrotors_env_args(env, parser):
                                                                  "its contiguous env range on GPU LOCAL_RANK")
     p.add_argument("--quads_gather_obs", default=False, type=str2bool, help="with --quads_num_gpus > 1: after every step every rank also "
                                                                             "receives the observation rows of all shards (env.gathered_obs())")
-    p.add_argument("--quads_obs_wire", default="bf16", type=str, choices=["bf16", "f32"], help="wire format of the gathered rows")
+    p.add_argument("--quads_obs_wire", default="bf16", type=str, choices=["q8", "bf16", "f32"], help="wire format of the gathered rows (q8: bf16 self columns + 8-bit fixed-point neighbour block, include/quadswarm_exchange.h; env.gathered_obs_f32() dequantises)")
+    p.add_argument("--quads_obs_transport", default="rccl", type=str, choices=["rccl", "peer"],
+                   help="how the gathered rows travel: rccl = torch.distributed all-gather (default: the transport that is validated wherever RCCL is); "
+                        "peer = the library's peer stores into hipIpc-mapped windows (opt-in: start-up self-check + a comparison against an RCCL "
+                        "gather of the same rows on every rank, else all ranks fall back to rccl together)")
 
 
 DEFAULT_QUAD_REWARD_SHAPING = dict(quad_rewards=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0,
@@ -312,7 +316,7 @@ class BatchedQuadSwarm:
     is a list of num_agents dicts on steps where an episode ended (empty dicts for the others) and `[]` otherwise."""
 
     def __init__(self, num_envs, reward_shaping_scheme=None, annealing=None, device=0, seed=0, replay_buffer_sample_prob=0.0,
-                 num_gpus=1, gather_obs=False, obs_wire="bf16", write_rew_info=False, _vec=None, **env_kwargs):
+                 num_gpus=1, gather_obs=False, obs_wire="bf16", obs_transport="rccl", write_rew_info=False, _vec=None, **env_kwargs):
         """num_gpus > 1: `num_envs` is the global batch; this process (one per GPU under torchrun) steps its contiguous shard on GPU
         LOCAL_RANK.  gather_obs: the observation rows of all shards are exchanged after every step (parallel.ObsExchange) and available
         from gathered_obs()."""
@@ -332,7 +336,7 @@ class BatchedQuadSwarm:
         self.vec = _vec if _vec is not None else QuadSwarmVecEnv(num_envs, device=device, seed=seed, env_id_offset=env_id_offset, episode_sums=True,
                                                                  write_rew_info=write_rew_info, **env_kwargs)
         if gather_obs:
-            self.vec.attach_exchange(self._make_exchange(num_gpus, obs_wire))
+            self.vec.attach_exchange(self._make_exchange(num_gpus, obs_wire, obs_transport))
         self.num_envs, self.agents_per_env = num_envs, self.vec.num_agents_per_env
         self.num_agents = self.vec.num_agents
         self.is_multiagent = True
@@ -353,9 +357,11 @@ class BatchedQuadSwarm:
         self._steps_to_done = self._ep_steps              # control steps until the earliest possible episode end
         self._truncated = None
 
-    def _make_exchange(self, world, wire):
-        """peer-store exchange of the observation rows between the shards (include/quadswarm_exchange.h); RCCL all-gather of the
-        packed rows if the peers' windows cannot be mapped or the start-up self-check fails on any rank (same rule as bench.py)"""
+    def _make_exchange(self, world, wire, transport="rccl"):
+        """The exchange of the observation rows between the shards.  Default: RCCL all-gather of the packed rows.  transport="peer"
+        (opt-in, --quads_obs_transport peer): the library's peer stores into hipIpc-mapped windows (include/quadswarm_exchange.h), kept
+        only if on EVERY rank the windows could be mapped, the start-up self-check passed and the rows of a first exchanged reset equal
+        what an RCCL gather of the same rows delivers (ObsExchange.verify); otherwise all ranks fall back to RCCL together."""
         import torch
         import torch.distributed as dist
         from . import parallel
@@ -363,6 +369,9 @@ class BatchedQuadSwarm:
         torch.cuda.set_device(st.device)
         if world > 1 and not dist.is_initialized():
             dist.init_process_group("nccl", device_id=torch.device("cuda", st.device))
+        self.obs_transport = "rccl"
+        if transport == "rccl":
+            return parallel.ObsExchange(st, world, self.rank, transport="rccl", wire=wire, hold=True)
 
         def all_agree(flag):
             if world == 1:
@@ -383,10 +392,18 @@ class BatchedQuadSwarm:
             except Exception:   # noqa: BLE001
                 ok = False
             ok = all_agree(ok)
+        if ok:   # ... and through the real producer of the rows: an exchanged reset, compared with an RCCL gather of the same rows
+            try:
+                ex.reset()
+                ok = ex.verify()[0]
+            except Exception:   # noqa: BLE001
+                ok = False
+            ok = all_agree(ok)
         if not ok:
             if ex is not None:
                 ex.close()
             ex = parallel.ObsExchange(st, world, self.rank, transport="rccl", wire=wire, hold=True)
+        self.obs_transport = ex.transport
         return ex
 
     def gathered_obs(self):
@@ -395,6 +412,17 @@ class BatchedQuadSwarm:
         if self.vec.exchange is None:
             raise RuntimeError("create the env with gather_obs=True (--quads_gather_obs=True)")
         return self.vec.exchange.latest()
+
+    def gathered_obs_f32(self):
+        """gathered_obs() as float32 [global envs * N, obs_dim] whatever the wire (bf16 widened, q8 dequantised on the device)"""
+        if self.vec.exchange is None:
+            raise RuntimeError("create the env with gather_obs=True (--quads_gather_obs=True)")
+        return self.vec.exchange.latest_f32()
+
+    def check_exchange(self):
+        """raises QsError if the observation exchange ever timed out (parallel.ObsExchange.check); step() calls it on episode-end steps"""
+        if self.vec.exchange is not None:
+            self.vec.exchange.check()
 
     @property
     def unwrapped(self):
@@ -445,6 +473,7 @@ class BatchedQuadSwarm:
         self._steps_to_done -= 1
         if self._steps_to_done <= 0:      # the only steps on which the host looks at the device
             st, n = self.vec.stepper, self.agents_per_env
+            self.check_exchange()         # (a timed-out exchange means stale gathered rows since: raise instead of training on them)
             finished = np.nonzero(st.to_host("done").reshape(self.num_envs, n)[:, 0])[0]
             if len(finished):
                 infos = self._episode_infos(finished)
@@ -484,7 +513,10 @@ class BatchedQuadSwarm:
         return EpisodeInfos(self.num_agents, n, builder)
 
     def close(self):
-        self.vec.close()
+        try:
+            self.check_exchange()
+        finally:
+            self.vec.close()
 
 
 def _domain_random_kwargs(cfg, use_replay_buffer):
@@ -617,7 +649,7 @@ def make_quadrotor_env_batched(cfg, **kwargs):
     reward_shaping, annealing = _shaping_from_cfg(cfg)
     return BatchedQuadSwarm(
         cfg.quads_num_envs, reward_shaping_scheme=reward_shaping, annealing=annealing,
-        num_gpus=getattr(cfg, "quads_num_gpus", 1), gather_obs=getattr(cfg, "quads_gather_obs", False), obs_wire=getattr(cfg, "quads_obs_wire", "bf16"),
+        num_gpus=getattr(cfg, "quads_num_gpus", 1), gather_obs=getattr(cfg, "quads_gather_obs", False), obs_wire=getattr(cfg, "quads_obs_wire", "bf16"), obs_transport=getattr(cfg, "quads_obs_transport", "rccl"),
         **_env_kwargs_from_cfg(cfg))
 
 

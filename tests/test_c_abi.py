@@ -30,7 +30,7 @@ def test_library_exports_every_symbol_of_the_exchange_header():
     native.build()
     lib = C.CDLL(native.LIB_PATH)
     text = open(os.path.join(REPO, "include", "quadswarm_exchange.h")).read()
-    declared = sorted(set(re.findall(r"^(?:int|void \*|const char \*)\s*\*?(qs_\w+)\(", text, flags=re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|int64_t|void \*|const char \*)\s*\*?(qs_\w+)\(", text, flags=re.M)))
     assert len(declared) >= 12, declared
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/quadswarm_exchange.h but not exported"

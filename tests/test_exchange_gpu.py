@@ -19,15 +19,19 @@ WORKER = os.path.join(REPO, "tests", "xchg_worker.py")
 def _expected_rows(total_envs, wire, action_batches):
     """rows of the un-sharded stepper after the reset and after each action batch (an int t = batch t of the global action set)"""
     import torch
-    from quad_swarm_rl_amd import config as qcfg, native
+    from quad_swarm_rl_amd import config as qcfg, native, parallel
     from tests import xchg_worker as xw
     cfg = qcfg.make_config(num_envs=total_envs, seed=7, precision="f32", write_rew_info=False, **xw.KW)
     st = native.Stepper(cfg, device=0)
     acts = torch.as_tensor(xw.global_actions(max(action_batches) + 1 if action_batches else 1, total_envs, cfg.num_agents)).cuda()
     obs = st.tensor("obs")
 
+    q8 = native.wire_q8_layout(cfg, st.obs_dim)
+
     def rows():
         torch.cuda.synchronize()
+        if wire == "q8":   # the wire bytes of the un-sharded rows by the plain-torch specification of the format
+            return parallel.quantize_rows_reference(obs, "q8", q8).cpu().numpy()
         r = obs.to(torch.bfloat16).float() if wire == "bf16" else obs.clone()
         return r.cpu().numpy()
 
@@ -40,7 +44,7 @@ def _expected_rows(total_envs, wire, action_batches):
     return out
 
 
-def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout=300, transport="peer", hold=1):
+def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout=300, transport="peer", hold=1, verify=0):
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     with tempfile.TemporaryDirectory() as td:
         port = 29600 + (os.getpid() % 300)
@@ -49,7 +53,7 @@ def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout
             out = os.path.join(td, f"r{r}.npz")
             outs.append(out)
             cmd = [sys.executable, WORKER, "--mode", mode, "--rank", str(r), "--world", str(world), "--port", str(port), "--wire", wire, "--envs", str(envs),
-                   "--steps", str(steps), "--graph", str(graph), "--replays", str(replays), "--transport", transport, "--hold", str(hold), "--out", out]
+                   "--steps", str(steps), "--graph", str(graph), "--replays", str(replays), "--transport", transport, "--hold", str(hold), "--verify", str(verify), "--out", out]
             procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         logs = []
         for p in procs:
@@ -87,7 +91,7 @@ def _check(results, mode, world, wire, graph, steps, replays, envs=16):
                 assert np.array_equal(got[i], exp[k]), f"{mode} wire={wire} graph={graph}: rank {r}, record {i} differs (max {np.abs(got[i] - exp[k]).max()})"
 
 
-@pytest.mark.parametrize("wire", ["f32", "bf16"])
+@pytest.mark.parametrize("wire", ["f32", "bf16", "q8"])
 @pytest.mark.parametrize("graph", [0, 6])
 def test_two_processes_on_one_gpu_gather_equals_unsharded(wire, graph):
     """north_star's sharding with one process per rank: both processes map each other's windows with hipIpcOpenMemHandle."""
@@ -95,7 +99,7 @@ def test_two_processes_on_one_gpu_gather_equals_unsharded(wire, graph):
     _check(res, "proc", 2, wire, graph, 10, 3)
 
 
-@pytest.mark.parametrize("wire,graph,hold", [("f32", 0, 1), ("bf16", 6, 1), ("bf16", 0, 0), ("f32", 6, 0)])
+@pytest.mark.parametrize("wire,graph,hold", [("f32", 0, 1), ("bf16", 6, 1), ("bf16", 0, 0), ("f32", 6, 0), ("q8", 0, 1), ("q8", 6, 0)])
 def test_two_processes_fused_push_from_the_step_kernel(wire, graph, hold):
     """the FUSED transport (qs_set_obs_exchange): the team step kernels store their rows into both processes' windows themselves;
     hold = 1: reader mode (wait / release launches around the reads), hold = 0: the step launch acknowledges on its own"""
@@ -109,6 +113,42 @@ def test_two_endpoints_in_one_process(wire, graph):
     the graph form is covered with one process per rank above, which is the deployment)"""
     res = _run_workers("local", 2, wire, graph)
     _check(res, "local", 2, wire, graph, 10, 3)
+
+
+def test_two_processes_verify_against_an_independent_gather():
+    """ObsExchange.verify(): the rows in the windows (fused epilogue, q8 wire) equal what torch.distributed gathers from the same float32 rows"""
+    res = _run_workers("proc", 2, "q8", 0, steps=4, transport="fused", hold=1, verify=1)
+    assert all(int(r[f"verify{k}"]) == 1 for k, r in enumerate(res))
+
+
+def test_q8_pack_unpack_and_error_bound():
+    """qs_obs_pack_rows(QS_WIRE_Q8) == the plain-torch specification bit for bit (C2 and C3 row shapes, an unaligned row count);
+    qs_obs_unpack_rows brings the neighbour block back to within clip / 254 and the other columns to their bf16 rounding"""
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native, parallel
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for kw, D in ((dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel"), 54),
+                  (dict(num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_obstacles=True, obst_density=0.2, obst_size=0.6,
+                        quads_mode="o_static_same_goal", obs_repr="xyz_vxyz_R_omega_floor"), 40)):
+        cfg = qcfg.make_config(num_envs=1, **kw)
+        q8 = native.wire_q8_layout(cfg, D)
+        rb = parallel.wire_row_bytes(D, "q8", q8)
+        assert rb == (72 if D == 54 else 68)
+        for R in (4096, 777):
+            x = (torch.rand((R, D), device="cuda", generator=g) * 2 - 1) * 12.0     # beyond the clip range too
+            x[:, q8.q0:q8.q1:6] = torch.round(x[:, q8.q0:q8.q1:6] * 12.7) / 12.7 + 0.5 / 12.7   # values on / near rounding ties
+            dst = torch.empty((R, rb), dtype=torch.uint8, device="cuda")
+            parallel.pack_rows(x, dst, q8=q8)
+            want = parallel.quantize_rows_reference(x, "q8", q8)
+            torch.cuda.synchronize()
+            assert torch.equal(dst, want), (D, R, (dst != want).sum().item())
+            back = parallel.unpack_rows(dst, D, "q8", q8)
+            torch.cuda.synchronize()
+            clip = torch.tensor([q8.clip[a % 6] for a in range(q8.q1 - q8.q0)], device="cuda")
+            nb = x[:, q8.q0:q8.q1].clamp(-clip, clip)
+            assert ((back[:, q8.q0:q8.q1] - nb).abs() <= clip / 254 * 1.0001 + 1e-6).all()
+            other = torch.cat([x[:, :q8.q0], x[:, q8.q1:]], 1)
+            assert torch.equal(torch.cat([back[:, :q8.q0], back[:, q8.q1:]], 1), other.to(torch.bfloat16).float())
 
 
 def test_four_ranks_in_one_process_bf16():
@@ -139,8 +179,9 @@ def test_pack_bf16_equals_torch_rounding():
     assert torch.equal(dst.view(torch.int16), odd.to(torch.bfloat16).view(torch.int16))
 
 
+@pytest.mark.parametrize("wire", ["bf16", "q8"])
 @pytest.mark.parametrize("transport", ["fused", "peer", "rccl"])
-def test_world1_graph_capture_matches_plain_stepping(transport):
+def test_world1_graph_capture_matches_plain_stepping(transport, wire):
     """world size 1 (what bench.py --force-gather runs on a 1-GPU box): [step -> exchange] x 8 as one HIP graph, replayed, equals
     the plain stepper on the same actions; the redirected observation output leaves qs_buffers.obs untouched."""
     import torch
@@ -152,7 +193,7 @@ def test_world1_graph_capture_matches_plain_stepping(transport):
     stride = acts[0].numel() * 4
     ref = native.Stepper(cfg, device=0)
     st = native.Stepper(cfg, device=0)
-    ex = parallel.ObsExchange(st, 1, 0, transport=transport, wire="bf16")
+    ex = parallel.ObsExchange(st, 1, 0, transport=transport, wire=wire)
     ex.reset()
     ref.reset()
     untouched = st.tensor("obs").clone()
@@ -166,8 +207,13 @@ def test_world1_graph_capture_matches_plain_stepping(transport):
             ref.step(acts[t].data_ptr())
         torch.cuda.synchronize()
         want = ref.tensor("obs")
-        assert torch.equal(ex.latest(), want.to(torch.bfloat16)), (transport, rep)
+        assert torch.equal(ex.latest(), parallel.quantize_rows_reference(want, wire, ex.q8)), (transport, rep)
         assert torch.equal(ex.local_rows(), want)
+        assert ex.verify()[0]
+        if wire == "q8":   # the consumer's float32 view: neighbour block within clip / 254 of the float32 rows
+            f = ex.latest_f32()
+            torch.cuda.synchronize()
+            assert (f[:, 18:54] - want[:, 18:54]).abs().max().item() <= 10.0 / 254 * 1.0001
     assert ex.status()["error"] == 0
     if transport != "fused":   # (the fused transport leaves the rows where the library puts them)
         assert torch.equal(st.tensor("obs"), untouched)

@@ -133,3 +133,37 @@ def test_backend_flag_has_no_cpu_fallback():
     cfg = p.parse_args(["--quads_num_gpus=2"])
     with pytest.raises(ValueError, match="quads_num_envs"):
         sf_env.make_quadrotor_env("quadrotor_multi", cfg)
+
+
+def test_q8_wire_reference_layout_and_error_bound():
+    """QS_WIRE_Q8 (include/quadswarm_exchange.h) by its plain-torch specification on the CPU: row bytes of the BASELINE shapes (<= 80, what
+    the >= 6x of north_star needs: DESIGN.md 7), section layout, round-half-even, clamping, and the clip / 254 error bound after dequantisation."""
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native, parallel
+    cfg = qcfg.make_config(num_envs=1, num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel")
+    q8 = native.wire_q8_layout(cfg, 54)
+    assert (q8.q0, q8.q1) == (18, 54) and list(q8.clip) == [10.0, 10.0, 10.0, 6.0, 6.0, 6.0]
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand((257, 54), generator=g) * 2 - 1) * 11.0
+    x[0, 18] = 10.0 * 0.5 / 127          # exactly half a step: rounds to the even neighbour 0
+    x[0, 19] = 10.0 * 1.5 / 127          # 1.5 steps -> 2
+    x[0, 21] = 7.0                       # beyond the velocity clip of 6 -> 127
+    w = parallel.quantize_rows_reference(x, "q8", q8)
+    assert w.shape == (257, 72) and w.dtype == torch.uint8
+    q = w[:, 36:].view(torch.int8)
+    assert (q[0, 0].item(), q[0, 1].item(), q[0, 3].item()) == (0, 2, 127)
+    assert torch.equal(w[:, :36].contiguous().view(torch.bfloat16).reshape(257, 18), x[:, :18].to(torch.bfloat16))
+    clip = torch.tensor([q8.clip[a % 6] for a in range(36)])
+    deq = q.float() * clip / 127.0
+    assert ((deq - x[:, 18:].clamp(-clip, clip)).abs() <= clip / 254 + 1e-6).all()
+    # C3: 19 self + 12 neighbour + 9 SDF columns -> 28 bf16 + 12 int8 = 68 bytes; an odd bf16 count is padded to a whole word
+    cfg3 = qcfg.make_config(num_envs=1, num_agents=8, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_obstacles=True, obst_density=0.2, obst_size=0.6,
+                            quads_mode="o_static_same_goal", obs_repr="xyz_vxyz_R_omega_floor")
+    q3 = native.wire_q8_layout(cfg3, 40)
+    w3 = parallel.quantize_rows_reference(torch.zeros((3, 40)), "q8", q3)
+    assert w3.shape == (3, 68)
+    q1 = native.WireQ8(); q1.q0, q1.q1 = 19, 25
+    for a in range(6):
+        q1.clip[a] = 1.0
+    assert parallel.quantize_rows_reference(torch.ones((2, 25)), "q8", q1).shape == (2, 2 * 20 + 8)   # 19 -> 20 bf16 slots, 6 -> 8 int8 slots
+    assert parallel.wire_row_bytes(54, "q8", q8) == 72 and parallel.wire_row_bytes(40, "q8", q3) == 68 and parallel.wire_row_bytes(25, "q8", q1) == 48

@@ -60,7 +60,7 @@ def test_command_line_flags_equal_reference():
     p = argparse.ArgumentParser()
     sf_env.add_quadrotors_env_args("quadrotor_multi", p)
     mine = {a.dest: a for a in p._actions if a.dest != "help"}
-    assert sorted(set(mine) - set(ref["flags"])) == ["quads_backend", "quads_device", "quads_gather_obs", "quads_num_envs", "quads_num_gpus", "quads_obs_wire", "quads_precision", "quads_seed"]
+    assert sorted(set(mine) - set(ref["flags"])) == ["quads_backend", "quads_device", "quads_gather_obs", "quads_num_envs", "quads_num_gpus", "quads_obs_transport", "quads_obs_wire", "quads_precision", "quads_seed"]
     assert len(ref["flags"]) == 37
     for name, r in ref["flags"].items():
         a = mine[name]

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--replays", type=int, default=3)
     ap.add_argument("--hold", type=int, default=1)
     ap.add_argument("--transport", default="peer", choices=["peer", "fused"])
+    ap.add_argument("--verify", type=int, default=0)
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -73,7 +74,7 @@ def main():
     def snap():
         rows = {r: exs[r].latest() for r in ranks}          # enqueue every rank's drain before the first host sync
         for r in ranks:
-            rec[r].append(rows[r].float().cpu().numpy())
+            rec[r].append(rows[r].cpu().numpy() if args.wire == "q8" else rows[r].float().cpu().numpy())   # q8: the raw wire bytes
 
     for r in ranks:
         exs[r].reset()
@@ -98,9 +99,13 @@ def main():
                 exs[r].step(act_dev[r].data_ptr() + t * stride)
             snap()
     torch.cuda.synchronize()
+    verified = {}
+    if args.verify:   # the gathered rows against an independent gather of the same rows through torch.distributed (ObsExchange.verify)
+        for r in ranks:
+            verified[r] = exs[r].verify() if args.mode == "proc" else (True, "")
     status = {r: exs[r].status() for r in ranks}
     np.savez(args.out, warm=warm, **{f"rows{r}": np.stack(rec[r]) for r in ranks}, **{f"err{r}": status[r]["error"] for r in ranks},
-             **{f"pushes{r}": status[r]["pushes"] for r in ranks})
+             **{f"pushes{r}": status[r]["pushes"] for r in ranks}, **{f"verify{r}": (1 if v[0] else 0) for r, v in verified.items()})
     for r in ranks:
         exs[r].close()
         steppers[r].close()
