@@ -230,7 +230,21 @@ class ObsExchange:
     releases a slot as soon as it has arrived (no in-place reader: the benchmark).
     """
 
-    def __init__(self, stepper, world, rank, transport="peer", wire="bf16", group=None, peers=None, hold=True):
+    def __init__(self, stepper, world, rank, transport="peer", wire="bf16", group=None, peers=None, hold=True, source=None):
+        """source: "target" (default) - the stepper writes the rows of consecutive steps into the two staging buffers (qs_set_obs_target)
+        and the exchange of step t runs under step t+1; "obs" - the rows are taken from the library's own observation buffer AFTER the
+        whole qs_step, on the stepping stream: what a stepper with the device-side replay wrapper needs (default there), whose replay
+        kernel restores observations into that buffer behind the step kernel (the push itself then sits between two steps; waiting
+        for the peers' rows still runs on the side stream)."""
+        if source is None:
+            source = "obs" if getattr(stepper, "replay_on", False) else "target"
+        if source not in ("target", "obs"):
+            raise ValueError("source must be 'target' or 'obs'")
+        if source == "obs" and transport == "fused":
+            raise native.QsError("the fused exchange sends the step kernel's own rows: with the device-side replay wrapper use transport='peer' or 'rccl'")
+        if source == "target" and getattr(stepper, "replay_on", False):
+            raise native.QsError("a stepper with the device-side replay wrapper restores observations into qs_buffers.obs: use source='obs'")
+        self.source = source
         if stepper.real_size != 4:
             raise ValueError("the exchange moves float32 observation rows (production precision)")
         if transport not in ("fused", "peer", "rccl"):
@@ -323,6 +337,25 @@ class ObsExchange:
             self._pending_release = False
 
     def _exchange(self, buf, keep=False):
+        if self.source == "obs":   # rows from the library's buffer, converted / pushed on the stepping stream (the next step overwrites them)
+            if self.transport == "peer":
+                self.x.push(self.st.ptr("obs"), stream=self.main)
+            else:
+                pack_rows(self.st.tensor("obs"), self._packed[buf], stream=self.main, q8=self.q8)
+            self._stepped[buf].record(self.main)
+            self.comm.wait_event(self._stepped[buf])
+            if self.transport == "peer":
+                if keep:
+                    self.x.wait(stream=self.comm)
+                else:
+                    self.x.wait_release(stream=self.comm)
+            else:
+                with torch.cuda.stream(self.comm):
+                    if self.world > 1 or dist.is_initialized():
+                        dist.all_gather_into_tensor(self._out[buf], self._packed[buf], group=self.group)
+                    else:
+                        self._out[buf].copy_(self._packed[buf])
+            return
         if self.transport == "peer":
             self.x.push(self.x.staging_ptr(buf), stream=self.comm)
             if keep:
@@ -364,6 +397,12 @@ class ObsExchange:
             return
         if self._used[buf]:
             self.main.wait_event(self._done[buf])                    # the push that read staging[buf] two steps ago has finished
+        if self.source == "obs":
+            self.st.step(actions_ptr, stream=self.main)              # (step kernel + replay kernel)
+            self._exchange(buf, keep)
+            self._done[buf].record(self.comm)
+            self._used[buf] = True
+            return
         self.st.set_obs_target(self.x.staging_ptr(buf))
         self.st.step(actions_ptr, stream=self.main)
         self._stepped[buf].record(self.main)
@@ -404,10 +443,13 @@ class ObsExchange:
             self.k += 1
             return
         buf = self.k & 1
-        self.st.set_obs_target(self.x.staging_ptr(buf))
-        self.st.reset(stream=self.main)
-        self._stepped[buf].record(self.main)
-        self.comm.wait_event(self._stepped[buf])
+        if self.source == "obs":
+            self.st.reset(stream=self.main)
+        else:
+            self.st.set_obs_target(self.x.staging_ptr(buf))
+            self.st.reset(stream=self.main)
+            self._stepped[buf].record(self.main)
+            self.comm.wait_event(self._stepped[buf])
         self._exchange(buf, keep=self.hold)
         self._pending_release = self.hold and self.transport == "peer"
         self._done[buf].record(self.comm)
@@ -458,7 +500,7 @@ class ObsExchange:
                 self._capturing = False
         self._used = [False, False]                                    # everything recorded is ordered by the graph launch itself
         self._graph_steps = n
-        if self.transport != "fused":
+        if self.transport != "fused" and self.source == "target":
             self.st.set_obs_target(self.x.staging_ptr(self.k & 1))
         return self
 
@@ -566,7 +608,7 @@ class ObsExchange:
 
     def local_rows(self):
         """this rank's float32 rows of the most recent step (the staging buffer the stepper wrote; fused: the library's own `obs`)"""
-        if self.transport == "fused":
+        if self.transport == "fused" or self.source == "obs":
             return self.st.tensor("obs")
         return self.x.staging((self.k - 1) & 1)
 

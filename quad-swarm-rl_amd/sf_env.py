@@ -330,12 +330,15 @@ class BatchedQuadSwarm:
         self.num_gpus = num_gpus
         if local_rank is not None:
             device = local_rank
-        if gather_obs and replay_buffer_sample_prob > 0.0:
-            raise ValueError("--quads_gather_obs is not available together with the device-side replay wrapper (--replay_buffer_sample_prob > 0)")
         # (_vec: a ready-made vec env - the CPU test of the shaping / annealing / infos logic drives this class over a scripted stand-in)
         self.vec = _vec if _vec is not None else QuadSwarmVecEnv(num_envs, device=device, seed=seed, env_id_offset=env_id_offset, episode_sums=True,
                                                                  write_rew_info=write_rew_info, **env_kwargs)
-        if gather_obs:
+        self.use_replay_buffer = replay_buffer_sample_prob > 0.0        # quad_utils.py:34
+        self.replay_buffer_sample_prob = float(replay_buffer_sample_prob)
+        if self.use_replay_buffer:
+            self.vec.stepper.replay_enable(self.replay_buffer_sample_prob)
+        if gather_obs:   # (after the replay wrapper: with it the exchange sends the rows the replay kernel leaves in the library's buffer -
+            #               restored checkpoints included - instead of redirecting the step kernel's output: parallel.ObsExchange source="obs")
             self.vec.attach_exchange(self._make_exchange(num_gpus, obs_wire, obs_transport))
         self.num_envs, self.agents_per_env = num_envs, self.vec.num_agents_per_env
         self.num_agents = self.vec.num_agents
@@ -347,10 +350,6 @@ class BatchedQuadSwarm:
         self.reward_shaping_updated = True
         self.annealing = annealing
         self.training_info = {}
-        self.use_replay_buffer = replay_buffer_sample_prob > 0.0        # quad_utils.py:34
-        self.replay_buffer_sample_prob = float(replay_buffer_sample_prob)
-        if self.use_replay_buffer:
-            self.vec.stepper.replay_enable(self.replay_buffer_sample_prob)
         self._keys = qcfg.REW_INFO_KEYS
         self._warm = False                                # the torch kernels of the episode-end path are loaded by the first reset()
         self._ep_steps = self.vec.cfg.ep_len + 1          # an episode ends by time: tick > ep_len (quadrotor_single.py:353)

@@ -44,7 +44,7 @@ def _expected_rows(total_envs, wire, action_batches):
     return out
 
 
-def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout=300, transport="peer", hold=1, verify=0):
+def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout=300, transport="peer", hold=1, verify=0, replay=0.0):
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     with tempfile.TemporaryDirectory() as td:
         port = 29600 + (os.getpid() % 300)
@@ -53,7 +53,7 @@ def _run_workers(mode, world, wire, graph, steps=10, replays=3, envs=16, timeout
             out = os.path.join(td, f"r{r}.npz")
             outs.append(out)
             cmd = [sys.executable, WORKER, "--mode", mode, "--rank", str(r), "--world", str(world), "--port", str(port), "--wire", wire, "--envs", str(envs),
-                   "--steps", str(steps), "--graph", str(graph), "--replays", str(replays), "--transport", transport, "--hold", str(hold), "--verify", str(verify), "--out", out]
+                   "--steps", str(steps), "--graph", str(graph), "--replays", str(replays), "--transport", transport, "--hold", str(hold), "--verify", str(verify), "--replay", str(replay), "--out", out]
             procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
         logs = []
         for p in procs:
@@ -113,6 +113,43 @@ def test_two_endpoints_in_one_process(wire, graph):
     the graph form is covered with one process per rank above, which is the deployment)"""
     res = _run_workers("local", 2, wire, graph)
     _check(res, "local", 2, wire, graph, 10, 3)
+
+
+def test_two_processes_gather_with_the_device_side_replay_wrapper():
+    """train_local.sh trains with --replay_buffer_sample_prob=0.75 (reference train_local.sh:9): with the replay kernel behind every step the
+    exchange sends what it leaves in the library's buffer (ObsExchange source="obs") - restored checkpoints and the filed checkpoint's
+    observation included.  Two processes, 12 + 12 environments, 620 steps with planted collisions: every rank's gathered rows equal the
+    un-sharded replay-wrapped stepper's, and episodes were in fact replayed."""
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native
+    from tests import xchg_worker as xw
+    envs, steps, prob = 24, 620, 0.75
+    res = _run_workers("proc", 2, "f32", 0, steps=steps, envs=envs, timeout=600, replay=prob)
+    cfg = qcfg.make_config(num_envs=envs, seed=7, precision="f32", write_rew_info=False, episode_sums=True, **xw.REPLAY_KW)
+    st = native.Stepper(cfg, device=0)
+    st.replay_enable(prob)
+    acts = torch.as_tensor(xw.replay_actions(steps, envs, cfg.num_agents)).cuda()
+    obs = st.tensor("obs")
+    st.reset()
+    torch.cuda.synchronize()
+    exp = [obs.cpu().numpy().copy()]
+    st.replay_set_active(None)
+    for t in range(steps):
+        torch.cuda.synchronize()
+        xw.plant_collisions(st, 0)
+        st.step(acts[t].data_ptr())
+        torch.cuda.synchronize()
+        exp.append(obs.cpu().numpy().copy())
+    rs = st.replay_stats()
+    assert int(rs["replayed"].sum()) >= 2 and int(rs["buffer_len"].sum()) >= 2, (rs["replayed"], rs["buffer_len"])   # the scenario does replay
+    st.close()
+    assert sum(int(r[f"replayed{k}"]) for k, r in enumerate(res)) == int(rs["replayed"].sum())
+    for k, r in enumerate(res):
+        assert int(r[f"err{k}"]) == 0
+        got = r[f"rows{k}"]
+        assert got.shape[0] == steps + 1
+        for i in range(steps + 1):
+            assert np.array_equal(got[i], exp[i]), f"rank {k}: gathered rows after step {i} differ from the un-sharded replay-wrapped stepper"
 
 
 def test_two_processes_verify_against_an_independent_gather():
@@ -255,3 +292,29 @@ def test_obs_target_is_refused_with_device_replay():
     with pytest.raises(native.QsError):
         st.set_obs_target(st.ptr("rew_info"))
     st.close()
+
+
+@pytest.mark.parametrize("wire", ["bf16", "q8"])
+def test_batched_env_gathers_with_the_published_recipe_flags(wire):
+    """--quads_gather_obs together with --replay_buffer_sample_prob=0.75 (what train_local.sh trains with) at world size 1: the env steps,
+    gathered_obs() is the wire form of the rows step() returned, check_exchange() stays quiet"""
+    import torch
+    from quad_swarm_rl_amd import parallel
+    from quad_swarm_rl_amd.sf_env import BatchedQuadSwarm
+    env = BatchedQuadSwarm(16, device=0, seed=3, replay_buffer_sample_prob=0.75, num_gpus=1, gather_obs=True, obs_wire=wire, num_agents=8,
+                           neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, quads_mode="mix", ep_time=0.4)
+    assert env.obs_transport == "rccl" and env.vec.exchange.source == "obs"
+    obs, _ = env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(90):   # two episode ends inside
+        act = torch.rand((env.num_agents, 4), device="cuda", generator=g) * 2 - 1
+        out = env.step(act)
+        rows = out[0]["obs"]
+        got = env.gathered_obs()
+        torch.cuda.synchronize()
+        assert torch.equal(got, parallel.quantize_rows_reference(rows, wire, env.vec.exchange.q8)), t
+    f = env.gathered_obs_f32()
+    torch.cuda.synchronize()
+    assert f.shape == rows.shape and (f[:, :18] - rows[:, :18]).abs().max().item() < 0.05
+    env.check_exchange()
+    env.close()

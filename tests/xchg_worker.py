@@ -25,6 +25,25 @@ def global_actions(steps, total_envs, n, seed=0):
     return np.random.RandomState(seed).uniform(-1, 1, size=(steps, total_envs * n, 4)).astype(np.float32)
 
 
+# ---- the replay scenario (--replay P): drones that hover (crash rewards stay at zero), a collision planted at tick 169 in every third
+# environment, 2.6-s episodes, every replay buffer switched on: checkpoints, filed events and restored episodes within ~600 steps ----
+REPLAY_KW = dict(num_agents=4, neighbor_visible_num=2, neighbor_obs_type="pos_vel", use_numba=True, ep_time=2.6)
+
+
+def replay_actions(steps, total_envs, n, seed=1):
+    return (0.06 + np.random.RandomState(seed).uniform(-0.02, 0.02, size=(steps, total_envs * n, 4))).astype(np.float32)
+
+
+def plant_collisions(stepper, first_global_env):
+    """two drones 3 cm apart at tick 169 in the environments whose GLOBAL index is a multiple of 3 (the same envs however the batch is sharded)"""
+    ticks = stepper.to_host("tick")
+    for e in np.nonzero(ticks == 169)[0]:
+        if (first_global_env + int(e)) % 3 == 0:
+            s, tk = stepper.get_state(int(e))
+            s[1, 0:3] = s[0, 0:3] + np.array([0.03, 0.0, 0.0]); s[1, 3:6] = s[0, 3:6]
+            stepper.set_state(int(e), s, tk)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=["proc", "local"], required=True)
@@ -39,6 +58,7 @@ def main():
     ap.add_argument("--hold", type=int, default=1)
     ap.add_argument("--transport", default="peer", choices=["peer", "fused"])
     ap.add_argument("--verify", type=int, default=0)
+    ap.add_argument("--replay", type=float, default=0.0, help="device-side replay wrapper with this sample probability (the replay scenario above, eager steps)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
 
@@ -46,8 +66,9 @@ def main():
     from quad_swarm_rl_amd import config as qcfg, native, parallel
 
     W, E = args.world, args.envs // args.world
-    N = KW["num_agents"]
-    acts = global_actions(max(args.steps, args.graph), args.envs, N)
+    kw = REPLAY_KW if args.replay > 0 else KW
+    N = kw["num_agents"]
+    acts = replay_actions(args.steps, args.envs, N) if args.replay > 0 else global_actions(max(args.steps, args.graph), args.envs, N)
     ranks = [args.rank] if args.mode == "proc" else list(range(W))
     if args.mode == "proc":
         import torch.distributed as dist
@@ -55,8 +76,10 @@ def main():
 
     steppers, exs, act_dev = {}, {}, {}
     for r in ranks:
-        cfg = qcfg.make_config(num_envs=E, seed=7, env_id_offset=r * E, precision="f32", write_rew_info=False, **KW)
+        cfg = qcfg.make_config(num_envs=E, seed=7, env_id_offset=r * E, precision="f32", write_rew_info=False, episode_sums=args.replay > 0, **kw)
         steppers[r] = native.Stepper(cfg, device=0)
+        if args.replay > 0:
+            steppers[r].replay_enable(args.replay)
         act_dev[r] = torch.as_tensor(acts[:, r * E * N:(r + 1) * E * N]).cuda().contiguous()
     if args.mode == "proc":
         r = args.rank
@@ -79,6 +102,9 @@ def main():
     for r in ranks:
         exs[r].reset()
     snap()
+    if args.replay > 0:
+        for r in ranks:
+            steppers[r].replay_set_active(None)
     stride = E * N * 4 * 4
     if args.graph:
         warm = 0
@@ -96,6 +122,9 @@ def main():
         warm = 0
         for t in range(args.steps):
             for r in ranks:
+                if args.replay > 0:
+                    torch.cuda.synchronize()
+                    plant_collisions(steppers[r], r * E)
                 exs[r].step(act_dev[r].data_ptr() + t * stride)
             snap()
     torch.cuda.synchronize()
@@ -104,7 +133,13 @@ def main():
         for r in ranks:
             verified[r] = exs[r].verify() if args.mode == "proc" else (True, "")
     status = {r: exs[r].status() for r in ranks}
-    np.savez(args.out, warm=warm, **{f"rows{r}": np.stack(rec[r]) for r in ranks}, **{f"err{r}": status[r]["error"] for r in ranks},
+    extra = {}
+    if args.replay > 0:
+        for r in ranks:
+            rs = steppers[r].replay_stats()
+            extra[f"replayed{r}"] = int(rs["replayed"].sum())
+            extra[f"buffer{r}"] = int(rs["buffer_len"].sum())
+    np.savez(args.out, warm=warm, **extra, **{f"rows{r}": np.stack(rec[r]) for r in ranks}, **{f"err{r}": status[r]["error"] for r in ranks},
              **{f"pushes{r}": status[r]["pushes"] for r in ranks}, **{f"verify{r}": (1 if v[0] else 0) for r, v in verified.items()})
     for r in ranks:
         exs[r].close()
