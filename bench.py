@@ -656,6 +656,11 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(workload, args.cpu_seconds)
+            cb = out["cpu_baseline"]
+            # the ratio is always quoted WITH the thread count it was measured on: a CPU-over-GPU ratio is not a
+            # statement about kernel quality - roofline.frac is
+            cb["gpu_over_cpu"] = {"ratio": value / cb["value"], "cpu_threads": cb["cores"], "ratio_per_thread": value / cb["single_thread"],
+                                  "statement": f"{value / cb['value']:.1f}x the C oracle on {cb['cores']} host threads (cgroup quota {cb['cgroup_cpu_quota']}) of a {cb['cpu_model']}"}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

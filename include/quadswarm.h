@@ -278,14 +278,17 @@ int qs_get_kernel_time(qs_handle *h, double *avg_ms, int64_t *launches);
  * Noise tape (test instrument).  tape_host = [num_envs][len_per_env] float64: for every
  * environment the sequence of random draws the REFERENCE made (values in their final units, in its call order -
  * oracle/ref_harness/capture.py records them from the reference's numpy streams).  While a tape is set, qs_reset /
- * qs_step run a float64 flavour of the kernels in which every draw pops the tape instead of the counter-based stream,
- * so that a fixture captured from the reference (actions + tape + outputs) is replayed straight through the HIP
- * arithmetic (tests/test_hip_vs_reference.py) - the method of gym_art/quadrotor_multi/tests/test_numba_opt.py:59-119,
- * which compares two implementations under identical injected noise.  Requires QS_PRECISION_F64; NULL / 0 returns to the
- * Philox stream.  qs_get_tape_pos: draws consumed so far, per environment.
+ * qs_step run a flavour of the kernels (of the handle's precision) in which every draw pops the tape instead of the
+ * counter-based stream, so that a fixture captured from the reference (actions + tape + outputs) is replayed straight
+ * through the HIP arithmetic - the method of gym_art/quadrotor_multi/tests/test_numba_opt.py:59-119, which compares two
+ * implementations under identical injected noise: free-running in float64 (tests/test_hip_vs_reference.py, 1e-9), one
+ * step at a time from the reference's recorded states in float32 (tests/test_hip_vs_reference_f32.py, 1e-5).  NULL / 0
+ * returns to the Philox stream.  qs_get_tape_pos: draws consumed so far, per environment; qs_set_tape_pos: move the
+ * cursors (teacher forcing: the recorded tape position of the step about to be replayed).
  */
 int qs_set_noise_tape(qs_handle *h, const double *tape_host, int64_t len_per_env);
 int qs_get_tape_pos(qs_handle *h, int32_t *pos_host /* [num_envs] */);
+int qs_set_tape_pos(qs_handle *h, const int32_t *pos_host /* [num_envs] */);
 
 /*
  * Environment snapshots: device-side deep copies of single environments, replacing `deepcopy(self.env)` of the

@@ -30,8 +30,8 @@
 extern "C" int qs_obs_dim(const qs_config *c);
 extern "C" int qs_destroy(struct qs_handle *h);
 // noise-tape flavour of the kernels (qs_tape_kernels.hip, compiled with QS_TAPE)
-extern "C" int qs_tape_lds_bytes(const qs_config *cfg, int obs_dim, int full);
-extern "C" int qs_tape_launch(int which, const qs_config *cfg, int obs_dim, int full, const void *consts_f64, const void *ptrs, const void *actions, void *stream);
+extern "C" int qs_tape_lds_bytes(const qs_config *cfg, int obs_dim, int full, int real_size);
+extern "C" int qs_tape_launch(int which, const qs_config *cfg, int obs_dim, int full, int real_size, const void *consts, const void *ptrs, const void *actions, void *stream);
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(QS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
@@ -618,7 +618,7 @@ int qs_destroy(qs_handle *h) {
 
 static int launch_reset(qs_handle *h, hipStream_t s) {
     if (h->d_tape) {
-        hipError_t e = (hipError_t)qs_tape_launch(0, &h->cfg, h->obs_dim, h->full ? 1 : 0, &h->kd, &h->pf, nullptr, s);
+        hipError_t e = (hipError_t)qs_tape_launch(0, &h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size, h->real_size == 8 ? (const void *)&h->kd : (const void *)&h->kf, &h->pf, nullptr, s);
         if (e != hipSuccess) return fail(QS_ERR_HIP, std::string("tape reset kernel: ") + hipGetErrorString(e));
         return QS_OK;
     }
@@ -673,9 +673,10 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
         HIP_TRY(hipEventRecord(e0, s));
     }
     if (h->d_tape) {   // noise-tape flavour: one launch per control step
-        const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * sizeof(double);
+        const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * (size_t)h->real_size;
         for (int t = 0; t < ksteps; ++t) {
-            hipError_t e = (hipError_t)qs_tape_launch(1, &h->cfg, h->obs_dim, h->full ? 1 : 0, &h->kd, &h->pf, (const char *)actions + stride * t, s);
+            hipError_t e = (hipError_t)qs_tape_launch(1, &h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size, h->real_size == 8 ? (const void *)&h->kd : (const void *)&h->kf, &h->pf,
+                                                     (const char *)actions + stride * t, s);
             if (e != hipSuccess) return fail(QS_ERR_HIP, std::string("tape step kernel: ") + hipGetErrorString(e));
         }
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
@@ -1015,9 +1016,8 @@ int qs_set_noise_tape(qs_handle *h, const double *tape_host, int64_t len_per_env
     h->tape_len = 0;
     h->pf.tape = nullptr; h->pf.tape_pos = nullptr; h->pf.tape_len = 0;
     if (!tape_host || len_per_env <= 0) return QS_OK;   // back to the counter-based stream
-    if (h->real_size != 8) return fail(QS_ERR_UNSUPPORTED, "the noise tape is replayed by the float64 kernels: create the handle with QS_PRECISION_F64");
     if (len_per_env > 0x7fffff00ll) return fail(QS_ERR_INVALID, "tape too long");
-    if (qs_tape_lds_bytes(&h->cfg, h->obs_dim, h->full ? 1 : 0) > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "noise tape: the single-wave layout does not fit the LDS");
+    if (qs_tape_lds_bytes(&h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size) > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "noise tape: the single-wave layout does not fit the LDS");
     const size_t E = h->cfg.num_envs, bytes = E * (size_t)len_per_env * sizeof(double);
     HIP_TRY(hipMalloc((void **)&h->d_tape, bytes));
     HIP_TRY(hipMalloc((void **)&h->d_tape_pos, E * sizeof(int32_t)));
@@ -1025,6 +1025,16 @@ int qs_set_noise_tape(qs_handle *h, const double *tape_host, int64_t len_per_env
     HIP_TRY(hipMemset(h->d_tape_pos, 0, E * sizeof(int32_t)));
     h->tape_len = len_per_env;
     h->pf.tape = h->d_tape; h->pf.tape_pos = h->d_tape_pos; h->pf.tape_len = len_per_env;
+    return QS_OK;
+}
+
+int qs_set_tape_pos(qs_handle *h, const int32_t *pos_host) {
+    if (!h || !pos_host) return fail(QS_ERR_INVALID, "null argument");
+    if (!h->d_tape) return fail(QS_ERR_INVALID, "no noise tape set");
+    for (int e = 0; e < h->cfg.num_envs; ++e) if (pos_host[e] < 0 || pos_host[e] > h->tape_len) return fail(QS_ERR_INVALID, "tape position out of range");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(h->d_tape_pos, pos_host, (size_t)h->cfg.num_envs * sizeof(int32_t), hipMemcpyHostToDevice));
     return QS_OK;
 }
 

@@ -148,6 +148,7 @@ def lib():
         L.qs_replay_set_active.argtypes = [vp, C.POINTER(C.c_uint8)]
         L.qs_set_noise_tape.argtypes = [vp, C.POINTER(C.c_double), C.c_int64]
         L.qs_get_tape_pos.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.qs_set_tape_pos.argtypes = [vp, C.POINTER(C.c_int32)]
         L.qs_set_obs_target.argtypes = [vp, vp]
         L.qs_set_obs_exchange.argtypes = [vp, vp, C.c_int32]
         L.qs_xchg_fused_desc.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
@@ -185,7 +186,7 @@ EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_defau
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_state_array_copy", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_spec_status", "qs_kernel_flavor",
                     "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
-                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target", "qs_set_obs_exchange"]
+                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_set_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target", "qs_set_obs_exchange"]
 # include/quadswarm_exchange.h
 EXCHANGE_SYMBOLS = ["qs_xchg_create", "qs_xchg_destroy", "qs_xchg_export", "qs_xchg_attach", "qs_xchg_attach_local", "qs_xchg_staging",
                     "qs_xchg_gathered", "qs_xchg_push", "qs_xchg_wait", "qs_xchg_release", "qs_xchg_wait_release", "qs_xchg_fused_desc", "qs_xchg_status", "qs_obs_pack", "qs_xchg_last_error",
@@ -349,6 +350,11 @@ class Stepper:
         out = np.zeros(self.E, dtype=np.int32)
         _check(lib().qs_get_tape_pos(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
+
+    def set_tape_pos(self, pos):
+        """move the per-environment tape cursors (teacher forcing from a fixture's recorded tape positions)"""
+        a = np.ascontiguousarray(np.broadcast_to(np.asarray(pos, dtype=np.int32), (self.E,)))
+        _check(lib().qs_set_tape_pos(self._h, a.ctypes.data_as(C.POINTER(C.c_int32))))
 
     @property
     def specialized(self):

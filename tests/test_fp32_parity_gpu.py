@@ -71,7 +71,7 @@ def test_free_running_f32_event_free_windows(case, team, spec, monkeypatch):
         monkeypatch.setenv("QS_TEAM", team)
     if spec is not None:
         monkeypatch.setenv("QS_SPEC", spec)
-    E, steps, tol = 6, 100, 1e-4
+    E, steps, tol = 6, 100, 1e-5   # north_star's tolerance (round 3 ran this at 1e-4; the worst relative error seen was 3e-6)
     pr = thp.Pair(case, E, "f32", seed=4321)
     N = pr.N
     rng = np.random.RandomState(21)

@@ -456,13 +456,15 @@ def test_determinism_and_sharding_invariance():
         np.testing.assert_array_equal(a, np.concatenate([b, c], axis=0))
 
 
-def test_full_size_properties_c2():
-    """BASELINE configs[1] at full size (8 drones x 1024 envs, fp32 production kernels): properties that do not need the
-    oracle - sharding invariance (two 512-env handles == one 1024-env handle, bit for bit), finite outputs, mask / counter
-    consistency, auto-reset cadence."""
+@pytest.mark.parametrize("case,E", [("c2_n8_dw", 1024), ("c3_n8_obst", 1024), ("c4_n32_svs", 512)])
+def test_full_size_properties(case, E):
+    """BASELINE configs[1] / [2] and the per-GPU shard of configs[3] at full size (8 x 1024, 8 x 1024 with obstacles, 32 x 512 on the
+    4-wave pair-once team kernel; fp32 production kernels): properties that do not need the oracle - sharding invariance (two half-size
+    handles == one full-size handle, bit for bit), finite outputs, mask / counter consistency, obstacle-hit indices in range, auto-reset
+    cadence."""
     from quad_swarm_rl_amd import native
-    kw = dict(CASES["c2_n8_dw"], ep_time=0.3)
-    E, N, steps = 1024, 8, 40
+    kw = dict(CASES[case], ep_time=0.3)
+    N, steps = kw["num_agents"], 40
     rng = np.random.RandomState(11)
     acts = rng.uniform(-1, 1, size=(steps, E * N, 4)).astype(np.float32)
 
@@ -476,20 +478,23 @@ def test_full_size_properties_c2():
             st.from_host("actions", acts[t, lo:hi])
             st.step()
             out.append((st.to_host("obs").copy(), st.to_host("reward").copy(), st.to_host("done").copy(),
-                        st.to_host("unique_col_mask").copy(), st.to_host("counters").copy(), st.to_host("col_pair_mask").copy()))
+                        st.to_host("unique_col_mask").copy(), st.to_host("counters").copy(), st.to_host("col_pair_mask").copy(),
+                        st.to_host("obst_new_mask").copy(), st.to_host("obst_hit_idx").copy(), st.to_host("room_new_mask").copy()))
         st.check_errors()
+        M = st.cfg.num_obstacles
         st.close()
-        return out
+        return out, M
 
-    full, a, b = run(E, 0), run(E // 2, 0), run(E // 2, E // 2)
+    (full, M), (a, _), (b, _) = run(E, 0), run(E // 2, 0), run(E // 2, E // 2)
     for t in range(steps):
-        obs, rew, done, uniq, cnt, pairs = full[t]
-        for k in range(6):
+        obs, rew, done, uniq, cnt, pairs, obst_new, ohit, room = full[t]
+        for k in range(9):
             axis = 1 if k == 4 else 0
             np.testing.assert_array_equal(full[t][k], np.concatenate([a[t][k], b[t][k]], axis=axis), err_msg=f"step {t} output {k}")
         assert np.isfinite(obs).all() and np.isfinite(rew).all()
         assert done.all() == ((t + 1) % 31 == 0) and done.any() == done.all()          # ep_len 30: done on every 31st step, all envs
-        assert (uniq >> N == 0).all()                                                    # ids are drone indices < N
+        assert (uniq >> np.uint64(N) == 0).all() and (obst_new >> np.uint64(N) == 0).all() and (room >> np.uint64(N) == 0).all()   # ids are drone indices < N
+        assert ((ohit >= -1) & (ohit < max(M, 1))).all() and (kw.get("use_obstacles") or (ohit == -1).all())        # first-hit obstacle index
         pm = pairs.reshape(E, N)
         for d in range(N):                                                              # pair bits only above the own index
             assert ((pm[:, d] & ((1 << (d + 1)) - 1)) == 0).all()
