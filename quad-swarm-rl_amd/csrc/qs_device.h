@@ -17,6 +17,9 @@ enum : uint32_t {
     F_PREV_WALL = 1u << 4, F_PREV_CEIL = 1u << 5, F_PREV_ROOM = 1u << 6, F_PREV_OBST = 1u << 7,
     F_REACHED = 1u << 8, F_COL_AGENT_OK = 1u << 9, F_COL_OBST_OK = 1u << 10,
     F_IN_COL = 1u << 11,   // this drone's id was in a colliding pair last step (prev_ids of quadrotor_multi.py:440)
+    // bookkeeping rows that are only touched when they matter (DESIGN.md 4a "bytes"): the state of those rows in HBM is described by a flag
+    F_RING_LIVE = 1u << 12,   // dist_ring of this drone holds maintained values; clear = every entry counts as "far" (see goal_distance_log)
+    F_NEWPAIR_NZ = 1u << 13,  // the new_pair_mask word last stored for this drone was non-zero (clear = the word in HBM is 0: no store needed for a 0)
     F_SVD_SHIFT = 16, F_SVD_MASK = 0xffu << 16
 };
 

@@ -1055,6 +1055,8 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
         for (int q = 0; q < 9; ++q) blk_at<real>(p.blk, p.blk.rot, q, e, i, N) = d.rot[q];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { blk_at<real>(p.blk, p.blk.rot_damp, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.cmds_damp, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.ring, q, e, i, N) = 0; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) blk_at<real>(p.blk, p.blk.sums, q, e, i, N) = 0;   // the step kernels leave the sums alone until the episode's 5-s window opens (qs_step_sem.h)
         blk_at<uint32_t>(p.blk, p.blk.flags, 0, e, i, N) = d.flags;
         blk_at<uint64_t>(p.blk, p.blk.pair, 0, e, i, N) = 0;
         p.new_pair_mask[g] = 0;

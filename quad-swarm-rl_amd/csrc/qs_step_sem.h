@@ -150,22 +150,45 @@ __device__ __forceinline__ void collision_rewards(const Consts<real> &c, const r
 
 // distance-to-goal log, reached_goal (:542-546), windowed sums for the episode stats (:649-661).  metric: approach_goal_metric of the
 // env's scenario.
+//
+// Both logs are PRIVATE state (nothing but reached_goal and the three distance_to_goal_* statistics of a finished episode depends on
+// them), kept so that their rows in HBM are touched only on the steps that can matter (the throughput kernels skip the loads / stores
+// wave-uniformly; the others keep the same representation so that every kernel of a handle reads what any other wrote):
+//  * dist_ring (the last 4 distances; reached_goal = mean of 5 < metric * dt, i.e. within millimetres of the goal): a mean of five
+//    non-negative values is below x only if every one of them is below 5 x, so a distance >= 8 * metric * dt can never be part of a
+//    triggering window.  Such entries are not maintained: the ring of a drone is valid only while F_RING_LIVE says so (set while the
+//    ring holds at least one "near" entry and the goal has not been reached); otherwise every entry stands for "far" (1e30).  The
+//    decisions are the reference's exactly - a window that contains a far entry gives false in both forms, with a margin of 1.6x.
+//  * dist_sums (sums of the last 1 / 3 / 5 s): zero in HBM from the reset until the 5-s window of the episode opens (they used to be
+//    stored as zeros on every step before it), accumulated from there, zeroed again by the step that ends the episode.
 template <typename real>
-__device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real metric, int tick, uint32_t &flags, real ring[4], real sums[3], const real *ri, real eps_dist[3]) {
+__device__ __forceinline__ bool ring_near(const Consts<real> &c, real metric, real dist) { return dist * c.inv_dt < (real)8 * metric; }
+template <typename real>
+__device__ __forceinline__ bool sums_window_open(const Consts<real> &c, int tick) { return tick > c.ep_len + 1 - 5 * c.control_freq; }
+// does this drone's ring row have to be read (and written back) on this step?
+template <typename real>
+__device__ __forceinline__ bool ring_needed(const Consts<real> &c, real metric, uint32_t flags, const real *ri) {
+    return !(flags & F_REACHED) && ((flags & F_RING_LIVE) || ring_near<real>(c, metric, -ri[QS_RI_RAW_POS]));
+}
+template <typename real>
+__device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real metric, int tick, bool done, uint32_t &flags, real ring[4], real sums[3], const real *ri, real eps_dist[3]) {
     const real dnow = -ri[QS_RI_RAW_POS];
+    if (!(flags & F_RING_LIVE)) { ring[0] = ring[1] = ring[2] = ring[3] = (real)1e30; }   // not maintained = far (also: whatever the row holds after a reset)
     if (tick >= 5 && !(flags & F_REACHED)) {
         real mean5 = ((((ring[3] + ring[2]) + ring[1]) + ring[0]) + dnow) * (real)0.2;
         if (mean5 * c.inv_dt < metric) flags |= F_REACHED;
     }
     ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = dnow;
+    const bool live = !(flags & F_REACHED) && (ring_near<real>(c, metric, ring[0]) | ring_near<real>(c, metric, ring[1]) | ring_near<real>(c, metric, ring[2]) | ring_near<real>(c, metric, ring[3]));
+    flags = live ? (flags | F_RING_LIVE) : (flags & ~F_RING_LIVE);
     const int total = c.ep_len + 1;
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
         const int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * c.control_freq;
-        real sum = (tick == 1) ? (real)0 : sums[w];
+        real sum = (tick == 1 || !sums_window_open<real>(c, tick)) ? (real)0 : sums[w];
         if (tick > total - win) sum += dnow;
-        sums[w] = sum;
         eps_dist[w] = c.inv_dt * (sum * c.inv_win[w]);
+        sums[w] = done ? (real)0 : sum;
     }
 }
 
