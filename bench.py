@@ -556,6 +556,7 @@ def main():
         st.step(aptr + (t % ring) * astride, stream=stream)
     kernel_ms, launches = st.kernel_time()
     st.set_profiling(False)
+    st_team = bool(st.team)
     kernel_name, flavor = st.kernel_name, ("config-specialised, " if st.specialized else "generic, ") + f"{st.waves_per_workgroup} wave{'s' if st.waves_per_workgroup > 1 else ''} per workgroup"
     specialized = bool(st.specialized)
     if exchange is not None:
@@ -591,6 +592,45 @@ def main():
             "shaped_episode_sums_and_rew_info": quick(episode_sums=True, write_rew_info=True, extra_bytes=268),
             "downwash_off": quick(kw_over=dict(use_downwash=False)),
         }
+        # resident-state stepping (include/quadswarm.h qs_step_gated): ONE launch per 64 control steps keeps the state in registers,
+        # waits per step and workgroup for the step's actions and publishes its outputs; the actions come from a producer kernel on another
+        # stream (qs_gate_produce: copies each batch of the pre-drawn table into the gate's ring, written through the L2, then raises the flags)
+        # - running ahead of the stepper (bounded by the 64-slot ring), or closed loop (the batch of step s only after the outputs of s - 1).
+        def gated_line(closed_loop):
+            try:
+                c2 = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f32", write_rew_info=args.rew_info, **kw)
+                s2 = native.Stepper(c2, device=local_rank)
+                s2.gate_create(ring_len=ring, wg_per_group=8)
+                s2.reset(stream=stream)
+                torch.cuda.synchronize()
+                side, feed = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+                k, reps = 64, max(2, min(max(args.steps, 200), 2000) // 64)
+                s2.step_gated(k, stream=side); s2.gate_produce(aptr, ring, k, closed_loop, stream=feed)   # warm-up launch pair
+                torch.cuda.synchronize()
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                ev0.record(side)
+                for _ in range(reps):
+                    s2.step_gated(k, stream=side)
+                    s2.gate_produce(aptr, ring, k, closed_loop, stream=feed)
+                ev1.record(side)
+                torch.cuda.synchronize()
+                host = time.perf_counter() - t0
+                d = ev0.elapsed_time(ev1) * 1e-3
+                st2 = s2.gate_status()
+                s2.check_errors()
+                rec = {"value": T * 2 * reps * k / d, "kernel_avg_us": 1e6 * d / (reps * k), "host_clock_us_per_step": 1e6 * host / (reps * k), "steps": reps * k,
+                       "steps_per_launch": k, "specialized": bool(s2.specialized), "gate_status": st2,
+                       "achieved_GBs": ALGO_BYTES_PER_DRONE_STEP[workload] * T / (d / (reps * k)) / 1e9,
+                       "producer": "closed loop: batch s is written only after the outputs of step s - 1 of the same workgroups are published" if closed_loop
+                                   else "runs ahead of the stepper, bounded by the 64-slot action ring"}
+                s2.close()
+                return rec
+            except Exception as exc:   # noqa: BLE001 - an optional extra must not cost the bench line
+                return {"status": "failed", "error": f"{type(exc).__name__}: {exc}"}
+        if st_team:
+            variants["resident_state_gated_producer_ahead"] = gated_line(False)
+            variants["resident_state_gated_closed_loop"] = gated_line(True)
         if not kw.get("use_obstacles"):
             # what train_local.sh trains on: --quads_mode=mix (scenarios/mix.py: every env draws one of the non-obstacle scenarios per
             # episode) with the device-side episode sums - the full-scenario kernels; 700 warm-up steps so that the

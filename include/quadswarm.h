@@ -224,6 +224,43 @@ int qs_step(qs_handle *h, const void *actions_dev, void *stream);
  * one launch sequence, optionally replayed from a captured hipGraph). */
 int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream);
 
+/*
+ * Resident-state stepping: the step kernel stays on the GPU across control steps.
+ *
+ * The reference steps its environments one `env.step(actions)` call at a time (quadrotor_multi.py:413); here that is one kernel launch
+ * per control step, and at the BASELINE shapes (8192 drones = 128 workgroups) a launch is as long as the dependent-launch gap plus one
+ * workgroup's critical path, of which ~1.4 us is the state's round trip through HBM.  qs_step_gated(h, k) instead launches ONE kernel for
+ * k control steps that keeps the drone state in registers / LDS (the multi-step kernels of qs_step_many) and, per control step and
+ * workgroup, WAITS until the step's actions are in the action ring and PUBLISHES when the step's outputs (observation rows, reward,
+ * done, collision masks) are in HBM - through sequence words in device memory, so that the producer of the actions (the policy's
+ * kernels on another stream) runs concurrently:
+ *     producer, for sequence number s (1-based, counted since qs_gate_create), for the workgroups of group g:
+ *         wait done_flag[w] >= s - 1 for the group's workgroups w   (closed loop: the policy reads the outputs of step s - 1)
+ *         write the actions of the group's drones into  action_ring + ((s - 1) % ring_len) * action_stride_bytes   (real [E*N][4])
+ *         make them visible at device scope (write-through stores / release), then act_flag[g] = s
+ *     stepper (this library): waits act_flag[g] >= s, steps, writes the outputs through the L2, then done_flag[w] = s.
+ * Workgroup w steps the environments [w * envs_per_workgroup, (w + 1) * envs_per_workgroup); group g = w / wg_per_group.  All waits
+ * are bounded (QS_GATE_TIMEOUT_MS, default 500 ms of the device wall clock): a missing producer raises status bit 1 and the launch runs on
+ * without waiting instead of hanging the GPU.  The producer MUST be able to run while the gated launch is resident: issue it on another
+ * stream.  State is written back to HBM at the end of the launch (qs_get_state, snapshots and plain qs_step work between gated
+ * launches).  Team kernels only (qs_kernel_flavor); not together with the replay wrapper, a noise tape or the fused exchange.
+ * qs_gate_produce: the trivial producer used by bench.py and the tests - k steps of the protocol above with the action batches taken
+ * round-robin from a table of n_src batches resident in HBM (closed_loop = 0: runs ahead, bounded only by the ring).
+ * qs_gate_status: out[0] = status bits (1 = action wait timed out, 2 = producer wait timed out), out[1] = steps launched,
+ * out[2] = min act_flag, out[3] = min done_flag (synchronises the device).
+ */
+typedef struct qs_gate_info_t {
+    void *action_ring; int64_t action_stride_bytes; int32_t ring_len;
+    int32_t groups, wg_per_group, workgroups, envs_per_workgroup;
+    unsigned long long *act_flag, *done_flag;
+    int64_t steps_launched, steps_fed;
+} qs_gate_info_t;
+int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group);
+int qs_gate_info(qs_handle *h, qs_gate_info_t *out);
+int qs_step_gated(qs_handle *h, int32_t k, void *stream);
+int qs_gate_produce(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, int32_t closed_loop, void *stream);
+int qs_gate_status(qs_handle *h, int64_t out[4]);
+
 int qs_sync(qs_handle *h, void *stream);
 int qs_get_buffers(qs_handle *h, qs_buffers *out);
 

@@ -114,4 +114,41 @@ __device__ __forceinline__ bool poll_ge(const unsigned long long *p, unsigned lo
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Resident-state stepping (include/quadswarm.h: qs_gate_*, qs_step_gated): the multi-step team kernels keep the drone state in registers
+// across control steps and, per step, WAIT for the step's actions and PUBLISH that its outputs are in HBM - through per-workgroup
+// sequence words in device memory, so that whoever produces the actions (a policy's kernels on another stream, the trivial producer
+// of the benchmark) runs concurrently, with no kernel boundary and no state round trip between two control steps.  Everything is on
+// ONE device: agent-scope accesses (`sc1`: the L2s of the 8 XCDs are not coherent with each other, so data handed between concurrently
+// running kernels is written through / read past them), relaxed flags behind `s_waitcnt vmcnt(0)` of the data, bounded polls.
+// ------------------------------------------------------------------------------------------------
+struct Gate {   // (sequence numbers: control steps since the gate was created, 1-based; a launch is told its base as a kernel argument)
+    unsigned long long timeout_ticks;
+    char *act_ring;                      // [ring_len][T][4] real: the action batch of sequence number s is slot (s - 1) % ring_len
+    unsigned long long act_stride;       // bytes of one batch
+    unsigned int ring_len, groups, wg_per_group, blocks;
+    unsigned int status, pad;            // status bits: 1 = an action wait timed out (the launch then stopped waiting), 2 = a producer wait timed out
+    unsigned long long *act_flag;        // [groups]  producer -> stepper: the actions of sequence number <= act_flag[g] for the workgroups of group g are in the ring
+    unsigned long long *done_flag;       // [blocks]  stepper -> consumers: obs / reward / done of sequence number done_flag[w] of workgroup w's environments are in HBM
+};
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool poll_ge_agent(const unsigned long long *p, unsigned long long want, unsigned long long timeout_ticks) {
+    if (ld_agent(p) >= want) return true;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < timeout_ticks) {
+        if (ld_agent(p) >= want) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return ld_agent(p) >= want;
+}
+// agent-scope data accesses: loads that miss this XCD's L2, stores that are written through it
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t ld16_sc1(const void *p) { u32x4_t v; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ unsigned int ld4_sc1(const void *p) { unsigned int v; asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ void st16_sc1(void *p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8_sc1(void *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st4_sc1(void *p, unsigned int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st1_sc1(void *p, unsigned int v) { asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
 }   // namespace qsx

@@ -77,6 +77,10 @@ struct qs_handle {
     double *d_tape = nullptr;
     int32_t *d_tape_pos = nullptr;
     int64_t tape_len = 0;
+    // resident-state stepping (qs_gate_create / qs_step_gated): device descriptor + action ring + sequence flags, one allocation
+    qsx::Gate *d_gate = nullptr;
+    qsx::Gate gate_host = {};
+    unsigned long long gate_step_seq = 0, gate_prod_seq = 0;   // control steps launched so far by qs_step_gated / fed so far by qs_gate_produce
     // profiling of the step kernel
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -609,6 +613,7 @@ int qs_destroy(qs_handle *h) {
     if (h->h_mask) (void)hipHostFree(h->h_mask);
     if (h->d_tape) (void)hipFree(h->d_tape);
     if (h->d_tape_pos) (void)hipFree(h->d_tape_pos);
+    if (h->d_gate) (void)hipFree(h->d_gate);
     for (auto &ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -660,7 +665,7 @@ int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream) {
     return QS_OK;
 }
 
-static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int ksteps = 1) {
+static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int ksteps = 1, bool gated = false) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling) {
         if (h->events_used == h->events.size()) {
@@ -687,10 +692,11 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     // the fused exchange epilogue exists in the one-step kernels only: a multi-step launch would advance the environments without sending
     // their rows and desynchronise push / wait sequence numbers (qs_step_many splits into single steps while an exchange is set)
     if (pf.xchg != nullptr && ksteps > 1) return fail(QS_ERR_UNSUPPORTED, "multi-step launches do not exchange observation rows: qs_set_obs_exchange is active");
+    if (gated) pf.xchg = (const qsx::XchgDev *)h->d_gate;   // the multi-step team kernels read the exchange slot as their gate (qs_step_team.inc)
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
-        HIP_TRY(hipModuleLaunchKernel(ksteps == 1 ? h->spec_step : h->spec_rollout, h->blocks, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
+        HIP_TRY(hipModuleLaunchKernel((ksteps == 1 && !gated) ? h->spec_step : h->spec_rollout, h->blocks, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
     }
@@ -698,7 +704,7 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
                                                                              (const TYPE *)actions, h->lds, h->epb, ##__VA_ARGS__)
 #define QS_LAUNCH_ALL(CONSTS, PTRS, TYPE) do { \
         if (h->team) { \
-            if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); } \
+            if (ksteps == 1 && !gated) { if (h->full) QS_LAUNCH(qs_step_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); } \
             else { if (h->full) QS_LAUNCH(qs_rollout_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); else QS_LAUNCH(qs_rollout_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); } \
         } else { \
             if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_kernel_full, QS_WAVE, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_kernel, QS_WAVE, CONSTS, PTRS, TYPE); } \
@@ -750,6 +756,114 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
         int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream, (k - t) < per ? (k - t) : per);
         if (rc != QS_OK) return rc;
     }
+    return QS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Resident-state stepping (include/quadswarm.h)
+// ------------------------------------------------------------------------------------------------
+// the benchmark's / the tests' producer: per control step it (closed_loop: waits until the outputs of the previous step of ITS workgroups
+// are published, else: only until the ring slot is free), copies the group's share of the next action batch from a table resident in HBM
+// into the ring - written through the L2 - and raises the group's sequence word
+__global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, const char *src, unsigned int n_src, unsigned long long seq0, int k, int closed_loop,
+                                                                unsigned long long wg_bytes, unsigned long long batch_bytes) {
+    const unsigned int grp = blockIdx.x, w0 = grp * G->wg_per_group, w1 = (w0 + G->wg_per_group < G->blocks) ? w0 + G->wg_per_group : G->blocks;
+    const unsigned long long lo = (unsigned long long)w0 * wg_bytes, hi0 = (unsigned long long)w1 * wg_bytes, hi = hi0 < batch_bytes ? hi0 : batch_bytes;
+    __shared__ int dead;
+    if (threadIdx.x == 0) dead = 0;
+    __syncthreads();
+    for (int t = 0; t < k; ++t) {
+        const unsigned long long seq = seq0 + (unsigned long long)t + 1;
+        const unsigned long long need = closed_loop ? seq - 1 : (seq > G->ring_len ? seq - G->ring_len : 0);
+        if (need > 0 && !dead && threadIdx.x < w1 - w0) {
+            if (!qsx::poll_ge_agent(&G->done_flag[w0 + threadIdx.x], need, G->timeout_ticks)) { dead = 1; atomicOr(&G->status, 2u); }
+        }
+        __syncthreads();
+        const char *from = src + ((seq - 1) % n_src) * batch_bytes;
+        char *to = G->act_ring + ((seq - 1) % G->ring_len) * G->act_stride;
+        for (unsigned long long off = lo + 16ull * threadIdx.x; off < hi; off += 16ull * 256) qsx::st16_sc1(to + off, *(const qsx::u32x4_t *)(from + off));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) qsx::st_agent(&G->act_flag[grp], seq);
+    }
+}
+
+int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group) {
+    if (!h || ring_len < 1 || ring_len > 65536 || wg_per_group < 1) return fail(QS_ERR_INVALID, "qs_gate_create: bad argument");
+    if (h->d_gate) return fail(QS_ERR_INVALID, "qs_gate_create: the handle has a gate already");
+    if (!h->team) return fail(QS_ERR_UNSUPPORTED, "resident-state stepping lives in the team kernels (batches up to ~8 waves per CU, see qs_kernel_flavor): larger batches are bandwidth-bound, not launch-bound");
+    if (h->replay_on || h->d_tape) return fail(QS_ERR_UNSUPPORTED, "resident-state stepping is not available with the device-side replay wrapper or a noise tape");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t T = (size_t)h->cfg.num_envs * h->cfg.num_agents, stride = (T * 4 * (size_t)h->real_size + 255) & ~(size_t)255;
+    const unsigned int groups = (unsigned int)((h->blocks + wg_per_group - 1) / wg_per_group);
+    const size_t o_ring = 256, o_act = o_ring + stride * (size_t)ring_len, o_done = o_act + (((size_t)groups * 8 + 255) & ~(size_t)255), total = o_done + (((size_t)h->blocks * 8 + 255) & ~(size_t)255);
+    char *base = nullptr;
+    HIP_TRY(hipMalloc((void **)&base, total));
+    HIP_TRY(hipMemset(base, 0, total));
+    qsx::Gate g;
+    memset(&g, 0, sizeof g);
+    int khz = 100000;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    long ms = 500;
+    if (const char *ev = getenv("QS_GATE_TIMEOUT_MS")) { const long v = atol(ev); if (v > 0) ms = v; }
+    g.timeout_ticks = (unsigned long long)khz * (unsigned long long)ms;
+    g.act_ring = base + o_ring; g.act_stride = stride; g.ring_len = (unsigned int)ring_len; g.groups = groups; g.wg_per_group = (unsigned int)wg_per_group; g.blocks = (unsigned int)h->blocks;
+    g.act_flag = (unsigned long long *)(base + o_act); g.done_flag = (unsigned long long *)(base + o_done);
+    HIP_TRY(hipMemcpy(base, &g, sizeof g, hipMemcpyHostToDevice));
+    HIP_TRY(hipDeviceSynchronize());
+    h->d_gate = (qsx::Gate *)base; h->gate_host = g; h->gate_step_seq = 0; h->gate_prod_seq = 0;
+    return QS_OK;
+}
+
+int qs_gate_info(qs_handle *h, qs_gate_info_t *out) {
+    if (!h || !out) return fail(QS_ERR_INVALID, "null argument");
+    if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
+    const qsx::Gate &g = h->gate_host;
+    out->action_ring = g.act_ring; out->action_stride_bytes = (int64_t)g.act_stride; out->ring_len = (int32_t)g.ring_len;
+    out->act_flag = g.act_flag; out->done_flag = g.done_flag; out->groups = (int32_t)g.groups; out->wg_per_group = (int32_t)g.wg_per_group; out->workgroups = (int32_t)g.blocks;
+    out->envs_per_workgroup = h->epb; out->steps_launched = (int64_t)h->gate_step_seq; out->steps_fed = (int64_t)h->gate_prod_seq;
+    return QS_OK;
+}
+
+int qs_step_gated(qs_handle *h, int32_t k, void *stream) {
+    if (!h || k < 1) return fail(QS_ERR_INVALID, "bad argument");
+    if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
+    if (h->profiling || h->replay_on || h->d_tape || h->pf.xchg) return fail(QS_ERR_UNSUPPORTED, "qs_step_gated: not available with per-launch profiling, the replay wrapper, a noise tape or the fused exchange");
+    HIP_TRY(hipSetDevice(h->device));
+    // the kernel's action-pointer argument carries the sequence base of this launch (qs_step_team.inc)
+    int rc = launch_step(h, (const void *)(uintptr_t)h->gate_step_seq, (hipStream_t)stream, k, true);
+    if (rc == QS_OK) h->gate_step_seq += (unsigned long long)k;
+    return rc;
+}
+
+int qs_gate_produce(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, int32_t closed_loop, void *stream) {
+    if (!h || !src_actions_dev || n_src < 1 || k < 1) return fail(QS_ERR_INVALID, "bad argument");
+    if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
+    if (((uintptr_t)src_actions_dev) & 15) return fail(QS_ERR_INVALID, "qs_gate_produce: the action table must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned long long T = (unsigned long long)h->cfg.num_envs * h->cfg.num_agents;
+    const unsigned long long wg_bytes = (unsigned long long)h->epb * h->cfg.num_agents * 4 * h->real_size, batch_bytes = T * 4 * h->real_size;
+    hipLaunchKernelGGL(qs_gate_producer_kernel, dim3(h->gate_host.groups), dim3(256), 0, (hipStream_t)stream, h->d_gate, (const char *)src_actions_dev, (unsigned int)n_src,
+                       h->gate_prod_seq, (int)k, (int)(closed_loop != 0), wg_bytes, batch_bytes);
+    HIP_TRY(hipGetLastError());
+    h->gate_prod_seq += (unsigned long long)k;
+    return QS_OK;
+}
+
+int qs_gate_status(qs_handle *h, int64_t out[4]) {
+    if (!h || !out) return fail(QS_ERR_INVALID, "null argument");
+    if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    qsx::Gate g;
+    HIP_TRY(hipMemcpy(&g, h->d_gate, sizeof g, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> a(g.groups), d(g.blocks);
+    HIP_TRY(hipMemcpy(a.data(), g.act_flag, a.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(d.data(), g.done_flag, d.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long amin = ~0ull, dmin = ~0ull;
+    for (auto v : a) amin = v < amin ? v : amin;
+    for (auto v : d) dmin = v < dmin ? v : dmin;
+    out[0] = g.status; out[1] = (int64_t)h->gate_step_seq; out[2] = (int64_t)amin; out[3] = (int64_t)dmin;
     return QS_OK;
 }
 

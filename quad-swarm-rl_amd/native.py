@@ -65,6 +65,13 @@ def build(force=False, verbose=False):
 _lib = None
 
 
+class GateInfo(C.Structure):
+    """qs_gate_info_t (include/quadswarm.h): the action ring and the sequence words of resident-state stepping"""
+    _fields_ = [("action_ring", C.c_void_p), ("action_stride_bytes", C.c_int64), ("ring_len", C.c_int32),
+                ("groups", C.c_int32), ("wg_per_group", C.c_int32), ("workgroups", C.c_int32), ("envs_per_workgroup", C.c_int32),
+                ("act_flag", C.c_void_p), ("done_flag", C.c_void_p), ("steps_launched", C.c_int64), ("steps_fed", C.c_int64)]
+
+
 class WireQ8(C.Structure):
     """qs_wire_q8 (include/quadswarm_exchange.h): the 8-bit fixed-point block [q0, q1) of an observation row and its clip ranges"""
     _fields_ = [("q0", C.c_int32), ("q1", C.c_int32), ("clip", C.c_float * 6)]
@@ -149,6 +156,11 @@ def lib():
         L.qs_set_noise_tape.argtypes = [vp, C.POINTER(C.c_double), C.c_int64]
         L.qs_get_tape_pos.argtypes = [vp, C.POINTER(C.c_int32)]
         L.qs_set_tape_pos.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.qs_gate_create.argtypes = [vp, C.c_int32, C.c_int32]
+        L.qs_gate_info.argtypes = [vp, C.POINTER(GateInfo)]
+        L.qs_step_gated.argtypes = [vp, C.c_int32, vp]
+        L.qs_gate_produce.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.qs_gate_status.argtypes = [vp, C.POINTER(C.c_int64)]
         L.qs_set_obs_target.argtypes = [vp, vp]
         L.qs_set_obs_exchange.argtypes = [vp, vp, C.c_int32]
         L.qs_xchg_fused_desc.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
@@ -186,7 +198,7 @@ EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_defau
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_state_array_copy", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_spec_status", "qs_kernel_flavor",
                     "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
-                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_set_tape_pos", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target", "qs_set_obs_exchange"]
+                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_set_tape_pos", "qs_gate_create", "qs_gate_info", "qs_step_gated", "qs_gate_produce", "qs_gate_status", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target", "qs_set_obs_exchange"]
 # include/quadswarm_exchange.h
 EXCHANGE_SYMBOLS = ["qs_xchg_create", "qs_xchg_destroy", "qs_xchg_export", "qs_xchg_attach", "qs_xchg_attach_local", "qs_xchg_staging",
                     "qs_xchg_gathered", "qs_xchg_push", "qs_xchg_wait", "qs_xchg_release", "qs_xchg_wait_release", "qs_xchg_fused_desc", "qs_xchg_status", "qs_obs_pack", "qs_xchg_last_error",
@@ -350,6 +362,28 @@ class Stepper:
         out = np.zeros(self.E, dtype=np.int32)
         _check(lib().qs_get_tape_pos(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
+
+    # ---- resident-state stepping (include/quadswarm.h: qs_gate_*) -------------------------------------
+    def gate_create(self, ring_len=64, wg_per_group=8):
+        _check(lib().qs_gate_create(self._h, ring_len, wg_per_group))
+
+    def gate_info(self):
+        out = GateInfo()
+        _check(lib().qs_gate_info(self._h, C.byref(out)))
+        return out
+
+    def step_gated(self, k, stream=None):
+        """ONE launch for k control steps: per step it waits for the step's actions in the gate's ring and publishes its outputs"""
+        _check(lib().qs_step_gated(self._h, int(k), self._stream_ptr(stream)))
+
+    def gate_produce(self, src_ptr, n_src, k, closed_loop=False, stream=None):
+        """the trivial producer: k steps, action batches round-robin from a table of n_src batches at device address src_ptr"""
+        _check(lib().qs_gate_produce(self._h, C.c_void_p(int(src_ptr)), int(n_src), int(k), 1 if closed_loop else 0, self._stream_ptr(stream)))
+
+    def gate_status(self):
+        out = (C.c_int64 * 4)()
+        _check(lib().qs_gate_status(self._h, out))
+        return dict(error=int(out[0]), steps_launched=int(out[1]), min_act_flag=int(out[2]), min_done_flag=int(out[3]))
 
     def set_tape_pos(self, pos):
         """move the per-environment tape cursors (teacher forcing from a fixture's recorded tape positions)"""

@@ -1,0 +1,108 @@
+"""Resident-state stepping (include/quadswarm.h: qs_gate_create / qs_step_gated / qs_gate_produce): ONE launch for k control steps that
+waits per step for the step's actions and publishes its outputs, fed by a producer kernel on another stream.  The result must be the
+open-loop multi-step launch's (qs_step_many: the same kernel without the gate) bit for bit, and one-launch-per-step stepping's (which the
+oracle parity suite pins against the reference: tests/test_hip_parity.py) with every flag / mask / counter exact in float64 - float64
+and float32, closed loop (the producer waits for the previous step's outputs) and running ahead, across several
+launches, across auto-resets, with plain steps in between; a missing producer is reported instead of hanging the GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ARRAYS = ("obs", "reward", "done", "pos", "vel", "rot", "omega", "thrust_rot_damp", "thrust_cmds_damp", "ou_state", "goal", "col_pair_mask", "new_pair_mask",
+          "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_hit_idx", "ep_stats", "ep_counters")
+
+
+def _pair(case, E, precision, seed=3, **over):
+    from quad_swarm_rl_amd import config as qcfg, native
+    from tests import test_hip_parity as thp
+    kw = dict(thp.CASES[case], **over)
+    cfg = qcfg.make_config(num_envs=E, seed=seed, precision=precision, **kw)
+    return native.Stepper(cfg, device=0), native.Stepper(cfg, device=0), cfg
+
+
+def _same(a, b, where):
+    for nm in ARRAYS:
+        x, y = a.to_host(nm), b.to_host(nm)
+        assert np.array_equal(x, y), f"{where}: {nm} differs (max abs {np.abs(x.astype(np.float64) - y.astype(np.float64)).max()})"
+    fa, fb = a.to_host("flags"), b.to_host("flags")
+    assert np.array_equal(fa & 0xfff, fb & 0xfff) and np.array_equal(fa >> 16, fb >> 16), f"{where}: flags differ"
+
+
+@pytest.mark.parametrize("case,precision,closed_loop", [("c2_n8_dw", "f64", True), ("c2_n8_dw", "f32", False), ("c4_n32_svs", "f64", False),
+                                                        ("c3_n8_obst", "f32", True), ("c2_n8_dw", "f32", True)])
+def test_gated_launch_equals_one_launch_per_step(case, precision, closed_loop):
+    import torch
+    E, K, launches = 40, 24, 3
+    plain, gated, cfg = _pair(case, E, precision, ep_time=0.5)   # 50-step episodes: auto-resets inside the second launch
+    if not gated.team:
+        pytest.skip("team kernels only")
+    T = E * cfg.num_agents
+    dt = torch.float64 if precision == "f64" else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(5)
+    table = (torch.rand((K * launches + 4, T, 4), device="cuda", generator=g, dtype=dt) * 2 - 1).contiguous()
+    esz = table.element_size()
+    gated.gate_create(ring_len=8, wg_per_group=2)
+    info = gated.gate_info()
+    assert info.ring_len == 8 and info.wg_per_group == 2 and info.groups == (info.workgroups + 1) // 2 and info.envs_per_workgroup == 64 // cfg.num_agents
+    side, feed = torch.cuda.Stream(), torch.cuda.Stream()
+    from quad_swarm_rl_amd import native
+    stepwise = native.Stepper(cfg, device=0)
+    plain.reset(); gated.reset(); stepwise.reset()
+    torch.cuda.synchronize()
+    _same(plain, gated, "after reset")
+    step = 0
+    for l in range(launches):
+        gated.step_gated(K, stream=side)
+        gated.gate_produce(table.data_ptr() + step * T * 4 * esz, K, K, closed_loop=closed_loop, stream=feed)
+        plain.step_many(table[step].data_ptr(), K)     # the same multi-step kernel, open loop over the same batches: bit-identical arithmetic
+        if precision == "f64" and l == 0:              # ... and one launch per control step: equal up to instruction selection between the two kernels
+            for t in range(K):
+                stepwise.step(table[step + t].data_ptr())
+        torch.cuda.synchronize()
+        if precision == "f64" and l == 0:
+            for nm in ("done", "tick", "counters", "col_pair_mask", "new_pair_mask", "unique_col_mask", "obst_new_mask", "room_new_mask", "obst_hit_idx"):
+                assert np.array_equal(stepwise.to_host(nm), gated.to_host(nm)), f"{nm} differs from one-launch-per-step stepping"
+            for nm in ("obs", "reward", "pos", "vel", "rot", "omega"):
+                np.testing.assert_allclose(gated.to_host(nm), stepwise.to_host(nm), rtol=0, atol=1e-8, err_msg=nm)
+        step += K
+        st = gated.gate_status()
+        assert st["error"] == 0 and st["min_done_flag"] == step and st["min_act_flag"] == step, st
+        _same(plain, gated, f"{case} {precision} after gated launch {l}")
+        if l == 0:   # a plain step in between: the state was written back, the gate keeps counting from where it was
+            plain.step(table[-1].data_ptr()); gated.step(table[-1].data_ptr())
+            torch.cuda.synchronize()
+            _same(plain, gated, "plain step between gated launches")
+    plain.check_errors(); gated.check_errors()
+    plain.close(); gated.close(); stepwise.close()
+
+
+def test_missing_producer_is_reported_not_hung(monkeypatch):
+    import time
+    import torch
+    monkeypatch.setenv("QS_GATE_TIMEOUT_MS", "40")
+    a, b, cfg = _pair("c2_n8_dw", 16, "f32")
+    a.close()
+    b.gate_create(ring_len=4, wg_per_group=1)
+    b.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    b.step_gated(50)                     # nobody feeds the ring
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 5.0     # ONE bounded wait, then the launch stops waiting
+    st = b.gate_status()
+    assert st["error"] & 1 and st["min_done_flag"] == 50
+    b.close()
+
+
+def test_gate_is_refused_where_it_cannot_work():
+    from quad_swarm_rl_amd import config as qcfg, native
+    from tests import test_hip_parity as thp
+    cfg = qcfg.make_config(num_envs=8, seed=1, precision="f32", episode_sums=True, **thp.CASES["c2_n8_dw"])
+    st = native.Stepper(cfg, device=0)
+    with pytest.raises(native.QsError):
+        st.step_gated(4)                                  # no gate yet
+    st.replay_enable(0.5)
+    with pytest.raises(native.QsError):
+        st.gate_create()                                  # not with the device-side replay wrapper
+    st.close()
