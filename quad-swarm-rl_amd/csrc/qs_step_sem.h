@@ -155,14 +155,14 @@ __device__ __forceinline__ void collision_rewards(const Consts<real> &c, const r
 // them), kept so that their rows in HBM are touched only on the steps that can matter (the throughput kernels skip the loads / stores
 // wave-uniformly; the others keep the same representation so that every kernel of a handle reads what any other wrote):
 //  * dist_ring (the last 4 distances; reached_goal = mean of 5 < metric * dt, i.e. within millimetres of the goal): a mean of five
-//    non-negative values is below x only if every one of them is below 5 x, so a distance >= 8 * metric * dt can never be part of a
-//    triggering window.  Such entries are not maintained: the ring of a drone is valid only while F_RING_LIVE says so (set while the
+//    non-negative values is below x only if every one of them is below 5 x, so a logged value >= 5.5 * metric * dt can never be part of a
+//    triggering window (the logged value is the raw position cost, control_dt * distance: "near" means within 2.75 * metric metres).  Such entries are not maintained: the ring of a drone is valid only while F_RING_LIVE says so (set while the
 //    ring holds at least one "near" entry and the goal has not been reached); otherwise every entry stands for "far" (1e30).  The
-//    decisions are the reference's exactly - a window that contains a far entry gives false in both forms, with a margin of 1.6x.
+//    decisions are the reference's exactly - a window that contains a far entry gives false in both forms, with a margin of 10 %.
 //  * dist_sums (sums of the last 1 / 3 / 5 s): zero in HBM from the reset until the 5-s window of the episode opens (they used to be
 //    stored as zeros on every step before it), accumulated from there, zeroed again by the step that ends the episode.
 template <typename real>
-__device__ __forceinline__ bool ring_near(const Consts<real> &c, real metric, real dist) { return dist * c.inv_dt < (real)8 * metric; }
+__device__ __forceinline__ bool ring_near(const Consts<real> &c, real metric, real dist) { return dist * c.inv_dt < (real)5.5 * metric; }
 template <typename real>
 __device__ __forceinline__ bool sums_window_open(const Consts<real> &c, int tick) { return tick > c.ep_len + 1 - 5 * c.control_freq; }
 // does this drone's ring row have to be read (and written back) on this step?

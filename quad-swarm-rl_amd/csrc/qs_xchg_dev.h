@@ -131,8 +131,10 @@ struct Gate {   // (sequence numbers: control steps since the gate was created, 
     unsigned long long *act_flag;        // [groups]  producer -> stepper: the actions of sequence number <= act_flag[g] for the workgroups of group g are in the ring
     unsigned long long *done_flag;       // [blocks]  stepper -> consumers: obs / reward / done of sequence number done_flag[w] of workgroup w's environments are in HBM
 };
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (the gate's ring and sequence words live in fine-grained, uncached device memory - qs_gate_create - like the exchange's flag windows;
+// relaxed system-scope accesses go straight to it)
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ bool poll_ge_agent(const unsigned long long *p, unsigned long long want, unsigned long long timeout_ticks) {
     if (ld_agent(p) >= want) return true;
     const unsigned long long t0 = wall_clock64();
@@ -144,8 +146,8 @@ __device__ __forceinline__ bool poll_ge_agent(const unsigned long long *p, unsig
 }
 // agent-scope data accesses: loads that miss this XCD's L2, stores that are written through it
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t ld16_sc1(const void *p) { u32x4_t v; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ unsigned int ld4_sc1(const void *p) { unsigned int v; asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ u32x4_t ld16_sc1(const void *p) { u32x4_t v; asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ unsigned int ld4_sc1(const void *p) { unsigned int v; asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
 __device__ __forceinline__ void st16_sc1(void *p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st8_sc1(void *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void st4_sc1(void *p, unsigned int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }

@@ -797,8 +797,14 @@ int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group) {
     const size_t T = (size_t)h->cfg.num_envs * h->cfg.num_agents, stride = (T * 4 * (size_t)h->real_size + 255) & ~(size_t)255;
     const unsigned int groups = (unsigned int)((h->blocks + wg_per_group - 1) / wg_per_group);
     const size_t o_ring = 256, o_act = o_ring + stride * (size_t)ring_len, o_done = o_act + (((size_t)groups * 8 + 255) & ~(size_t)255), total = o_done + (((size_t)h->blocks * 8 + 255) & ~(size_t)255);
+    // Fine-grained (uncached) device memory: the ring and the sequence words are handed between kernels that run CONCURRENTLY, mostly on
+    // different XCDs, whose L2s are not coherent with each other - an `sc1` load that hits a stale line of its own XCD's L2 is how a first
+    // version of this took 7.8 ms per closed-loop step (profiles/r04c_bench_c2_default.json); uncached memory has no such line
     char *base = nullptr;
-    HIP_TRY(hipMalloc((void **)&base, total));
+    if (hipExtMallocWithFlags((void **)&base, total, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(QS_ERR_HIP, "qs_gate_create: fine-grained (uncached) device memory is not available: resident-state stepping needs it for its action ring and sequence words");
+    }
     HIP_TRY(hipMemset(base, 0, total));
     qsx::Gate g;
     memset(&g, 0, sizeof g);

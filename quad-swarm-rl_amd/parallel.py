@@ -75,7 +75,8 @@ def pack_rows(src, dst, stream=None, q8=None):
     rows, with the library's converter (qs_obs_pack_rows)."""
     wire = "bf16" if dst.dtype == torch.bfloat16 else ("q8" if dst.dtype == torch.uint8 else "f32")
     s = stream if stream is not None else torch.cuda.current_stream(src.device)
-    _xcheck(native.lib().qs_obs_pack_rows(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.shape[0], src.shape[1], WIRE[wire],
+    rows, cols = (src.shape[0], src.shape[1]) if src.dim() == 2 else (src.numel(), 1)   # (f32 / bf16 are element-wise: any shape)
+    _xcheck(native.lib().qs_obs_pack_rows(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), rows, cols, WIRE[wire],
                                           C.byref(q8) if q8 is not None else None, C.c_void_p(s.cuda_stream)))
     return dst
 
