@@ -96,7 +96,9 @@ template <typename T> struct BufRow {
 #define QS_BUF_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void *)(p).blk.base, 0, (p).blk.bytes, 0x00020000)
 // blocked state array: the workgroup's block (blockIdx.x: one block = the environments of one workgroup), row pitch 64 elements
 // (a compile-time constant: component offsets fold into the instruction's immediate), lane = position inside the wave
-#define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (uint32_t)(blockIdx.x * (p).blk.block_bytes + (p).blk.name), (uint32_t)(64 * sizeof(TYPE)), (uint32_t)((threadIdx.x & 63) * sizeof(TYPE))}
+// (QS_BLK: the state block a workgroup is working on - blockIdx.x, or the loop variable of the persistent form of the single-wave step kernel)
+#define QS_BLK blockIdx.x
+#define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (uint32_t)(QS_BLK * (p).blk.block_bytes + (p).blk.name), (uint32_t)(64 * sizeof(TYPE)), (uint32_t)((threadIdx.x & 63) * sizeof(TYPE))}
 // flat component-major array (per-step outputs): row pitch T elements, lane offset = global drone index
 #define QS_ROWF(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (p).blk.name, (uint32_t)((T) * sizeof(TYPE)), (uint32_t)((g) * sizeof(TYPE))}
 
@@ -781,7 +783,8 @@ __device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLay
 // ------------------------------------------------------------------------------------------------
 template <typename real, bool FULL, bool TEAM = false, bool STREAM = false>
 __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem, int epb, const RngKey &key,
-                                        bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3]) {
+                                        bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3], int blk = -1) {
+    const int bidx = blk < 0 ? (int)blockIdx.x : blk;   // (the persistent form of the single-wave step kernel passes the block it is working on)
     const Consts<real> &c = *cp;
     const Ptrs<real> &p = *pp;
     const LdsLayout &L = *Lp;
@@ -791,7 +794,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     real *s_goal = (real *)(smem + L.off_goal), *s_obs = (real *)(smem + L.off_obs), *s_obst = (real *)(smem + L.off_obst);
     real *s_metric = (real *)(smem + L.off_metric);
     uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
-    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = blockIdx.x * epb + le, base = le * N;
+    const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = bidx * epb + le, base = le * N;
     const int M_ = c.num_obstacles;
     real *myobs = STREAM ? (real *)(smem + L.off_self) + tid * c.self_dim : s_obs + tid * c.obs_dim;   // STREAM: dense self block + rows stage
     int *tidx = (int *)(smem + L.off_scratch) + le * (2 * L.scr_cap + 32), *tval = tidx + L.scr_cap, *prev_row = tidx + 2 * L.scr_cap, *cur_row = prev_row + 16;
@@ -990,7 +993,7 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     if (TEAM) QS_WAVE_SYNC(); else __syncthreads();
     if (STREAM) {   // single-wave kernels: the rows of the re-initialised envs go out through the rows stage
         const uint64_t rowmask = __ballot(do_reset);
-        const int first_env = blockIdx.x * epb;
+        const int first_env = bidx * epb;
         int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
         stream_rows<real>(c, L, p.obs + (size_t)first_env * N * c.obs_dim, (const real *)(smem + L.off_self), (real *)(smem + L.off_rows), N, i, le, base, tid,
                           s_pos, s_vel, s_metric, s_obst, d.pos, stale_vel, do_reset, nenv * N, rowmask,

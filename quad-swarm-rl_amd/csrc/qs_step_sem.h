@@ -398,11 +398,13 @@ __device__ __forceinline__ void scenario_phase_full(const Consts<real> &c, const
 // the fast kernels' only stepping scenario: swarm_vs_swarm swaps the two formations every U(4,6) s (swarm_vs_swarm.py:59-79).
 // env_goals: the env's goal rows in LDS (>= 2N + 6 rows); the centres live in scen_real[0..5][e].
 template <typename real, typename Sync>
-__device__ __forceinline__ void svs_phase(const Consts<real> &c, const Ptrs<real> &p, const RngKey &key, bool active, int N, int E, int e, int i, int tick, int svs_period,
+// returns (wave-uniform) whether any environment of the wave got new goals on this step
+__device__ __forceinline__ bool svs_phase(const Consts<real> &c, const Ptrs<real> &p, const RngKey &key, bool active, int N, int E, int e, int i, int tick, int svs_period,
                                           real *env_goals, int *scr, real goal[3], int *s_cur_env, Sync sync) {
-    if (c.scenario != QS_SCENARIO_SWARM_VS_SWARM) return;
+    if (c.scenario != QS_SCENARIO_SWARM_VS_SWARM) return false;
     const bool sw = active && svs_period > 0 && tick % svs_period == 0 && tick > 0;
-    if (__builtin_expect(__ballot(sw) != 0, 0)) {
+    const bool any_sw = __ballot(sw) != 0;
+    if (__builtin_expect(any_sw, 0)) {
 #ifndef QS_TAPE
         if (N / 2 >= 3) {   // the wave builds the two formations: lane i makes goal row i (svs_create_formations_wave, qs_device.h)
             real c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0};
@@ -441,6 +443,7 @@ __device__ __forceinline__ void svs_phase(const Consts<real> &c, const Ptrs<real
             for (int q = 0; q < 3; ++q) goal[q] = env_goals[i * 3 + q];
         }
     }
+    return any_sw;
 }
 
 }  // namespace qs

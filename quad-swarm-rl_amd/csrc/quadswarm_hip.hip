@@ -43,6 +43,7 @@ struct qs_handle {
     int obs_dim = 0, epb = 1, blocks = 0;
     LdsLayout lds;
     bool full = false;     // scenario outside the fast set => kernels compiled with QS_SCEN_FULL
+    int cus = 256, persist_per_cu = 0;   // QS_PERSIST: workgroups per CU of the persistent single-wave step kernel (0 = off)
     int team = 0;          // waves per workgroup of the team kernels (qs_step_team.inc): 4 generic, 8 (or 4) specialised; 0 = single-wave kernels
     // config-specialised code object (qs_spec_kernels.hip), when one is cached / could be built
     // environment snapshots (qs_snapshot_*): `snap_slots` packed copies of one environment's complete state
@@ -520,6 +521,9 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         int cus = 256;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         h->team = team_default(h->blocks, cus, cfg->num_agents) ? QS_TEAM_WAVES : 0;
+        h->cus = cus;
+        // experiment: only objects built with -DQS_PERSIST_LOOP (QS_SPEC_EXTRA_FLAGS) walk over several state blocks per workgroup
+        if (const char *ev = getenv("QS_PERSIST")) { const char *xf = getenv("QS_SPEC_EXTRA_FLAGS"); if (xf && strstr(xf, "QS_PERSIST_LOOP")) h->persist_per_cu = atoi(ev); }
         const char *ev = getenv("QS_TEAM");
         if (ev && ev[0] == '0') h->team = 0;
         else if (ev && (ev[0] == '1' || ev[0] == '4' || ev[0] == '8')) h->team = QS_TEAM_WAVES;
@@ -696,7 +700,10 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
-        HIP_TRY(hipModuleLaunchKernel((ksteps == 1 && !gated) ? h->spec_step : h->spec_rollout, h->blocks, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
+        // persistent form of the single-wave step kernel (QS_PERSIST = workgroups per CU, 0 = one workgroup per state block)
+        int grid = h->blocks;
+        if (!h->team && ksteps == 1 && !gated && h->persist_per_cu > 0 && (long)h->persist_per_cu * h->cus < (long)h->blocks) grid = h->persist_per_cu * h->cus;
+        HIP_TRY(hipModuleLaunchKernel((ksteps == 1 && !gated) ? h->spec_step : h->spec_rollout, grid, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
     }
