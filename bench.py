@@ -600,7 +600,9 @@ def main():
             try:
                 c2 = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f32", write_rew_info=args.rew_info, **kw)
                 s2 = native.Stepper(c2, device=local_rank)
-                s2.gate_create(ring_len=ring, wg_per_group=8)
+                # producer groups: 1 workgroup per group keeps the closed-loop chain shortest (6.98 - 7.25 us per step against 7.5 - 7.8 with 8),
+                # 8 per group the producer cheapest when it runs ahead (tools/gated_probe.py, profiles/r04e_gated_probe_c2.txt)
+                s2.gate_create(ring_len=ring, wg_per_group=1 if closed_loop else 8)
                 s2.reset(stream=stream)
                 torch.cuda.synchronize()
                 side, feed = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
