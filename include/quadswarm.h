@@ -241,8 +241,9 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
  *     stepper (this library): waits act_flag[g] >= s, steps, writes the outputs through the L2, then done_flag[w] = s.
  * Workgroup w steps the environments [w * envs_per_workgroup, (w + 1) * envs_per_workgroup); group g = w / wg_per_group.  All waits
  * are bounded (QS_GATE_TIMEOUT_MS, default 500 ms of the device wall clock): a missing producer raises status bit 1 and the launch runs on
- * without waiting instead of hanging the GPU.  The producer MUST be able to run while the gated launch is resident: issue it on another
- * stream.  State is written back to HBM at the end of the launch (qs_get_state, snapshots and plain qs_step work between gated
+ * without waiting instead of hanging the GPU.  The producer MUST be able to run while the gated launch is resident: issue it on another,
+ * NORMAL-priority stream (the library runs the gated kernel on a highest-priority stream of its own - a different hardware queue pool -
+ * ordered with `stream` through events: two streams of equal priority may share a queue, and a queue runs its kernels one by one).  State is written back to HBM at the end of the launch (qs_get_state, snapshots and plain qs_step work between gated
  * launches).  Team kernels only (qs_kernel_flavor); not together with the replay wrapper, a noise tape or the fused exchange.
  * qs_gate_produce: the trivial producer used by bench.py and the tests - k steps of the protocol above with the action batches taken
  * round-robin from a table of n_src batches resident in HBM (closed_loop = 0: runs ahead, bounded only by the ring).

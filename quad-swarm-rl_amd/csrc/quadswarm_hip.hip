@@ -82,6 +82,13 @@ struct qs_handle {
     qsx::Gate *d_gate = nullptr;
     qsx::Gate gate_host = {};
     unsigned long long gate_step_seq = 0, gate_prod_seq = 0;   // control steps launched so far by qs_step_gated / fed so far by qs_gate_produce
+    // The gated launch must be RESIDENT while its producer runs: two streams of one process may share a hardware queue (the runtime maps
+    // streams onto a few HSA queues per priority level), and a queue runs its kernels one after the other - the producer behind a stepper
+    // that waits for it would be a bounded deadlock (seen: 500 ms per launch in one of two otherwise identical bench runs).  The gated
+    // kernel therefore runs on a stream of the library's own with the HIGHEST priority - a different queue pool than the caller's normal-
+    // priority streams - stream-ordered with the caller's stream through two events.
+    hipStream_t gate_stream = nullptr;
+    hipEvent_t gate_ev_in = nullptr, gate_ev_out = nullptr;
     // profiling of the step kernel
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -618,6 +625,9 @@ int qs_destroy(qs_handle *h) {
     if (h->d_tape) (void)hipFree(h->d_tape);
     if (h->d_tape_pos) (void)hipFree(h->d_tape_pos);
     if (h->d_gate) (void)hipFree(h->d_gate);
+    if (h->gate_stream) (void)hipStreamDestroy(h->gate_stream);
+    if (h->gate_ev_in) (void)hipEventDestroy(h->gate_ev_in);
+    if (h->gate_ev_out) (void)hipEventDestroy(h->gate_ev_out);
     for (auto &ev : h->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -824,6 +834,13 @@ int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group) {
     g.act_flag = (unsigned long long *)(base + o_act); g.done_flag = (unsigned long long *)(base + o_done);
     HIP_TRY(hipMemcpy(base, &g, sizeof g, hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
+    {
+        int least = 0, greatest = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&h->gate_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipEventCreateWithFlags(&h->gate_ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&h->gate_ev_out, hipEventDisableTiming));
+    }
     h->d_gate = (qsx::Gate *)base; h->gate_host = g; h->gate_step_seq = 0; h->gate_prod_seq = 0;
     return QS_OK;
 }
@@ -843,10 +860,17 @@ int qs_step_gated(qs_handle *h, int32_t k, void *stream) {
     if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
     if (h->profiling || h->replay_on || h->d_tape || h->pf.xchg) return fail(QS_ERR_UNSUPPORTED, "qs_step_gated: not available with per-launch profiling, the replay wrapper, a noise tape or the fused exchange");
     HIP_TRY(hipSetDevice(h->device));
+    // stream-ordered behind everything on the caller's stream, and the caller's stream behind the launch - but the kernel itself sits in the
+    // library's high-priority queue (see qs_handle::gate_stream)
+    HIP_TRY(hipEventRecord(h->gate_ev_in, (hipStream_t)stream));
+    HIP_TRY(hipStreamWaitEvent(h->gate_stream, h->gate_ev_in, 0));
     // the kernel's action-pointer argument carries the sequence base of this launch (qs_step_team.inc)
-    int rc = launch_step(h, (const void *)(uintptr_t)h->gate_step_seq, (hipStream_t)stream, k, true);
-    if (rc == QS_OK) h->gate_step_seq += (unsigned long long)k;
-    return rc;
+    int rc = launch_step(h, (const void *)(uintptr_t)h->gate_step_seq, h->gate_stream, k, true);
+    if (rc != QS_OK) return rc;
+    h->gate_step_seq += (unsigned long long)k;
+    HIP_TRY(hipEventRecord(h->gate_ev_out, h->gate_stream));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->gate_ev_out, 0));
+    return QS_OK;
 }
 
 int qs_gate_produce(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, int32_t closed_loop, void *stream) {
