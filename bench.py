@@ -615,6 +615,7 @@ def main():
                 for _ in range(reps):
                     s2.step_gated(k, stream=side)
                     s2.gate_produce(aptr, ring, k, closed_loop, stream=feed)
+                    s2.gate_wait(stream=side)   # `side` behind the launch - issued after the producer's launch (include/quadswarm.h)
                 ev1.record(side)
                 torch.cuda.synchronize()
                 host = time.perf_counter() - t0

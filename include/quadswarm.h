@@ -242,8 +242,10 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
  * Workgroup w steps the environments [w * envs_per_workgroup, (w + 1) * envs_per_workgroup); group g = w / wg_per_group.  All waits
  * are bounded (QS_GATE_TIMEOUT_MS, default 500 ms of the device wall clock): a missing producer raises status bit 1 and the launch runs on
  * without waiting instead of hanging the GPU.  The producer MUST be able to run while the gated launch is resident: issue it on another,
- * NORMAL-priority stream (the library runs the gated kernel on a highest-priority stream of its own - a different hardware queue pool -
- * ordered with `stream` through events: two streams of equal priority may share a queue, and a queue runs its kernels one by one).  State is written back to HBM at the end of the launch (qs_get_state, snapshots and plain qs_step work between gated
+ * NORMAL-priority stream.  The library runs the gated kernel on a highest-priority stream of its own - a different hardware queue pool -
+ * behind `stream` (an event); nothing is made to wait for it unless asked (qs_gate_wait, qs_sync, a device synchronize): the runtime maps
+ * the streams of a process onto a few hardware queues, a queue processes its packets in order, and a wait for the gated launch that lands
+ * in the producer's queue AHEAD of the producer is a (bounded) deadlock - seen in one of three otherwise identical runs before this rule.  State is written back to HBM at the end of the launch (qs_get_state, snapshots and plain qs_step work between gated
  * launches).  Team kernels only (qs_kernel_flavor); not together with the replay wrapper, a noise tape or the fused exchange.
  * qs_gate_produce: the trivial producer used by bench.py and the tests - k steps of the protocol above with the action batches taken
  * round-robin from a table of n_src batches resident in HBM (closed_loop = 0: runs ahead, bounded only by the ring).
@@ -258,7 +260,8 @@ typedef struct qs_gate_info_t {
 } qs_gate_info_t;
 int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group);
 int qs_gate_info(qs_handle *h, qs_gate_info_t *out);
-int qs_step_gated(qs_handle *h, int32_t k, void *stream);
+int qs_step_gated(qs_handle *h, int32_t k, void *stream);   /* ordered BEHIND `stream`; runs on the library's own queue */
+int qs_gate_wait(qs_handle *h, void *stream);                /* orders `stream` behind the last gated launch (issue it AFTER the producer's work) */
 int qs_gate_produce(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, int32_t closed_loop, void *stream);
 int qs_gate_status(qs_handle *h, int64_t out[4]);
 

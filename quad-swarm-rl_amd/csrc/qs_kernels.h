@@ -1104,6 +1104,10 @@ __device__ __forceinline__ Consts<real> qs_spec_consts(const Consts<real> &rt) {
 #undef QS_MULTI
 #define QS_MULTI 1
 #include "qs_step_team.inc"
+#undef QS_GATED
+#define QS_GATED 1
+#include "qs_step_team.inc"
+#undef QS_GATED
 #undef QS_MULTI
 #else
 #define QS_MULTI 0
@@ -1169,6 +1173,10 @@ __global__ void __launch_bounds__(QS_WAVE) qs_tape_reset_kernel(const Consts<rea
 #undef QS_MULTI
 #define QS_MULTI 1
 #include "qs_step_team.inc"
+#undef QS_GATED
+#define QS_GATED 1
+#include "qs_step_team.inc"
+#undef QS_GATED
 #undef QS_MULTI
 #undef QS_SCEN_FULL
 #define QS_SCEN_FULL 1
@@ -1177,6 +1185,10 @@ __global__ void __launch_bounds__(QS_WAVE) qs_tape_reset_kernel(const Consts<rea
 #undef QS_MULTI
 #define QS_MULTI 1
 #include "qs_step_team.inc"
+#undef QS_GATED
+#define QS_GATED 1
+#include "qs_step_team.inc"
+#undef QS_GATED
 #undef QS_MULTI
 #undef QS_SCEN_FULL
 

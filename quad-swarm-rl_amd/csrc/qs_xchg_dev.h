@@ -73,7 +73,7 @@ __device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8De
     }
     const int m = 4 * (j - q.w16), nq = q.q1 - q.q0;
     unsigned int o = 0;
-#pragma unroll
+#pragma unroll 1
     for (int u = 0; u < 4; ++u) {
         const int mm = m + u;
         if (mm < nq) {

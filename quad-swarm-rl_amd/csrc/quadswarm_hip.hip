@@ -53,7 +53,7 @@ struct qs_handle {
     char *snap_pool = nullptr;
     int32_t snap_slots = 0;
     hipModule_t spec_mod = nullptr;
-    hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr;
+    hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr, spec_gated = nullptr;   // (spec_gated: team objects only)
     std::string spec_note;   // why the handle runs the generic kernels (empty when it runs a config-specialised code object)
     Consts<float> kf;    // kernel constants, passed by value in the kernarg segment
     Consts<double> kd;
@@ -87,6 +87,7 @@ struct qs_handle {
     // that waits for it would be a bounded deadlock (seen: 500 ms per launch in one of two otherwise identical bench runs).  The gated
     // kernel therefore runs on a stream of the library's own with the HIGHEST priority - a different queue pool than the caller's normal-
     // priority streams - stream-ordered with the caller's stream through two events.
+    bool gate_pending = false;   // a gated launch was issued and has not been joined on the host since
     hipStream_t gate_stream = nullptr;
     hipEvent_t gate_ev_in = nullptr, gate_ev_out = nullptr;
     // profiling of the step kernel
@@ -555,10 +556,11 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
                     hipModuleGetFunction(&h->spec_rollout, h->spec_mod, "qs_spec_rollout") == hipSuccess &&
                     hipModuleGetFunction(&h->spec_reset, h->spec_mod, "qs_spec_reset") == hipSuccess) {
                     h->team = spec_team;   // specialised kernels in use
+                    if (spec_team > 0 && hipModuleGetFunction(&h->spec_gated, h->spec_mod, "qs_spec_gated") != hipSuccess) { (void)hipGetLastError(); h->spec_gated = nullptr; }
                 } else {
                     (void)hipGetLastError();
                     if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
-                    h->spec_step = h->spec_rollout = h->spec_reset = nullptr;
+                    h->spec_step = h->spec_rollout = h->spec_reset = h->spec_gated = nullptr;
                     h->spec_note = "cannot load " + path;
                 }
             } else {
@@ -661,9 +663,21 @@ static int launch_reset(qs_handle *h, hipStream_t s) {
     return QS_OK;
 }
 
+// A gated launch (qs_step_gated) runs on the library's own stream and nothing waits for it by itself: every other entry point that touches
+// the handle's device state first joins it - stream-ordered where the call takes a stream, on the host where it copies synchronously.
+static int gate_join_stream(qs_handle *h, hipStream_t s) {
+    if (h->gate_pending) { HIP_TRY(hipStreamWaitEvent(s, h->gate_ev_out, 0)); }
+    return QS_OK;
+}
+static int gate_join_host(qs_handle *h) {
+    if (h->gate_pending) { HIP_TRY(hipStreamSynchronize(h->gate_stream)); h->gate_pending = false; }
+    return QS_OK;
+}
+
 int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    if (int jr = gate_join_stream(h, (hipStream_t)stream)) return jr;
     hipStream_t s = (hipStream_t)stream;
     const int E = h->cfg.num_envs;
     for (int e = 0; e < E; ++e) h->h_mask[e] = env_mask_host ? (env_mask_host[e] ? 1 : 0) : 1;
@@ -713,7 +727,8 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
         // persistent form of the single-wave step kernel (QS_PERSIST = workgroups per CU, 0 = one workgroup per state block)
         int grid = h->blocks;
         if (!h->team && ksteps == 1 && !gated && h->persist_per_cu > 0 && (long)h->persist_per_cu * h->cus < (long)h->blocks) grid = h->persist_per_cu * h->cus;
-        HIP_TRY(hipModuleLaunchKernel((ksteps == 1 && !gated) ? h->spec_step : h->spec_rollout, grid, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
+        if (gated && !h->spec_gated) return fail(QS_ERR_UNSUPPORTED, "the specialised code object of this handle has no resident-state kernel");
+        HIP_TRY(hipModuleLaunchKernel(gated ? h->spec_gated : (ksteps == 1 ? h->spec_step : h->spec_rollout), grid, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
     }
@@ -721,7 +736,8 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
                                                                              (const TYPE *)actions, h->lds, h->epb, ##__VA_ARGS__)
 #define QS_LAUNCH_ALL(CONSTS, PTRS, TYPE) do { \
         if (h->team) { \
-            if (ksteps == 1 && !gated) { if (h->full) QS_LAUNCH(qs_step_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); } \
+            if (gated) { if (h->full) QS_LAUNCH(qs_gated_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); else QS_LAUNCH(qs_gated_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); } \
+            else if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE); } \
             else { if (h->full) QS_LAUNCH(qs_rollout_team_full, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); else QS_LAUNCH(qs_rollout_team, QS_TEAM_THREADS, CONSTS, PTRS, TYPE, ksteps); } \
         } else { \
             if (ksteps == 1) { if (h->full) QS_LAUNCH(qs_step_kernel_full, QS_WAVE, CONSTS, PTRS, TYPE); else QS_LAUNCH(qs_step_kernel, QS_WAVE, CONSTS, PTRS, TYPE); } \
@@ -750,6 +766,7 @@ static int launch_replay(qs_handle *h, hipStream_t s) {
 int qs_step(qs_handle *h, const void *actions_dev, void *stream) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->gate_pending) { if (int jr = gate_join_stream(h, (hipStream_t)stream)) return jr; }
     int rc = launch_step(h, actions_dev ? actions_dev : h->d_actions, (hipStream_t)stream);
     if (rc == QS_OK && h->replay_on) { rc = launch_replay(h, (hipStream_t)stream); h->replay_stepped = true; }
     return rc;
@@ -758,6 +775,7 @@ int qs_step(qs_handle *h, const void *actions_dev, void *stream) {
 int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream) {
     if (!h || !actions_dev || k < 0) return fail(QS_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->gate_pending) { if (int jr = gate_join_stream(h, (hipStream_t)stream)) return jr; }
     const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * h->real_size;
     if (h->profiling || h->replay_on || h->pf.xchg) {   // per-step HIP events / the replay kernel behind every step / the fused exchange epilogue: one launch per control step
         for (int32_t t = 0; t < k; ++t) {
@@ -798,7 +816,9 @@ __global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, con
         __syncthreads();
         const char *from = src + ((seq - 1) % n_src) * batch_bytes;
         char *to = G->act_ring + ((seq - 1) % G->ring_len) * G->act_stride;
-        for (unsigned long long off = lo + 16ull * threadIdx.x; off < hi; off += 16ull * 256) qsx::st16_sc1(to + off, *(const qsx::u32x4_t *)(from + off));
+        // system-scope write-through: the flag below must not become visible before the batch (`sc1` alone was seen to let it: one run in three
+        // of the run-ahead parity test read a stale batch)
+        for (unsigned long long off = lo + 16ull * threadIdx.x; off < hi; off += 16ull * 256) qsx::st16_wt(to + off, *(const qsx::u32x4_t *)(from + off));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) qsx::st_agent(&G->act_flag[grp], seq);
@@ -869,7 +889,17 @@ int qs_step_gated(qs_handle *h, int32_t k, void *stream) {
     if (rc != QS_OK) return rc;
     h->gate_step_seq += (unsigned long long)k;
     HIP_TRY(hipEventRecord(h->gate_ev_out, h->gate_stream));
-    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->gate_ev_out, 0));
+    h->gate_pending = true;
+    // NOT waited for on `stream` here: a wait packet in the caller's hardware queue would hold back whatever shares that queue - possibly
+    // the producer this launch is waiting for.  qs_gate_wait orders a stream behind the launch when the caller asks for it.
+    return QS_OK;
+}
+
+int qs_gate_wait(qs_handle *h, void *stream) {
+    if (!h) return fail(QS_ERR_INVALID, "null handle");
+    if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->gate_step_seq > 0) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, h->gate_ev_out, 0));
     return QS_OK;
 }
 
@@ -907,6 +937,7 @@ int qs_gate_status(qs_handle *h, int64_t out[4]) {
 int qs_sync(qs_handle *h, void *stream) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    if (int jr = gate_join_host(h)) return jr;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return QS_OK;
 }
@@ -1046,6 +1077,7 @@ static int snapshot_io(qs_handle *h, int32_t env, int32_t slot, bool save, hipSt
     if (env < 0 || env >= h->cfg.num_envs) return fail(QS_ERR_INVALID, "env out of range");
     if (slot < 0 || slot >= h->snap_slots) return fail(QS_ERR_INVALID, "snapshot slot out of range (qs_snapshot_pool first)");
     HIP_TRY(hipSetDevice(h->device));
+    if (h->gate_pending) { if (int jr = gate_join_stream(h, s)) return jr; }
     char *dst = h->snap_pool + h->snap_bytes * (size_t)slot;
     for (const auto &a : h->snap_arrays) {
         const size_t gb = a.group ? (size_t)env / a.group : 0, ge = a.group ? (size_t)env - gb * a.group : (size_t)env;

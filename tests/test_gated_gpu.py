@@ -55,6 +55,7 @@ def test_gated_launch_equals_one_launch_per_step(case, precision, closed_loop):
     for l in range(launches):
         gated.step_gated(K, stream=side)
         gated.gate_produce(table.data_ptr() + step * T * 4 * esz, K, K, closed_loop=closed_loop, stream=feed)
+        gated.gate_wait(stream=side)     # (after the producer's launch: a wait for the gated kernel must never sit in front of its producer)
         plain.step_many(table[step].data_ptr(), K)     # the same multi-step kernel, open loop over the same batches: bit-identical arithmetic
         if precision == "f64" and l == 0:              # ... and one launch per control step: equal up to instruction selection between the two kernels
             for t in range(K):

@@ -55,6 +55,7 @@ for wgpg in (1, 2, 4, 8, 16):
                 for _ in range(reps):
                     s2.step_gated(k, stream=side)
                     s2.gate_produce(aptr, ring, k, closed, stream=feed)
+                    s2.gate_wait(stream=side)
             out.append(timed(run, reps * k))
         stt = s2.gate_status()
         print(f"{wl}: gated, {wgpg:2d} workgroups per producer group, {k:3d} steps per launch: producer ahead {out[0]:.3f} us, closed loop {out[1]:.3f} us per step (status {stt['error']})")

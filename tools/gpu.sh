@@ -17,7 +17,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 BIG="c2:131072 c3:131072 c4:32768"
 kt() { # rocprofv3 kernel stats of one workload
   wl=$1
-  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rocprof_kt_${tag}_$wl -o k -- python $R/bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --prewarm 0 > $R/gpurun_out/kt_${tag}_$wl.json 2> $R/gpurun_out/kt_${tag}_$wl.err )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rocprof_kt_${tag}_$wl -o k -- python $R/bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants > $R/gpurun_out/kt_${tag}_$wl.json 2> $R/gpurun_out/kt_${tag}_$wl.err )
   db=$(ls /tmp/rocprof_kt_${tag}_$wl/*.db /tmp/rocprof_kt_${tag}_$wl/*/*.db 2>/dev/null | head -1)
   [ -n "$db" ] && python $R/tools/rocprof_summary.py $db "rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants" > $R/gpurun_out/kt_${tag}_${wl}_stats.txt
   head -4 $R/gpurun_out/kt_${tag}_${wl}_stats.txt
