@@ -170,7 +170,11 @@ template <typename real>
 __device__ __forceinline__ bool ring_needed(const Consts<real> &c, real metric, uint32_t flags, const real *ri) {
     return !(flags & F_REACHED) && ((flags & F_RING_LIVE) || ring_near<real>(c, metric, -ri[QS_RI_RAW_POS]));
 }
-template <typename real>
+// LAZY: the kernel skips the rows' loads / stores on the steps that cannot matter (the throughput kernels) and therefore decides liveness
+// from the values.  The kernels that load and store every row anyway (team, multi-step, gated: the latency regime, where ~40 instructions
+// on the physics wave's critical path are 0.1 us of an 8 us step - measured: profiles/r04g_ab_tree_vs_r03.txt) keep every entry exact and
+// simply mark the ring live while the goal is not reached; both forms read what the other wrote.
+template <typename real, bool LAZY>
 __device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real metric, int tick, bool done, uint32_t &flags, real ring[4], real sums[3], const real *ri, real eps_dist[3]) {
     const real dnow = -ri[QS_RI_RAW_POS];
     if (!(flags & F_RING_LIVE)) { ring[0] = ring[1] = ring[2] = ring[3] = (real)1e30; }   // not maintained = far (also: whatever the row holds after a reset)
@@ -179,13 +183,14 @@ __device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real me
         if (mean5 * c.inv_dt < metric) flags |= F_REACHED;
     }
     ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = dnow;
-    const bool live = !(flags & F_REACHED) && (ring_near<real>(c, metric, ring[0]) | ring_near<real>(c, metric, ring[1]) | ring_near<real>(c, metric, ring[2]) | ring_near<real>(c, metric, ring[3]));
+    bool live = !(flags & F_REACHED);
+    if (LAZY) live = live && (ring_near<real>(c, metric, ring[0]) | ring_near<real>(c, metric, ring[1]) | ring_near<real>(c, metric, ring[2]) | ring_near<real>(c, metric, ring[3]));
     flags = live ? (flags | F_RING_LIVE) : (flags & ~F_RING_LIVE);
     const int total = c.ep_len + 1;
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
         const int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * c.control_freq;
-        real sum = (tick == 1 || !sums_window_open<real>(c, tick)) ? (real)0 : sums[w];
+        real sum = (tick == 1 || (LAZY && !sums_window_open<real>(c, tick))) ? (real)0 : sums[w];   // (not LAZY: the row holds zeros outside the window anyway)
         if (tick > total - win) sum += dnow;
         eps_dist[w] = c.inv_dt * (sum * c.inv_win[w]);
         sums[w] = done ? (real)0 : sum;
