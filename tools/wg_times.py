@@ -41,6 +41,28 @@ if warm:
     st.sync()
 rows = []
 S = 16
+GATED = int(os.environ.get("QS_WG_GATED", "0"))   # > 0: resident-state launches of this many control steps (qs_step_gated, producer running ahead)
+if GATED:
+    import torch
+    tab = (torch.rand((64, st.T, 4), device="cuda") * 2 - 1).contiguous()
+    st.gate_create(ring_len=64, wg_per_group=8)
+    side, feed = torch.cuda.Stream(), torch.cuda.Stream()
+    per_wg, spans, skews = [], [], []
+    for rep in range(12):
+        st.step_gated(GATED, stream=side); st.gate_produce(tab.data_ptr(), 64, GATED, False, stream=feed); st.gate_wait(stream=side)
+        torch.cuda.synchronize()
+        buf = (C.c_ulonglong * (S * blocks))()
+        n = L.qs_debug_wg_times(st._h, buf, blocks)
+        a = np.array(buf[:S * n], dtype=np.uint64).reshape(n, S).astype(np.int64)
+        if rep >= 2:
+            per_wg.append((a[:, 5] - a[:, 4]) * 10.0 / GATED); spans.append((a[:, 5].max() - a[:, 4].min()) * 10.0 / GATED); skews.append((a[:, 4].max() - a[:, 4].min()) * 10.0)
+    per_wg = np.stack(per_wg)
+    print(f"workload {wl}: resident-state launches of {GATED} control steps, {n} workgroups x {st.waves_per_workgroup} waves (producer ahead)")
+    print(f"  per control step: workgroup wall time median {np.median(per_wg) / 1e3:.3f} us (min {per_wg.min() / 1e3:.3f}, max {per_wg.max() / 1e3:.3f}); "
+          f"first start -> last end of the launch / steps: median {np.median(spans) / 1e3:.3f} us")
+    print(f"  start skew of the launch (last workgroup's start after the first): median {np.median(skews) / 1e3:.2f} us ONCE per {GATED} steps = {np.median(skews) / 1e3 / GATED:.3f} us per step; "
+          f"state loads / stores: once per launch")
+    sys.exit(0)
 for t in range(60):
     st.from_host("actions", rng.uniform(-1, 1, size=(st.T, 4)))
     st.step()
