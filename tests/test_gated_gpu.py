@@ -91,6 +91,37 @@ def test_gated_launch_equals_one_launch_per_step(case, precision, closed_loop):
     plain.close(); gated.close(); stepwise.close()
 
 
+@pytest.mark.parametrize("spec,mode", [("off", "static_same_goal"), (None, "mix")])
+def test_gated_generic_kernels_and_full_scenario_set(spec, mode, monkeypatch):
+    """the other instantiations of the gated body: the generic library kernels (QS_SPEC=off) and the full scenario set (`mix`: per-env scenario
+    state in LDS across the steps of a launch) - float64, closed loop, against the open-loop multi-step launch"""
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native
+    from tests import test_hip_parity as thp
+    if spec is not None:
+        monkeypatch.setenv("QS_SPEC", spec)
+    E, K = 24, 20
+    kw = dict(thp.CASES["c2_n8_dw"], quads_mode=mode, ep_time=0.3)
+    cfg = qcfg.make_config(num_envs=E, seed=9, precision="f64", **kw)
+    plain, gated = native.Stepper(cfg, device=0), native.Stepper(cfg, device=0)
+    assert gated.team and (spec is None) == bool(gated.specialized)
+    T = E * cfg.num_agents
+    g = torch.Generator(device="cuda").manual_seed(6)
+    table = (torch.rand((2 * K, T, 4), device="cuda", generator=g, dtype=torch.float64) * 2 - 1).contiguous()
+    gated.gate_create(ring_len=4, wg_per_group=1)
+    side, feed = torch.cuda.Stream(), torch.cuda.Stream()
+    plain.reset(); gated.reset()
+    for l in range(2):   # the second launch crosses the 30-step episodes' auto-reset
+        gated.step_gated(K, stream=side)
+        gated.gate_produce(table[l * K].data_ptr(), K, K, closed_loop=True, stream=feed)
+        gated.gate_wait(stream=side)
+        plain.step_many(table[l * K].data_ptr(), K)
+        torch.cuda.synchronize()
+        assert gated.gate_status()["error"] == 0
+        _same(plain, gated, f"QS_SPEC={spec} {mode} launch {l}", True)
+    plain.close(); gated.close()
+
+
 def test_missing_producer_is_reported_not_hung(monkeypatch):
     import time
     import torch
