@@ -424,10 +424,8 @@ __device__ __forceinline__ void scenario_phase_full(const Consts<real> &c, const
 // env_goals: the env's goal rows in LDS (>= 2N + 6 rows); the centres live in scen_real[0..5][e].
 template <typename real, typename Sync>
 // returns (wave-uniform) whether any environment of the wave got new goals on this step
-// pre: the env's six centre values fetched at kernel entry (one-step team kernels: the swap used to start with a dependent round trip to HBM -
-// 6.4 k shader cycles in the step's slowest workgroup, profiles/r04l_wg_c4_steady.txt), or nullptr = load them here.
 __device__ __forceinline__ bool svs_phase(const Consts<real> &c, const Ptrs<real> &p, const RngKey &key, bool active, int N, int E, int e, int i, int tick, int svs_period,
-                                          real *env_goals, int *scr, real goal[3], int *s_cur_env, Sync sync, const real *pre = nullptr) {
+                                          real *env_goals, int *scr, real goal[3], int *s_cur_env, Sync sync) {
     if (c.scenario != QS_SCENARIO_SWARM_VS_SWARM) return false;
     const bool sw = active && svs_period > 0 && tick % svs_period == 0 && tick > 0;
     const bool any_sw = __ballot(sw) != 0;
@@ -435,13 +433,8 @@ __device__ __forceinline__ bool svs_phase(const Consts<real> &c, const Ptrs<real
 #ifndef QS_TAPE
         if (N / 2 >= 3) {   // the wave builds the two formations: lane i makes goal row i (svs_create_formations_wave, qs_device.h)
             real c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0};
-            if (pre) {
-#pragma unroll
-                for (int q = 0; q < 3; ++q) { c1[q] = pre[3 + q]; c2[q] = pre[q]; }
-            } else {
-                if (sw) { for (int q = 0; q < 3; ++q) { c1[q] = p.scen_real[(3 + q) * E + e]; c2[q] = p.scen_real[q * E + e]; } }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every lane holds the old centres before lane 0 swaps them
-            }
+            if (sw) { for (int q = 0; q < 3; ++q) { c1[q] = p.scen_real[(3 + q) * E + e]; c2[q] = p.scen_real[q * E + e]; } }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every lane holds the old centres before lane 0 swaps them
             if (sw && i == 0) { for (int q = 0; q < 3; ++q) { p.scen_real[q * E + e] = c1[q]; p.scen_real[(3 + q) * E + e] = c2[q]; } }
             Formation<real> F;
             RngKey kc = key;                      // the out-of-line callee takes the key by reference: a copy that lives in this cold
