@@ -892,9 +892,19 @@ __device__ __forceinline__ void formation_rows_wave(const RngKey &key, const For
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (on && needs_mean) {   // grid / cube: centre the formation; the mean is summed in row order like the serial loop
         real mean[3] = {0, 0, 0};
-        for (int k = 0; k < n; ++k)
+        for (int k0 = 0; k0 < n; k0 += 4) {   // four rows per LDS round trip; summed in row order like the serial loop
+            real row[4][3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) mean[q] += goals[(r0 + k) * 3 + q];
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) row[u][q] = goals[(r0 + ((k0 + u < n) ? k0 + u : n - 1)) * 3 + q];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + u < n) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) mean[q] += row[u][q];
+                }
+        }
 #pragma unroll
         for (int q = 0; q < 3; ++q) { mean[q] /= (real)n; g[q] = g[q] - mean[q] + cen[q]; }
     }
@@ -909,9 +919,15 @@ __device__ __forceinline__ void formation_rows_wave(const RngKey &key, const For
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (on && do_shuffle) {
         int pos = li;
-        for (int k = 1; k < n; ++k) {
-            const int j = scr[r0 + k];
-            pos = (pos == k) ? j : ((pos == j) ? k : pos);
+        for (int k0 = 1; k0 < n; k0 += 8) {   // eight swap partners per LDS round trip (a lone wave pays ~130 cycles per dependent LDS read: 15 of them were 2 k cycles of the goal swap)
+            int jj[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) jj[u] = scr[r0 + ((k0 + u < n) ? k0 + u : n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u;
+                if (k < n) pos = (pos == k) ? jj[u] : ((pos == jj[u]) ? k : pos);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) g[q] = goals[(r0 + pos) * 3 + q];
