@@ -72,15 +72,16 @@ __device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8De
         return lo | (hi << 16);
     }
     const int m = 4 * (j - q.w16), nq = q.q1 - q.q0;
+    const int a0 = m % 6;   // = 0, 4 or 2: the column kind (3 relative-position, 3 relative-velocity columns per neighbour) of the word's first byte
     unsigned int o = 0;
-#pragma unroll 1
+#pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int mm = m + u;
-        if (mm < nq) {
-            const int a = mm % 6;
-            const float sc = a == 0 ? q.scale[0] : a == 1 ? q.scale[1] : a == 2 ? q.scale[2] : a == 3 ? q.scale[3] : a == 4 ? q.scale[4] : q.scale[5];
-            o |= q8_byte(row[q.q0 + mm], sc) << (8 * u);
-        }
+        // kind of byte u = (a0 + u) % 6: positions share one scale and velocities another for the usual isotropic clips, but every column keeps its own
+        const int a = (a0 + u >= 6) ? a0 + u - 6 : a0 + u;
+        const float sc = a == 0 ? q.scale[0] : a == 1 ? q.scale[1] : a == 2 ? q.scale[2] : a == 3 ? q.scale[3] : a == 4 ? q.scale[4] : q.scale[5];
+        const float x = row[q.q0 + (mm < nq ? mm : 0)];
+        o |= (mm < nq ? q8_byte(x, sc) : 0u) << (8 * u);
     }
     return o;
 }
