@@ -410,6 +410,14 @@ void *qs_xchg_fused_desc(qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *
     return x->desc;
 }
 
+// library-internal (qs_set_obs_exchange): does the endpoint carry `cols`-column rows in wire `wire` and, for QS_WIRE_Q8, the block [q0, q1)?
+int qs_xchg_row_layout_is(qs_xchg *x, int32_t cols, int32_t q0, int32_t q1) {
+    if (!x) return 0;
+    if (x->cols != cols) return 0;
+    if (x->wire != QS_WIRE_Q8) return 1;
+    return (x->q8.D == cols && x->q8.q0 == q0 && x->q8.q1 == q1) ? 1 : 0;
+}
+
 int qs_xchg_status(qs_xchg *x, int64_t out[4]) {
     if (!x || !out) return fail(-1, "null argument");
     XTRY(hipSetDevice(x->device));

@@ -958,6 +958,7 @@ int qs_set_obs_target(qs_handle *h, void *obs_dev) {
 
 extern "C" void *qs_xchg_fused_desc(struct qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *n_out);
 extern "C" const char *qs_xchg_last_error(void);
+extern "C" int qs_xchg_row_layout_is(struct qs_xchg *x, int32_t cols, int32_t q0, int32_t q1);
 int qs_set_obs_exchange(qs_handle *h, struct qs_xchg *xchg, int32_t auto_ack) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     if (!xchg) { h->pf.xchg = nullptr; return QS_OK; }
@@ -968,6 +969,11 @@ int qs_set_obs_exchange(qs_handle *h, struct qs_xchg *xchg, int32_t auto_ack) {
     void *desc = qs_xchg_fused_desc(xchg, h->blocks, auto_ack, &n);
     if (!desc) return fail(QS_ERR_INVALID, std::string("qs_set_obs_exchange: ") + qs_xchg_last_error());
     if (n != (int64_t)h->cfg.num_envs * h->cfg.num_agents * h->obs_dim) return fail(QS_ERR_INVALID, "qs_set_obs_exchange: the endpoint's rows * cols must be E*N * obs_dim");
+    {   // the kernels rebuild a QS_WIRE_Q8 layout from their own constants: the neighbour block behind the self observation
+        const int self_dim = h->cfg.obs_repr == 0 ? 18 : (h->cfg.obs_repr == 1 ? 19 : 24);
+        if (!qs_xchg_row_layout_is(xchg, h->obs_dim, self_dim, self_dim + 6 * h->cfg.num_neighbors))
+            return fail(QS_ERR_INVALID, "qs_set_obs_exchange: the endpoint's row layout is not this configuration's (QS_WIRE_Q8: q0 = self columns, q1 = q0 + 6 * visible neighbours)");
+    }
     h->pf.xchg = (const qsx::XchgDev *)desc;
     return QS_OK;
 }
