@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) qs_obs_unpack_kernel(const char *src, flo
             const char *row = src + r * (long long)q.row_words * 4;
             if (c >= q.q0 && c < q.q1) {
                 const int mm = c - q.q0;
-                v = (float)((const signed char *)(row + 4 * q.w16))[mm] / q.scale[mm % 6];
+                v = (float)((const signed char *)(row + 4 * q.w16))[mm] / q8_scale(q, mm % 6);
             } else {
                 const int b = c < q.q0 ? c : c - (q.q1 - q.q0);
                 v = __uint_as_float((unsigned int)((const unsigned short *)row)[b] << 16);
@@ -211,7 +211,9 @@ static bool q8_dev(int32_t cols, const qs_wire_q8 *l, Q8Dev &q) {
     const int c16 = cols - (l->q1 - l->q0), n8 = l->q1 - l->q0;
     q.w16 = (c16 + 1) / 2;
     q.row_words = q.w16 + (n8 + 3) / 4;
-    for (int a = 0; a < 6; ++a) { if (!(l->clip[a] > 0.0f)) return false; q.scale[a] = (float)(127.0 / (double)l->clip[a]); }
+    float sc[6];
+    for (int a = 0; a < 6; ++a) { if (!(l->clip[a] > 0.0f)) return false; sc[a] = (float)(127.0 / (double)l->clip[a]); }
+    q.s0 = sc[0]; q.s1 = sc[1]; q.s2 = sc[2]; q.s3 = sc[3]; q.s4 = sc[4]; q.s5 = sc[5];
     return true;
 }
 

@@ -19,7 +19,8 @@ struct Local {   // device memory of the owning rank only
 struct Q8Dev {
     int D, q0, q1;        // columns; the int8 block
     int w16, row_words;   // 4-byte words of the bf16 section / of the whole row
-    float scale[6];       // 127 / clip
+    float s0, s1, s2, s3, s4, s5;   // 127 / clip of the six column kinds - named fields, not an array: a select over array elements is
+                                    // turned into an indexed read of a private (scratch) copy by the compiler, ~10 us per C4 step
 };
 
 // The fused form: what a step kernel needs to store its observation rows into every rank's window itself (qs_set_obs_exchange).
@@ -58,32 +59,43 @@ __device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+// (every layout value by VALUE: with the struct passed by reference the compiler turns the select over its adjacent scale fields into an indexed
+//  load, which pins the whole struct in scratch memory - 28-48 bytes of private segment and ~10 us per C4 step in the fused epilogue)
+__device__ __forceinline__ float q8_scale_of(int a, float s0, float s1, float s2, float s3, float s4, float s5) {
+    float sc = s0;
+    sc = a == 1 ? s1 : sc; sc = a == 2 ? s2 : sc; sc = a == 3 ? s3 : sc; sc = a == 4 ? s4 : sc; sc = a == 5 ? s5 : sc;
+    return sc;
+}
+__device__ __forceinline__ float q8_scale(const Q8Dev &q, int a) { return q8_scale_of(a, q.s0, q.s1, q.s2, q.s3, q.s4, q.s5); }
 // QS_WIRE_Q8: 4-byte word j of the wire row of the float32 row `row` (LDS or global memory)
 __device__ __forceinline__ unsigned int q8_byte(float x, float scale) {
     const float v = __builtin_rintf(x * scale);                       // round half to even (v_rndne_f32)
     const int q = (int)__builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);   // (NaN -> -127 by the min / max order: not a value the env produces)
     return (unsigned int)q & 0xffu;
 }
-__device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8Dev &q, int j) {
-    if (j < q.w16) {
-        const int b0 = 2 * j, b1 = b0 + 1, nq = q.q1 - q.q0;
-        const int c0 = b0 < q.q0 ? b0 : b0 + nq, c1 = b1 < q.q0 ? b1 : b1 + nq;
-        const unsigned int lo = c0 < q.D ? f32_to_bf16_rne(row[c0]) : 0u, hi = c1 < q.D ? f32_to_bf16_rne(row[c1]) : 0u;
+__device__ __forceinline__ unsigned int q8_row_word_v(const float *row, int D, int q0, int q1, int w16, float s0, float s1, float s2, float s3, float s4, float s5, int j) {
+    const int nq = q1 - q0;
+    if (j < w16) {
+        const int b0 = 2 * j, b1 = b0 + 1;
+        const int c0 = b0 < q0 ? b0 : b0 + nq, c1 = b1 < q0 ? b1 : b1 + nq;
+        const unsigned int lo = c0 < D ? f32_to_bf16_rne(row[c0]) : 0u, hi = c1 < D ? f32_to_bf16_rne(row[c1]) : 0u;
         return lo | (hi << 16);
     }
-    const int m = 4 * (j - q.w16), nq = q.q1 - q.q0;
+    const int m = 4 * (j - w16);
     const int a0 = m % 6;   // = 0, 4 or 2: the column kind (3 relative-position, 3 relative-velocity columns per neighbour) of the word's first byte
     unsigned int o = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int mm = m + u;
-        // kind of byte u = (a0 + u) % 6: positions share one scale and velocities another for the usual isotropic clips, but every column keeps its own
         const int a = (a0 + u >= 6) ? a0 + u - 6 : a0 + u;
-        const float sc = a == 0 ? q.scale[0] : a == 1 ? q.scale[1] : a == 2 ? q.scale[2] : a == 3 ? q.scale[3] : a == 4 ? q.scale[4] : q.scale[5];
-        const float x = row[q.q0 + (mm < nq ? mm : 0)];
+        const float sc = q8_scale_of(a, s0, s1, s2, s3, s4, s5);
+        const float x = row[q0 + (mm < nq ? mm : 0)];
         o |= (mm < nq ? q8_byte(x, sc) : 0u) << (8 * u);
     }
     return o;
+}
+__device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8Dev &q, int j) {
+    return q8_row_word_v(row, q.D, q.q0, q.q1, q.w16, q.s0, q.s1, q.s2, q.s3, q.s4, q.s5, j);
 }
 
 // Flags: relaxed system-scope accesses (they bypass the caches; no fence per access - an acquire / release at system scope invalidates
