@@ -15,11 +15,12 @@ auto-resets included.
 N > 1 (BASELINE.json configs[3], "C4"): 32 drones x 512 envs PER GPU (4096 envs at 8 GPUs), swarm_vs_swarm, and the exchange
 of the observation rows after every step INSIDE the timed region (north_star: "a single ... gather of observations over xGMI
 per rollout step"): every rank ends each step with the rows of all ranks.  [step -> exchange] x 64 is ONE captured HIP graph per
-rank (quad-swarm-rl_amd/parallel.py: ObsExchange); exchange(t) runs on a second stream under step(t+1); the wire format is
-bfloat16 (--wire f32 for bit-exact rows).  --transport fused: the step kernel itself stores its rows into every rank's hipIpc-mapped
+rank (quad-swarm-rl_amd/parallel.py: ObsExchange); exchange(t) runs on a second stream under step(t+1); the wire format at N > 1 is
+q8 - 72-byte rows: bf16 self columns + 8-bit fixed-point neighbour block, error <= 0.039 m / 0.024 m/s - (--wire bf16: 108-byte rows, --wire f32:
+bit-exact 216-byte rows; bf16 is the default of --force-gather at N = 1).  --transport fused: the step kernel itself stores its rows into every rank's hipIpc-mapped
 receive window (include/quadswarm_exchange.h; no launch besides the step), peer: the same windows filled by a push kernel on a second
 stream, rccl: RCCL all-gather of the packed rows (stepped eagerly: torch's collective is not recorded into a graph), auto (default): fused (peer for batches that run the single-wave kernels) if every
-rank could map its peers' windows and passed the start-up self-check, else rccl; torch: round 2's eager per-step all_gather.  The rate of the
+rank could map its peers' windows, passed the start-up self-check and holds the same rows an RCCL gather delivers (ObsExchange.verify), else rccl; torch: round 2's eager per-step all_gather.  The rate of the
 same shards stepping with no exchange is measured right after and reported as config.secondary (--no-gather makes it the
 headline; --workload / --envs-per-gpu override the shape).
 
@@ -334,8 +335,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
     ap.add_argument("--no-overlap", action="store_true", help="--transport torch: gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--transport", default="auto", choices=["auto", "fused", "peer", "rccl", "torch"], help="observation exchange (see the module docstring)")
-    ap.add_argument("--wire", default="bf16", choices=["q8", "bf16", "f32"], help="wire format of the exchanged rows (q8: bf16 self / SDF columns + 8-bit "
-                                                                                  "fixed-point neighbour block, 72 bytes per C4 row: include/quadswarm_exchange.h)")
+    ap.add_argument("--wire", default=None, choices=["q8", "bf16", "f32"], help="wire format of the exchanged rows (q8: bf16 self / SDF columns + 8-bit "
+                                                                                "fixed-point neighbour block, 72 bytes per C4 row: include/quadswarm_exchange.h).  Default: q8 at "
+                                                                                "--gpus N > 1 (the per-link time of a C4 step is 15 us with it, 23 with bf16: DESIGN.md 7), bf16 at N = 1")
     ap.add_argument("--segment", type=int, default=64, help="control steps per captured [step -> exchange] graph (0 = eager launches)")
     ap.add_argument("--no-variants", action="store_true", help="skip config.variants (shaped / rew_info / downwash-off / seeds 1, 2 runs of the same workload)")
     ap.add_argument("--no-c5-train", action="store_true", help="where sample_factory imports: do not run the C5 training (tools/train_c5.py)")
@@ -350,6 +352,8 @@ def main():
                                                            "bracket around K empty steps, rank 0 prints one JSON line with value null")
     args = ap.parse_args()
 
+    if args.wire is None:
+        args.wire = "q8" if args.gpus > 1 else "bf16"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` started directly: become the launcher of its own N ranks (one process per GPU); the ranks re-enter
         # main() with RANK / LOCAL_RANK / WORLD_SIZE set and rank 0 prints the one JSON line on the inherited stdout
