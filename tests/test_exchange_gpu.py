@@ -294,16 +294,43 @@ def test_obs_target_is_refused_with_device_replay():
     st.close()
 
 
-@pytest.mark.parametrize("wire", ["bf16", "q8"])
-def test_batched_env_gathers_with_the_published_recipe_flags(wire):
+def test_exchange_timeout_is_sticky_and_raises():
+    """a rank whose peer is late must not go on consuming stale rows silently - the timeout is sticky, check() / the next step() raise"""
+    import torch
+    from quad_swarm_rl_amd import config as qcfg, native, parallel
+    from tests import xchg_worker as xw
+    os.environ["QS_XCHG_TIMEOUT_MS"] = "40"
+    try:
+        cfg = qcfg.make_config(num_envs=8, seed=7, precision="f32", write_rew_info=False, **xw.KW)
+        st = native.Stepper(cfg, device=0)
+        ex = parallel.ObsExchange(st, 2, 0, transport="peer", wire="bf16", peers=[], hold=True)
+        silent = parallel.PeerExchange(st.T, st.obs_dim, 2, 1, wire="bf16")     # rank 1 exists but never pushes
+    finally:
+        del os.environ["QS_XCHG_TIMEOUT_MS"]
+    ex.x.attach_local(silent)
+    silent.attach_local(ex.x)
+    ex.reset()                         # the wait for rank 1's rows gives up after 40 ms
+    torch.cuda.synchronize()
+    with pytest.raises(native.QsError, match="timed out"):
+        ex.check()
+    acts = torch.zeros((st.T, 4), device="cuda")
+    with pytest.raises(native.QsError, match="timed out"):
+        ex.step(acts.data_ptr())       # sticky: no further steps on a failed exchange
+    with pytest.raises(native.QsError):
+        ex.latest()
+    ex.close(); silent.close(); st.close()
+
+
+@pytest.mark.parametrize("wire,transport", [("bf16", "rccl"), ("q8", "rccl"), ("q8", "peer")])
+def test_batched_env_gathers_with_the_published_recipe_flags(wire, transport):
     """--quads_gather_obs together with --replay_buffer_sample_prob=0.75 (what train_local.sh trains with) at world size 1: the env steps,
     gathered_obs() is the wire form of the rows step() returned, check_exchange() stays quiet"""
     import torch
     from quad_swarm_rl_amd import parallel
     from quad_swarm_rl_amd.sf_env import BatchedQuadSwarm
-    env = BatchedQuadSwarm(16, device=0, seed=3, replay_buffer_sample_prob=0.75, num_gpus=1, gather_obs=True, obs_wire=wire, num_agents=8,
-                           neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, quads_mode="mix", ep_time=0.4)
-    assert env.obs_transport == "rccl" and env.vec.exchange.source == "obs"
+    env = BatchedQuadSwarm(16, device=0, seed=3, replay_buffer_sample_prob=0.75, num_gpus=1, gather_obs=True, obs_wire=wire, obs_transport=transport,
+                           num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, quads_mode="mix", ep_time=0.4)
+    assert env.obs_transport == transport and env.vec.exchange.source == "obs"   # (peer: self-check and verify() passed, else it would have fallen back)
     obs, _ = env.reset()
     g = torch.Generator(device="cuda").manual_seed(0)
     for t in range(90):   # two episode ends inside
