@@ -596,7 +596,7 @@ def main():
             "shaped_episode_sums_and_rew_info": quick(episode_sums=True, write_rew_info=True, extra_bytes=268),
             "downwash_off": quick(kw_over=dict(use_downwash=False)),
         }
-        # resident-state stepping (include/quadswarm.h qs_step_gated): ONE launch per 64 control steps keeps the state in registers,
+        # resident-state stepping (include/quadswarm.h qs_step_gated): ONE launch per 256 control steps keeps the state in registers,
         # waits per step and workgroup for the step's actions and publishes its outputs; the actions come from a producer kernel on another
         # stream (qs_gate_produce: copies each batch of the pre-drawn table into the gate's ring, written through the L2, then raises the flags)
         # - running ahead of the stepper (bounded by the 64-slot ring), or closed loop (the batch of step s only after the outputs of s - 1).
@@ -610,7 +610,7 @@ def main():
                 s2.reset(stream=stream)
                 torch.cuda.synchronize()
                 side, feed = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-                k, reps = 64, max(2, min(max(args.steps, 200), 2000) // 64)
+                k, reps = 256, max(2, min(max(args.steps, 200), 2000) // 256)   # 256 control steps per launch (64: + 0.4 us per step, tools/gated_probe.py)
                 s2.step_gated(k, stream=side); s2.gate_produce(aptr, ring, k, closed_loop, stream=feed)   # warm-up launch pair
                 torch.cuda.synchronize()
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
