@@ -170,26 +170,6 @@ template <typename real>
 __device__ __forceinline__ bool ring_needed(const Consts<real> &c, real metric, uint32_t flags, const real *ri) {
     return !(flags & F_REACHED) && ((flags & F_RING_LIVE) || ring_near<real>(c, metric, -ri[QS_RI_RAW_POS]));
 }
-#ifdef QS_AB_TEAM_OLDLOG   // A/B only: round 3's form (every row exact, no flags) - NOT compatible with the lazy rows of the throughput kernels
-template <typename real>
-__device__ __forceinline__ void goal_distance_log_r03(const Consts<real> &c, real metric, int tick, uint32_t &flags, real ring[4], real sums[3], const real *ri, real eps_dist[3]) {
-    const real dnow = -ri[QS_RI_RAW_POS];
-    if (tick >= 5 && !(flags & F_REACHED)) {
-        real mean5 = ((((ring[3] + ring[2]) + ring[1]) + ring[0]) + dnow) * (real)0.2;
-        if (mean5 * c.inv_dt < metric) flags |= F_REACHED;
-    }
-    ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = dnow;
-    const int total = c.ep_len + 1;
-#pragma unroll
-    for (int w = 0; w < 3; ++w) {
-        const int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * c.control_freq;
-        real sum = (tick == 1) ? (real)0 : sums[w];
-        if (tick > total - win) sum += dnow;
-        sums[w] = sum;
-        eps_dist[w] = c.inv_dt * (sum * c.inv_win[w]);
-    }
-}
-#endif
 // LAZY: the kernel skips the rows' loads / stores on the steps that cannot matter (the throughput kernels) and therefore decides liveness
 // from the values.  The kernels that load and store every row anyway (team, multi-step, gated: the latency regime, where ~40 instructions
 // on the physics wave's critical path are 0.1 us of an 8 us step - measured: profiles/r04g_ab_tree_vs_r03.txt) keep every entry exact and
