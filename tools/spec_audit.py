@@ -56,6 +56,24 @@ class Recorder:
 
         native.Stepper.__getattribute__ = fake_getattr
         native.Stepper.__init__ = fake_init
+        # tests that move a policy / a tensor to the GPU before they create their handle: let them get as far as the handle
+        import torch
+        from quad_swarm_rl_amd import policy
+        torch.nn.Module.cuda = lambda self_, *a, **k: self_
+        torch.Tensor.cuda = lambda self_, *a, **k: self_
+        policy.FusedQuadEncoder.__init__ = lambda self_, *a, **k: None
+        from quad_swarm_rl_amd import rollout
+        rollout.GaussianActionHead.__init__ = lambda self_, *a, **k: None
+
+        def on_cpu(fn):
+            def wrapped(*a, **k):
+                k.pop("device", None)
+                return fn(*a, **k)
+            return wrapped
+        for name in ("rand", "randn", "zeros", "ones", "empty", "full", "tensor", "arange", "as_tensor", "randint"):
+            setattr(torch, name, on_cpu(getattr(torch, name)))
+        gen = torch.Generator
+        torch.Generator = lambda device=None: gen()
 
 
 def resolve(item):
