@@ -150,25 +150,38 @@ def cpu_baseline(workload, seconds):
                 os_cpu_count=os.cpu_count())
 
 
-def c5_record(run_training):
-    """BASELINE.json configs[4] ("C5": C2 inside Sample Factory APPO).  Sample Factory is not part of this image and cannot be
-    installed (no network): the bench line records the exact import error, or - where it imports - the FPS of tools/train_c5.py
-    (the reference's train_local.sh flag set, 2e5 env steps)."""
+def c5_record(run_training, iterations=6):
+    """BASELINE.json configs[4] ("C5": the C2 batch inside an APPO training loop, train_local.sh:1-18 through swarm_rl/train.py:16-33).
+    Where Sample Factory imports, tools/train_c5.py runs the reference's flag set through it and its FPS is recorded.  This image has no
+    Sample Factory and no network: the record then holds the exact import error AND a run of the in-tree PPO harness (tools/ppo_c5.py: the
+    same flag set, BatchedQuadSwarm with replay / shaping / annealing as the environment, the fixture-pinned encoder restatement as the
+    policy, a synchronous PPO learner on PyTorch-ROCm) - `iterations` rollouts of 128 steps x 8192 agents with one update pass each: agent
+    steps per second of the whole loop, of the sampling half alone, and the mean reward terms of the first and the last rollout."""
     import subprocess
+    sf_error = None
     try:
         import sample_factory  # noqa: F401
     except Exception as exc:   # noqa: BLE001 - the exact error is what is recorded
-        return {"status": "not run", "error": f"{type(exc).__name__}: {exc}",
-                "stand_in": "tests/test_sf_protocol_gpu.py drives the batched env through Sample Factory's vectorised-env protocol; tools/bench_rollout.py "
-                            "times the device-resident encoder -> head -> step loop"}
+        sf_error = f"{type(exc).__name__}: {exc}"
     if not run_training:
-        return {"status": "sample_factory importable; training skipped (--no-c5-train)"}
+        return {"status": "training skipped (--no-c5-train)", "sample_factory": sf_error or "importable"}
+    script = "train_c5.py" if sf_error is None else "ppo_c5.py"
+    argv = [sys.executable, os.path.join(REPO, "tools", script)] + ([] if sf_error is None else [f"--iterations={iterations}", "--quiet"])
     try:
-        out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "train_c5.py")], capture_output=True, text=True, timeout=1200)
+        out = subprocess.run(argv, capture_output=True, text=True, timeout=1200)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-        return json.loads(lines[-1]) if lines else {"status": "failed", "stderr_tail": out.stderr[-500:]}
+        if not lines:
+            return {"status": "failed", "sample_factory": sf_error or "importable", "stderr_tail": out.stderr[-500:]}
+        rec = json.loads(lines[-1])
+        if sf_error is None:
+            return rec
+        return {"status": "ran: in-tree PPO harness (tools/ppo_c5.py); Sample Factory itself is not installed", "sample_factory": sf_error,
+                "fps_agent_steps_per_s": rec["fps"], "agent_steps": rec["agent_steps"], "seconds": rec["seconds"], "first_rollout": rec["first"],
+                "last_rollout": rec["last"], "recipe": "train_local.sh flags: mix, replay 0.75, annealing 3e8, attention encoder, 6 neighbours, lr 1e-4, "
+                                                       f"rollout {rec['rollout']}, batch {rec['batch_size']}, 1024 envs x 8 quads",
+                "learning_test": "tests/test_c5_training_gpu.py"}
     except Exception as exc:   # noqa: BLE001
-        return {"status": "failed", "error": f"{type(exc).__name__}: {exc}"}
+        return {"status": "failed", "sample_factory": sf_error or "importable", "error": f"{type(exc).__name__}: {exc}"}
 
 
 def closed_loop_record(device):
@@ -233,40 +246,51 @@ def make_exchange(st, world, rank, transport, wire, dist, dev, info):
         return bool(t.item())
 
     if transport in ("auto", "peer", "fused"):
-        ex, why = None, ""
         kind = "peer" if transport == "peer" or not st.team else "fused"   # fused: the step kernel pushes its own rows (team kernels)
-        try:
-            ex = parallel.ObsExchange(st, world, rank, transport=kind, wire=wire, hold=False)
-        except Exception as exc:   # noqa: BLE001 - recorded; the fallback is a different transport, not a different result
-            why = f"{type(exc).__name__}: {exc}"
-        attached = all_agree(ex is not None)
-        ok = False
-        if attached:
+        info["attempts"] = []
+        for fenced in (False, True):   # the relaxed flag protocol, then its fenced variant (QS_XCHG_FENCED, include/quadswarm_exchange.h), then RCCL
+            ex, why, att = None, "", {"flags": "fenced" if fenced else "relaxed"}
             try:
-                ok, why = ex.self_check()
-            except Exception as exc:   # noqa: BLE001
-                ok, why = False, f"{type(exc).__name__}: {exc}"
-            ok = all_agree(ok)
-        info["peer_self_check"] = "passed on every rank" if ok else ("failed" + (f" here: {why}" if why else " on another rank"))
-        if ok:   # ... and through the real producer of the rows (fused: the step kernels' epilogue is not what self_check exercises): the rows of
-            #      an exchanged reset + two steps against an RCCL gather of the same float32 rows, on every rank
-            try:
-                ex.reset()
-                ok, why = ex.verify()
-                for t in range(2):
-                    if ok:
-                        ex.step(info["_actions_ptr"])
-                        torch.cuda.synchronize()
-                        ok, why = ex.verify()
-            except Exception as exc:   # noqa: BLE001
-                ok, why = False, f"{type(exc).__name__}: {exc}"
-            ok = all_agree(ok)
-            info["verified_against_rccl_gather_before"] = "equal on every rank" if ok else ("differs" + (f" here: {why}" if why else " on another rank"))
-        if ok:
-            info["transport"] = kind
-            return ex
-        if ex is not None:
-            ex.close()
+                ex = parallel.ObsExchange(st, world, rank, transport=kind, wire=wire, hold=False, fenced=fenced)
+            except Exception as exc:   # noqa: BLE001 - recorded; the fallback is a different transport, not a different result
+                why = f"{type(exc).__name__}: {exc}"
+            ok = all_agree(ex is not None)
+            att["windows_mapped"] = "on every rank" if ok else ("failed" + (f" here: {why}" if why else " on another rank"))
+            if ok:
+                try:
+                    ok, why = ex.self_check()
+                except Exception as exc:   # noqa: BLE001
+                    ok, why = False, f"{type(exc).__name__}: {exc}"
+                ok = all_agree(ok)
+                att["peer_self_check"] = "passed on every rank" if ok else ("failed" + (f" here: {why}" if why else " on another rank"))
+            if ok:   # ... and through the real producer of the rows (fused: the step kernels' epilogue is not what self_check exercises): the rows of
+                #      an exchanged reset + two steps against an RCCL gather of the same float32 rows, on every rank.  Every rank-local action is
+                #      agreed on before the next collective (verify() does that for its own local part): a rank that raised in reset() / step() while
+                #      the others entered verify()'s all-gather would leave mismatched collectives behind
+                for t in range(3):
+                    try:
+                        if t == 0:
+                            ex.reset()
+                        else:
+                            ex.step(info["_actions_ptr"])
+                            torch.cuda.synchronize()
+                    except Exception as exc:   # noqa: BLE001
+                        ok, why = False, f"{type(exc).__name__}: {exc}"
+                    ok = all_agree(ok)
+                    if not ok:
+                        break
+                    ok, why = ex.verify()
+                    ok = all_agree(ok)
+                    if not ok:
+                        break
+                att["verified_against_rccl_gather_before"] = "equal on every rank" if ok else ("differs" + (f" here: {why}" if why else " on another rank"))
+            info["attempts"].append(att)
+            info.update({k: v for k, v in att.items() if k != "flags"})
+            if ok:
+                info["transport"], info["flag_protocol"] = kind, att["flags"]
+                return ex
+            if ex is not None:
+                ex.close()
     info["transport"] = "rccl"
     return parallel.ObsExchange(st, world, rank, transport="rccl", wire=wire, hold=False)
 
@@ -305,12 +329,32 @@ def dry_run(args, rank, world):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     seen = dist.get_world_size()
     workload = args.workload or ("c2" if world == 1 else "c4")
+    # what every rank would step, and what the exchange would put on every link - the host arithmetic of the N-rank run, no GPU involved
+    from quad_swarm_rl_amd import config as qcfg, native, parallel
+    w = WORKLOADS[workload]
+    E = args.envs_per_gpu or w["num_envs"]
+    lo, hi = parallel.shard_range(world * E, world, rank)
+    cfg = qcfg.make_config(num_envs=E, seed=0, env_id_offset=lo, precision="f32", write_rew_info=False, **w["kw"])
+    mine = {"rank": rank, "envs": [lo, hi], "env_id_offset": int(cfg.env_id_offset), "drones": E * cfg.num_agents}
+    shards = [None] * world
+    dist.all_gather_object(shards, mine)
+    per_wire = None
+    try:
+        D = int(native.lib().qs_obs_dim(cfg))
+        per_wire = {}
+        for wire in ("f32", "bf16", "q8"):
+            rb = parallel.wire_row_bytes(D, wire, native.wire_q8_layout(cfg, D) if wire == "q8" else None)
+            link = E * cfg.num_agents * rb
+            per_wire[wire] = {"row_bytes": rb, "lossy": wire != "f32", "bytes_per_link_per_step": link, "predicted_link_us_per_step_at_77_GB_per_s": 1e6 * link / 77e9,
+                              "ms_per_step": None, "exchange_cost_us_per_step": None, "verified_against_rccl_gather_before": None, "verified_against_rccl_gather_after": None}
+    except Exception as exc:   # noqa: BLE001 - e.g. the library is not built on this machine
+        per_wire = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         print(json.dumps({"metric": "env-steps/s (drones x envs x sim_steps)", "value": None, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-                          "data": "synthetic", "dry_run": True,
+                          "data": "synthetic", "dry_run": True, "wire": args.wire if world > 1 and not args.no_gather else None,
                           "config": {"workload": workload, "ranks_seen_by_process_group": seen, "backend": "gloo",
-                                     "bracket_host_seconds_max_over_ranks": float(tmax.item()),
+                                     "bracket_host_seconds_max_over_ranks": float(tmax.item()), "shards": shards, "exchange_per_wire": per_wire,
                                      "launch": "self-launched ranks" if os.environ.get("TORCHELASTIC_RUN_ID") else "single process"}}), flush=True)
     dist.destroy_process_group()
     return 0
@@ -335,12 +379,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
     ap.add_argument("--no-overlap", action="store_true", help="--transport torch: gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--transport", default="auto", choices=["auto", "fused", "peer", "rccl", "torch"], help="observation exchange (see the module docstring)")
-    ap.add_argument("--wire", default=None, choices=["q8", "bf16", "f32"], help="wire format of the exchanged rows (q8: bf16 self / SDF columns + 8-bit "
-                                                                                "fixed-point neighbour block, 72 bytes per C4 row: include/quadswarm_exchange.h).  Default: q8 at "
-                                                                                "--gpus N > 1 (the per-link time of a C4 step is 15 us with it, 23 with bf16: DESIGN.md 7), bf16 at N = 1")
+    ap.add_argument("--wire", default="bf16", choices=["q8", "bf16", "f32"], help="wire format of the exchanged rows.  Default bf16 - the wire the Sample Factory env "
+                                                                                  "defaults to (--quads_obs_wire).  f32 is the bit-exact one; q8 (bf16 self / SDF columns + 8-bit fixed-point "
+                                                                                  "neighbour block, 72 bytes per C4 row, error <= 0.039 m / 0.024 m/s: include/quadswarm_exchange.h) is a LOSSY "
+                                                                                  "opt-in outside the 1e-5 observation tolerance.  The line names the wire in its top-level `wire` field")
     ap.add_argument("--segment", type=int, default=64, help="control steps per captured [step -> exchange] graph (0 = eager launches)")
     ap.add_argument("--no-variants", action="store_true", help="skip config.variants (shaped / rew_info / downwash-off / seeds 1, 2 runs of the same workload)")
-    ap.add_argument("--no-c5-train", action="store_true", help="where sample_factory imports: do not run the C5 training (tools/train_c5.py)")
+    ap.add_argument("--no-c5-train", action="store_true", help="do not run the C5 training (tools/train_c5.py through Sample Factory where it imports, else the in-tree PPO harness tools/ppo_c5.py)")
     ap.add_argument("--no-f64", action="store_true", help="skip the f64 line (same workload through the float64 kernels)")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip config.c5.closed_loop_without_sample_factory (encoder -> action -> step as a HIP graph)")
     ap.add_argument("--rew-info", action="store_true", help="also write the 17-term reward-info matrix every step (logging output)")
@@ -348,12 +393,12 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="headline mode: step the timed region as open-loop rollouts of this many steps per "
                                                           "launch (qs_step_many: state stays in registers between the steps)")
     ap.add_argument("--rollout-steps", type=int, default=64, help="steps per launch of the extra open-loop measurement (0 = skip)")
+    ap.add_argument("--no-wire-sweep", action="store_true", help="with an observation exchange: measure the headline's wire only (config.exchange_per_wire otherwise holds f32, bf16 and q8)")
+    ap.add_argument("--no-reset-crossing", action="store_true", help="do not pre-advance episode clocks when the timed region is shorter than an episode (config.auto_reset)")
     ap.add_argument("--dry-run", action="store_true", help="launch path only: ranks rendezvous over gloo (no GPU needed), take the barriers of the timed "
                                                            "bracket around K empty steps, rank 0 prints one JSON line with value null")
     args = ap.parse_args()
 
-    if args.wire is None:
-        args.wire = "q8" if args.gpus > 1 else "bf16"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` started directly: become the launcher of its own N ranks (one process per GPU); the ranks re-enter
         # main() with RANK / LOCAL_RANK / WORLD_SIZE set and rank 0 prints the one JSON line on the inherited stdout
@@ -436,13 +481,20 @@ def main():
             gather.drain()   # the launch stream waits for the in-flight collectives: the closing event sees them
 
     seg = 0
-    if exchange is not None:   # reset (its rows are exchanged like a step's), then [step -> exchange] x seg as one HIP graph, captured before
-        exchange.reset()       # any timed region (the eager steps capture() takes first are untimed)
+
+    def prepare_exchange(info):
+        """reset (its rows are exchanged like a step's), then [step -> exchange] x seg as one HIP graph, captured before any timed region (the
+        eager steps capture() takes first are untimed)"""
+        nonlocal seg
+        exchange.reset()
         seg = min(args.segment, ring, max(args.steps, 2)) & ~1   # (a whole number of segments fits the timed region also at --steps 20)
-        if seg >= 2 and xinfo.get("transport") == "rccl":
+        if seg >= 2 and info.get("transport") == "rccl":
             seg = 0            # torch's collective must not be recorded into a graph (parallel.ObsExchange.capture): eager steps
         if seg >= 2:
             exchange.capture([aptr + t * astride for t in range(seg)])
+
+    if exchange is not None:
+        prepare_exchange(xinfo)
 
     def run_exchange(k):
         """exactly k control steps, each followed by the exchange of its rows: whole segments as graph replays, the rest eagerly"""
@@ -497,6 +549,21 @@ def main():
         s0.close()
     if exchange is None:
         st.reset(stream=stream)
+    # "auto-reset included"  also when the timed region is shorter than an episode: the episode clocks of the share of the
+    # environments that a window of K steps sees ending in the steady state (E * K / ep_len of them, at least one), spread over the batch, are
+    # advanced so that they end - statistics snapshot + device-side reset + fresh observation - at evenly spread steps INSIDE the timed
+    # region.  Longer regions cross the episodes' natural end (all environments at once, the way the reference's synchronous loop does).
+    crossing = {"envs_ending_inside_the_timed_region": 0, "how": "the region covers whole episodes: every environment ends naturally"}
+    if args.warmup + args.steps <= cfg.ep_len and not args.no_reset_crossing:
+        torch.cuda.synchronize()
+        n_cross = max(1, int(round(E * args.steps / (cfg.ep_len + 1))))
+        tick = st.to_host("tick")
+        for j in range(n_cross):
+            e = (j * E) // n_cross
+            tick[e] = cfg.ep_len - args.warmup - (j * args.steps) // n_cross   # ends with timed step (j * K) // n_cross: tick + 1 > ep_len there
+        st.from_host("tick", tick)
+        crossing = {"envs_ending_inside_the_timed_region": n_cross, "how": f"episode clocks of {n_cross} of {E} environments (= E * K / episode length) pre-advanced so that "
+                                                                           "their episodes end at evenly spread timed steps"}
     head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None, xchg=use_gather and exchange is not None)
     st.check_errors()
     if exchange is not None:
@@ -533,6 +600,42 @@ def main():
         if use_gather:
             kernel_region_s, kernel_region_steps = sdev, sk
             secondary["exchange_cost_us_per_step"] = 1e6 * (head_dev / args.steps - sdev / sk)
+    # every wire on the same shards, same bracketing: the measured step with the exchange, what the exchange costs over the
+    # independent shards, verify() before (make_exchange) and after the timed steps, the predicted per-link time.  f32 is the bit-exact wire;
+    # bf16 and q8 are lossy (q8 beyond the 1e-5 observation tolerance): the headline's wire is named in the top-level `wire` field.
+    wire_table = None
+    if use_gather and exchange is not None and not args.no_wire_sweep and dist is not None:
+        base_ms = secondary["ms_per_step"] if secondary else None
+
+        def wire_entry(info, dev_s, k):
+            rb = exchange.x.row_bytes
+            ent = {"transport": info.get("transport"), "flag_protocol": info.get("flag_protocol"), "row_bytes": rb, "lossy": exchange.wire != "f32",
+                   "ms_per_step": 1e3 * dev_s / k, "value": world * T * 2 * k / dev_s,
+                   "exchange_cost_us_per_step": (1e3 * (1e3 * dev_s / k - base_ms)) if base_ms is not None else None,
+                   "predicted_link_us_per_step_at_77_GB_per_s": 1e6 * T * rb / 77e9,
+                   "verified_against_rccl_gather_before": info.get("verified_against_rccl_gather_before"),
+                   "verified_against_rccl_gather_after": info.get("verified_against_rccl_gather_after")}
+            return ent
+
+        wire_table = {args.wire: wire_entry(xinfo, head_dev, args.steps)}
+        for w_name in ("f32", "bf16", "q8"):
+            if w_name == args.wire:
+                continue
+            wi = {"requested": args.transport, "wire": w_name, "_actions_ptr": aptr}
+            try:
+                exchange.close()
+                exchange = make_exchange(st, world, rank, args.transport, w_name, dist, dev, wi)
+                wi.pop("_actions_ptr", None)
+                prepare_exchange(wi)
+                wd, _ = timed(st, aptr, astride, min(args.warmup, 50), args.steps, None, xchg=True)
+                torch.cuda.synchronize()
+                v_ok, v_why = exchange.verify()
+                wi["verified_against_rccl_gather_after"] = "equal" if v_ok else f"differs: {v_why}"
+                wire_table[w_name] = wire_entry(wi, wd, args.steps)
+                wire_table[w_name]["status"] = exchange.status()
+            except Exception as exc:   # noqa: BLE001 - recorded
+                wire_table[w_name] = {"error": f"{type(exc).__name__}: {exc}"}
+                break
     if kernel_region_s is None:   # gather headline without secondary: a short step-only region for the roofline
         kernel_region_steps = max(args.steps, 50)
         kernel_region_s, _ = timed(st, aptr, astride, 10, kernel_region_steps, None)
@@ -680,6 +783,7 @@ def main():
             "metric": "env-steps/s (drones x envs x sim_steps)", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * head_dev / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "wire": (args.wire if use_gather else None),   # the observation exchange's wire format (f32 = bit-exact; bf16 / q8 are lossy), null without an exchange
             "config": {"workload": f"{workload}: {N} drones x {E} envs per GPU ({world * E} envs in total), {kw.get('quads_mode', 'static_same_goal')}, "
                                    f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
                        "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N, "ranks_seen_by_process_group": ranks_seen,
@@ -689,7 +793,9 @@ def main():
                        "obs_gather": gather_desc if use_gather else ("none: env shards are independent, no data-path collective (--no-gather)" if world > 1 else "none"),
                        "gather_bytes_per_gpu_per_step": int((world - 1) * T * D * wire_b) if use_gather else 0,
                        "exchange": xinfo if (use_gather or secondary) else None,
+                       "exchange_per_wire": wire_table,
                        "secondary": secondary,
+                       "auto_reset": crossing,
                        "launch": f"open-loop rollout, {min(args.graph, ring)} steps per launch" if args.graph > 0 and not use_gather else "one launch per control step",
                        "device_prewarm_steps_on_a_scratch_handle": args.prewarm, "open_loop_rollout": rollout, "f64": f64, "rew_info": bool(args.rew_info), "variants": variants,
                        "c5": dict(c5_record(not args.no_c5_train), closed_loop_without_sample_factory=closed_loop_record(local_rank)) if world == 1 and not args.no_secondary and not args.no_closed_loop

@@ -249,6 +249,15 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
  * launches).  Team kernels only (qs_kernel_flavor); not together with the replay wrapper, a noise tape or the fused exchange.
  * qs_gate_produce: the trivial producer used by bench.py and the tests - k steps of the protocol above with the action batches taken
  * round-robin from a table of n_src batches resident in HBM (closed_loop = 0: runs ahead, bounded only by the ring).
+ * qs_gate_produce_verify: the same producer in closed-loop mode that ALSO consumes the stepper's outputs the way a policy would - after seeing
+ * done_flag >= s for its workgroups it executes an agent-scope acquire (see "Visibility" below) and reads the observation rows and rewards of
+ * step s - and writes sums_dev[t * groups + g] = the sum of their 32-bit words for step t of this call and group g (test instrument).
+ * Visibility: the stepper stores its outputs with system-scope write-through stores and drains them before it raises done_flag.  A CONSUMER
+ * that runs concurrently with the gated launch and has seen done_flag[w] >= s (a relaxed system-scope load; the flags live in uncached memory)
+ * must execute an agent-scope acquire - `__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")`, i.e. `buffer_inv sc1` - before it reads workgroup
+ * w's rows of step s: the L2 of the consumer's XCD is not coherent with the stepper's and may still hold the rows of step s - 1.  A PRODUCER
+ * writes its action rows with system-scope write-through stores (`global_store ... sc0 sc1`), waits for them (`s_waitcnt vmcnt(0)`), then stores
+ * act_flag (the ring and the flags are uncached memory: no acquire is needed on the stepper's side).
  * qs_gate_status: out[0] = status bits (1 = action wait timed out, 2 = producer wait timed out), out[1] = steps launched,
  * out[2] = min act_flag, out[3] = min done_flag (synchronises the device).
  */
@@ -263,6 +272,7 @@ int qs_gate_info(qs_handle *h, qs_gate_info_t *out);
 int qs_step_gated(qs_handle *h, int32_t k, void *stream);   /* ordered BEHIND `stream`; runs on the library's own queue */
 int qs_gate_wait(qs_handle *h, void *stream);                /* orders `stream` behind the last gated launch (issue it AFTER the producer's work) */
 int qs_gate_produce(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, int32_t closed_loop, void *stream);
+int qs_gate_produce_verify(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, unsigned long long *sums_dev, void *stream);
 int qs_gate_status(qs_handle *h, int64_t out[4]);
 
 int qs_sync(qs_handle *h, void *stream);

@@ -57,6 +57,7 @@ def lib():
         _lib.qso_set_state.argtypes = [C.c_void_p, dp, C.c_int32]
         _lib.qso_get_info.argtypes = [C.c_void_p, C.POINTER(QsoInfo)]
         _lib.qso_set_reward_coeffs.argtypes = [C.c_void_p, dp]
+        _lib.qso_set_numpy126_quirk.argtypes = [C.c_void_p, C.c_int32]
         _lib.qso_step_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, dp, dp, u8p]
         _lib.qso_rollout_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, u8p]
         _lib.qso_rollout_batch_threads.argtypes = [C.POINTER(C.c_void_p), C.c_int32, dp, C.c_int32, C.c_int32, dp, dp, u8p, C.c_int32]
@@ -134,6 +135,10 @@ class OracleEnv:
     def set_reward_coeffs(self, coeffs):
         c = np.ascontiguousarray(coeffs, dtype=np.float64)
         lib().qso_set_reward_coeffs(self._h, _dp(c))
+
+    def set_numpy126_quirk(self, on=True):
+        """NumPy-1.26 value-based casting of the omega damping factor after a float32 omega (numpy floor mode)"""
+        lib().qso_set_numpy126_quirk(self._h, 1 if on else 0)
 
     def close(self):
         if self._h:

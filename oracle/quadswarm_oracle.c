@@ -74,6 +74,7 @@ struct qso_env {
     /* rng */
     const double *tape;
     int64_t tape_n, tape_i;
+    int32_t np126;   /* qso_set_numpy126_quirk: NumPy-1.26 value-based casting of the omega damping term (App. D), off by default */
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -224,14 +225,28 @@ static double torque_rot_omega(qso_env *e, drone_t *d, const double cmds_in[4], 
     double cr[3] = {a[1] * Iw[2] - a[2] * Iw[1], a[2] * Iw[0] - a[0] * Iw[2], a[0] * Iw[1] - a[1] * Iw[0]};
     /* NB (App. D): in the numpy path omega is a float32 array right after reset / a floor crash.  Under the
      * reference's pinned NumPy 1.26 (value-based casting) that makes (1-damp)*dt evaluate in float32 for ONE
-     * sub-step (2e-8 relative); under NumPy >= 2 (the run the golden fixtures come from) damp_omega_quadratic is
-     * a float64 scalar and the expression stays float64.  The oracle follows the fixtures: no dt quirk.  The
-     * in-place `omega += ...` of the collision responses on such a float32 array IS kept (add_omega). */
-    double dtq = dt;
+     * sub-step (2e-8 relative); under NumPy >= 2 (the run most golden fixtures come from) damp_omega_quadratic is
+     * a float64 scalar and the expression stays float64.  Default: the fixtures' semantics (no dt quirk); the
+     * 1.26 behaviour is a switch (below).  The in-place `omega += ...` of the collision responses on such a
+     * float32 array IS kept (add_omega). */
+    /* qso_set_numpy126_quirk(e, 1): the reference AS PINNED (setup.py:14: numpy 1.26.4).  There `self.damp_omega_quadratic` (an np.float64
+     * scalar) times `self.omega ** 2` (a float32 array for the one sub-step after set_state / a floor crash, quadrotor_dynamics.py:188,:430)
+     * is a FLOAT32 array by value-based casting, and so are its clip, `1.0 - ...` and the product with the Python float `dt` (:324-325): the
+     * factor (1 - damp) * dt is rounded to float32 (dt -> 0.004999999888) before it meets the float64 `omega_dot`.  Pinned by the fixture
+     * `c1_single_numpy_np126` (captured under NumPy 2 with that scalar made a Python float, which NEP 50 treats the same way). */
+    const int quirk = e->np126 && c->floor_mode == QS_FLOOR_NUMPY && (d->flags & F_OMEGA_F32);
     for (int k = 0; k < 3; ++k) {
         double od = (1.0 / c->inertia[k]) * (cr[k] + torque[k]);
+        if (quirk) {
+            const float o32 = (float)om[k], sq = o32 * o32;
+            float damp32 = (float)c->damp_omega_quadratic * sq;
+            damp32 = damp32 < 0.0f ? 0.0f : (damp32 > 1.0f ? 1.0f : damp32);
+            const float f32 = (1.0f - damp32) * (float)dt;
+            om[k] = clipd(om[k] + (double)f32 * od, -c->omega_max, c->omega_max);
+            continue;
+        }
         double damp = clipd(c->damp_omega_quadratic * (om[k] * om[k]), 0.0, 1.0);
-        om[k] = clipd(om[k] + (1.0 - damp) * dtq * od, -c->omega_max, c->omega_max);
+        om[k] = clipd(om[k] + (1.0 - damp) * dt * od, -c->omega_max, c->omega_max);
     }
     d->flags &= ~F_OMEGA_F32;
     /* position (:563) */
@@ -1518,6 +1533,7 @@ void qso_set_tape(qso_env *e, const double *tape, int64_t n) { e->tape = tape; e
 int64_t qso_tape_pos(const qso_env *e) { return e->tape_i; }
 void qso_get_info(const qso_env *e, qso_info *out) { *out = e->info; }
 void qso_set_reward_coeffs(qso_env *e, const double *coeffs) { memcpy(e->c.rew_coeff, coeffs, sizeof e->c.rew_coeff); }
+void qso_set_numpy126_quirk(qso_env *e, int32_t on) { e->np126 = on ? 1 : 0; }
 
 void qso_get_state(const qso_env *e, double *s, int32_t *tick) {
     for (int i = 0; i < e->c.num_agents; ++i, s += QS_STATE_STRIDE) {

@@ -56,6 +56,8 @@ void qso_get_state(const qso_env *e, double *state /* [N*QS_STATE_STRIDE] */, in
 void qso_set_state(qso_env *e, const double *state, int32_t tick);
 void qso_get_info(const qso_env *e, qso_info *out);
 void qso_set_reward_coeffs(qso_env *e, const double *coeffs);
+/* numpy floor mode only: evaluate the omega damping factor the way NumPy 1.26's value-based casting does; default off */
+void qso_set_numpy126_quirk(qso_env *e, int32_t on);
 
 /* Batched convenience for the CPU baseline: step `num` independent envs (OpenMP over envs if built with it). */
 void qso_step_batch(qso_env **envs, int32_t num, const double *actions, double *obs, double *rew, uint8_t *done);

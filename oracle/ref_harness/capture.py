@@ -138,7 +138,14 @@ def default_cfg(**over):
 
 
 def make_env(cfg):
-    """Mirrors swarm_rl/env_wrappers/quad_utils.py:20-65 (make_quadrotor_env_multi)."""
+    """Mirrors swarm_rl/env_wrappers/quad_utils.py:20-65 (make_quadrotor_env_multi).
+    Two emulation switches for what this container cannot run (numba, NumPy 1.26 - the reference's pins, setup.py:14), both OFF unless a case asks:
+      cfg["numba_float32_ou"]  - the jitclass stub rounds OUNoiseNumba's float32 members (theta, sigma, mu) to float32 like numba does
+      cfg["numpy126_omega_quirk"] - `damp_omega_quadratic` becomes a Python float, so that NumPy 2's promotion (NEP 50: a Python scalar takes the
+                                 array's dtype) evaluates `damp * omega ** 2 ... * dt` on a float32 omega in float32 - what NumPy 1.26's value-
+                                 based casting does with the np.float64 scalar the reference holds (quadrotor_dynamics.py:322-325)"""
+    import numba.experimental as nbx
+    nbx.EMULATE_FLOAT32_FIELDS = bool(cfg.get("numba_float32_ou", False))
     dynamics_change = dict(noise=dict(thrust_noise_ratio=cfg["thrust_noise_ratio"]),
                            damp=dict(vel=0, omega_quadratic=0))
     env = QuadrotorEnvMulti(
@@ -157,6 +164,9 @@ def make_env(cfg):
     )
     for i, e in enumerate(env.envs):
         e.np_random = RecordingNpRandom(1000 + i)
+        if cfg.get("numpy126_omega_quirk", False):
+            e.dynamics.damp_omega_quadratic = float(e.dynamics.damp_omega_quadratic)
+    nbx.EMULATE_FLOAT32_FIELDS = False
     return env
 
 
@@ -416,13 +426,37 @@ def c1_single_numpy():
                                             rew_coeff=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0,
                                                            orient=1.0, yaw=0.0, quadcol_bin=0.0,
                                                            quadcol_bin_smooth_max=0.0, quadcol_bin_obst=0.0)),
-             steps=400, seed=11)
+             steps=1000, seed=11)   # BASELINE config 1 as written: 1000 steps
+
+
+C1_NUMPY = dict(num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none", use_downwash=False, use_numba=False, collision_falloff_radius=-1.0,
+                rew_coeff=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0, quadcol_bin=0.0, quadcol_bin_smooth_max=0.0,
+                               quadcol_bin_obst=0.0))
+
+
+@case
+def c1_single_numpy_np126():
+    # config 1 under the NumPy-1.26 promotion of the omega damping term (see make_env): random actions crash the drone within a few dozen steps and
+    # keep it bouncing - every floor crash / reset leaves a float32 omega for one sub-step
+    run_case("c1_single_numpy_np126", default_cfg(numpy126_omega_quirk=True, **C1_NUMPY), steps=1000, seed=11)
 
 
 @case
 def c1_single_numba():
     run_case("c1_single_numba", default_cfg(num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none",
-                                            use_downwash=False, use_numba=True), steps=300, seed=12)
+                                            use_downwash=False, use_numba=True), steps=1000, seed=12)   # config 1's length
+
+
+@case
+def c1_single_numba_f32ou():
+    # the numba path with OUNoiseNumba's float32 theta / sigma (numba_utils.py:67-74) emulated by the jitclass stub
+    run_case("c1_single_numba_f32ou", default_cfg(num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none", use_downwash=False, use_numba=True,
+                                                  numba_float32_ou=True), steps=1000, seed=12)
+
+
+@case
+def c2_n8_numba_f32ou():
+    run_case("c2_n8_numba_f32ou", default_cfg(numba_float32_ou=True), steps=200, seed=21)
 
 
 @case
@@ -481,7 +515,7 @@ def c3_n8_obst_episode():
 
 @case
 def c4_n32_svs():
-    run_case("c4_n32_svs", default_cfg(num_agents=32, quads_mode="swarm_vs_swarm"), steps=40, seed=41)
+    run_case("c4_n32_svs", default_cfg(num_agents=32, quads_mode="swarm_vs_swarm"), steps=120, seed=41)
 
 
 @case

@@ -29,14 +29,18 @@ def vectorize(*dargs, **dkwargs):
 
 
 class _T:
+    def __init__(self, name="any"):
+        self.name = name
+
     def __getitem__(self, item):
-        return self
+        return _T(self.name + "[]")
 
     def __call__(self, *a, **k):
         return self
 
 
-int32 = float32 = double = boolean = float64 = int64 = _T()
+int32 = double = boolean = float64 = int64 = _T()
+float32 = _T("float32")   # (its own object: the jitclass stub can tell which fields numba would store as float32)
 
 
 class types:

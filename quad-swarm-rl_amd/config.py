@@ -90,7 +90,7 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
                 sense_noise="default", thrust_noise_ratio=0.05, sim_freq=200.0, sim_steps=2,
                 seed=0, env_id_offset=0, precision="f32", write_rew_info=True, episode_sums=False,
                 domain_random=False, obst_density_random=False, obst_size_random=False,
-                obst_density_min=0.05, obst_density_max=0.2, obst_size_min=0.3, obst_size_max=0.6):
+                obst_density_min=0.05, obst_density_max=0.2, obst_size_min=0.3, obst_size_max=0.6, numba_float32_ou=None):
     """Build a QsConfig.  Argument names/defaults follow the reference's `--quads_*` flags
     (swarm_rl/env_wrappers/quadrotor_params.py:15-120) and QuadrotorEnvMulti.__init__."""
     if num_agents < 1 or num_agents > QS_MAX_AGENTS:
@@ -120,6 +120,15 @@ def make_config(num_envs=1, num_agents=8, ep_time=15.0, rew_coeff=None, obs_repr
     for k in ("motor_tau_up", "motor_tau_down", "motor_linearity", "vel_damp", "damp_omega_quadratic", "omega_max",
               "gravity", "thrust_noise_sigma", "ou_theta"):
         setattr(c, k, af[k])
+    # OUNoiseNumba is a jitclass whose theta / sigma / mu members are declared float32 (numba_utils.py:67-74): the numba path's thrust noise runs
+    # with theta = float32(0.15), sigma = float32(0.2 * ratio) widened back to float64 - 4e-8 / 2e-8 away from the numpy path's OUNoise
+    # (quad_utils.py:253-279).  Default: follows use_numba; pinned by the `*_f32ou` fixtures (captured with the jitclass stub emulating the float32
+    # members); the older fixtures were captured under the plain stub and say numba_float32_ou=False (tests/golden_util.py).
+    if numba_float32_ou is None:
+        numba_float32_ou = bool(use_numba)
+    if numba_float32_ou:
+        c.thrust_noise_sigma = float(np.float32(c.thrust_noise_sigma))
+        c.ou_theta = float(np.float32(c.ou_theta))
     c.dt = 1.0 / sim_freq
     c.sim_steps = sim_steps
     c.ep_len = int(ep_time / (c.dt * sim_steps))                      # quadrotor_single.py:158

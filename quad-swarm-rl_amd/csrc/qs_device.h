@@ -93,6 +93,8 @@ __device__ __forceinline__ bool not_finite(float x) {
 __device__ __forceinline__ bool not_finite(double x) {
     return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull || fabs(x) > 3.0e38;
 }
+__device__ __forceinline__ bool bits_differ(float a, float b) { return __builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, b); }
+__device__ __forceinline__ bool bits_differ(double a, double b) { return __builtin_bit_cast(uint64_t, a) != __builtin_bit_cast(uint64_t, b); }
 template <typename real> __device__ __forceinline__ real clipr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 // fp32: one v_med3_f32 instead of two compare + select pairs (identical for every non-NaN x when lo <= hi)
 template <> __device__ __forceinline__ float clipr<float>(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }

@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256) qs_xchg_push_kernel(PushArgs a) {
         const unsigned int t = atomicAdd(&a.loc->ticket[d], 1u);
         if (t == gridDim.x - 1) {                                     // ... and this is the last workgroup of destination d
             a.loc->ticket[d] = 0;
+            fence_release_sys(a.fenced);
             st_sys(&a.flag_win[d]->arrive[slot][a.rank], seq);
             const unsigned int g = atomicAdd(&a.loc->ticket_all, 1u);
             if (g == gridDim.y - 1) { a.loc->ticket_all = 0; __threadfence(); a.loc->push_seq = seq; }
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(256) qs_xchg_push_kernel(PushArgs a) {
     }
 }
 
-struct ReleaseArgs { FlagWin *flag_win[QS_XCHG_MAX_RANKS]; Local *loc; int world, rank; };
+struct ReleaseArgs { FlagWin *flag_win[QS_XCHG_MAX_RANKS]; Local *loc; int world, rank, fenced; };
 // consumer: wait for the rows of sequence number wait_seq + 1 from every source; with `release` also hand the slot back at once
 // (a consumer that does not read the rows in place, e.g. the benchmark, or one that copies them out in this same kernel's shadow)
 __global__ void __launch_bounds__(64) qs_xchg_wait_kernel(FlagWin *mine, ReleaseArgs a, unsigned long long timeout_ticks, int release) {
@@ -134,6 +135,7 @@ __global__ void __launch_bounds__(64) qs_xchg_wait_kernel(FlagWin *mine, Release
     const int slot = (int)(seq & 1), r = threadIdx.x;
     bool ok = true;
     if (r < a.world) ok = poll_ge(&mine->arrive[slot][r], seq, timeout_ticks);
+    fence_acquire_sys(a.fenced);   // (the readers of the rows are later launches on this stream: the invalidate is in place before they start)
     if (__any(!ok) && r == 0) atomicOr(&a.loc->status, (unsigned int)QS_XCHG_ERR_ARRIVE_TIMEOUT);
     if (release && r < a.world) st_sys(&a.flag_win[r]->ack[a.rank], seq);
     if (r == 0) { a.loc->wait_seq = seq; if (release) a.loc->release_seq = seq; }
@@ -199,6 +201,7 @@ struct qs_xchg {
     bool opened[QS_XCHG_MAX_RANKS] = {};   // mapped with hipIpcOpenMemHandle (to be closed)
     XchgDev *desc = nullptr;               // device copy of what a step kernel needs for the fused push (qs_xchg_fused_desc)
     unsigned long long timeout_ticks = 0;
+    int fenced = 0;                        // created under QS_XCHG_FENCED=1: the fenced variant of the flag protocol (qs_xchg_dev.h)
     Q8Dev q8 = {};                         // wire == QS_WIRE_Q8
     size_t rank_bytes = 0;                 // bytes of one rank's rows in a window slot
 };
@@ -272,6 +275,7 @@ static int xchg_create(int device, int world, int rank, int64_t rows, int32_t co
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
     x->timeout_ticks = (unsigned long long)khz * QS_XCHG_TIMEOUT_MS;
     if (const char *ev = getenv("QS_XCHG_TIMEOUT_MS")) { const long v = atol(ev); if (v > 0) x->timeout_ticks = (unsigned long long)khz * (unsigned long long)v; }
+    if (const char *ev = getenv("QS_XCHG_FENCED")) x->fenced = atoi(ev) != 0 ? 1 : 0;
     x->peer_data[rank] = x->data;
     x->peer_flags[rank] = x->flags;
     *out = x;
@@ -358,7 +362,7 @@ int qs_xchg_push(qs_xchg *x, const void *src_f32, void *stream) {
     a.src = (const float *)src_f32; a.staging[0] = x->staging[0]; a.staging[1] = x->staging[1];
     for (int r = 0; r < x->world; ++r) { a.data_win[r] = x->peer_data[r]; a.flag_win[r] = x->peer_flags[r]; }
     a.mine = x->flags; a.loc = x->loc; a.n = x->n; a.slot_bytes = (long long)x->slot_bytes; a.world = x->world; a.rank = x->rank; a.wire = x->wire;
-    a.timeout_ticks = x->timeout_ticks; a.q8 = x->q8; a.rows = x->rows;
+    a.timeout_ticks = x->timeout_ticks; a.q8 = x->q8; a.rows = x->rows; a.fenced = x->fenced;
     hipLaunchKernelGGL(qs_xchg_push_kernel, dim3(grid_parts(x->n), x->world), dim3(256), 0, (hipStream_t)stream, a);
     XTRY(hipGetLastError());
     return 0;
@@ -367,7 +371,7 @@ int qs_xchg_push(qs_xchg *x, const void *src_f32, void *stream) {
 static void release_args(qs_xchg *x, ReleaseArgs &a) {
     memset(&a, 0, sizeof a);
     for (int r = 0; r < x->world; ++r) a.flag_win[r] = x->peer_flags[r];
-    a.loc = x->loc; a.world = x->world; a.rank = x->rank;
+    a.loc = x->loc; a.world = x->world; a.rank = x->rank; a.fenced = x->fenced;
 }
 
 static int launch_wait(qs_xchg *x, void *stream, int release) {
@@ -405,7 +409,7 @@ void *qs_xchg_fused_desc(qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *
     memset(&d, 0, sizeof d);
     for (int r = 0; r < x->world; ++r) { d.data_win[r] = x->peer_data[r]; d.flag_win[r] = x->peer_flags[r]; }
     d.mine = x->flags; d.loc = x->loc; d.n = x->n; d.slot_bytes = (long long)x->slot_bytes; d.world = x->world; d.rank = x->rank; d.wire = x->wire;
-    d.auto_ack = auto_ack ? 1 : 0; d.blocks = (unsigned int)blocks; d.timeout_ticks = x->timeout_ticks; d.q8 = x->q8;
+    d.auto_ack = auto_ack ? 1 : 0; d.blocks = (unsigned int)blocks; d.timeout_ticks = x->timeout_ticks; d.q8 = x->q8; d.fenced = x->fenced;
     if (!x->desc && hipMalloc((void **)&x->desc, sizeof d) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(x->desc, &d, sizeof d, hipMemcpyHostToDevice) != hipSuccess) { g_err = "descriptor upload failed"; return nullptr; }
     if (n_out) *n_out = x->n;

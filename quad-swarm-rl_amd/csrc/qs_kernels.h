@@ -34,6 +34,16 @@ using namespace qs;
 // the traffic-only kernels of tools/ubench_hbm.hip: 113.7 -> 97.6 us for 2^20 drones.  pos .. pair are byte
 // offsets of an array's first row INSIDE a block; the per-step outputs (newpair, reward, done, ohit) stay flat component-major
 // arrays behind the blocks (absolute offsets) - their consumers read them as plain vectors.
+// bytes of one state block: 40 rows of 64 reals (pos 3, vel 3, rot 9, omega 3, rot_damp 4, cmds_damp 4, ou 4, goal 3, ring 4, sums 3), the flags row
+// (u32), the pair-mask row (u64) - create_typed (quadswarm_hip.hip) lays the rows out and checks this figure
+static inline int qs_block_bytes(int real_size) { return 40 * 64 * real_size + 64 * 4 + 64 * 8; }
+// byte offsets of the arrays inside a state block, in the order create_typed lays the rows out (it checks them): literals for the code that
+// addresses the block's LDS image (qs_step_team.inc, section H)
+template <typename real> struct BlkOff {
+    static constexpr uint32_t row = 64 * sizeof(real);
+    static constexpr uint32_t pos = 0, vel = 3 * row, rot = 6 * row, omega = 15 * row, rot_damp = 18 * row, cmds_damp = 22 * row, ou = 26 * row, goal = 30 * row,
+                              ring = 33 * row, sums = 37 * row, flags = 40 * row, pair = 40 * row + 256, bytes = 40 * row + 768;
+};
 struct StateBlk { char *base; uint32_t bytes, block_bytes, epb, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit; };
 // element (component q of drone i of env e) of a blocked array, for the code outside the step kernels' buffer-resource views
 template <typename TT> __device__ __forceinline__ TT &blk_at(const StateBlk &b, uint32_t arr, int q, int e, int i, int N) {
@@ -80,6 +90,7 @@ template <typename real> struct Ptrs {
 // One array of the state allocation seen from one lane: element type T, `row_bytes` between components, this lane's element
 // `lane_off` bytes into a row; `off` = scalar offset of the array's first row (for a blocked array: of this wave's block too).
 typedef unsigned int qs_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int qs_u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct BufRow {
     __amdgpu_buffer_rsrc_t r;
     uint32_t off, row_bytes, lane_off;
@@ -239,6 +250,9 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
         o += u;
     }
     L.total = (o + 15) & ~15;
+    // team kernels: at the end of a launch the state block's image (qs_block_bytes) overlays the LDS rows of the step from offset 0, four
+    // "row unchanged" words behind it (qs_step_team.inc, section H)
+    if (team && L.total < qs_block_bytes(real_size) + 16) L.total = qs_block_bytes(real_size) + 16;
     return L;
 }
 

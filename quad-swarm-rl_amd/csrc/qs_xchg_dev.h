@@ -37,6 +37,7 @@ struct XchgDev {
     unsigned int blocks;        // workgroups of one step launch (set by qs_set_obs_exchange)
     unsigned long long timeout_ticks;
     Q8Dev q8;                   // wire == QS_WIRE_Q8
+    int fenced;                 // QS_XCHG_FENCED=1: a system-scope release fence in front of every flag store, an acquire fence behind every flag wait
 };
 
 struct PushArgs {
@@ -51,6 +52,7 @@ struct PushArgs {
     unsigned long long timeout_ticks;
     Q8Dev q8;
     long long rows;             // rows per rank (wire == QS_WIRE_Q8: n = rows * q8.D)
+    int fenced;
 };
 
 __device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
@@ -105,6 +107,13 @@ __device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8De
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// The FENCED variant of the protocol (endpoints created under QS_XCHG_FENCED=1; opt-in fallback if ObsExchange.verify() ever fails on a real
+// xGMI node, before giving the transport up for RCCL): whoever stores a flag first executes a system-scope RELEASE fence (buffer_wbl2 sc0 sc1 +
+// wait: everything this XCD's L2 still holds goes out), whoever has seen a flag executes a system-scope ACQUIRE fence (buffer_inv sc0 sc1).
+// One fence per launch and direction - on the wave that stores / polls the flags - not one per workgroup (that form cost ~20 us per step).
+__device__ __forceinline__ void fence_release_sys(int fenced) { if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
+__device__ __forceinline__ void fence_acquire_sys(int fenced) { if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
+
 // Write-through stores for the rows that go into a window (own or a peer's): `sc0 sc1` = system scope, the line leaves the L2 at once.
 // With them a workgroup only has to wait for its own stores (s_waitcnt vmcnt(0)) before it takes its ticket - no system-scope release
 // fence per workgroup, which on this part writes the whole L2 back and cost ~20 us per step when 128-256 workgroups each issued one
@@ -157,13 +166,18 @@ __device__ __forceinline__ bool poll_ge_agent(const unsigned long long *p, unsig
     }
     return ld_agent(p) >= want;
 }
-// agent-scope data accesses: loads that miss this XCD's L2, stores that are written through it
+// Data handed between concurrently running kernels.  Stepper -> consumer (observation rows, reward, done, masks; ordinary coarse-grained
+// device memory): SYSTEM-scope write-through stores (`sc0 sc1`, like the producer's ring writes: with `sc1` alone a flag was seen to overtake
+// its batch), drained (s_waitcnt vmcnt(0)) before done_flag is raised.  A consumer that has seen done_flag >= s executes an agent-scope
+// acquire (`buffer_inv sc1` = __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")) before it reads the rows: its own XCD's L2 may still hold
+// the rows of step s - 1 (include/quadswarm.h; tests/test_gated_gpu.py runs such a consumer against a resident launch).
+// Producer -> stepper (the action ring, uncached memory): `sc0 sc1` loads.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4_t ld16_sc1(const void *p) { u32x4_t v; asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
 __device__ __forceinline__ unsigned int ld4_sc1(const void *p) { unsigned int v; asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ void st16_sc1(void *p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st8_sc1(void *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st4_sc1(void *p, unsigned int v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st1_sc1(void *p, unsigned int v) { asm volatile("global_store_byte %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st16_sc1(void *p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8_sc1(void *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st4_sc1(void *p, unsigned int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st1_sc1(void *p, unsigned int v) { asm volatile("global_store_byte %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 
 }   // namespace qsx

@@ -364,6 +364,10 @@ template <typename real> static int create_typed(qs_handle *h) {
         const size_t o_pos = rows(3, R), o_vel = rows(3, R), o_rot = rows(9, R), o_omega = rows(3, R), o_rd = rows(4, R), o_cd = rows(4, R), o_ou = rows(4, R),
                      o_goal = rows(3, R), o_ring = rows(4, R), o_sums = rows(3, R), o_flags = rows(1, 4), o_pair = rows(1, 8);
         const size_t block_bytes = row;
+        typedef BlkOff<real> BO;
+        if ((int)block_bytes != qs_block_bytes((int)R) || block_bytes != BO::bytes || o_pos != BO::pos || o_vel != BO::vel || o_rot != BO::rot || o_omega != BO::omega || o_rd != BO::rot_damp ||
+            o_cd != BO::cmds_damp || o_ou != BO::ou || o_goal != BO::goal || o_ring != BO::ring || o_sums != BO::sums || o_flags != BO::flags || o_pair != BO::pair)
+            return fail(QS_ERR_INVALID, "state block layout out of step with BlkOff / qs_block_bytes()");
         size_t off = NBLK * block_bytes;
         auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
         const size_t o_newpair = carve(T * 8), o_reward = carve(T * R), o_done = carve(T), o_ohit = carve(T * 4);
@@ -486,7 +490,9 @@ int qs_default_config(qs_config *c, int32_t num_envs, int32_t num_agents) {
     c->dt = 1.0 / 200.0; c->sim_steps = 2;
     c->motor_tau_up = c->motor_tau_down = 4 * c->dt / (0.15 + 1e-6);
     c->motor_linearity = 1.0; c->vel_damp = 0; c->damp_omega_quadratic = 0; c->omega_max = 40.0; c->gravity = 9.81;
-    c->thrust_noise_sigma = 0.2 * 0.05; c->ou_theta = 0.15;
+    // the numba path (floor_mode below): OUNoiseNumba keeps theta / sigma in float32 members (numba_utils.py:67-74) - the values the jitted
+    // reference computes with are the float32 roundings widened back to double (config.make_config: numba_float32_ou)
+    c->thrust_noise_sigma = (double)(float)(0.2 * 0.05); c->ou_theta = (double)(float)0.15;
     c->ep_len = (int)(15.0 / (c->dt * c->sim_steps));
     c->room_lo[0] = -5; c->room_lo[1] = -5; c->room_lo[2] = 0; c->room_hi[0] = 5; c->room_hi[1] = 5; c->room_hi[2] = 10;
     c->floor_mode = QS_FLOOR_NUMBA;
@@ -800,20 +806,45 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
 // the benchmark's / the tests' producer: per control step it (closed_loop: waits until the outputs of the previous step of ITS workgroups
 // are published, else: only until the ring slot is free), copies the group's share of the next action batch from a table resident in HBM
 // into the ring - written through the L2 - and raises the group's sequence word
+// `sums` (qs_gate_produce_verify, closed loop only): the kernel is also a CONSUMER of the stepper's outputs the way the protocol describes one -
+// having seen done_flag >= s for its workgroups it executes an agent-scope acquire and reads the observation rows and rewards of step s with
+// plain loads - and records a checksum (the sum of their 32-bit words) per step and group, WHILE the gated launch is resident and working on
+// step s + 1.  tests/test_gated_gpu.py compares the sums with those of a one-launch-per-step twin.
 __global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, const char *src, unsigned int n_src, unsigned long long seq0, int k, int closed_loop,
-                                                                unsigned long long wg_bytes, unsigned long long batch_bytes) {
+                                                                unsigned long long wg_bytes, unsigned long long batch_bytes,
+                                                                unsigned long long *sums, const unsigned int *obs_words, const unsigned int *rew_words,
+                                                                unsigned long long obs_words_per_wg, unsigned long long rew_words_per_wg,
+                                                                unsigned long long obs_words_total, unsigned long long rew_words_total) {
     const unsigned int grp = blockIdx.x, w0 = grp * G->wg_per_group, w1 = (w0 + G->wg_per_group < G->blocks) ? w0 + G->wg_per_group : G->blocks;
     const unsigned long long lo = (unsigned long long)w0 * wg_bytes, hi0 = (unsigned long long)w1 * wg_bytes, hi = hi0 < batch_bytes ? hi0 : batch_bytes;
     __shared__ int dead;
+    __shared__ unsigned long long acc;
     if (threadIdx.x == 0) dead = 0;
     __syncthreads();
-    for (int t = 0; t < k; ++t) {
+    for (int t = 0; t <= k; ++t) {
         const unsigned long long seq = seq0 + (unsigned long long)t + 1;
-        const unsigned long long need = closed_loop ? seq - 1 : (seq > G->ring_len ? seq - G->ring_len : 0);
-        if (need > 0 && !dead && threadIdx.x < w1 - w0) {
-            if (!qsx::poll_ge_agent(&G->done_flag[w0 + threadIdx.x], need, G->timeout_ticks)) { dead = 1; atomicOr(&G->status, 2u); }
+        if (t == k && sums == nullptr) break;   // (the extra round only reads the last step's outputs)
+        const unsigned long long need = (closed_loop || t == k) ? seq - 1 : (seq > G->ring_len ? seq - G->ring_len : 0);
+        if (need > 0 && !dead) {   // every workgroup of the group, 256 at a time (a group may hold all ~512 workgroups of a team handle)
+            for (unsigned int w = w0 + threadIdx.x; w < w1; w += 256)
+                if (!qsx::poll_ge_agent(&G->done_flag[w], need, G->timeout_ticks)) { dead = 1; atomicOr(&G->status, 2u); break; }
         }
         __syncthreads();
+        if (sums != nullptr && t >= 1) {   // the outputs of sequence number seq - 1 (a step of THIS call), read the way a policy would read them
+            if (threadIdx.x == 0) acc = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this XCD's L2 may hold the rows of the step before
+            __syncthreads();
+            unsigned long long part = 0;
+            const unsigned long long o0 = (unsigned long long)w0 * obs_words_per_wg, o1u = (unsigned long long)w1 * obs_words_per_wg, o1 = o1u < obs_words_total ? o1u : obs_words_total;
+            for (unsigned long long j = o0 + threadIdx.x; j < o1; j += 256) part += obs_words[j];
+            const unsigned long long r0 = (unsigned long long)w0 * rew_words_per_wg, r1u = (unsigned long long)w1 * rew_words_per_wg, r1 = r1u < rew_words_total ? r1u : rew_words_total;
+            for (unsigned long long j = r0 + threadIdx.x; j < r1; j += 256) part += rew_words[j];
+            atomicAdd(&acc, part);
+            __syncthreads();
+            if (threadIdx.x == 0) sums[(unsigned long long)(t - 1) * G->groups + grp] = acc;
+            __syncthreads();
+        }
+        if (t == k) break;
         const char *from = src + ((seq - 1) % n_src) * batch_bytes;
         char *to = G->act_ring + ((seq - 1) % G->ring_len) * G->act_stride;
         // system-scope write-through: the flag below must not become visible before the batch (`sc1` alone was seen to let it: one run in three
@@ -856,10 +887,11 @@ int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group) {
     HIP_TRY(hipDeviceSynchronize());
     {
         int least = 0, greatest = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&h->gate_stream, hipStreamNonBlocking, greatest));
-        HIP_TRY(hipEventCreateWithFlags(&h->gate_ev_in, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&h->gate_ev_out, hipEventDisableTiming));
+        hipError_t er = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (er == hipSuccess && !h->gate_stream) er = hipStreamCreateWithPriority(&h->gate_stream, hipStreamNonBlocking, greatest);
+        if (er == hipSuccess && !h->gate_ev_in) er = hipEventCreateWithFlags(&h->gate_ev_in, hipEventDisableTiming);
+        if (er == hipSuccess && !h->gate_ev_out) er = hipEventCreateWithFlags(&h->gate_ev_out, hipEventDisableTiming);
+        if (er != hipSuccess) { (void)hipFree(base); return fail(QS_ERR_HIP, std::string("qs_gate_create: ") + hipGetErrorString(er)); }
     }
     h->d_gate = (qsx::Gate *)base; h->gate_host = g; h->gate_step_seq = 0; h->gate_prod_seq = 0;
     return QS_OK;
@@ -911,7 +943,23 @@ int qs_gate_produce(qs_handle *h, const void *src_actions_dev, int32_t n_src, in
     const unsigned long long T = (unsigned long long)h->cfg.num_envs * h->cfg.num_agents;
     const unsigned long long wg_bytes = (unsigned long long)h->epb * h->cfg.num_agents * 4 * h->real_size, batch_bytes = T * 4 * h->real_size;
     hipLaunchKernelGGL(qs_gate_producer_kernel, dim3(h->gate_host.groups), dim3(256), 0, (hipStream_t)stream, h->d_gate, (const char *)src_actions_dev, (unsigned int)n_src,
-                       h->gate_prod_seq, (int)k, (int)(closed_loop != 0), wg_bytes, batch_bytes);
+                       h->gate_prod_seq, (int)k, (int)(closed_loop != 0), wg_bytes, batch_bytes, (unsigned long long *)nullptr, (const unsigned int *)nullptr,
+                       (const unsigned int *)nullptr, 0ull, 0ull, 0ull, 0ull);
+    HIP_TRY(hipGetLastError());
+    h->gate_prod_seq += (unsigned long long)k;
+    return QS_OK;
+}
+
+int qs_gate_produce_verify(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, unsigned long long *sums_dev, void *stream) {
+    if (!h || !src_actions_dev || !sums_dev || n_src < 1 || k < 1) return fail(QS_ERR_INVALID, "bad argument");
+    if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
+    if (((uintptr_t)src_actions_dev) & 15) return fail(QS_ERR_INVALID, "qs_gate_produce_verify: the action table must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned long long T = (unsigned long long)h->cfg.num_envs * h->cfg.num_agents, rows_wg = (unsigned long long)h->epb * h->cfg.num_agents, wpr = h->real_size / 4;
+    const unsigned long long wg_bytes = rows_wg * 4 * h->real_size, batch_bytes = T * 4 * h->real_size;
+    hipLaunchKernelGGL(qs_gate_producer_kernel, dim3(h->gate_host.groups), dim3(256), 0, (hipStream_t)stream, h->d_gate, (const char *)src_actions_dev, (unsigned int)n_src,
+                       h->gate_prod_seq, (int)k, 1, wg_bytes, batch_bytes, sums_dev, (const unsigned int *)h->pf.obs, (const unsigned int *)h->pf.reward,
+                       rows_wg * h->obs_dim * wpr, rows_wg * wpr, T * h->obs_dim * wpr, T * wpr);
     HIP_TRY(hipGetLastError());
     h->gate_prod_seq += (unsigned long long)k;
     return QS_OK;
@@ -1264,6 +1312,7 @@ int qs_debug_timing(qs_handle *h, unsigned long long *out128) {   // [4 waves][3
 int qs_check_errors(qs_handle *h) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    if (int jr = gate_join_host(h)) return jr;   // the gated kernel's stream is non-blocking: a null-stream copy does not wait for it by itself
     uint32_t f = 0;
     HIP_TRY(hipMemcpy(&f, h->pf.error_flag, sizeof f, hipMemcpyDeviceToHost));
     if (f) return fail(QS_ERR_NAN_REWARD, "QuadEnv: reward is Nan");

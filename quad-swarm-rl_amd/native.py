@@ -161,6 +161,7 @@ def lib():
         L.qs_step_gated.argtypes = [vp, C.c_int32, vp]
         L.qs_gate_wait.argtypes = [vp, vp]
         L.qs_gate_produce.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.qs_gate_produce_verify.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
         L.qs_gate_status.argtypes = [vp, C.POINTER(C.c_int64)]
         L.qs_set_obs_target.argtypes = [vp, vp]
         L.qs_set_obs_exchange.argtypes = [vp, vp, C.c_int32]
@@ -199,7 +200,7 @@ EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_defau
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_state_array_copy", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_spec_status", "qs_kernel_flavor",
                     "qs_snapshot_pool", "qs_snapshot_save", "qs_snapshot_load", "qs_snapshot_copy",
-                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_set_tape_pos", "qs_gate_create", "qs_gate_info", "qs_step_gated", "qs_gate_wait", "qs_gate_produce", "qs_gate_status", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target", "qs_set_obs_exchange"]
+                    "qs_set_noise_tape", "qs_get_tape_pos", "qs_set_tape_pos", "qs_gate_create", "qs_gate_info", "qs_step_gated", "qs_gate_wait", "qs_gate_produce", "qs_gate_produce_verify", "qs_gate_status", "qs_replay_enable", "qs_replay_stats", "qs_replay_set_active", "qs_set_obs_target", "qs_set_obs_exchange"]
 # include/quadswarm_exchange.h
 EXCHANGE_SYMBOLS = ["qs_xchg_create", "qs_xchg_destroy", "qs_xchg_export", "qs_xchg_attach", "qs_xchg_attach_local", "qs_xchg_staging",
                     "qs_xchg_gathered", "qs_xchg_push", "qs_xchg_wait", "qs_xchg_release", "qs_xchg_wait_release", "qs_xchg_fused_desc", "qs_xchg_status", "qs_obs_pack", "qs_xchg_last_error",
@@ -384,6 +385,11 @@ class Stepper:
     def gate_produce(self, src_ptr, n_src, k, closed_loop=False, stream=None):
         """the trivial producer: k steps, action batches round-robin from a table of n_src batches at device address src_ptr"""
         _check(lib().qs_gate_produce(self._h, C.c_void_p(int(src_ptr)), int(n_src), int(k), 1 if closed_loop else 0, self._stream_ptr(stream)))
+
+    def gate_produce_verify(self, src_ptr, n_src, k, sums_ptr, stream=None):
+        """closed-loop producer that also consumes the stepper's outputs concurrently: sums[t * groups + g] = sum of the 32-bit words of the
+        observation rows and rewards of step t as the producer saw them behind done_flag + an agent-scope acquire (test instrument)"""
+        _check(lib().qs_gate_produce_verify(self._h, C.c_void_p(int(src_ptr)), int(n_src), int(k), C.c_void_p(int(sums_ptr)), self._stream_ptr(stream)))
 
     def gate_status(self):
         out = (C.c_int64 * 4)()

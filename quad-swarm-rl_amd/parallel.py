@@ -129,18 +129,34 @@ def gather_window_handles(blob, world, group=None):
 class PeerExchange:
     """One endpoint of the peer-store exchange (thin wrapper of the qs_xchg_* C ABI)."""
 
-    def __init__(self, rows, cols, world, rank, device=0, wire="bf16", q8=None):
-        """q8: the native.WireQ8 layout (wire="q8" only; native.wire_q8_layout(cfg, obs_dim))"""
+    def __init__(self, rows, cols, world, rank, device=0, wire="bf16", q8=None, fenced=None):
+        """q8: the native.WireQ8 layout (wire="q8" only; native.wire_q8_layout(cfg, obs_dim)).  fenced: True / False = the fenced / relaxed
+        variant of the flag protocol (include/quadswarm_exchange.h, QS_XCHG_FENCED), None = whatever the environment says"""
         self.rows, self.cols, self.world, self.rank, self.device, self.wire, self.q8 = rows, cols, world, rank, device, wire, q8
         self._x = C.c_void_p()
+        import os
+        saved = os.environ.get("QS_XCHG_FENCED")
+        if fenced is not None:   # (the library reads the switch when it creates the endpoint)
+            os.environ["QS_XCHG_FENCED"] = "1" if fenced else "0"
+        self.fenced = os.environ.get("QS_XCHG_FENCED", "0") not in ("", "0")
+        try:
+            self._create(device, world, rank, rows, cols, wire, q8)
+        finally:
+            if fenced is not None:
+                if saved is None:
+                    os.environ.pop("QS_XCHG_FENCED", None)
+                else:
+                    os.environ["QS_XCHG_FENCED"] = saved
+        self.row_bytes = wire_row_bytes(cols, wire, q8)
+        self._views = {}
+
+    def _create(self, device, world, rank, rows, cols, wire, q8):
         if wire == "q8":
             if q8 is None:
                 raise ValueError("wire='q8' needs the row layout (native.wire_q8_layout)")
             _xcheck(native.lib().qs_xchg_create_q8(device, world, rank, rows, cols, C.byref(q8), C.byref(self._x)))
         else:
             _xcheck(native.lib().qs_xchg_create(device, world, rank, rows, cols, WIRE[wire], C.byref(self._x)))
-        self.row_bytes = wire_row_bytes(cols, wire, q8)
-        self._views = {}
 
     def close(self):
         if self._x:
@@ -231,8 +247,8 @@ class ObsExchange:
     releases a slot as soon as it has arrived (no in-place reader: the benchmark).
     """
 
-    def __init__(self, stepper, world, rank, transport="peer", wire="bf16", group=None, peers=None, hold=True, source=None):
-        """source: "target" (default) - the stepper writes the rows of consecutive steps into the two staging buffers (qs_set_obs_target)
+    def __init__(self, stepper, world, rank, transport="peer", wire="bf16", group=None, peers=None, hold=True, source=None, fenced=None):
+        """fenced: the fenced variant of the window transports' flag protocol (PeerExchange); source: "target" (default) - the stepper writes the rows of consecutive steps into the two staging buffers (qs_set_obs_target)
         and the exchange of step t runs under step t+1; "obs" - the rows are taken from the library's own observation buffer AFTER the
         whole qs_step, on the stepping stream: what a stepper with the device-side replay wrapper needs (default there), whose replay
         kernel restores observations into that buffer behind the step kernel (the push itself then sits between two steps; waiting
@@ -265,7 +281,7 @@ class ObsExchange:
             # raised before the collective would leave the others waiting in it.  All ranks then fail (or succeed) together.
             self.x, blob, err = None, None, None
             try:
-                self.x = PeerExchange(T, D, world, rank, device=stepper.device, wire=wire, q8=self.q8)
+                self.x = PeerExchange(T, D, world, rank, device=stepper.device, wire=wire, q8=self.q8, fenced=fenced)
                 blob = self.x.export()
             except Exception as exc:   # noqa: BLE001 - re-raised below, after the collective
                 err = exc
@@ -280,7 +296,7 @@ class ObsExchange:
                 raise err
             self.x.attach(blobs)
         else:
-            self.x = PeerExchange(T, D, world if windows else 1, rank if windows else 0, device=stepper.device, wire=wire, q8=self.q8)
+            self.x = PeerExchange(T, D, world if windows else 1, rank if windows else 0, device=stepper.device, wire=wire, q8=self.q8, fenced=fenced)
         if windows:
             if peers is not None:          # in-process wiring (tests, one process driving several shards)
                 for p in peers:
@@ -568,10 +584,26 @@ class ObsExchange:
         self_check() this goes through whatever produced the rows in the windows: the step kernel's fused epilogue on the real
         topology included.  Collective: call it on every rank at the same step (needs hold=True, or a quiet exchange: nothing may
         overwrite the slot meanwhile).  bench.py runs it before and after its timed region, sf_env when a window transport is opted into."""
-        got = self.latest().clone()
+        # the part that can fail on ONE rank (a sticky timeout, a bad window) runs first and is agreed on by all ranks BEFORE anyone enters
+        # the all-gather: a rank that raised here while the others sat in the collective would leave mismatched collectives behind
+        got = mine = None
+        local_error = ""
+        try:
+            got = self.latest().clone()
+            mine = torch.empty((self.st.T, got.shape[1]), dtype=got.dtype, device=self.device)
+            pack_rows(self.local_rows(), mine, stream=self.main, q8=self.q8)
+        except Exception as exc:   # noqa: BLE001 - reported as the reason, on every rank
+            local_error = f"{type(exc).__name__}: {exc}"
+        if self.world > 1:
+            flag = torch.tensor([0 if local_error else 1], device=self.device, dtype=torch.int32)
+            with torch.cuda.stream(self.main):
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            self.main.synchronize()
+            if int(flag.item()) == 0:
+                return False, local_error or "another rank could not read its gathered rows"
+        elif local_error:
+            return False, local_error
         dt = got.dtype
-        mine = torch.empty((self.st.T, got.shape[1]), dtype=dt, device=self.device)
-        pack_rows(self.local_rows(), mine, stream=self.main, q8=self.q8)
         if self.world > 1:
             want = torch.empty_like(got)
             with torch.cuda.stream(self.main):

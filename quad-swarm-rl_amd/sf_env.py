@@ -380,28 +380,35 @@ class BatchedQuadSwarm:
             return bool(t.item())
 
         ex = None
-        try:
-            ex = parallel.ObsExchange(st, world, self.rank, transport="peer", wire=wire, hold=True)
-        except Exception:   # noqa: BLE001 - every rank takes the same decision below
+        for fenced in (False, True):   # the relaxed flag protocol first, its fenced variant (QS_XCHG_FENCED) second, RCCL last
             ex = None
-        ok = all_agree(ex is not None)
-        if ok:
             try:
-                ok = ex.self_check()[0]
-            except Exception:   # noqa: BLE001
-                ok = False
-            ok = all_agree(ok)
-        if ok:   # ... and through the real producer of the rows: an exchanged reset, compared with an RCCL gather of the same rows
-            try:
-                ex.reset()
-                ok = ex.verify()[0]
-            except Exception:   # noqa: BLE001
-                ok = False
-            ok = all_agree(ok)
-        if not ok:
+                ex = parallel.ObsExchange(st, world, self.rank, transport="peer", wire=wire, hold=True, fenced=fenced)
+            except Exception:   # noqa: BLE001 - every rank takes the same decision below
+                ex = None
+            ok = all_agree(ex is not None)
+            if ok:
+                try:
+                    ok = ex.self_check()[0]
+                except Exception:   # noqa: BLE001
+                    ok = False
+                ok = all_agree(ok)
+            if ok:   # ... and through the real producer of the rows: an exchanged reset, compared with an RCCL gather of the same rows.  The
+                try:  # reset (no collective inside) is agreed on first; verify() agrees on its own local part before it enters its all-gather
+                    ex.reset()
+                except Exception:   # noqa: BLE001
+                    ok = False
+                ok = all_agree(ok)
+            if ok:
+                ok = all_agree(ex.verify()[0])
+            if ok:
+                break
             if ex is not None:
                 ex.close()
+                ex = None
+        if ex is None:
             ex = parallel.ObsExchange(st, world, self.rank, transport="rccl", wire=wire, hold=True)
+        self.obs_protocol = "rccl" if ex.transport == "rccl" else ("fenced flags" if ex.x.fenced else "relaxed flags")
         self.obs_transport = ex.transport
         return ex
 

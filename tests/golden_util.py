@@ -25,6 +25,8 @@ def config_from_golden(cfg, **over):
         obst_density=cfg["obst_density"], obst_size=cfg["obst_size"], obst_spawn_area=cfg["obst_spawn_area"],
         use_downwash=cfg["use_downwash"], use_numba=cfg["use_numba"], quads_mode=cfg["quads_mode"],
         room_dims=cfg["room_dims"], sense_noise=cfg["sense_noise"], thrust_noise_ratio=cfg["thrust_noise_ratio"],
+        # fixtures captured under the plain numba stub ran OUNoiseNumba with float64 members; the `*_f32ou` ones with numba's float32 members
+        numba_float32_ou=bool(cfg.get("numba_float32_ou", False)),
     )
     kw.update(over)
     return qcfg.make_config(**kw)

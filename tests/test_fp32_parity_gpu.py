@@ -20,6 +20,7 @@ from quad_swarm_rl_amd import config as qcfg
 pytestmark = pytest.mark.gpu
 
 from tests import test_hip_parity as thp   # noqa: E402
+from tests import tolerances as tolr   # noqa: E402
 
 BASELINE_SHAPED = ["c1_single", "c2_n8_dw", "c2_n8_k2_numpy_wall", "c2_n5_kall_short", "c3_n8_obst", "c3_n8_obst_short", "c4_n32_svs"]
 
@@ -82,7 +83,7 @@ def test_free_running_f32_event_free_windows(case, team, spec, monkeypatch):
     N = pr.N
     rng = np.random.RandomState(21)
     oobs, hobs = pr.reset()
-    np.testing.assert_allclose(hobs, oobs, rtol=0, atol=2e-5)
+    tolr.check(f"free-running {case} team={team} spec={spec}", "obs_reset", hobs, oobs, tolr.allowed_obs(oobs, tol), "after reset")
     alive = np.ones(E, dtype=bool)
     window = np.zeros(E, dtype=int)
     worst, by, first = 0.0, {}, {}   # worst relative error per quantity (value, step), first step on which a quantity left the tolerance
@@ -104,12 +105,14 @@ def test_free_running_f32_event_free_windows(case, team, spec, monkeypatch):
             window[e] = t + 1
             sd = pr.D - 6 * pr.cfg.num_neighbors - (9 if pr.cfg.use_obstacles else 0)
             for nm, a, b in (("obs", o[0][e][:, :sd] if tie else o[0][e], h[0][e][:, :sd] if tie else h[0][e]), ("reward", o[1][e], h[1][e]), ("rew_info", o[3][e], h[3][e])):
-                err = np.abs(a - b).max()
-                rel = err / (1.0 + np.abs(a).max())
+                # per quantity (tests/tolerances.py): |err| / allowed, allowed = tol absolute (angular-velocity columns, reward terms: tol * max(1, |x|))
+                rel = tol * tolr.excess(b, a, tolr.allowed_obs(a, tol) if nm == "obs" else tolr.allowed_rel(a, tol))
                 worst = max(worst, rel)
                 if rel > by.get(nm, (0.0, 0))[0]:
                     by[nm] = (rel, t)
-                if rel > tol * (1.0 if t < HORIZON else 2.0) and nm not in first:
+                if tolr.REPORT:
+                    tolr.check(f"free-running {case} team={team} spec={spec} {'<' if t < HORIZON else '>='}{HORIZON}", nm, b, a, tolr.allowed_obs(a, tol) if nm == "obs" else tolr.allowed_rel(a, tol))
+                elif rel > tol * (1.0 if t < HORIZON else 2.0) and nm not in first:
                     first[nm] = (t, e, rel)
             np.testing.assert_array_equal(o[2][e], h[2][e])
         # discrete outputs of the environments still inside their window
@@ -128,18 +131,20 @@ def test_free_running_f32_event_free_windows(case, team, spec, monkeypatch):
             assert not cp[e].any()
             s, _ = oe.get_state()
             for nm, a, b in (("pos", st_pos[e], s[:, 0:3]), ("vel", st_vel[e], s[:, 3:6]), ("rot", st_rot[e], s[:, 6:15]), ("omega", st_om[e], s[:, 15:18])):
-                err = np.abs(a - b).max()
-                rel = err / (1.0 + np.abs(b).max())
+                al = tolr.allowed_rel(b, tol) if nm == "omega" else tolr.allowed_abs(b, tol)
+                rel = tol * tolr.excess(a, b, al)
                 worst = max(worst, rel)
                 if rel > by.get(nm, (0.0, 0))[0]:
                     by[nm] = (rel, t)
-                if rel > tol * (1.0 if t < HORIZON else 2.0) and nm not in first:
+                if tolr.REPORT:
+                    tolr.check(f"free-running {case} team={team} spec={spec} {'<' if t < HORIZON else '>='}{HORIZON}", nm, a, b, al)
+                elif rel > tol * (1.0 if t < HORIZON else 2.0) and nm not in first:
                     first[nm] = (t, e, rel)
         if not alive.any():
             break
-    print(f"{case} team={team} spec={spec}: event-free windows {window.tolist()} steps, worst relative error {worst:.2e}; per quantity (error, step): "
+    print(f"{case} team={team} spec={spec}: event-free windows {window.tolist()} steps, worst error in units of its bound x 1e-5: {worst:.2e}; per quantity (error, step): "
           + ", ".join(f"{k} {v[0]:.1e}@{v[1]}" for k, v in sorted(by.items())))
-    assert not first, f"{case}: free-running float32 left {tol:g} (2x beyond step {HORIZON}) * (1 + max|x|): first (step, env, error) per quantity {first}; worst per quantity {by}"
+    assert not first, f"{case}: free-running float32 left its per-quantity bound ({tol:g} absolute; angular velocity / reward terms relative; 2x beyond step {HORIZON}): first (step, env, error) per quantity {first}; worst per quantity {by}"
     assert window.max() >= 40 and np.median(window) >= 20, f"windows too short to mean anything: {window.tolist()}"
     pr.hip.check_errors()
     pr.close()

@@ -122,6 +122,59 @@ def test_gated_generic_kernels_and_full_scenario_set(spec, mode, monkeypatch):
     plain.close(); gated.close()
 
 
+@pytest.mark.parametrize("case,wg_per_group", [("c2_n8_dw", 1), ("c2_n8_dw", 3), ("c4_n32_svs", 2)])
+def test_a_concurrent_consumer_sees_each_steps_outputs(case, wg_per_group):
+    """The visibility half of the protocol (include/quadswarm.h "Visibility"): a consumer kernel that runs WHILE the gated launch is resident,
+    has seen done_flag >= s and executed an agent-scope acquire must read the observation rows and rewards of step s - not those of step s - 1
+    from its own XCD's L2, not rows whose write-through is still in flight.  qs_gate_produce_verify is such a consumer (and the closed-loop
+    producer of step s + 1): its per-step, per-group checksums must equal those of a one-launch-per-step twin fed the same actions."""
+    import torch
+    E, K = 96, 40
+    twin, gated, cfg = _pair(case, E, "f32", ep_time=0.3)   # 30-step episodes: an auto-reset inside the launch
+    if not gated.team:
+        pytest.skip("team kernels only")
+    N, D = cfg.num_agents, gated.obs_dim
+    T = E * N
+    g = torch.Generator(device="cuda").manual_seed(11)
+    table = (torch.rand((K, T, 4), device="cuda", generator=g, dtype=torch.float32) * 2 - 1).contiguous()
+    # the twin runs the SAME kernel (bit-identical arithmetic) one control step per launch, with a host synchronise after every step
+    gated.gate_create(ring_len=4, wg_per_group=wg_per_group)
+    twin.gate_create(ring_len=4, wg_per_group=wg_per_group)
+    info = gated.gate_info()
+    rows_wg = info.envs_per_workgroup * N
+    sums = torch.zeros((K, info.groups), dtype=torch.int64, device="cuda")
+    side, feed = torch.cuda.Stream(), torch.cuda.Stream()
+    twin.reset(); gated.reset()
+    torch.cuda.synchronize()
+    for rep in range(3):   # (three resident launches back to back: 3 * K hand-overs per group)
+        sums.zero_()
+        torch.cuda.synchronize()
+        gated.step_gated(K, stream=side)
+        gated.gate_produce_verify(table.data_ptr(), K, K, sums.data_ptr(), stream=feed)
+        gated.gate_wait(stream=side)
+        want = torch.zeros((K, info.groups), dtype=torch.int64, device="cuda")
+        for t in range(K):
+            twin.step_gated(1, stream=side)
+            twin.gate_produce(table[t].data_ptr(), 1, 1, closed_loop=False, stream=feed)
+            twin.gate_wait(stream=side)
+            torch.cuda.synchronize()
+            words = torch.cat((twin.tensor("obs").reshape(T, D).view(torch.int32).to(torch.int64) & 0xffffffff,
+                               (twin.tensor("reward").reshape(T, 1).view(torch.int32).to(torch.int64) & 0xffffffff)), dim=1).sum(dim=1)   # per drone
+            per_wg = torch.zeros(info.workgroups * rows_wg, dtype=torch.int64, device="cuda")
+            per_wg[:T] = words
+            per_wg = per_wg.reshape(info.workgroups, rows_wg).sum(dim=1)
+            pad = torch.zeros(info.groups * wg_per_group, dtype=torch.int64, device="cuda")
+            pad[:info.workgroups] = per_wg
+            want[t] = pad.reshape(info.groups, wg_per_group).sum(dim=1)
+        torch.cuda.synchronize()
+        st = gated.gate_status()
+        assert st["error"] == 0 and twin.gate_status()["error"] == 0, st
+        assert int((want != 0).sum()) == K * info.groups          # (a checksum of nothing would also "agree")
+        bad = (sums != want).nonzero()
+        assert bad.numel() == 0, f"launch {rep}: {bad.shape[0]} of {K * info.groups} (step, group) checksums differ, first at {bad[0].tolist()}"
+    twin.close(); gated.close()
+
+
 def test_missing_producer_is_reported_not_hung(monkeypatch):
     import time
     import torch

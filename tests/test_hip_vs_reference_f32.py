@@ -21,10 +21,13 @@ import numpy as np
 import pytest
 
 from tests import golden_util as gu
+from tests import tolerances as tolr
 from tests.test_oracle_vs_reference import CASES, EDGE_CASES, SCEN_CASES
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+MAX_EXCUSED = 3          # per fixture, whatever its length (rounds 1-4: 5 % of the steps)
+EXCUSED = {}             # fixture -> (excused, steps), printed by the last test of the module
 DISCRETE = ("flags", "col_pair_mask", "new_pair_mask", "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_hit_idx", "done")
 RESYNC = ("flags", "col_pair_mask", "counters")
 
@@ -64,13 +67,10 @@ def test_reference_fixture_teacher_forced_through_f32(name, monkeypatch):
         pytest.skip(str(exc))
     D = st64.obs_dim
 
-    def tol_of(ref):
-        return TOL * (1.0 + np.abs(ref).max())
-
+    ctx = f"fixture {name} f32"
     st64.reset(); st32.reset()
     np.testing.assert_array_equal(st32.tape_pos(), g["tape_pos"][0], err_msg="float32 reset consumed a different number of draws than the reference")
-    e0 = np.abs(st32.to_host("obs").reshape(n, D) - g["obs0"]).max()
-    assert e0 <= tol_of(g["obs0"]), f"obs after reset: {e0}"
+    tolr.check(ctx, "obs_reset", st32.to_host("obs").reshape(n, D), g["obs0"], tolr.allowed_obs(g["obs0"], TOL), "after reset")
 
     force = {int(t): k for k, t in enumerate(g["force_steps"])}
     steps = g["actions"].shape[0]
@@ -120,17 +120,30 @@ def test_reference_fixture_teacher_forced_through_f32(name, monkeypatch):
                     v = (v & ~np.uint32(0x3000)) | (st32.to_host(nm) & np.uint32(0x3000))
                 st32.from_host(nm, v)
             continue
+        # per quantity (tests/tolerances.py): observation columns absolute 1e-5 (angular-velocity columns 1e-5 * max(1, |w|)), reward
+        # 1e-5 * max(1, |r|) - against the REFERENCE's recorded outputs; post-step state against the twin, the same rule per state column
         obs, rew = st32.to_host("obs").reshape(n, D), st32.to_host("reward")
-        for nm, got, ref in (("obs", obs, g["obs"][t]), ("rew", rew, g["rew"][t])):
-            err = np.abs(got - ref).max()
-            if err > tol_of(ref) and boundary:
-                excused += 1
-                break
-            assert err <= tol_of(ref), f"{name} step {t}: {nm} differs from the REFERENCE's recorded output by {err} (tolerance {tol_of(ref)})"
-            worst = max(worst, err / (1.0 + np.abs(ref).max()))
+        floats = (("obs", obs, g["obs"][t], tolr.allowed_obs(g["obs"][t], TOL)), ("reward", rew, g["rew"][t], tolr.allowed_rel(g["rew"][t], TOL)))
+        if boundary and any(tolr.excess(got, ref, al) > 1.0 for _, got, ref, al in floats):
+            excused += 1
+        else:
+            for nm, got, ref, al in floats:
+                worst = max(worst, tolr.check(ctx, nm, got, ref, al, f"step {t}: differs from the REFERENCE's recorded output"))
         s32, s64 = st32.get_state(0)[0], st64.get_state(0)[0]
-        err = np.abs(s32[:, :30] - s64[:, :30]).max()
-        assert boundary or err <= tol_of(s64[:, :30]), f"{name} step {t}: post-step state differs by {err}"
-    assert excused <= max(2, steps // 20), f"{name}: {excused} of {steps} steps excused as float32 boundary cases"
-    print(f"{name}: worst float32 error / (1 + max|x|) = {worst:.2e}, {excused} of {steps} steps excused")
+        if not boundary:
+            worst = max(worst, tolr.check(ctx, "state", s32[:, :30], s64[:, :30], tolr.allowed_state(s64[:, :30], TOL), f"step {t}: post-step state"))
+    EXCUSED[name] = (excused, steps)
+    assert excused <= MAX_EXCUSED or tolr.REPORT, f"{name}: {excused} of {steps} steps excused as float32 boundary cases (cap {MAX_EXCUSED})"
+    print(f"{name}: worst float32 |err| / allowed = {worst:.2f}, {excused} of {steps} steps excused as documented boundary cases")
     st64.close(); st32.close()
+
+
+def test_excused_steps_summary():
+    """the excused-step counts of every fixture in one place (run with -s to see them): a fixed small cap per fixture, stated in the output"""
+    if not EXCUSED:
+        pytest.skip("run together with the fixture tests")
+    total = sum(e for e, _ in EXCUSED.values())
+    print("\nexcused float32 boundary steps per fixture: " + ", ".join(f"{k} {e}/{n}" for k, (e, n) in sorted(EXCUSED.items()) if e) + f"; {total} in total over {len(EXCUSED)} fixtures")
+    assert all(e <= MAX_EXCUSED for e, _ in EXCUSED.values()) or tolr.REPORT
+    if tolr.REPORT:
+        tolr._worst["excused_steps|max_per_fixture"] = float(max(e for e, _ in EXCUSED.values()))

@@ -97,3 +97,30 @@ def test_philox_mode_is_deterministic_and_keyed_by_global_env_id():
     assert np.abs(oa - oc).max() > 1e-3
     act = np.random.RandomState(0).uniform(-1, 1, size=(4, 4))
     np.testing.assert_array_equal(a.step(act)[0], b.step(act)[0])
+
+
+def test_bezier_goals_lie_on_a_quadratic_curve_by_de_casteljau():
+    """scenarios/ep_rand_bezier.py:33-39 moves the goal along `bezier.Curve(nodes, degree=2).evaluate_multi(linspace(0, 1, 500))`.  The `bezier`
+    package is not in the capture container: the fixture came through a Bernstein-form stand-in (oracle/ref_harness/stubs/bezier).  An
+    INDEPENDENT evaluation pins what any correct implementation of that call must return: the control points are recovered from three recorded
+    goals of a leg, every other goal of the leg must then equal the de Casteljau construction (repeated linear interpolation - no Bernstein
+    polynomial, no Horner form) at its parameter, to 1e-12; the oracle's own evaluator (quadswarm_oracle.c, QS_SCENARIO_EP_RAND_BEZIER) reproduces
+    the same fixture to 1e-9 (tests/test_oracle_vs_reference.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s_ep_rand_bezier.npz"))
+    goal, tick = g["s_goal"][:, 0, :], g["s_tick"][:, 0]          # after control step k: the goal and the env's tick (= k + 1 inside the episode)
+    control_steps = 500                                            # int(5 s * control_freq), ep_rand_bezier.py:12-13
+    leg = [k for k in range(len(tick)) if 2 <= tick[k] <= control_steps - 1 and k + 1 == tick[k]]   # first leg of the first episode: ticks 2 .. 499
+    assert len(leg) > 400
+    s_of = lambda k: (tick[k] % control_steps) / (control_steps - 1.0)     # np.linspace(0, 1, control_steps)[t]
+    fit = [leg[0], leg[len(leg) // 2], leg[-1]]
+    basis = np.array([[(1 - s_of(k)) ** 2, 2 * (1 - s_of(k)) * s_of(k), s_of(k) ** 2] for k in fit])
+    nodes = np.linalg.solve(basis, goal[fit])                     # rows: P0, P1, P2
+    worst = 0.0
+    for k in leg:
+        s = s_of(k)
+        b01, b12 = (1 - s) * nodes[0] + s * nodes[1], (1 - s) * nodes[1] + s * nodes[2]      # de Casteljau, level 1
+        worst = max(worst, np.abs((1 - s) * b01 + s * b12 - goal[k]).max())                    # level 2
+    assert worst < 1e-12, worst
+    # the curve starts at the goal that was current when the leg was drawn (nodes[:, 0] = self.goals[0], :35) and is not a straight line
+    assert np.abs(nodes[0] - g["s_goal"][0, 0]).max() < 0.1 and np.linalg.norm(np.cross(nodes[1] - nodes[0], nodes[2] - nodes[0])) > 1e-3

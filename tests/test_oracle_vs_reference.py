@@ -22,7 +22,12 @@ EDGE_CASES = ["e_n64_k20", "e_n33_k8_numpy_wall", "e_n40_kall_svs", "x_n8_blind"
               "x_hitbox", "x_svs_odd", "e_n17_kall_obst", "x_n40_obst", "e_n2_k1_swap", "e_n1_obst"]
 CASES = ["c1_single_numpy", "c1_single_numba", "c2_n8_random", "c2_n8_hover_svd", "c2_n8_events", "c2_n8_episode",
          "c2_n8_k2_numpy", "c2_n8_kall", "c3_n8_obst", "c3_n8_obst_episode", "c4_n32_svs", "c4_n6_svs_switch",
-         "c4_svs_resets"]
+         "c4_svs_resets",
+         # the numba path with OUNoiseNumba's float32 theta / sigma members (numba_utils.py:67-74), captured with the jitclass stub emulating them
+         "c1_single_numba_f32ou", "c2_n8_numba_f32ou"]
+# the reference under its pinned NumPy 1.26 (setup.py:14): the omega damping factor in float32 for the sub-step after a float32 omega
+#  - an ORACLE switch (qso_set_numpy126_quirk); the HIP stepper follows NumPy >= 2 like every other fixture
+QUIRK_CASES = ["c1_single_numpy_np126"]
 TOL = 1e-9
 
 
@@ -55,12 +60,14 @@ def check_episode_stats(st, info, n, use_obstacles):
         assert cnt[9] == st["num_collisions_obst_quad_3_5"] and cnt[10] == st["num_collisions_obst_quad_5"]
 
 
-@pytest.mark.parametrize("name", CASES + SCEN_CASES + EDGE_CASES)
-def test_replay(name):
+@pytest.mark.parametrize("name", CASES + SCEN_CASES + EDGE_CASES + QUIRK_CASES)
+def test_replay(name, quirk=None):
     g, cfgd = gu.load(name)
     cfg = gu.config_from_golden(cfgd)
     n = cfgd["num_agents"]
     env = orc.OracleEnv(cfg, tape=g["tape"])
+    if cfgd.get("numpy126_omega_quirk", False) if quirk is None else quirk:
+        env.set_numpy126_quirk(True)
     obs0 = env.reset()
     assert env.tape_pos == g["tape_pos"][0], "reset consumed a different number of draws than the reference"
     np.testing.assert_allclose(obs0, g["obs0"], rtol=0, atol=TOL)
@@ -125,3 +132,31 @@ def test_replay(name):
     assert checked_eps == len(ep_stats)
 
     print(f"{name}: worst abs err {worst:.3e}")
+
+
+def test_the_emulation_fixtures_pin_what_they_claim():
+    """each variant fixture must FAIL without its switch - otherwise it pins nothing: the NumPy-1.26 fixture with the oracle's quirk off, the
+    float32-OU fixtures with float64 theta / sigma"""
+    with pytest.raises(AssertionError):
+        test_replay("c1_single_numpy_np126", quirk=False)
+    for name in ("c1_single_numba_f32ou", "c2_n8_numba_f32ou"):
+        g, cfgd = gu.load(name)
+        assert cfgd["numba_float32_ou"] is True
+        cfg = gu.config_from_golden(dict(cfgd, numba_float32_ou=False))
+        assert cfg.ou_theta == 0.15 and gu.config_from_golden(cfgd).ou_theta == float(np.float32(0.15))
+        env = orc.OracleEnv(cfg, tape=g["tape"])
+        env.reset()
+        worst = 0.0
+        for t in range(g["actions"].shape[0]):
+            obs, rew, done, ri = env.step(g["actions"][t])
+            worst = max(worst, np.abs(obs - g["obs"][t]).max())
+        assert worst > 10 * TOL, f"{name}: float64 OU parameters reproduce the fixture to {worst}"
+        env.close()
+
+
+def test_config_1_at_its_stated_length():
+    """BASELINE.json configs[0]: single_quad, 1000 steps - both floor-semantics fixtures hold all 1000 control steps"""
+    for name in ("c1_single_numpy", "c1_single_numba", "c1_single_numpy_np126", "c1_single_numba_f32ou"):
+        g, cfgd = gu.load(name)
+        assert cfgd["num_agents"] == 1 and g["actions"].shape[0] == 1000
+    assert gu.load("c4_n32_svs")[0]["actions"].shape[0] >= 120

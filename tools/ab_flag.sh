@@ -13,7 +13,7 @@ for we in $shapes; do
   for rep in 1 2; do
     for v in A B; do
       if [ $v = B ]; then export QS_SPEC_EXTRA_FLAGS="$flags"; [ -n "$AB_B_ENV" ] && export $AB_B_ENV; else unset QS_SPEC_EXTRA_FLAGS; [ -n "$AB_B_ENV" ] && unset ${AB_B_ENV%%=*}; fi
-      us=$(timeout 300 python bench.py --workload $wl --envs-per-gpu $E --steps 400 --warmup 50 --prewarm 200 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants 2>>gpurun_out/${tag}_ab.err | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.3f frac %.4f' % (1e3*d['ms_per_step'], d['roofline']['frac']))")
+      us=$(timeout 300 python bench.py --workload $wl --envs-per-gpu $E --steps 400 --warmup 50 --prewarm 200 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train 2>>gpurun_out/${tag}_ab.err | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.3f frac %.4f' % (1e3*d['ms_per_step'], d['roofline']['frac']))")
       echo "$wl E=$E rep $rep variant $v: $us" | tee -a $out
     done
   done

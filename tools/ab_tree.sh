@@ -11,7 +11,7 @@ print(sys.argv[1], round(d["ms_per_step"]*1e3,3), "us per step; open-loop", roun
 for rep in 1 2 3; do
   for tree in . build_exp/old; do
     for wl in $wls; do
-      ( cd $R/$tree; python bench.py --workload $wl --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --steps 3000 2>/dev/null | python -c "$fmt" "$tree $wl" ) | tee -a $R/gpurun_out/${tag}_ab_tree.txt
+      ( cd $R/$tree; python bench.py --workload $wl --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train --steps 3000 2>/dev/null | python -c "$fmt" "$tree $wl" ) | tee -a $R/gpurun_out/${tag}_ab_tree.txt
     done
   done
 done

@@ -42,5 +42,30 @@ for name, prob in (("no_replay", 0.0), ("replay_0.75", 0.75)):
     dt = total / steps
     res[name] = {"us_per_step": dt * 1e6, "agent_steps_per_s": env.num_agents / dt, "env_steps_per_s (x2 sim steps)": env.num_agents * 2 / dt, "steps_with_infos": n_info,
                  "ms_per_step_with_infos": 1e3 * t_info / max(n_info, 1), "us_per_step_without_infos": 1e6 * (total - t_info) / max(steps - n_info, 1)}
+    if name == "no_replay":   # where a step() call's time goes, layer by layer (same env, same kernel): the C ABI through ctypes alone, the vec env's
+        # step(), the batched env's step(); and the kernel's own duration from HIP events (what the GPU needs per step whatever the host does)
+        from quad_swarm_rl_amd import native
+        vec, st = env.vec, env.vec.stepper
+        qs_step, h, ptr = native.lib().qs_step, st._h, act.data_ptr()
+        raw = torch._C._cuda_getCurrentRawStream
+        layers = {}
+        for lname, fn in (("ctypes_qs_step", lambda: qs_step(h, ptr, raw(0))), ("vec_env_step", lambda: vec.step(act)), ("batched_env_step", lambda: env.step(act))):
+            for _ in range(200):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2000):
+                fn()
+            torch.cuda.synchronize()
+            layers[lname] = 1e6 * (time.perf_counter() - t0) / 2000
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(2000):
+            qs_step(h, ptr, raw(0))
+        ev1.record()
+        torch.cuda.synchronize()
+        layers["gpu_us_per_step_by_events"] = 1e3 * ev0.elapsed_time(ev1) / 2000
+        layers["kernel"] = st.kernel_name
+        res["layers_us_per_step"] = layers
     env.close()
 print(json.dumps(res))

@@ -17,9 +17,9 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 BIG="c2:131072 c3:131072 c4:32768"
 kt() { # rocprofv3 kernel stats of one workload
   wl=$1
-  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rocprof_kt_${tag}_$wl -o k -- python $R/bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants > $R/gpurun_out/kt_${tag}_$wl.json 2> $R/gpurun_out/kt_${tag}_$wl.err )
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rocprof_kt_${tag}_$wl -o k -- python $R/bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train > $R/gpurun_out/kt_${tag}_$wl.json 2> $R/gpurun_out/kt_${tag}_$wl.err )
   db=$(ls /tmp/rocprof_kt_${tag}_$wl/*.db /tmp/rocprof_kt_${tag}_$wl/*/*.db 2>/dev/null | head -1)
-  [ -n "$db" ] && python $R/tools/rocprof_summary.py $db "rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants" > $R/gpurun_out/kt_${tag}_${wl}_stats.txt
+  [ -n "$db" ] && python $R/tools/rocprof_summary.py $db "rocprofv3 --kernel-trace --stats -- python bench.py --workload $wl --steps 2000 --warmup 100 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train" > $R/gpurun_out/kt_${tag}_${wl}_stats.txt
   head -4 $R/gpurun_out/kt_${tag}_${wl}_stats.txt
 }
 for task in "$@"; do
@@ -37,8 +37,8 @@ for task in "$@"; do
       timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_bench_c2_steps20.json 2>> gpurun_out/${tag}_err.txt ;;
     lines)
       : > gpurun_out/${tag}_bench_lines.txt
-      for wl in c2 c3 c4; do timeout 300 python bench.py --workload $wl --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants >> gpurun_out/${tag}_bench_lines.txt 2>> gpurun_out/${tag}_err.txt; done
-      for we in $BIG; do timeout 300 python bench.py --workload ${we%%:*} --envs-per-gpu ${we##*:} --steps 400 --warmup 50 --prewarm 200 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants >> gpurun_out/${tag}_bench_lines.txt 2>> gpurun_out/${tag}_err.txt; done
+      for wl in c2 c3 c4; do timeout 300 python bench.py --workload $wl --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train >> gpurun_out/${tag}_bench_lines.txt 2>> gpurun_out/${tag}_err.txt; done
+      for we in $BIG; do timeout 300 python bench.py --workload ${we%%:*} --envs-per-gpu ${we##*:} --steps 400 --warmup 50 --prewarm 200 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train >> gpurun_out/${tag}_bench_lines.txt 2>> gpurun_out/${tag}_err.txt; done
       python - <<PY
 import json
 for l in open("gpurun_out/${tag}_bench_lines.txt"):
