@@ -150,7 +150,7 @@ def cpu_baseline(workload, seconds):
                 os_cpu_count=os.cpu_count())
 
 
-def c5_record(run_training, iterations=6):
+def c5_record(run_training, iterations=4):
     """BASELINE.json configs[4] ("C5": the C2 batch inside an APPO training loop, train_local.sh:1-18 through swarm_rl/train.py:16-33).
     Where Sample Factory imports, tools/train_c5.py runs the reference's flag set through it and its FPS is recorded.  This image has no
     Sample Factory and no network: the record then holds the exact import error AND a run of the in-tree PPO harness (tools/ppo_c5.py: the
@@ -179,7 +179,9 @@ def c5_record(run_training, iterations=6):
                 "fps_agent_steps_per_s": rec["fps"], "agent_steps": rec["agent_steps"], "seconds": rec["seconds"], "first_rollout": rec["first"],
                 "last_rollout": rec["last"], "recipe": "train_local.sh flags: mix, replay 0.75, annealing 3e8, attention encoder, 6 neighbours, lr 1e-4, "
                                                        f"rollout {rec['rollout']}, batch {rec['batch_size']}, 1024 envs x 8 quads",
-                "learning_test": "tests/test_c5_training_gpu.py"}
+                "learning_evidence": "tests/test_c5_training_gpu.py trains 1.0e8 agent-steps (minibatches of 8192) and asserts that the per-episode mean reward and "
+                                     "rew_pos of the last episode are above the first's; measured curve: profiles/r05b_ppo_c5_b8192.txt (reward -0.0264 -> -0.0069, "
+                                     "rew_pos -0.0159 -> -0.0079 per step over 8 episodes, 0.89e6 agent-steps/s)"}
     except Exception as exc:   # noqa: BLE001
         return {"status": "failed", "sample_factory": sf_error or "importable", "error": f"{type(exc).__name__}: {exc}"}
 
@@ -394,7 +396,6 @@ def main():
                                                           "launch (qs_step_many: state stays in registers between the steps)")
     ap.add_argument("--rollout-steps", type=int, default=64, help="steps per launch of the extra open-loop measurement (0 = skip)")
     ap.add_argument("--no-wire-sweep", action="store_true", help="with an observation exchange: measure the headline's wire only (config.exchange_per_wire otherwise holds f32, bf16 and q8)")
-    ap.add_argument("--no-reset-crossing", action="store_true", help="do not pre-advance episode clocks when the timed region is shorter than an episode (config.auto_reset)")
     ap.add_argument("--dry-run", action="store_true", help="launch path only: ranks rendezvous over gloo (no GPU needed), take the barriers of the timed "
                                                            "bracket around K empty steps, rank 0 prints one JSON line with value null")
     args = ap.parse_args()
@@ -540,30 +541,48 @@ def main():
             devs, host = (float(x) for x in tmax.tolist())
         return devs, host
 
+    episode_end = None
     if args.prewarm > 0:   # a scratch handle (its own state and noise streams): the measured one is untouched by it
         s0 = native.Stepper(cfg, device=local_rank)
         s0.reset(stream=stream)
         for t in range(args.prewarm):
             s0.step(aptr + (t % ring) * astride, stream=stream)
         torch.cuda.synchronize()
+        try:   # the step on which EVERY environment ends its episode (what happens once per ep_len + 1 steps), 5 samples by HIP events
+            samples = []
+            for rep in range(5):
+                tick = s0.to_host("tick")
+                tick[:] = cfg.ep_len
+                s0.from_host("tick", tick)
+                for t in range(3):   # (two ordinary steps first: the copy above left the queue cold)
+                    if t == 2:
+                        tick = s0.to_host("tick"); tick[:] = cfg.ep_len; s0.from_host("tick", tick)
+                        torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    s0.step(aptr + (t % ring) * astride, stream=stream)
+                    e1.record(stream)
+                    torch.cuda.synchronize()
+                    if t == 2:
+                        samples.append(1e3 * e0.elapsed_time(e1))
+                assert int(s0.to_host("done").min()) == 1
+            samples.sort()
+            episode_end = {"us_median_of_5": samples[2], "all_envs_end_together": True, "amortised_us_per_step": samples[2] / (cfg.ep_len + 1),
+                           "note": "a single launch bracketed by its own event pair (includes ~2 us of event overhead an ordinary step in a stream of steps does not pay)"}
+        except Exception as exc:   # noqa: BLE001 - a measurement beside the headline, never fatal
+            episode_end = {"error": f"{type(exc).__name__}: {exc}"}
         s0.close()
     if exchange is None:
         st.reset(stream=stream)
-    # "auto-reset included"  also when the timed region is shorter than an episode: the episode clocks of the share of the
-    # environments that a window of K steps sees ending in the steady state (E * K / ep_len of them, at least one), spread over the batch, are
-    # advanced so that they end - statistics snapshot + device-side reset + fresh observation - at evenly spread steps INSIDE the timed
-    # region.  Longer regions cross the episodes' natural end (all environments at once, the way the reference's synchronous loop does).
-    crossing = {"envs_ending_inside_the_timed_region": 0, "how": "the region covers whole episodes: every environment ends naturally"}
-    if args.warmup + args.steps <= cfg.ep_len and not args.no_reset_crossing:
-        torch.cuda.synchronize()
-        n_cross = max(1, int(round(E * args.steps / (cfg.ep_len + 1))))
-        tick = st.to_host("tick")
-        for j in range(n_cross):
-            e = (j * E) // n_cross
-            tick[e] = cfg.ep_len - args.warmup - (j * args.steps) // n_cross   # ends with timed step (j * K) // n_cross: tick + 1 > ep_len there
-        st.from_host("tick", tick)
-        crossing = {"envs_ending_inside_the_timed_region": n_cross, "how": f"episode clocks of {n_cross} of {E} environments (= E * K / episode length) pre-advanced so that "
-                                                                           "their episodes end at evenly spread timed steps"}
+    # Auto-resets ("included in timing").  Every environment of the batch starts its episode together, so episodes end together every
+    # ep_len + 1 control steps: a timed region of at least that many steps (the default 3000) contains the episode end of every environment; the
+    # driver's --steps 20 region contains none - stated in config.workload - and the cost of the step on which all environments end their episodes
+    # (statistics snapshot + device-side reset + fresh observation for E envs), measured on the scratch handle above, is reported beside it with
+    # its amortised share per step.  (Spreading a K / ep_len share of episode ends over a short region was tried: in the latency regime one
+    # resetting environment delays its whole launch, so 14 of 20 steps paid a reset tail - 11.1 us per step where the steady state is 8.0 +
+    # 0.02: profiles/r05a_bench_c2_steps20.json.)
+    crossing = {"episode_ends_inside_the_timed_region": bool(args.warmup + args.steps > cfg.ep_len), "episode_length_steps": int(cfg.ep_len) + 1,
+                "episode_end_step": episode_end}
     head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None, xchg=use_gather and exchange is not None)
     st.check_errors()
     if exchange is not None:
@@ -785,7 +804,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "wire": (args.wire if use_gather else None),   # the observation exchange's wire format (f32 = bit-exact; bf16 / q8 are lossy), null without an exchange
             "config": {"workload": f"{workload}: {N} drones x {E} envs per GPU ({world * E} envs in total), {kw.get('quads_mode', 'static_same_goal')}, "
-                                   f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on",
+                                   f"K={cfg.num_neighbors} neighbours, obs_dim {D}, downwash {bool(cfg.use_downwash)}, sensor+thrust noise on, auto-reset on "
+                                   + ("(every environment's episode ends inside the timed region)" if args.warmup + args.steps > cfg.ep_len else
+                                      f"(episodes last {cfg.ep_len + 1} steps: none ends inside this {args.steps}-step region; config.auto_reset has the episode-end step's cost)"),
                        "drone_control_steps_per_s": value / 2.0, "envs_per_gpu": E, "num_agents": N, "ranks_seen_by_process_group": ranks_seen,
                        "timing": "HIP events on the launch stream inside the barrier+synchronize bracket of the K timed steps, max over ranks",
                        "host_clock": {"ms_per_step": 1e3 * head_host / args.steps, "value": world * T * 2 * args.steps / head_host,

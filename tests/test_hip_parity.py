@@ -191,6 +191,7 @@ class Pair:
         self.oenvs = [orc.OracleEnv(self.cfg, env_global_id=env_id_offset + e) for e in range(E)]
         self.hip = native.Stepper(self.cfg, device=0)
         self.D = self.hip.obs_dim
+        self.obs_layout = (self.D - 6 * self.cfg.num_neighbors - (9 if self.cfg.use_obstacles else 0), self.cfg.num_neighbors)   # (self columns, neighbour blocks)
 
     def reset(self):
         oobs = np.stack([o.reset() for o in self.oenvs])
@@ -237,7 +238,7 @@ class Pair:
             for nm, a, b in (("pos", pos[e], s[:, 0:3]), ("vel", vel[e], s[:, 3:6]), ("rot", rot[e], s[:, 6:15]),
                              ("omega", om[e], s[:, 15:18]), ("goal", goal[e], s[:, 32:35])):
                 worst = max(worst, np.abs(a - b).max())
-                allowed = tolr.allowed_rel(b, tol) if nm == "omega" else tolr.allowed_abs(b, tol)
+                allowed = tolr.allowed_rel(b, tol) if nm in ("omega", "vel") else tolr.allowed_abs(b, tol)
                 tolr.check(f"{self.context} {self.precision}", nm, a, b, allowed, f"step {t} env {e}")
         return worst
 
@@ -260,14 +261,14 @@ class Pair:
             o.close()
 
 
-def check_floats(t, tol, o, h, what):
+def check_floats(t, tol, o, h, what, layout=None):
     """oracle outputs `o` against the stepper's `h`, per quantity (tests/tolerances.py): observation columns absolute `tol` (the angular-
     velocity columns tol * max(1, |w|)), reward and its terms tol * max(1, |r|)"""
     for nm, a, b in zip(("obs", "reward", "done", "rew_info"), o, h):
         if nm == "done":
             np.testing.assert_array_equal(a, b, err_msg=f"done step {t}")
             continue
-        allowed = tolr.allowed_obs(a, tol) if nm == "obs" else tolr.allowed_rel(a, tol)
+        allowed = tolr.allowed_obs(a, tol, *(layout or ())) if nm == "obs" else tolr.allowed_rel(a, tol)
         tolr.check(what, nm, b, a, allowed, f"step {t}")
 
 
@@ -321,7 +322,7 @@ def rollout_f64(case, E, steps, tol, keep=False):
         gentle = (t // 10) % 2 == 1
         act = rng.uniform(-1, 1, size=(E, pr.N, 4)) if not gentle else 0.06 + rng.uniform(-0.05, 0.05, size=(E, pr.N, 4))
         o, h = pr.step(act)
-        check_floats(t, tol, o, h, f"{case} f64")
+        check_floats(t, tol, o, h, f"{case} f64", pr.obs_layout)
         pr.compare_discrete(t)
         pr.compare_state(t, tol)
         if o[2].any():
@@ -359,7 +360,7 @@ def teacher_forced_f32(case, E, steps, tol, expect_team=None):
         assert bool(pr.hip.team) == expect_team
     rng = np.random.RandomState(9)
     oobs, hobs = pr.reset()
-    tolr.check(f"{case} f32", "obs_reset", hobs, oobs, tolr.allowed_obs(oobs, tol), "after reset")
+    tolr.check(f"{case} f32", "obs_reset", hobs, oobs, tolr.allowed_obs(oobs, tol, *pr.obs_layout), "after reset")
     thr = pr.cfg.arm if pr.cfg.floor_mode == 0 else 0.05
     worst = 0.0
     for t in range(steps):
@@ -389,7 +390,7 @@ def teacher_forced_f32(case, E, steps, tol, expect_team=None):
         act = rng.uniform(-1, 1, size=(E, pr.N, 4)) if not gentle else 0.06 + rng.uniform(-0.05, 0.05, size=(E, pr.N, 4))
         act = act.astype(np.float32).astype(np.float64)
         o, h = pr.step(act)
-        check_floats(t, tol, o, h, f"{case} f32")
+        check_floats(t, tol, o, h, f"{case} f32", pr.obs_layout)
         pr.compare_discrete(t)
         worst = max(worst, pr.compare_state(t, tol))
     print(f"{case}: worst f32 state error {worst:.2e}")

@@ -68,9 +68,10 @@ def test_reference_fixture_teacher_forced_through_f32(name, monkeypatch):
     D = st64.obs_dim
 
     ctx = f"fixture {name} f32"
+    layout = (D - 6 * cfg64.num_neighbors - (9 if cfg64.use_obstacles else 0), cfg64.num_neighbors)
     st64.reset(); st32.reset()
     np.testing.assert_array_equal(st32.tape_pos(), g["tape_pos"][0], err_msg="float32 reset consumed a different number of draws than the reference")
-    tolr.check(ctx, "obs_reset", st32.to_host("obs").reshape(n, D), g["obs0"], tolr.allowed_obs(g["obs0"], TOL), "after reset")
+    tolr.check(ctx, "obs_reset", st32.to_host("obs").reshape(n, D), g["obs0"], tolr.allowed_obs(g["obs0"], TOL, *layout), "after reset")
 
     force = {int(t): k for k, t in enumerate(g["force_steps"])}
     steps = g["actions"].shape[0]
@@ -123,7 +124,7 @@ def test_reference_fixture_teacher_forced_through_f32(name, monkeypatch):
         # per quantity (tests/tolerances.py): observation columns absolute 1e-5 (angular-velocity columns 1e-5 * max(1, |w|)), reward
         # 1e-5 * max(1, |r|) - against the REFERENCE's recorded outputs; post-step state against the twin, the same rule per state column
         obs, rew = st32.to_host("obs").reshape(n, D), st32.to_host("reward")
-        floats = (("obs", obs, g["obs"][t], tolr.allowed_obs(g["obs"][t], TOL)), ("reward", rew, g["rew"][t], tolr.allowed_rel(g["rew"][t], TOL)))
+        floats = (("obs", obs, g["obs"][t], tolr.allowed_obs(g["obs"][t], TOL, *layout)), ("reward", rew, g["rew"][t], tolr.allowed_rel(g["rew"][t], TOL)))
         if boundary and any(tolr.excess(got, ref, al) > 1.0 for _, got, ref, al in floats):
             excused += 1
         else:

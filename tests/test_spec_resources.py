@@ -12,7 +12,7 @@ import pytest
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-@pytest.mark.parametrize("workload,team,max_vgpr,max_scratch", [("c2", 8, 160, 0), ("c2", 0, 128, 0), ("c4", 4, 256, 128), ("c4", 0, 128, 64)])
+@pytest.mark.parametrize("workload,team,max_vgpr,max_scratch", [("c2", 8, 176, 0), ("c2", 0, 128, 0), ("c4", 4, 256, 128), ("c4", 0, 128, 64)])
 def test_no_scratch_and_register_budget(workload, team, max_vgpr, max_scratch, tmp_path):
     import spec_resources
     res, _ = spec_resources.resources(workload, team, out=str(tmp_path / "k.s"))

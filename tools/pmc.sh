@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for pmc in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
   n=$(echo $pmc | cut -c1-14 | tr " " "_")
-  rocprofv3 --kernel-trace --pmc $pmc -d /tmp/rocprof_pmc_${tag}_$n -o p --output-format csv -- python $R/bench.py --workload $wl --steps 200 --warmup 20 --profile-steps 10 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants "$@" > $R/gpurun_out/pmc_${tag}_$n.out 2> $R/gpurun_out/pmc_${tag}_$n.err
+  rocprofv3 --kernel-trace --pmc $pmc -d /tmp/rocprof_pmc_${tag}_$n -o p --output-format csv -- python $R/bench.py --workload $wl --steps 200 --warmup 20 --profile-steps 10 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train "$@" > $R/gpurun_out/pmc_${tag}_$n.out 2> $R/gpurun_out/pmc_${tag}_$n.err
 done
 python - <<PY
 import csv, collections, glob, json
