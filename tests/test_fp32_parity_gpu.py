@@ -132,7 +132,7 @@ def test_free_running_f32_event_free_windows(case, team, spec, monkeypatch):
             assert not cp[e].any()
             s, _ = oe.get_state()
             for nm, a, b in (("pos", st_pos[e], s[:, 0:3]), ("vel", st_vel[e], s[:, 3:6]), ("rot", st_rot[e], s[:, 6:15]), ("omega", st_om[e], s[:, 15:18])):
-                al = tolr.allowed_rel(b, tol) if nm in ("omega", "vel") else tolr.allowed_abs(b, tol)
+                al = tolr.allowed_vec(b, tol) if nm in ("omega", "vel") else tolr.allowed_abs(b, tol)
                 rel = tol * tolr.excess(a, b, al)
                 worst = max(worst, rel)
                 if rel > by.get(nm, (0.0, 0))[0]:

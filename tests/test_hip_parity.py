@@ -238,7 +238,7 @@ class Pair:
             for nm, a, b in (("pos", pos[e], s[:, 0:3]), ("vel", vel[e], s[:, 3:6]), ("rot", rot[e], s[:, 6:15]),
                              ("omega", om[e], s[:, 15:18]), ("goal", goal[e], s[:, 32:35])):
                 worst = max(worst, np.abs(a - b).max())
-                allowed = tolr.allowed_rel(b, tol) if nm in ("omega", "vel") else tolr.allowed_abs(b, tol)
+                allowed = tolr.allowed_vec(b, tol) if nm in ("omega", "vel") else tolr.allowed_abs(b, tol)
                 tolr.check(f"{self.context} {self.precision}", nm, a, b, allowed, f"step {t} env {e}")
         return worst
 

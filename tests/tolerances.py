@@ -15,7 +15,12 @@ densest obstacle cases (2.1e-5 / 1.8e-5): the response sets speeds of several m/
 per unit.  Free-running float32 (tests/test_fp32_parity_gpu.py) is not the per-step claim: rounding accumulates in a feedback-free integrator,
 and that test states its own envelope - 3 x these bounds inside the first 60 control steps, 8 x up to step 100 (measured: 2.0 x / 5.8 x).
 
-    EXTRA = {quantity: factor}   (empty: nothing needs more than the rules above)
+"Relative" is relative to the NORM of the 3-vector a component belongs to (a rotated / rescaled vector's rounding error scales with its length,
+not with the component that happens to be small).  One listed exception - EXTRA below - instead of a looser global rule: the velocity behind an
+obstacle-collision response in the two densest obstacle cases.  The response's direction is (pos - obstacle) / |pos - obstacle| and its speed
+the drone's (collisions/obstacles.py:8-40): inside or near the centre of an obstacle that division amplifies the float32 rounding of the forced
+position (2.4e-7 m at 4 m) by 1 / distance - 2e-5 m/s at 5 cm and a few m/s, for ANY float32 implementation.  Measured worst 2.1e-5
+(profiles/r05a_tolerance_report.json); allowed there: 3 x the rule.
 
 QS_TOL_REPORT=<path>: nothing is asserted by check(); the worst err / allowed per (context, quantity) is merged into <path> as JSON - how the
 bounds above were checked against every parity case before they became assertions."""
@@ -26,18 +31,30 @@ import os
 import numpy as np
 
 REPORT = os.environ.get("QS_TOL_REPORT")
-EXTRA = {}
+# (context substring, quantity) -> factor on the allowed error: the quantities that honestly need more than the rule, with the reason above
+EXTRA = {("x_dense_obst", "vel"): 3.0, ("x_dense_obst", "obs"): 3.0, ("x_n40_obst", "vel"): 3.0, ("x_n40_obst", "obs"): 3.0}
 _worst = {}
 
 
-def _allowed(ref, tol, rel_cols=(), relative=False):
+def extra_factor(context, quantity):
+    f = 1.0
+    for (ctx, q), v in EXTRA.items():
+        if q == quantity and ctx in context:
+            f = max(f, v)
+    return f
+
+
+def _allowed(ref, tol, rel_cols=(), relative=False, vector=False):
+    """relative=True: every element tol * max(1, |x|) (vector=True: |x| = the norm over the last axis, for [..., 3] arrays of vectors);
+    rel_cols: column slices (3-vectors) of the last axis that are relative to their norm, everything else absolute"""
     ref = np.asarray(ref, dtype=np.float64)
     if relative:
-        return tol * np.maximum(1.0, np.abs(ref))
+        mag = np.linalg.norm(ref, axis=-1, keepdims=True) if vector else np.abs(ref)
+        return tol * np.maximum(1.0, mag) * np.ones_like(ref)
     a = np.full(ref.shape, tol)
     for cols in rel_cols:
         if ref.shape[-1] >= cols.stop:
-            a[..., cols] = tol * np.maximum(1.0, np.abs(ref[..., cols]))
+            a[..., cols] = tol * np.maximum(1.0, np.linalg.norm(ref[..., cols], axis=-1, keepdims=True))
     return a
 
 
@@ -63,6 +80,11 @@ def allowed_rel(ref, tol):
     return _allowed(ref, tol, relative=True)
 
 
+def allowed_vec(ref, tol):
+    """[..., 3] vectors (velocity, angular velocity): every component tol * max(1, |vector|)"""
+    return _allowed(ref, tol, relative=True, vector=True)
+
+
 def allowed_abs(ref, tol):
     return _allowed(ref, tol)
 
@@ -77,7 +99,7 @@ def excess(got, ref, allowed):
 
 def check(context, quantity, got, ref, allowed, msg=""):
     """assert |got - ref| <= allowed elementwise (times EXTRA[quantity] where listed); returns err / allowed.  In report mode: records only."""
-    x = excess(got, ref, allowed * EXTRA.get(quantity, 1.0))
+    x = excess(got, ref, allowed * extra_factor(context, quantity))
     if REPORT:
         key = f"{context}|{quantity}"
         _worst[key] = max(_worst.get(key, 0.0), x)
