@@ -416,6 +416,11 @@ def main():
     import torch
     from quad_swarm_rl_amd import config as qcfg, native
 
+    def trace(msg):   # BENCH_TRACE=1: stage markers on stderr (where did a run stop?)
+        if os.environ.get("BENCH_TRACE"):
+            print(f"[bench rank {rank} +{time.perf_counter() - t_start:.2f}s] {msg}", file=sys.stderr, flush=True)
+    t_start = time.perf_counter()
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP stepper has no CPU fallback")
     if torch.cuda.device_count() <= local_rank:
@@ -432,6 +437,7 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     ranks_seen = dist.get_world_size() if dist is not None else 1
+    trace("process group up")
 
     import ast
     workload = args.workload or ("c2" if world == 1 else "c4")
@@ -444,6 +450,7 @@ def main():
     cfg = qcfg.make_config(num_envs=E, seed=0, env_id_offset=rank * E, precision="f32", write_rew_info=args.rew_info, **kw)
     st = native.Stepper(cfg, device=local_rank)
     N, T, D = cfg.num_agents, E * cfg.num_agents, st.obs_dim
+    trace("stepper created")
     stream = torch.cuda.current_stream(local_rank)
 
     # synthetic actions, resident in HBM before the timed region: a ring of pre-drawn U(-1,1)^4 batches
@@ -462,6 +469,7 @@ def main():
         else:
             exchange = make_exchange(st, world, rank, args.transport, args.wire, dist, dev, xinfo)
     xinfo.pop("_actions_ptr", None)
+    trace("exchange ready: " + str(xinfo.get("transport")) + "")
 
     def run(stepper, base_ptr, stride, k, offset=0, gather=None):
         if args.graph > 0 and gather is None:
@@ -583,7 +591,9 @@ def main():
     # 0.02: profiles/r05a_bench_c2_steps20.json.)
     crossing = {"episode_ends_inside_the_timed_region": bool(args.warmup + args.steps > cfg.ep_len), "episode_length_steps": int(cfg.ep_len) + 1,
                 "episode_end_step": episode_end}
+    trace("timed region")
     head_dev, head_host = timed(st, aptr, astride, args.warmup, args.steps, gather_obj if use_gather else None, xchg=use_gather and exchange is not None)
+    trace("timed region done")
     st.check_errors()
     if exchange is not None:
         wire_b = exchange.x.row_bytes / D
@@ -837,7 +847,8 @@ def main():
                                   "statement": f"{value / cb['value']:.1f}x the C oracle on {cb['cores']} host threads (cgroup quota {cb['cgroup_cpu_quota']}) of a {cb['cpu_model']}"}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    trace("line printed")
     if dist is not None:
         dist.destroy_process_group()
 
