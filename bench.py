@@ -847,10 +847,21 @@ def main():
                                   "statement": f"{value / cb['value']:.1f}x the C oracle on {cb['cores']} host threads (cgroup quota {cb['cgroup_cpu_quota']}) of a {cb['cpu_model']}"}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    trace("line printed")
+        line = json.dumps(out)
+    else:
+        line = None
     if dist is not None:
         dist.destroy_process_group()
+    # RCCL writes its version banner to the C-level stdout (NCCL_DEBUG=VERSION in this image), which is flushed when the process ends - BEHIND a
+    # line printed from Python.  The one JSON line must be the LAST line of rank 0's stdout: flush the C streams first, then print.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    if line is not None:
+        print(line, flush=True)
+    trace("line printed")
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ def test_no_scratch_and_register_budget(workload, team, max_vgpr, max_scratch, t
 def test_full_scenario_kernels_keep_the_constant_block_out_of_scratch(workload, team, max_vgpr, max_scratch, tmp_path):
     """`--quads_mode mix` (train_local.sh) runs the full-scenario kernels.  Their per-episode scenario code once stayed out of line in the
     specialised objects and took the constant block by reference: 552 bytes of scratch per lane, every literal a memory load, 22 us per
-    step for EVERY scenario of that set against 9 us for the same shape on static_same_goal (profiles/r03i_scenario_times.txt)."""
+    step for EVERY scenario of that set against 9 us for the same shape on static_same_goal (profiles/history/r03i_scenario_times_before.txt)."""
     import spec_resources
     res, _ = spec_resources.resources(workload, team, out=str(tmp_path / "k.s"), quads_mode="mix")
     assert res["qs_spec_step"]["scratch"] <= max_scratch, res["qs_spec_step"]
