@@ -562,21 +562,24 @@ template <typename real>
 __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o, real radius) {
     const real res = (real)0.1;
     real gx[3] = {px - res, px, px + res}, gy[3] = {py - res, py, py + res};
-    real mind[9];
+    // min over the obstacles of the SQUARED distance, one square root per cell at the end: the square root is monotone, so
+    // min_k sqrt(d2_k) == sqrt(min_k d2_k) - 9 instead of 9 * M quarter-rate v_sqrt_f32 per drone and step (the reference's start value 100.0,
+    // utils.py:17, is the cap 100^2 on the squared side)
+    real mind2[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) mind[q] = (real)100;
+    for (int q = 0; q < 9; ++q) mind2[q] = (real)10000;
     for (int k = 0; k < M_; ++k) {
         real x = ox[k], y = oy[k];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
             for (int b = 0; b < 3; ++b) {
-                real dx = gx[a] - x, dy = gy[b] - y, dist = M<real>::sqrt(dx * dx + dy * dy);
-                mind[a * 3 + b] = dist < mind[a * 3 + b] ? dist : mind[a * 3 + b];
+                real dx = gx[a] - x, dy = gy[b] - y, d2 = dx * dx + dy * dy;
+                mind2[a * 3 + b] = d2 < mind2[a * 3 + b] ? d2 : mind2[a * 3 + b];
             }
     }
 #pragma unroll
-    for (int q = 0; q < 9; ++q) o[q] = mind[q] - radius;
+    for (int q = 0; q < 9; ++q) o[q] = M<real>::sqrt(mind2[q]) - radius;
 }
 
 // The neighbour and SDF columns of the wave's rows -> rows stage -> HBM together with the self columns (obs_copy_rows), one row
