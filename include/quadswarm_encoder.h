@@ -69,6 +69,14 @@ typedef struct qs_enc_params {
     float *act_out;                 /* fp32 [B, head_dim] */
     const uint32_t *sample_counter;
     uint32_t sample_seed_lo, sample_seed_hi;
+    /* optional trajectory copy, for rollout segments: the FIRST kernel of the forward pass also copies, for every agent, the reward and the done
+       flag of the environment step that produced the observations it is reading (traj_rew_src[B] -> traj_rew_dst[B], traj_done_src[B] ->
+       traj_done_dst[B]) - the reward / done copy of step t rides on the policy's launch of step t + 1 instead of a launch of its own
+       (qs_rollout_post).  traj_rew_dst == NULL: no copy. */
+    const float *traj_rew_src;
+    float *traj_rew_dst;
+    const uint8_t *traj_done_src;
+    uint8_t *traj_done_dst;
 } qs_enc_params;
 
 size_t qs_enc_sizeof_params(void);

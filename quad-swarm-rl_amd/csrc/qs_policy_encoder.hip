@@ -86,7 +86,21 @@ struct EncParams {
     float *act_out;                 // fp32 [B, head_dim]
     const uint32_t *sample_counter;
     uint32_t sample_seed_lo, sample_seed_hi;
+    // optional trajectory copy (rollout segments): the first kernel of a forward pass also copies the reward and the done flag of every agent
+    // of its workgroup - the outputs of the environment step that produced THESE observations - to traj_rew_dst / traj_done_dst
+    const float *traj_rew_src;
+    float *traj_rew_dst;
+    const uint8_t *traj_done_src;
+    uint8_t *traj_done_dst;
 };
+
+// (rollout segments) reward / done of the previous control step -> trajectory, by the workgroup that owns the agents [a0, a0 + agents)
+__device__ __forceinline__ void traj_copy(const EncParams &P, int a0, int agents, int B) {
+    if (P.traj_rew_dst != nullptr) {
+        const int a = a0 + (int)threadIdx.x;
+        if ((int)threadIdx.x < agents && a < B) { P.traj_rew_dst[a] = P.traj_rew_src[a]; P.traj_done_dst[a] = P.traj_done_src[a]; }
+    }
+}
 
 #ifdef ENC_TIMING   // phase stamps of workgroup 0, wave 0 (tools/enc_quick.py prints them)
 __device__ unsigned long long enc_stamps[16];
@@ -362,6 +376,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
     const float invB = 1.0f / (float)B;
+    traj_copy(P, a0, ENC_TA, B);
     const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
 #pragma unroll 4
     for (int idx = tid; idx < NB * ENC_TA * 32; idx += 64 * ENC_WAVES) {
@@ -619,6 +634,7 @@ __device__ __forceinline__ void mha_body(const float *__restrict__ obs, int B, c
     float *red_ln = red_s + 4 * 2 * 4 * 16;                           // [8 waves][2 tokens][2 (sum, sum of squares)][16]
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT, nbw = P.nbr_dim * NB;
+    traj_copy(P, a0, ENC_TA, B);
 
     for (int idx = tid; idx < ENC_TA * 128; idx += 64 * ENC_WAVES) {   // columns as bf16, zero padded: [self 32 | obstacle 32 | neighbours 64]
         const int a = idx >> 7, c = idx & 127, ga = a0 + a;
@@ -804,6 +820,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     const int mt0 = wave * ENC_MT;   // first of this wave's 16-feature tiles of a 256-wide layer
 
     ENC_STAMP(0);
+    traj_copy(P, a0, ENC_TA, B);
     // ---- stage the observation rows as bf16, zero padded to K = 32 ----
     // The 16 rows of the workgroup are one contiguous block of obs: read it coalesced (every load issued before the first use),
     // then scatter each element to its slot of the self / neighbour / obstacle staging rows.
@@ -1152,6 +1169,7 @@ __device__ __forceinline__ void wide_body(const float *__restrict__ obs, int B, 
     ENC_STAMP(0);
     WRing R;
     ring_fill(R, P.s1, mt0);   // in flight while the observations are staged
+    traj_copy(P, a0, ENC_WA, B);
     stage_obs_wide(obs, B, P, a0, x_self, x_nbr, x_obst);
     __syncthreads();
     ENC_STAMP(1);
@@ -1221,6 +1239,7 @@ __device__ __forceinline__ void embed_wide_body(const float *__restrict__ obs, i
     const EncLayer none = {nullptr, nullptr, 0, 0};
     WRing R;
     ring_fill(R, P.n1, mt0);
+    traj_copy(P, a0, ENC_WA, B);
     {
         const float invB = 1.0f / (float)B;
         const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);

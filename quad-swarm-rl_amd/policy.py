@@ -42,7 +42,8 @@ class EncParams(C.Structure):
                 ("mq", EncLayer), ("mk", EncLayer), ("mv", EncLayer), ("mfc", EncLayer), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p), ("head_dim", C.c_int32),
                 ("sample_step", C.c_uint32), ("sample_log_std", C.c_void_p), ("act_out", C.c_void_p), ("sample_counter", C.c_void_p),
-                ("sample_seed_lo", C.c_uint32), ("sample_seed_hi", C.c_uint32)]
+                ("sample_seed_lo", C.c_uint32), ("sample_seed_hi", C.c_uint32),
+                ("traj_rew_src", C.c_void_p), ("traj_rew_dst", C.c_void_p), ("traj_done_src", C.c_void_p), ("traj_done_dst", C.c_void_p)]
 
 
 _lib = None
@@ -442,10 +443,12 @@ class FusedQuadEncoder:
             raise ValueError(f"head: weight [h, {self.out_dim}] with 1 <= h <= 8, bias [h]")
         self._head = (w, b)
 
-    def forward_head(self, obs, head_out=None, features=None, sample=None):
+    def forward_head(self, obs, head_out=None, features=None, sample=None, traj=None):
         """head(encoder(obs)) -> [B, h] float32; the [B, 512] features are written only if a `features` tensor is passed.
         sample = (log_std [h], act_out [B, h], counter (int32 device tensor), step, seed): the epilogue also writes
-        act_out = head + exp(log_std) * N(0, 1), Philox keyed (seed, counter + step, agent) - qs_enc_params.sample_*."""
+        act_out = head + exp(log_std) * N(0, 1), Philox keyed (seed, counter + step, agent) - qs_enc_params.sample_*.
+        traj = (rew_src [B] float32, rew_dst [B], done_src [B] uint8, done_dst [B]): the first kernel of the pass also copies the reward / done
+        flags of the step that produced `obs` into a trajectory slot (qs_enc_params.traj_*)."""
         torch = self._torch
         assert obs.is_cuda and obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.params.obs_dim
         if getattr(self, "_head", None) is None:
@@ -463,10 +466,16 @@ class FusedQuadEncoder:
             assert act_out.is_contiguous() and act_out.shape == head_out.shape and act_out.dtype == torch.float32 and log_std.numel() == w.shape[0]
             P.sample_log_std, P.act_out, P.sample_counter = log_std.data_ptr(), act_out.data_ptr(), counter.data_ptr()
             P.sample_step, P.sample_seed_lo, P.sample_seed_hi = int(step) & 0xffffffff, int(seed) & 0xffffffff, (int(seed) >> 32) & 0xffffffff
+        if traj is not None:
+            rs, rd, ds, dd = traj
+            assert rs.dtype == torch.float32 and rd.dtype == torch.float32 and ds.dtype == torch.uint8 and dd.dtype == torch.uint8
+            assert all(x.is_contiguous() and x.numel() == B for x in traj)
+            P.traj_rew_src, P.traj_rew_dst, P.traj_done_src, P.traj_done_dst = rs.data_ptr(), rd.data_ptr(), ds.data_ptr(), dd.data_ptr()
         rc = lib().qs_enc_forward(obs.data_ptr(), B, C.byref(P), C.c_void_p(features.data_ptr() if features is not None else None),
                                   C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream))
         P.head_dim = 0
         P.sample_log_std = None
+        P.traj_rew_dst = None
         if rc != 0:
             raise native.QsError(f"qs_enc_forward failed ({rc}): {lib().qs_enc_last_error().decode()}")
         return head_out

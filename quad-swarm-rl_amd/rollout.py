@@ -45,8 +45,9 @@ class GraphedRollout:
 
         With the library's GaussianActionHead the segment has no glue launches at all: the encoder's epilogue evaluates the head AND
         samples the action into actions[t] (qs_enc_params.sample_*); the step writes its observation rows straight into obs[t + 1]
-        (qs_set_obs_target); one small launch behind it copies its rewards / done flags into rewards[t] / dones[t] (qs_rollout_post).
-        3 (attention: 4) dependent graph nodes per control step instead of 4 (5), and no observation copy.  (Tried and measured, C2 with
+        (qs_set_obs_target); its rewards / done flags are copied into rewards[t] / dones[t] by the first kernel of the NEXT step's forward pass
+        (qs_enc_params.traj_*; round 5 - a launch of its own, qs_rollout_post, until round 4 and still for the segment's last step).
+        2 (attention: 3) dependent graph nodes per control step, and no observation copy.  (Tried and measured, C2 with
         mean_embed, us per control step: this 32.9 (two glue launches per step: 34.3); the copy on a second stream as a parallel graph branch 46.3 - a fork / join costs
         more than the launch it hides; the copy inside the next forward pass's first launch 33.2; rewards / done redirected inside the
         step kernel 31.8, but + 0.08 us on every step of every user of the headline kernel - not taken.)"""
@@ -121,17 +122,20 @@ class GraphedRollout:
             main = self._torch_stream()
             self.obs[0].copy_(self._obs)      # the one observation copy of the segment: the rows the environments are in
             for t in range(n):
+                # the reward / done flags of step t - 1 ride on this forward pass's first kernel (qs_enc_params.traj_*): two dependent launches per
+                # control step (three with `attention`) instead of three (four); only the LAST step of the segment needs a copy launch of its own
+                traj = (self._rew, self.rewards[t - 1], self._done, self.dones[t - 1]) if t > 0 else None
                 if self.head.sample:
-                    self.encoder.forward_head(self.obs[t], head_out=self._mean, sample=(self.head.log_std, self.actions[t], self._counter, t, self._seed))
+                    self.encoder.forward_head(self.obs[t], head_out=self._mean, sample=(self.head.log_std, self.actions[t], self._counter, t, self._seed), traj=traj)
                 else:   # deterministic policy: the head's output IS the action
-                    self.encoder.forward_head(self.obs[t], head_out=self.actions[t])
+                    self.encoder.forward_head(self.obs[t], head_out=self.actions[t], traj=traj)
                 # step t: observation rows -> obs[t + 1] (the last step: the library's buffer, where the next segment starts)
                 st.set_obs_target(self.obs[t + 1].data_ptr() if t < last else None)
                 st.step(self.actions[t].data_ptr(), stream=main)
-                rc = policy.lib().qs_rollout_post(C.c_void_p(self._rew.data_ptr()), C.c_void_p(self.rewards[t].data_ptr()), C.c_void_p(self._done.data_ptr()),
-                                                  C.c_void_p(self.dones[t].data_ptr()), A, C.c_void_p(self._scratch_counter.data_ptr()), C.c_void_p(main.cuda_stream))
-                if rc != 0:
-                    raise native.QsError(f"qs_rollout_post failed ({rc})")
+            rc = policy.lib().qs_rollout_post(C.c_void_p(self._rew.data_ptr()), C.c_void_p(self.rewards[last].data_ptr()), C.c_void_p(self._done.data_ptr()),
+                                              C.c_void_p(self.dones[last].data_ptr()), A, C.c_void_p(self._scratch_counter.data_ptr()), C.c_void_p(main.cuda_stream))
+            if rc != 0:
+                raise native.QsError(f"qs_rollout_post failed ({rc})")
             self._counter.add_(n)             # the next replay draws fresh noise
             return
         for t in range(n):
