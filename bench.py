@@ -435,7 +435,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+        # (a collective that a failed rank never joins aborts after 3 minutes instead of the default 10: the driver runs N = 1, 2, 4, 8 back to back)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=180))
     ranks_seen = dist.get_world_size() if dist is not None else 1
     trace("process group up")
 
@@ -647,24 +649,53 @@ def main():
             return ent
 
         wire_table = {args.wire: wire_entry(xinfo, head_dev, args.steps)}
+
+        def agree(flag):   # every rank-local action of the sweep is agreed on before the next collective: a rank that failed alone must not leave the
+            if world == 1:   # others waiting in a barrier (they all skip the wire together instead)
+                return flag
+            t = torch.tensor([1 if flag else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
         for w_name in ("f32", "bf16", "q8"):
             if w_name == args.wire:
                 continue
             wi = {"requested": args.transport, "wire": w_name, "_actions_ptr": aptr}
+            err, new_exchange = None, None
             try:
                 exchange.close()
-                exchange = make_exchange(st, world, rank, args.transport, w_name, dist, dev, wi)
-                wi.pop("_actions_ptr", None)
-                prepare_exchange(wi)
-                wd, _ = timed(st, aptr, astride, min(args.warmup, 50), args.steps, None, xchg=True)
-                torch.cuda.synchronize()
-                v_ok, v_why = exchange.verify()
-                wi["verified_against_rccl_gather_after"] = "equal" if v_ok else f"differs: {v_why}"
-                wire_table[w_name] = wire_entry(wi, wd, args.steps)
-                wire_table[w_name]["status"] = exchange.status()
             except Exception as exc:   # noqa: BLE001 - recorded
-                wire_table[w_name] = {"error": f"{type(exc).__name__}: {exc}"}
+                err = f"close: {type(exc).__name__}: {exc}"
+            exchange = None
+            if agree(err is None):
+                try:
+                    new_exchange = make_exchange(st, world, rank, args.transport, w_name, dist, dev, wi)   # (agrees on its own steps)
+                except Exception as exc:   # noqa: BLE001
+                    err = f"create: {type(exc).__name__}: {exc}"
+            if agree(err is None and new_exchange is not None):
+                exchange = new_exchange
+                wi.pop("_actions_ptr", None)
+                try:
+                    prepare_exchange(wi)
+                except Exception as exc:   # noqa: BLE001
+                    err = f"prepare: {type(exc).__name__}: {exc}"
+            else:
+                err = err or "failed on another rank"
+            if not agree(err is None):
+                wire_table[w_name] = {"error": err or "failed on another rank"}
+                if exchange is not None:
+                    try:
+                        exchange.close()
+                    except Exception:   # noqa: BLE001
+                        pass
+                    exchange = None
                 break
+            wd, _ = timed(st, aptr, astride, min(args.warmup, 50), args.steps, None, xchg=True)
+            torch.cuda.synchronize()
+            v_ok, v_why = exchange.verify()
+            wi["verified_against_rccl_gather_after"] = "equal" if v_ok else f"differs: {v_why}"
+            wire_table[w_name] = wire_entry(wi, wd, args.steps)
+            wire_table[w_name]["status"] = exchange.status()
     if kernel_region_s is None:   # gather headline without secondary: a short step-only region for the roofline
         kernel_region_steps = max(args.steps, 50)
         kernel_region_s, _ = timed(st, aptr, astride, 10, kernel_region_steps, None)
