@@ -233,7 +233,7 @@ def pmc_traffic(workload, num_envs, kernel):
     return None
 
 
-def make_exchange(st, world, rank, transport, wire, dist, dev, info):
+def make_exchange(st, world, rank, transport, wire, dist, dev, info, protocols=(False, True)):
     """The observation exchange of this rank (quad-swarm-rl_amd/parallel.py).  auto / peer: the peer-store transport, kept only if
     EVERY rank could map its peers' windows and passed the start-up self-check (synthetic rows through both window slots); otherwise
     all ranks fall back to the RCCL all-gather together."""
@@ -250,7 +250,7 @@ def make_exchange(st, world, rank, transport, wire, dist, dev, info):
     if transport in ("auto", "peer", "fused"):
         kind = "peer" if transport == "peer" or not st.team else "fused"   # fused: the step kernel pushes its own rows (team kernels)
         info["attempts"] = []
-        for fenced in (False, True):   # the relaxed flag protocol, then its fenced variant (QS_XCHG_FENCED, include/quadswarm_exchange.h), then RCCL
+        for fenced in protocols:   # the relaxed flag protocol, then its fenced variant (QS_XCHG_FENCED, include/quadswarm_exchange.h), then RCCL
             ex, why, att = None, "", {"flags": "fenced" if fenced else "relaxed"}
             try:
                 ex = parallel.ObsExchange(st, world, rank, transport=kind, wire=wire, hold=False, fenced=fenced)
@@ -295,6 +295,9 @@ def make_exchange(st, world, rank, transport, wire, dist, dev, info):
                 ex.close()
     info["transport"] = "rccl"
     return parallel.ObsExchange(st, world, rank, transport="rccl", wire=wire, hold=False)
+
+
+FLAG_PROTOCOLS = {"auto": (False, True), "relaxed": (False,), "fenced": (True,)}
 
 
 def self_launch(n):
@@ -395,6 +398,8 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="headline mode: step the timed region as open-loop rollouts of this many steps per "
                                                           "launch (qs_step_many: state stays in registers between the steps)")
     ap.add_argument("--rollout-steps", type=int, default=64, help="steps per launch of the extra open-loop measurement (0 = skip)")
+    ap.add_argument("--flag-protocol", default="auto", choices=["auto", "relaxed", "fenced"], help="flag protocol of the window transports: auto = relaxed flags, the fenced "
+                                                                                                       "variant if verify() disagrees, then RCCL; relaxed / fenced = that one only (then RCCL)")
     ap.add_argument("--no-wire-sweep", action="store_true", help="with an observation exchange: measure the headline's wire only (config.exchange_per_wire otherwise holds f32, bf16 and q8)")
     ap.add_argument("--dry-run", action="store_true", help="launch path only: ranks rendezvous over gloo (no GPU needed), take the barriers of the timed "
                                                            "bracket around K empty steps, rank 0 prints one JSON line with value null")
@@ -469,7 +474,7 @@ def main():
             gather_obj = parallel.ObsGather(obs, overlap=not args.no_overlap)
             xinfo["transport"] = "torch"
         else:
-            exchange = make_exchange(st, world, rank, args.transport, args.wire, dist, dev, xinfo)
+            exchange = make_exchange(st, world, rank, args.transport, args.wire, dist, dev, xinfo, protocols=FLAG_PROTOCOLS[args.flag_protocol])
     xinfo.pop("_actions_ptr", None)
     trace("exchange ready: " + str(xinfo.get("transport")) + "")
 
@@ -669,7 +674,7 @@ def main():
             exchange = None
             if agree(err is None):
                 try:
-                    new_exchange = make_exchange(st, world, rank, args.transport, w_name, dist, dev, wi)   # (agrees on its own steps)
+                    new_exchange = make_exchange(st, world, rank, args.transport, w_name, dist, dev, wi, protocols=FLAG_PROTOCOLS[args.flag_protocol])   # (agrees on its own steps)
                 except Exception as exc:   # noqa: BLE001
                     err = f"create: {type(exc).__name__}: {exc}"
             if agree(err is None and new_exchange is not None):
