@@ -148,13 +148,19 @@ typedef struct qs_buffers {
     void *rew_info;       /* real  [QS_RI_COUNT, E*N] */
     void *actions;        /* real  [E*N, 4] staging buffer callers may fill instead of passing their own */
     /* state: WAVE-BLOCKED.  Block b holds the drones of the envs_per_block = 64 / N environments one wavefront steps
-       (envs b * envs_per_block ..., lane = local env * N + drone); inside a block every component of every state array is one
-       row of 64 elements, all rows of a block contiguous (state_block_bytes apart from the next block).  Each pointer below is
-       block 0's first row of its array:
-           element (component c, env e, drone i)  =  ptr + (e / envs_per_block) * state_block_bytes
-                                                         + (c * 64 + (e % envs_per_block) * N + i) * sizeof(element)
+       (envs b * envs_per_block ..., lane = local env * N + drone); inside a block the state arrays follow each other (64 lanes x
+       components each; blocks state_block_bytes apart).  Each pointer below is its array inside block 0.  Inside an array the element
+       order is one of two, fixed per handle (state_lane_major):
+           0 - rows: every component is a row of 64 elements
+               element (component c, env e, drone i)  =  ptr + (e / envs_per_block) * state_block_bytes
+                                                             + (c * 64 + (e % envs_per_block) * N + i) * sizeof(element)
+           1 - lane-major: the components of one drone are adjacent
+               element (component c, env e, drone i)  =  ptr + (e / envs_per_block) * state_block_bytes
+                                                             + (((e % envs_per_block) * N + i) * components + c) * sizeof(element)
        (quad-swarm-rl_amd/native.py: Stepper.to_host / from_host present them as plain [components, E*N] arrays through
-       qs_state_array_copy).  Why: a wave's 42 state rows are one 11 KB chunk of HBM instead of 42 scattered 256-byte pieces. */
+       qs_state_array_copy, whatever the order).  Why: everything a wave loads and stores per step is one 11 KB chunk of HBM.  The
+       specialised 8-wave team kernels (N <= 8, batches that do not fill the chip: the latency regime) run lane-major handles - one 12- /
+       16-byte access per array and lane, 14 per direction instead of 45; the throughput kernels keep the rows (csrc/qs_kernels.h). */
     void *pos, *vel, *omega;  /* real, 3 components */
     void *rot;                /* real, 9 components: row-major R */
     void *thrust_rot_damp, *thrust_cmds_damp, *ou_state; /* real, 4 components */
@@ -185,6 +191,7 @@ typedef struct qs_buffers {
     int32_t real_size;        /* 4 or 8 */
     int32_t state_block_bytes;/* bytes between the wave blocks of the state arrays */
     int32_t envs_per_block;   /* 64 / N */
+    int32_t state_lane_major; /* element order inside the blocked state arrays (see above) */
 } qs_buffers;
 
 typedef struct qs_handle qs_handle;

@@ -28,28 +28,38 @@ using namespace qs;
 // access where a flat 64-bit address needs three VALU instructions (about 90 accesses per drone-step; the throughput
 // regime of the single-wave kernels is VALU-bound).  The typed pointers below still point into the block.
 // The per-drone state lives in ONE allocation, wave-blocked: block b holds the drones of the `epb` environments one wave steps
-// (epb = 64 / N, lane = local env * N + drone), and inside a block every component of every state array is one row of 64
-// elements - pos x | pos y | pos z | vel x | ... | flags | pair mask - so that the 42 rows a wave loads and stores each step are one
-// contiguous `block_bytes` chunk (11 KB in float32) instead of 42 rows scattered over 42 component-major arrays.  Measured with
-// the traffic-only kernels of tools/ubench_hbm.hip: 113.7 -> 97.6 us for 2^20 drones.  pos .. pair are byte
-// offsets of an array's first row INSIDE a block; the per-step outputs (newpair, reward, done, ohit) stay flat component-major
-// arrays behind the blocks (absolute offsets) - their consumers read them as plain vectors.
-// bytes of one state block: 40 rows of 64 reals (pos 3, vel 3, rot 9, omega 3, rot_damp 4, cmds_damp 4, ou 4, goal 3, ring 4, sums 3), the flags row
-// (u32), the pair-mask row (u64) - create_typed (quadswarm_hip.hip) lays the rows out and checks this figure
+// (epb = 64 / N, lane = local env * N + drone), so that everything a wave loads and stores each step is one contiguous `block_bytes`
+// chunk (11 KB in float32) instead of 42 rows scattered over 42 component-major arrays (tools/ubench_hbm.hip: 113.7 -> 97.6 us for
+// 2^20 drones).  Inside a block the arrays follow each other - pos | vel | rot | omega | ... | flags | pair mask - and an
+// array of `comps` components per drone has one of TWO element orders, fixed per handle (StateBlk::lane_major):
+//   rows (0):       component-major, element (q, lane) at q * 64 + lane: every access is one 4-byte element per lane, 256 contiguous
+//                   bytes per wave - 45 loads and 45 stores per block and step.  The single-wave throughput kernels and the 4-wave team
+//                   kernels (N > 8) run on this order: in the bandwidth regime the narrow rows stream 1 % faster and leave the register
+//                   allocator free of tuple constraints (tools/ubench_rowwidth.hip, profiles/r05l_ab_layout.txt).
+//   lane-major (1): the components of one drone adjacent, element (q, lane) at lane * comps + q: a lane moves an array with ONE 12- or
+//                   16-byte access (`buffer_load_dwordx3/x4`), 14 loads and 14 stores per block and step.  The specialised 8-wave team
+//                   kernels (N <= 8: the latency regime of the headline) run on this order: wave 0 issues its loads in 240 instead of 600
+//                   clocks and its stores in 250 instead of 400 (same microbenchmark); C2 7.82 -> 7.64 us per step.
+// pos .. pair are byte offsets of an array INSIDE a block (the same for both orders); the per-step outputs (newpair, reward, done, ohit)
+// stay flat component-major arrays behind the blocks (absolute offsets) - their consumers read them as plain vectors.
+// bytes of one state block: 40 x 64 reals (pos 3, vel 3, rot 9, omega 3, rot_damp 4, cmds_damp 4, ou 4, goal 3, ring 4, sums 3), 64 flag words
+// (u32), 64 pair masks (u64) - create_typed (quadswarm_hip.hip) lays the arrays out and checks this figure
 static inline int qs_block_bytes(int real_size) { return 40 * 64 * real_size + 64 * 4 + 64 * 8; }
-// byte offsets of the arrays inside a state block, in the order create_typed lays the rows out (it checks them): literals for the code that
-// addresses the block's LDS image (qs_step_team.inc, section H)
+// byte offsets of the arrays inside a state block, in the order create_typed lays them out (it checks them)
 template <typename real> struct BlkOff {
     static constexpr uint32_t row = 64 * sizeof(real);
     static constexpr uint32_t pos = 0, vel = 3 * row, rot = 6 * row, omega = 15 * row, rot_damp = 18 * row, cmds_damp = 22 * row, ou = 26 * row, goal = 30 * row,
                               ring = 33 * row, sums = 37 * row, flags = 40 * row, pair = 40 * row + 256, bytes = 40 * row + 768;
 };
-struct StateBlk { char *base; uint32_t bytes, block_bytes, epb, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit; };
-// element (component q of drone i of env e) of a blocked array, for the code outside the step kernels' buffer-resource views
-template <typename TT> __device__ __forceinline__ TT &blk_at(const StateBlk &b, uint32_t arr, int q, int e, int i, int N) {
+// components per drone of the blocked arrays (the lane pitch inside an array, in elements)
+namespace blkc { constexpr int pos = 3, vel = 3, rot = 9, omega = 3, rot_damp = 4, cmds_damp = 4, ou = 4, goal = 3, ring = 4, sums = 3, flags = 1, pair = 1; }
+struct StateBlk { char *base; uint32_t bytes, block_bytes, epb, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit, lane_major; };
+// element (component q of drone i of env e) of a blocked array of `comps` components, for the code outside the step kernels' buffer-resource views
+template <typename TT> __device__ __forceinline__ TT &blk_at(const StateBlk &b, uint32_t arr, int comps, int q, int e, int i, int N) {
     const int blk = e / (int)b.epb, lane = (e - blk * (int)b.epb) * N + i;
-    return *(TT *)(b.base + (size_t)blk * b.block_bytes + arr + ((size_t)q * 64 + lane) * sizeof(TT));
+    return *(TT *)(b.base + (size_t)blk * b.block_bytes + arr + (b.lane_major ? (size_t)lane * comps + q : (size_t)q * 64 + lane) * sizeof(TT));
 }
+#define QS_BLK_AT(TT, b, name, q, e, i, N) blk_at<TT>((b), (b).name, blkc::name, (q), (e), (i), (N))
 
 template <typename real> struct Ptrs {
     StateBlk blk;
@@ -87,31 +97,86 @@ template <typename real> struct Ptrs {
     int64_t tape_len;
 };
 
-// One array of the state allocation seen from one lane: element type T, `row_bytes` between components, this lane's element
-// `lane_off` bytes into a row; `off` = scalar offset of the array's first row (for a blocked array: of this wave's block too).
+// One array of the state allocation seen from one lane: element type T; `off` = scalar offset of the array (for a blocked array: of this
+// wave's block too), `lane_off` = this lane's first byte inside it, `comp_bytes` = bytes between the components of one lane (a blocked
+// array: sizeof(T) in the lane-major order, a row of 64 elements otherwise; a flat component-major array: its row pitch), `wide` = the
+// lane's components are adjacent and ldv / stv may move them as 12- / 16-byte pieces.
 typedef unsigned int qs_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int qs_u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int qs_u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct BufRow {
     __amdgpu_buffer_rsrc_t r;
-    uint32_t off, row_bytes, lane_off;
+    uint32_t off, comp_bytes, lane_off;
+    bool wide;
     __device__ __forceinline__ T ld(int q = 0) const {
-        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + (uint32_t)q * row_bytes, 0));
-        else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, off + (uint32_t)q * row_bytes, 0));
+        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + (uint32_t)q * comp_bytes, 0));
+        else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, off + (uint32_t)q * comp_bytes, 0));
     }
     __device__ __forceinline__ void st(T v, int q = 0) const {
-        if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qs_u32x2, v), r, lane_off, off + (uint32_t)q * row_bytes, 0);
-        else if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, lane_off, off + (uint32_t)q * row_bytes, 0);
-        else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, r, lane_off, off + (uint32_t)q * row_bytes, 0);
+        if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qs_u32x2, v), r, lane_off, off + (uint32_t)q * comp_bytes, 0);
+        else if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, lane_off, off + (uint32_t)q * comp_bytes, 0);
+        else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, r, lane_off, off + (uint32_t)q * comp_bytes, 0);
+    }
+    // the D dwords from byte `at` of this lane's piece of a lane-major array, as the widest accesses that cover them (16, 12, 8, 4 bytes)
+    template <int D> __device__ __forceinline__ void ld_dwords(uint32_t *w, uint32_t at) const {
+        if constexpr (D >= 4) { const qs_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, off + at, 0); w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; if constexpr (D > 4) ld_dwords<D - 4>(w + 4, at + 16); }
+        else if constexpr (D == 3) { const qs_u32x3 x = __builtin_amdgcn_raw_buffer_load_b96(r, lane_off, off + at, 0); w[0] = x.x; w[1] = x.y; w[2] = x.z; }
+        else if constexpr (D == 2) { const qs_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + at, 0); w[0] = x.x; w[1] = x.y; }
+        else w[0] = __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, off + at, 0);
+    }
+    template <int D> __device__ __forceinline__ void st_dwords(const uint32_t *w, uint32_t at) const {
+        if constexpr (D >= 4) { const qs_u32x4 x = {w[0], w[1], w[2], w[3]}; __builtin_amdgcn_raw_buffer_store_b128(x, r, lane_off, off + at, 0); if constexpr (D > 4) st_dwords<D - 4>(w + 4, at + 16); }
+        else if constexpr (D == 3) { const qs_u32x3 x = {w[0], w[1], w[2]}; __builtin_amdgcn_raw_buffer_store_b96(x, r, lane_off, off + at, 0); }
+        else if constexpr (D == 2) { const qs_u32x2 x = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(x, r, lane_off, off + at, 0); }
+        else __builtin_amdgcn_raw_buffer_store_b32(w[0], r, lane_off, off + at, 0);
+    }
+    // all K components of this lane's drone (blocked arrays: K = the array's component count)
+    template <int K> __device__ __forceinline__ void ldv(T *dst) const {
+        if (!wide) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) dst[k] = ld(k);
+            return;
+        }
+        constexpr int D = K * (int)sizeof(T) / 4;
+        uint32_t w[D];
+        ld_dwords<D>(w, 0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if constexpr (sizeof(T) == 8) dst[k] = __builtin_bit_cast(T, (uint64_t)w[2 * k] | ((uint64_t)w[2 * k + 1] << 32));
+            else dst[k] = __builtin_bit_cast(T, w[k]);
+        }
+    }
+    template <int K> __device__ __forceinline__ void stv(const T *src) const {
+        if (!wide) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) st(src[k], k);
+            return;
+        }
+        constexpr int D = K * (int)sizeof(T) / 4;
+        uint32_t w[D];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if constexpr (sizeof(T) == 8) { const uint64_t u = __builtin_bit_cast(uint64_t, src[k]); w[2 * k] = (uint32_t)u; w[2 * k + 1] = (uint32_t)(u >> 32); }
+            else w[k] = __builtin_bit_cast(uint32_t, src[k]);
+        }
+        st_dwords<D>(w, 0);
     }
 };
 #define QS_BUF_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void *)(p).blk.base, 0, (p).blk.bytes, 0x00020000)
-// blocked state array: the workgroup's block (blockIdx.x: one block = the environments of one workgroup), row pitch 64 elements
-// (a compile-time constant: component offsets fold into the instruction's immediate), lane = position inside the wave
+// blocked state array: the workgroup's block (blockIdx.x: one block = the environments of one workgroup), lane = position inside the wave;
+// component offsets are compile-time constants next to the scalar block offset.  QS_LM: the element order of the handle's blocks - a literal
+// in a config-specialised object (lane-major <=> the 8-wave team kernels), the handle's flag in the generic kernels
 // (QS_BLK: the state block a workgroup is working on - blockIdx.x, or the loop variable of the persistent form of the single-wave step kernel)
 #define QS_BLK blockIdx.x
-#define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (uint32_t)(QS_BLK * (p).blk.block_bytes + (p).blk.name), (uint32_t)(64 * sizeof(TYPE)), (uint32_t)((threadIdx.x & 63) * sizeof(TYPE))}
+#if defined(QS_SPEC_TEAM)
+#define QS_LM(p) (QS_SPEC_TEAM == 8)
+#else
+#define QS_LM(p) ((p).blk.lane_major != 0)
+#endif
+#define QS_ROW(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (uint32_t)(QS_BLK * (p).blk.block_bytes + (p).blk.name), (uint32_t)((QS_LM(p) ? 1 : 64) * sizeof(TYPE)), \
+                                                                       (uint32_t)((threadIdx.x & 63) * ((QS_LM(p) ? blkc::name : 1) * sizeof(TYPE))), QS_LM(p)}
 // flat component-major array (per-step outputs): row pitch T elements, lane offset = global drone index
-#define QS_ROWF(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (p).blk.name, (uint32_t)((T) * sizeof(TYPE)), (uint32_t)((g) * sizeof(TYPE))}
+#define QS_ROWF(TYPE, name, rs, p, T, g) const BufRow<TYPE> b_##name = {rs, (p).blk.name, (uint32_t)((T) * sizeof(TYPE)), (uint32_t)((g) * sizeof(TYPE)), false}
 
 // (neighbour metric, drone index) as one unsigned key whose order is "smaller metric first, lower index first": the IEEE bit
 // pattern of a float is monotone after flipping the sign bit of non-negatives and all bits of negatives
@@ -250,9 +315,6 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
         o += u;
     }
     L.total = (o + 15) & ~15;
-    // team kernels: at the end of a launch the state block's image (qs_block_bytes) overlays the LDS rows of the step from offset 0, four
-    // "row unchanged" words behind it (qs_step_team.inc, section H)
-    if (team && L.total < qs_block_bytes(real_size) + 16) L.total = qs_block_bytes(real_size) + 16;
     return L;
 }
 
@@ -1059,8 +1121,8 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
     real goal[3] = {0, 0, 0}, stale_vel[3];
     const int es = in_range ? e : 0;   // (inactive lanes read drone 0's slot of a valid env, as before)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) stale_vel[q] = blk_at<real>(p.blk, p.blk.vel, q, es, in_range ? i : 0, N);
-    d.flags = blk_at<uint32_t>(p.blk, p.blk.flags, 0, es, in_range ? i : 0, N);
+    for (int q = 0; q < 3; ++q) stale_vel[q] = QS_BLK_AT(real, p.blk, vel, q, es, in_range ? i : 0, N);
+    d.flags = QS_BLK_AT(uint32_t, p.blk, flags, 0, es, in_range ? i : 0, N);
     if (FULL && in_range) scen_lds_load<real>(p, L, smem, E, e, le, i, N);
     if (FULL) __syncthreads();
     reset_body<real, FULL, false, true>(cp, &p, &L, smem, epb, key, do_reset, &d, goal, stale_vel);   // writes the obs rows itself
@@ -1068,17 +1130,17 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
     if (do_reset) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            blk_at<real>(p.blk, p.blk.pos, q, e, i, N) = d.pos[q]; blk_at<real>(p.blk, p.blk.vel, q, e, i, N) = 0;
-            blk_at<real>(p.blk, p.blk.omega, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.goal, q, e, i, N) = goal[q];
+            QS_BLK_AT(real, p.blk, pos, q, e, i, N) = d.pos[q]; QS_BLK_AT(real, p.blk, vel, q, e, i, N) = 0;
+            QS_BLK_AT(real, p.blk, omega, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, goal, q, e, i, N) = goal[q];
         }
 #pragma unroll
-        for (int q = 0; q < 9; ++q) blk_at<real>(p.blk, p.blk.rot, q, e, i, N) = d.rot[q];
+        for (int q = 0; q < 9; ++q) QS_BLK_AT(real, p.blk, rot, q, e, i, N) = d.rot[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { blk_at<real>(p.blk, p.blk.rot_damp, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.cmds_damp, q, e, i, N) = 0; blk_at<real>(p.blk, p.blk.ring, q, e, i, N) = 0; }
+        for (int q = 0; q < 4; ++q) { QS_BLK_AT(real, p.blk, rot_damp, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, cmds_damp, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, ring, q, e, i, N) = 0; }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) blk_at<real>(p.blk, p.blk.sums, q, e, i, N) = 0;   // the step kernels leave the sums alone until the episode's 5-s window opens (qs_step_sem.h)
-        blk_at<uint32_t>(p.blk, p.blk.flags, 0, e, i, N) = d.flags;
-        blk_at<uint64_t>(p.blk, p.blk.pair, 0, e, i, N) = 0;
+        for (int q = 0; q < 3; ++q) QS_BLK_AT(real, p.blk, sums, q, e, i, N) = 0;   // the step kernels leave the sums alone until the episode's 5-s window opens (qs_step_sem.h)
+        QS_BLK_AT(uint32_t, p.blk, flags, 0, e, i, N) = d.flags;
+        QS_BLK_AT(uint64_t, p.blk, pair, 0, e, i, N) = 0;
         p.new_pair_mask[g] = 0;
         p.obst_hit_idx[g] = -1;
         if (c.episode_sums) {
@@ -1396,12 +1458,12 @@ __global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf
     if (i >= N) return;
     double *s = buf + (size_t)i * QS_STATE_STRIDE;
     const StateBlk &B = p.blk;
-#define QS_S(arr, q) blk_at<real>(B, B.arr, q, env, i, N)
+#define QS_S(arr, q) QS_BLK_AT(real, B, arr, q, env, i, N)
     if (!set) {
         for (int q = 0; q < 3; ++q) { s[q] = QS_S(pos, q); s[3 + q] = QS_S(vel, q); s[15 + q] = QS_S(omega, q); s[32 + q] = QS_S(goal, q); }
         for (int q = 0; q < 9; ++q) s[6 + q] = QS_S(rot, q);
         for (int q = 0; q < 4; ++q) { s[18 + q] = QS_S(rot_damp, q); s[22 + q] = QS_S(cmds_damp, q); s[26 + q] = QS_S(ou, q); }
-        uint32_t f = blk_at<uint32_t>(B, B.flags, 0, env, i, N);
+        uint32_t f = QS_BLK_AT(uint32_t, B, flags, 0, env, i, N);
         s[30] = (f & F_ON_FLOOR) ? 1.0 : 0.0;
         s[31] = (double)((f & F_SVD_MASK) >> F_SVD_SHIFT);
         if (i == 0) *tick_io = p.tick[env];
@@ -1409,10 +1471,10 @@ __global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf
         for (int q = 0; q < 3; ++q) { QS_S(pos, q) = (real)s[q]; QS_S(vel, q) = (real)s[3 + q]; QS_S(omega, q) = (real)s[15 + q]; QS_S(goal, q) = (real)s[32 + q]; }
         for (int q = 0; q < 9; ++q) QS_S(rot, q) = (real)s[6 + q];
         for (int q = 0; q < 4; ++q) { QS_S(rot_damp, q) = (real)s[18 + q]; QS_S(cmds_damp, q) = (real)s[22 + q]; QS_S(ou, q) = (real)s[26 + q]; }
-        uint32_t f = blk_at<uint32_t>(B, B.flags, 0, env, i, N) & ~(F_ON_FLOOR | F_SVD_MASK);
+        uint32_t f = QS_BLK_AT(uint32_t, B, flags, 0, env, i, N) & ~(F_ON_FLOOR | F_SVD_MASK);
         if (s[30] != 0.0) f |= F_ON_FLOOR;
         f |= ((uint32_t)s[31] & 0xffu) << F_SVD_SHIFT;
-        blk_at<uint32_t>(B, B.flags, 0, env, i, N) = f;
+        QS_BLK_AT(uint32_t, B, flags, 0, env, i, N) = f;
 #undef QS_S
         if (i == 0 && *tick_io >= 0) p.tick[env] = *tick_io;
     }

@@ -359,7 +359,7 @@ template <typename real> static int create_typed(qs_handle *h) {
     const size_t EPB = QS_WAVE / N, NBLK = (E + EPB - 1) / EPB;   // environments per wave block, blocks
     {   // the state allocation (StateBlk, qs_kernels.h): wave-blocked state rows, then the flat per-step outputs; 32-bit offsets
         const size_t R = sizeof(real);
-        size_t row = 0;   // inside a block: every component of every state array is one row of 64 elements
+        size_t row = 0;   // inside a block: array after array, each 64 lanes x comps elements (component rows or lane-major: qs_kernels.h)
         auto rows = [&](size_t comps, size_t elem) { size_t o = row; row += comps * 64 * elem; return o; };
         const size_t o_pos = rows(3, R), o_vel = rows(3, R), o_rot = rows(9, R), o_omega = rows(3, R), o_rd = rows(4, R), o_cd = rows(4, R), o_ou = rows(4, R),
                      o_goal = rows(3, R), o_ring = rows(4, R), o_sums = rows(3, R), o_flags = rows(1, 4), o_pair = rows(1, 8);
@@ -376,7 +376,7 @@ template <typename real> static int create_typed(qs_handle *h) {
         if ((rc = dalloc(h, &blk, off)) != QS_OK) return rc;
         p.blk = {blk, (uint32_t)off, (uint32_t)block_bytes, (uint32_t)EPB, (uint32_t)o_pos, (uint32_t)o_vel, (uint32_t)o_rot, (uint32_t)o_omega, (uint32_t)o_rd, (uint32_t)o_cd,
                  (uint32_t)o_ou, (uint32_t)o_goal, (uint32_t)o_ring, (uint32_t)o_sums, (uint32_t)o_flags, (uint32_t)o_pair, (uint32_t)o_newpair, (uint32_t)o_reward,
-                 (uint32_t)o_done, (uint32_t)o_ohit};
+                 (uint32_t)o_done, (uint32_t)o_ohit, (uint32_t)(h->team == 8 ? 1 : 0)};   // lane-major <=> the specialised 8-wave team kernels step this handle
         // block 0's first row of each blocked array (what qs_buffers hands out; layout in include/quadswarm.h)
         p.pos = (real *)(blk + o_pos); p.vel = (real *)(blk + o_vel); p.rot = (real *)(blk + o_rot); p.omega = (real *)(blk + o_omega);
         p.rot_damp = (real *)(blk + o_rd); p.cmds_damp = (real *)(blk + o_cd); p.ou = (real *)(blk + o_ou); p.goal = (real *)(blk + o_goal);
@@ -436,14 +436,16 @@ template <typename real> static int create_typed(qs_handle *h) {
     b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters; b.run_sums = p.run_sums; b.ep_sums = p.ep_sums;
     b.obst_count = p.obst_count; b.obst_size_env = p.obst_size_env; b.obst_density_env = p.obst_density_env;
     b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
-    b.state_block_bytes = (int32_t)p.blk.block_bytes; b.envs_per_block = (int32_t)EPB;
+    b.state_block_bytes = (int32_t)p.blk.block_bytes; b.envs_per_block = (int32_t)EPB; b.state_lane_major = (int32_t)p.blk.lane_major;
     // what a deep copy of one reference env carries (quad_experience_replay.py:99-104 deep-copies the whole env): every
     // per-drone and per-env array except the noise-stream position (step_ctr: a restored env draws fresh noise, as the
     // reference's does from the global numpy stream) and the per-step outputs
     auto &sa = h->snap_arrays;
     sa.clear();
 #define SNAP_T(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), T, N, 0, 0, 0})
-#define SNAP_B(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), 64, N, 0, EPB, (size_t)p.blk.block_bytes})   /* wave-blocked state array */
+    // wave-blocked state array: `comps` rows of 64 elements, or (lane-major) the N drones of an env as ONE contiguous piece of N * comps elements
+#define SNAP_B(field, comps) sa.push_back(p.blk.lane_major ? qs_handle::SnapArray{(char *)p.field, sizeof(*p.field), 1, 64 * (size_t)(comps), N * (size_t)(comps), 0, EPB, (size_t)p.blk.block_bytes} \
+                                                           : qs_handle::SnapArray{(char *)p.field, sizeof(*p.field), (size_t)(comps), 64, N, 0, EPB, (size_t)p.blk.block_bytes})
 #define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1, 0, 0, 0})
     SNAP_B(pos, 3); SNAP_B(vel, 3); SNAP_B(rot, 9); SNAP_B(omega, 3); SNAP_B(rot_damp, 4); SNAP_B(cmds_damp, 4); SNAP_B(ou, 4); SNAP_B(goal, 3);
     SNAP_B(flags, 1); SNAP_B(pair_mask, 1); SNAP_T(new_pair_mask, 1); SNAP_T(obst_hit_idx, 1); SNAP_B(dist_ring, 4); SNAP_B(dist_sums, 3);
@@ -1097,19 +1099,35 @@ int qs_state_array_copy(qs_handle *h, void *host, void *dev_array, int32_t elem,
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     const size_t E = h->cfg.num_envs, N = h->cfg.num_agents, T = E * N, epb = h->bufs.envs_per_block, pitch = h->bufs.state_block_bytes;
-    const size_t full = E / epb, rem = E - full * epb;   // whole blocks, environments of the last partial one
-    for (int32_t c = 0; c < comps; ++c) {
-        char *dev = (char *)dev_array + (size_t)c * 64 * elem, *hst = (char *)host + (size_t)c * T * elem;
-        const size_t width = epb * N * elem;
-        if (full) {
-            if (to_device) HIP_TRY(hipMemcpy2D(dev, pitch, hst, width, width, full, hipMemcpyHostToDevice));
-            else HIP_TRY(hipMemcpy2D(hst, width, dev, pitch, width, full, hipMemcpyDeviceToHost));
+    if (!h->bufs.state_lane_major) {   // rows of 64 elements per component: one strided copy per component
+        const size_t full = E / epb, rem = E - full * epb;   // whole blocks, environments of the last partial one
+        for (int32_t c = 0; c < comps; ++c) {
+            char *dev = (char *)dev_array + (size_t)c * 64 * elem, *hst = (char *)host + (size_t)c * T * elem;
+            const size_t width = epb * N * elem;
+            if (full) {
+                if (to_device) HIP_TRY(hipMemcpy2D(dev, pitch, hst, width, width, full, hipMemcpyHostToDevice));
+                else HIP_TRY(hipMemcpy2D(hst, width, dev, pitch, width, full, hipMemcpyDeviceToHost));
+            }
+            if (rem) {
+                if (to_device) HIP_TRY(hipMemcpy(dev + full * pitch, hst + full * width, rem * N * elem, hipMemcpyHostToDevice));
+                else HIP_TRY(hipMemcpy(hst + full * width, dev + full * pitch, rem * N * elem, hipMemcpyDeviceToHost));
+            }
         }
-        if (rem) {
-            if (to_device) HIP_TRY(hipMemcpy(dev + full * pitch, hst + full * width, rem * N * elem, hipMemcpyHostToDevice));
-            else HIP_TRY(hipMemcpy(hst + full * width, dev + full * pitch, rem * N * elem, hipMemcpyDeviceToHost));
-        }
+        return QS_OK;
     }
+    // lane-major: per block 64 lanes x comps adjacent components (lane = local env * N + drone); host: [comps][E * N].  Through a staging copy of
+    // the blocks' pieces of this array (a debugging / test path: one strided copy and a transposition on the host)
+    const size_t nblk = (E + epb - 1) / epb, lanes = epb * N, width = lanes * comps * elem;
+    std::vector<char> stage(nblk * width);
+    if (!to_device || E % epb)   // (a partial last block: keep what its idle lanes hold)
+        HIP_TRY(hipMemcpy2D(stage.data(), width, dev_array, pitch, width, nblk, hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < nblk; ++b)
+        for (size_t l = 0; l < lanes && b * lanes + l < T; ++l)
+            for (int32_t c = 0; c < comps; ++c) {
+                char *st = stage.data() + b * width + (l * comps + c) * elem, *hs = (char *)host + ((size_t)c * T + b * lanes + l) * elem;
+                if (to_device) memcpy(st, hs, elem); else memcpy(hs, st, elem);
+            }
+    if (to_device) HIP_TRY(hipMemcpy2D(dev_array, pitch, stage.data(), width, width, nblk, hipMemcpyHostToDevice));
     return QS_OK;
 }
 

@@ -31,7 +31,7 @@ class QsBuffers(C.Structure):
         "thrust_cmds_damp", "ou_state", "goal", "flags", "obst_hit_idx", "col_pair_mask", "new_pair_mask",
         "unique_col_mask", "obst_new_mask", "room_new_mask", "counters", "tick", "obst_pos", "ep_stats",
         "ep_counters", "error_flag", "scenario_id", "ep_scenario", "run_sums", "ep_sums", "obst_count", "obst_size_env", "obst_density_env")] + [
-        ("obs_dim", C.c_int32), ("real_size", C.c_int32), ("state_block_bytes", C.c_int32), ("envs_per_block", C.c_int32)]
+        ("obs_dim", C.c_int32), ("real_size", C.c_int32), ("state_block_bytes", C.c_int32), ("envs_per_block", C.c_int32), ("state_lane_major", C.c_int32)]
 
 
 def build(force=False, verbose=False):
