@@ -226,13 +226,20 @@ static const char *const kSpecFlagsF32 = "-ffast-math -fno-slp-vectorize";
 // 11.76; the single-wave throughput kernels lose 1 % with it and keep the default (profiles/r03_sched_max_ilp_ab.txt).  Instruction order
 // only: results are bit-identical.  If the compiler fails on an object with it, the object is built without.
 static const char *const kSpecFlagsTeam = "-mllvm -amdgpu-sched-strategy=max-ilp";
+// 8-wave team objects (N <= 8) only: without the post-RA scheduler on top.  Round 5's scheduler sweeps (tools/sched_sweep.py, profiles/r05s_ /
+// r05t_sched_sweep.txt; same box, us per step): C2 7.65 -> 7.43-7.46, C3 8.01 -> 8.01, while the 4-wave C4 object loses with it (12.65 -> 13.3)
+// and keeps the flag above; every other knob of the sweep (clustering, reschedule stages, RP trackers, scheduling direction) stayed inside
+// +- 0.03 of these.  Instruction order only: results are bit-identical.
+static const char *const kSpecFlagsTeam8 = "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0";
+// (QS_SPEC_TEAM_FLAGS in the environment replaces both - part of the cache key like QS_SPEC_EXTRA_FLAGS: the sweeps of tools/sched_sweep.py)
+static const char *spec_team_flags(int team) { const char *ev = getenv("QS_SPEC_TEAM_FLAGS"); return ev ? ev : (team == 8 ? kSpecFlagsTeam8 : kSpecFlagsTeam); }
 
 // key = hash(header text, kernel sources, flags); false if the sources are not next to the library
 static bool spec_key(const std::string &header, std::string &key) {
     uint64_t h = fnv1a(14695981039346656037ull, header);
     h = fnv1a(h, kSpecFlags);
     h = fnv1a(h, kSpecFlagsF32);
-    h = fnv1a(h, kSpecFlagsTeam);
+    h = fnv1a(h, spec_team_flags(4)); h = fnv1a(h, spec_team_flags(8));   // (the header carries the team width: both strings, whichever applies)
     if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools/phase_timing.py
     const std::string dir = lib_dir();
     for (const char *src : kSpecSources) {
@@ -278,7 +285,7 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     const char *cc = getenv("HIPCC");
     const std::string src = lib_dir();
     auto command = [&](bool team_flags) {
-        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (team_flags ? kSpecFlagsTeam : "") + " " +
+        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (team_flags ? spec_team_flags(team) : "") + " " +
                (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src + "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
     };
     const bool team_obj = team > 0;
