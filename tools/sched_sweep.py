@@ -43,9 +43,19 @@ SWEEPS = {
         ("max-ilp, no memop clustering", MAXILP + " -mllvm -misched-cluster=0", ""),
         ("max-ilp, no unclustered high-RP stage", MAXILP + " -mllvm -amdgpu-disable-unclustered-high-rp-reschedule", ""),
     ],
+    "3": [   # source-level switches and optimisation level on the 8-wave default (c2 / c3 are the 8-wave shapes)
+        ("library default", None, ""),
+        ("state arrays loaded in first-use order", None, "-DQS_LD_ORDER=1"),
+        ("filters first, then the old order", None, "-DQS_LD_ORDER=2"),
+        ("own-branch counter", None, "-DQS_AB_OWN_CTR"),
+        ("own-branch counter + first-use order", None, "-DQS_AB_OWN_CTR -DQS_LD_ORDER=1"),
+        ("row skipping", None, "-DQS_SKIP_ROWS=1"),
+        ("-O2", None, "-O2"),
+        ("occupancy bias 0", NOPOST + " -mllvm -amdgpu-schedule-metric-bias=0", ""),
+    ],
 }
 VARIANTS = SWEEPS[os.environ.get("SWEEP", "1")]
-WORKLOADS = ("c2", "c3", "c4")
+WORKLOADS = tuple(os.environ.get("SWEEP_WORKLOADS", "c2,c3,c4").split(","))
 
 
 def env_of(team_flags, extra):
