@@ -34,3 +34,30 @@ def test_full_scenario_kernels_keep_the_constant_block_out_of_scratch(workload, 
     assert res["qs_spec_step"]["scratch"] <= max_scratch, res["qs_spec_step"]
     assert res["qs_spec_step"]["next_free_vgpr"] <= max_vgpr, res["qs_spec_step"]
     assert res["qs_spec_reset"]["scratch"] == 0, res["qs_spec_reset"]
+
+
+def _step_kernel_body(path):
+    text = open(path).read()
+    a = text.index("qs_spec_step:")
+    return text[a:text.index("s_endpgm", a)]
+
+
+def test_state_accesses_are_wide_on_lane_major_blocks_and_narrow_on_rows(tmp_path):
+    """the specialised 8-wave team kernel moves a lane-major state block with one 12- / 16-byte buffer access per array and lane
+    (5 x dwordx3 + 6 x dwordx4 + flags + pair mask per direction in float32); the single-wave throughput kernel of the same configuration and the
+    4-wave team kernel keep the 4-byte rows.  Read off the ISA: a change that silently falls back to 45 narrow accesses (or widens the
+    throughput kernels, which measured 1-3 % slower with it) fails here, without a GPU."""
+    import re
+    import spec_resources
+    _, path = spec_resources.resources("c2", 8, out=str(tmp_path / "team8.s"))
+    body = _step_kernel_body(path)
+    loads = re.findall(r"\bbuffer_load_(dword(?:x\d)?)\b", body)
+    stores = re.findall(r"\bbuffer_store_(dword(?:x\d)?)\b", body)
+    assert loads.count("dwordx3") == 5 and loads.count("dwordx4") == 6 and loads.count("dword") <= 3, sorted(loads)
+    assert stores.count("dwordx3") == 5 and stores.count("dwordx4") == 6, sorted(stores)
+    for wl, team in (("c2", 0), ("c4", 4)):
+        _, path = spec_resources.resources(wl, team, out=str(tmp_path / f"{wl}_{team}.s"))
+        body = _step_kernel_body(path)
+        wide = re.findall(r"\bbuffer_(?:load|store)_dwordx[34]\b", body)
+        assert not wide, (wl, team, wide)
+        assert len(re.findall(r"\bbuffer_load_dword\b", body)) >= 37, (wl, team)
