@@ -232,14 +232,24 @@ static const char *const kSpecFlagsTeam = "-mllvm -amdgpu-sched-strategy=max-ilp
 // +- 0.03 of these.  Instruction order only: results are bit-identical.
 static const char *const kSpecFlagsTeam8 = "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0";
 // (QS_SPEC_TEAM_FLAGS in the environment replaces both - part of the cache key like QS_SPEC_EXTRA_FLAGS: the sweeps of tools/sched_sweep.py)
+// single-wave fp32 objects (the throughput kernels, capped at 128 registers): the scheduler's AMDGPU-specific register-pressure trackers.  Round 5's
+// sweeps 4 / 5 (profiles/r05z_sched_sweep.txt, r05z5_sched_sweep.txt; 2^20 drones, same box, us per step): the C3 shape 118.6 -> 109.2,
+// 119.7 -> 114.0, 112.6 -> 108.2 (three interleaved pairs on two boxes: - 4 to - 8 %), the C2 and C4 shapes inside their run-to-run noise
+// (+- 2 %).  Instruction order and register assignment only.  The float64 parity objects keep the compiler's default.
+static const char *const kSpecFlagsSingleF32 = "-mllvm -amdgpu-use-amdgpu-trackers";
 static const char *spec_team_flags(int team) { const char *ev = getenv("QS_SPEC_TEAM_FLAGS"); return ev ? ev : (team == 8 ? kSpecFlagsTeam8 : kSpecFlagsTeam); }
+static const char *spec_sched_flags(int team, int precision) {
+    if (team > 0) return spec_team_flags(team);
+    if (const char *ev = getenv("QS_SPEC_SINGLE_FLAGS")) return ev;
+    return precision == QS_PRECISION_F64 ? "" : kSpecFlagsSingleF32;
+}
 
 // key = hash(header text, kernel sources, flags); false if the sources are not next to the library
 static bool spec_key(const std::string &header, std::string &key) {
     uint64_t h = fnv1a(14695981039346656037ull, header);
     h = fnv1a(h, kSpecFlags);
     h = fnv1a(h, kSpecFlagsF32);
-    h = fnv1a(h, spec_team_flags(4)); h = fnv1a(h, spec_team_flags(8));   // (the header carries the team width: both strings, whichever applies)
+    h = fnv1a(h, spec_team_flags(4)); h = fnv1a(h, spec_team_flags(8)); h = fnv1a(h, spec_sched_flags(0, QS_PRECISION_F32));   // (the header carries team width and precision: all strings, whichever applies)
     if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools/phase_timing.py
     const std::string dir = lib_dir();
     for (const char *src : kSpecSources) {
@@ -285,12 +295,12 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     const char *cc = getenv("HIPCC");
     const std::string src = lib_dir();
     auto command = [&](bool team_flags) {
-        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (team_flags ? spec_team_flags(team) : "") + " " +
+        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (team_flags ? spec_sched_flags(team, cfg->precision) : "") + " " +
                (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src + "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
     };
-    const bool team_obj = team > 0;
-    int rc = system(command(team_obj).c_str());
-    if ((rc != 0 || !file_exists(tmp)) && team_obj) { unlink(tmp.c_str()); rc = system(command(false).c_str()); }
+    const bool sched_flags = spec_sched_flags(team, cfg->precision)[0] != 0;   // (if the compiler fails on an object with them, the object is built without)
+    int rc = system(command(sched_flags).c_str());
+    if ((rc != 0 || !file_exists(tmp)) && sched_flags) { unlink(tmp.c_str()); rc = system(command(false).c_str()); }
     if (rc != 0 || !file_exists(tmp)) { unlink(tmp.c_str()); g_last_error = "specialised kernel build failed, see " + log; return ""; }
     if (rename(tmp.c_str(), out.c_str()) != 0) { unlink(tmp.c_str()); g_last_error = "cannot move code object into the cache"; return ""; }
     return out;

@@ -53,8 +53,26 @@ SWEEPS = {
         ("-O2", None, "-O2"),
         ("occupancy bias 0", NOPOST + " -mllvm -amdgpu-schedule-metric-bias=0", ""),
     ],
+    "4": [   # the single-wave throughput objects (SWEEP_TEAM=0 SWEEP_ENVS=131072): they are built without scheduler flags
+        ("library default", None, ""),
+        ("no post-RA scheduler", None, "-mllvm -enable-post-misched=0"),
+        ("max-ilp, no post-RA scheduler", None, NOPOST),
+        ("no memop clustering", None, "-mllvm -misched-cluster=0"),
+        ("occupancy bias 0", None, "-mllvm -amdgpu-schedule-metric-bias=0"),
+        ("AMDGPU RP trackers", None, "-mllvm -amdgpu-use-amdgpu-trackers"),
+    ],
+    "5": [   # combinations of what moved sweep 4
+        ("library default", None, ""),
+        ("AMDGPU RP trackers", None, "-mllvm -amdgpu-use-amdgpu-trackers"),
+        ("RP trackers, no memop clustering", None, "-mllvm -amdgpu-use-amdgpu-trackers -mllvm -misched-cluster=0"),
+        ("RP trackers, occupancy bias 0", None, "-mllvm -amdgpu-use-amdgpu-trackers -mllvm -amdgpu-schedule-metric-bias=0"),
+        ("occupancy bias 0, no memop clustering", None, "-mllvm -amdgpu-schedule-metric-bias=0 -mllvm -misched-cluster=0"),
+        ("RP trackers, bias 0, no clustering", None, "-mllvm -amdgpu-use-amdgpu-trackers -mllvm -amdgpu-schedule-metric-bias=0 -mllvm -misched-cluster=0"),
+    ],
 }
 VARIANTS = SWEEPS[os.environ.get("SWEEP", "1")]
+TEAM = os.environ.get("SWEEP_TEAM")      # "0": the single-wave objects (what batches that fill the chip run)
+ENVS = os.environ.get("SWEEP_ENVS")      # envs per GPU of the measured shape (default: the workload's own)
 WORKLOADS = tuple(os.environ.get("SWEEP_WORKLOADS", "c2,c3,c4").split(","))
 
 
@@ -71,8 +89,8 @@ def env_of(team_flags, extra):
 
 def build():
     code = ("import sys; sys.path.insert(0, %r)\nimport __graft_entry__ as g, bench\nfrom concurrent.futures import ProcessPoolExecutor\n"
-            "jobs = [(dict(bench.WORKLOADS[w]['kw'], num_envs=bench.WORKLOADS[w]['num_envs'], write_rew_info=False), 'f32') for w in %r]\n"
-            "with ProcessPoolExecutor(max_workers=4) as ex: print(len([p for p in ex.map(g._spec_one, jobs) if p]))\n" % (REPO, WORKLOADS))
+            "jobs = [(dict(bench.WORKLOADS[w]['kw'], num_envs=bench.WORKLOADS[w]['num_envs'], write_rew_info=False), 'f32') + %r for w in %r]\n"
+            "with ProcessPoolExecutor(max_workers=4) as ex: print(len([p for p in ex.map(g._spec_one, jobs) if p]))\n" % (REPO, (int(TEAM),) if TEAM else (), WORKLOADS))
     for name, tf, xf in VARIANTS:
         out = subprocess.run([sys.executable, "-c", code], env=env_of(tf, xf), capture_output=True, text=True)
         print(f"{name}: {out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:]} objects")
@@ -86,8 +104,10 @@ def run(reps, tag):
             for name, tf, xf in VARIANTS:
                 row = []
                 for wl in WORKLOADS:
-                    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--steps", "3000", "--cpu-seconds", "0", "--no-f64",
-                                          "--no-closed-loop", "--no-variants", "--no-c5-train"], env=env_of(tf, xf), capture_output=True, text=True, timeout=600)
+                    envs = ENVS.split(",")[WORKLOADS.index(wl)] if ENVS and "," in ENVS else ENVS
+                    shape = ["--envs-per-gpu", envs, "--steps", "300", "--warmup", "50", "--prewarm", "200", "--rollout-steps", "0"] if ENVS else ["--steps", "3000"]
+                    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", wl, "--cpu-seconds", "0", "--no-f64",
+                                          "--no-closed-loop", "--no-variants", "--no-c5-train"] + shape, env=env_of(tf, xf), capture_output=True, text=True, timeout=600)
                     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
                     d = json.loads(lines[-1]) if lines else None
                     row.append(f"{wl} {1e3 * d['ms_per_step']:.3f}" + ("" if d["roofline"].get("specialized") else " (GENERIC)") if d else f"{wl} failed")
