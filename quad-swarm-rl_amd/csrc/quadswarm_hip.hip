@@ -232,11 +232,15 @@ static const char *const kSpecFlagsTeam = "-mllvm -amdgpu-sched-strategy=max-ilp
 // +- 0.03 of these.  Instruction order only: results are bit-identical.
 static const char *const kSpecFlagsTeam8 = "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0";
 // (QS_SPEC_TEAM_FLAGS in the environment replaces both - part of the cache key like QS_SPEC_EXTRA_FLAGS: the sweeps of tools/sched_sweep.py)
-// single-wave fp32 objects (the throughput kernels, capped at 128 registers): the scheduler's AMDGPU-specific register-pressure trackers.  Round 5's
+// single-wave objects (the throughput kernels, capped at 128 registers): built with the compiler's default scheduler settings.  Experiment, NOT
+// taken: the scheduler's AMDGPU-specific register-pressure trackers (`-mllvm -amdgpu-use-amdgpu-trackers`; QS_SPEC_SINGLE_FLAGS sets it).  Round 5's
 // sweeps 4 / 5 (profiles/r05z_sched_sweep.txt, r05z5_sched_sweep.txt; 2^20 drones, same box, us per step): the C3 shape 118.6 -> 109.2,
-// 119.7 -> 114.0, 112.6 -> 108.2 (three interleaved pairs on two boxes: - 4 to - 8 %), the C2 and C4 shapes inside their run-to-run noise
-// (+- 2 %).  Instruction order and register assignment only.  The float64 parity objects keep the compiler's default.
-static const char *const kSpecFlagsSingleF32 = "-mllvm -amdgpu-use-amdgpu-trackers";
+// 119.7 -> 114.0, 112.6 -> 108.2 (three interleaved pairs on two boxes: - 4 to - 8 %; 44 -> 12 bytes of scratch per lane), the C2 and C4 shapes
+// inside their run-to-run noise - but with the flag as the default one float32 parity case of the single-wave kernels failed
+// (test_teacher_forced_f32_single_wave_kernels[e_n17_kall_obst], profiles/r05zz_single_wave_f32_parity.txt: 17 passed, 1 failed) in the last
+// GPU call of the round, with no budget left to find out why.  A flag that is supposed to change instruction order only and fails a parity
+// test is not shipped on a hunch: the default stays what the whole suite ran on.
+static const char *const kSpecFlagsSingleF32 = "";
 static const char *spec_team_flags(int team) { const char *ev = getenv("QS_SPEC_TEAM_FLAGS"); return ev ? ev : (team == 8 ? kSpecFlagsTeam8 : kSpecFlagsTeam); }
 static const char *spec_sched_flags(int team, int precision) {
     if (team > 0) return spec_team_flags(team);
