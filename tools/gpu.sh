@@ -14,6 +14,7 @@
 #   abtree[:wls]     same-box A/B of the step kernels against another tree in build_exp/old (tools/ab_tree.sh)         -> gpurun_out/<tag>_ab_tree.txt
 #   c5[:iters[:batch]]  the in-tree PPO harness on BASELINE config 5 (tools/ppo_c5.py), learning curve                 -> gpurun_out/<tag>_ppo_c5.txt
 #   gather           bench.py --workload c4 --force-gather: the exchange at world size 1, every wire                   -> gpurun_out/<tag>_bench_c4_gather_w1.json
+#   sweep:<n>        scheduler / switch sweep <n> of tools/sched_sweep.py (objects prebuilt with `SWEEP=<n> python tools/sched_sweep.py build`)  -> gpurun_out/<tag>_sched_sweep.txt
 tag=$1; shift
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -70,6 +71,7 @@ PY
     gather)
       timeout 300 python bench.py --workload c4 --force-gather --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train > gpurun_out/${tag}_bench_c4_gather_w1.json 2> gpurun_out/${tag}_bench_c4_gather_w1.err
       python -c "import json; d=json.loads(open('gpurun_out/${tag}_bench_c4_gather_w1.json').read().strip().splitlines()[-1]); print({w: (round(v['ms_per_step']*1e3,2), v['verified_against_rccl_gather_after']) for w, v in d['config']['exchange_per_wire'].items()})" ;;
+    sweep:*) SWEEP=${task#sweep:} SWEEP_TAG=$tag python tools/sched_sweep.py run 2 2>&1 | tail -30 ;;
     run:*) sc=${task#run:}; timeout 900 python $sc > gpurun_out/${tag}_$(basename $sc .py).txt 2>&1; tail -25 gpurun_out/${tag}_$(basename $sc .py).txt ;;
     *) echo "unknown task $task" ;;
   esac
