@@ -15,9 +15,11 @@ auto-resets included.
 N > 1 (BASELINE.json configs[3], "C4"): 32 drones x 512 envs PER GPU (4096 envs at 8 GPUs), swarm_vs_swarm, and the exchange
 of the observation rows after every step INSIDE the timed region (north_star: "a single ... gather of observations over xGMI
 per rollout step"): every rank ends each step with the rows of all ranks.  [step -> exchange] x 64 is ONE captured HIP graph per
-rank (quad-swarm-rl_amd/parallel.py: ObsExchange); exchange(t) runs on a second stream under step(t+1); the wire format at N > 1 is
-q8 - 72-byte rows: bf16 self columns + 8-bit fixed-point neighbour block, error <= 0.039 m / 0.024 m/s - (--wire bf16: 108-byte rows, --wire f32:
-bit-exact 216-byte rows; bf16 is the default of --force-gather at N = 1).  --transport fused: the step kernel itself stores its rows into every rank's hipIpc-mapped
+rank (quad-swarm-rl_amd/parallel.py: ObsExchange); exchange(t) runs on a second stream under step(t+1).  The HEADLINE wire is f32 - 216-byte rows,
+bit-exact: every rank holds the reference's float observations of all ranks; the lossy wires are measured on the same shards with the same bracketing
+and reported beside it as labelled variants (config.exchange_per_wire: bf16 = 108-byte rows, RNE; q8 = 72-byte rows, bf16 self columns + 8-bit
+fixed-point neighbour block, error <= 0.039 m / 0.024 m/s, outside the 1e-5 observation tolerance).  --wire picks another headline wire; the line
+names it in its top-level `wire` field.  --transport fused: the step kernel itself stores its rows into every rank's hipIpc-mapped
 receive window (include/quadswarm_exchange.h; no launch besides the step), peer: the same windows filled by a push kernel on a second
 stream, rccl: RCCL all-gather of the packed rows (stepped eagerly: torch's collective is not recorded into a graph), auto (default): fused (peer for batches that run the single-wave kernels) if every
 rank could map its peers' windows, passed the start-up self-check and holds the same rows an RCCL gather delivers (ObsExchange.verify), else rccl; torch: round 2's eager per-step all_gather.  The rate of the
@@ -222,15 +224,22 @@ def pmc_traffic(workload, num_envs, kernel):
     tools/pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, KiB units and gfx950 corrections of MI355X_MICROARCH.md);
     None when no measurement of this workload / batch / kernel is on file."""
     import glob
+    return pmc_traffic_record(workload, num_envs, kernel)[0]
+
+
+def pmc_traffic_record(workload, num_envs, kernel):
+    """(bytes per launch, where the figure comes from): it is NOT measured by the run that prints the line - PMC counters need rocprofv3 around
+    the process - but read from the committed PMC pass of the same workload / batch / kernel (newest round first)"""
+    import glob
     for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")), reverse=True):
-        try:   # newest round first
+        try:
             with open(path) as f:
                 rec = json.load(f).get(f"{workload}:{num_envs}:{kernel}")
             if rec:
-                return rec["fetch_bytes"] + rec["write_bytes"]
+                return rec["fetch_bytes"] + rec["write_bytes"], f"committed PMC file profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, tools/pmc.sh); not measured in this run"
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, None
 
 
 def make_exchange(st, world, rank, transport, wire, dist, dev, info, protocols=(False, True)):
@@ -384,10 +393,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the secondary measurement (independent shards / gather variant)")
     ap.add_argument("--no-overlap", action="store_true", help="--transport torch: gather on the compute stream instead of overlapping it with the next step")
     ap.add_argument("--transport", default="auto", choices=["auto", "fused", "peer", "rccl", "torch"], help="observation exchange (see the module docstring)")
-    ap.add_argument("--wire", default="bf16", choices=["q8", "bf16", "f32"], help="wire format of the exchanged rows.  Default bf16 - the wire the Sample Factory env "
-                                                                                  "defaults to (--quads_obs_wire).  f32 is the bit-exact one; q8 (bf16 self / SDF columns + 8-bit fixed-point "
-                                                                                  "neighbour block, 72 bytes per C4 row, error <= 0.039 m / 0.024 m/s: include/quadswarm_exchange.h) is a LOSSY "
-                                                                                  "opt-in outside the 1e-5 observation tolerance.  The line names the wire in its top-level `wire` field")
+    ap.add_argument("--wire", default="f32", choices=["q8", "bf16", "f32"], help="wire format of the HEADLINE's exchanged rows.  Default f32: bit-exact, the reference's float "
+                                                                                 "observations (the other two are measured as labelled lossy variants in config.exchange_per_wire).  bf16: RNE, 3 significant "
+                                                                                 "digits; q8 (bf16 self / SDF columns + 8-bit fixed-point neighbour block, 72 bytes per C4 row, error <= 0.039 m / 0.024 m/s: "
+                                                                                 "include/quadswarm_exchange.h): outside the 1e-5 observation tolerance.  The line names the wire in its top-level `wire` field")
     ap.add_argument("--segment", type=int, default=64, help="control steps per captured [step -> exchange] graph (0 = eager launches)")
     ap.add_argument("--no-variants", action="store_true", help="skip config.variants (shaped / rew_info / downwash-off / seeds 1, 2 runs of the same workload)")
     ap.add_argument("--no-c5-train", action="store_true", help="do not run the C5 training (tools/train_c5.py through Sample Factory where it imports, else the in-tree PPO harness tools/ppo_c5.py)")
@@ -869,7 +878,7 @@ def main():
                        else (c5_record(not args.no_c5_train) if world == 1 else None),
                        "overrides": args.set},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(workload, E, kernel_name), "kernel": kernel_name,
+                         "traffic": pmc_traffic_record(workload, E, kernel_name)[0], "traffic_source": pmc_traffic_record(workload, E, kernel_name)[1], "kernel": kernel_name,
                          "kernel_flavor": flavor, "specialized": specialized, "kernel_avg_us": region_kernel_ms * 1e3, "kernel_launches": kernel_region_steps,
                          "kernel_avg_us_event_pair_per_launch": kernel_ms * 1e3, "event_pair_launches": launches,
                          "algorithmic_bytes_per_launch": algo * T},

@@ -91,6 +91,11 @@ typedef struct qs_config {
     double motor_linearity, vel_damp, damp_omega_quadratic, omega_max, gravity;
     double thrust_noise_sigma; /* 0.2*thrust_noise_ratio, OU sigma (quadrotor_dynamics.py:168-173) */
     double ou_theta;           /* 0.15 */
+                               /* qs_default_config() fills both with their FLOAT32 roundings widened back - (double)(float)0.01, (double)(float)0.15 -
+                                * because its floor_mode is QS_FLOOR_NUMBA and the jitted reference keeps them in float32 jitclass members
+                                * (numba_utils.py:67-74).  A caller that switches floor_mode to QS_FLOOR_NUMPY (--quads_use_numba=False) must also
+                                * store the plain doubles 0.2 * ratio and 0.15 here (the numpy path's OUNoise, quad_utils.py:253-279; 2e-8 / 4e-8
+                                * away); the Python binding does both together (config.make_config: numba_float32_ou follows use_numba). */
 
     /* ---- simulation ---- */
     double dt;                 /* 1/sim_freq = 0.005 */
@@ -404,6 +409,21 @@ int qs_replay_set_active(qs_handle *h, const uint8_t *active_host /* [num_envs] 
  * qs_create() fail instead (bench.py and the full-size tests assert that the specialised object is what ran).
  */
 int qs_spec_build(const qs_config *cfg, int team, char *path_out, int cap);
+/* Code-object verification.  The compiler of this image (ROCm 7.2) can place a VGPR spill, reload, copy or rematerialised constant at the top
+ * of a control-flow join block IN FRONT OF the `s_or_b64 exec, exec, s[..]` that restores exec there; a wave that arrives with exec == 0 (it took
+ * the branch around the `then` side) then spills nothing and later reloads stale scratch memory.  qs_create() and qs_spec_build() disassemble every
+ * specialised object (llvm-objdump from QS_LLVM_BIN, default /opt/rocm/lib/llvm/bin), reject one that shows the pattern, rebuild it with other
+ * scheduler settings and use none if all do (generic kernels, loudly); a verified cache entry carries a `.ok` file next to it.
+ * qs_spec_verify() is that check for any file: a bundled or plain gfx950 code object, or a shared library with a .hip_fatbin section (every bundle
+ * in it).  Returns 0 = clean, 1 = pattern found (one line per place in report_out: kernel <label>: the block's first instructions), < 0 = could not
+ * be checked.  QS_SPEC_VERIFY=0 in the environment switches the check off for objects built in that process (tools that study a flagged object). */
+int qs_spec_verify(const char *path, char *report_out, int cap);
+/* The repair qs_create() / qs_spec_build() apply to an object that shows the pattern (and the Python build applies to the two libraries): the exec
+ * restore is moved to the front of its block prologue - straight-line code nobody jumps into, all other instructions keep their relative order -
+ * where that provably changes nothing else (no prologue instruction in front of it defines the mask it reads, no v_readlane among the last five
+ * prologue instructions, no DPP / lane operation right behind it, the byte sequence unique in the file).  Rewrites `path` in place; returns the
+ * number of places repaired, the ones left (with the reason) in left_out; < 0 on errors.  Callers verify again afterwards. */
+int qs_spec_repair(const char *path, char *left_out, int cap);
 int qs_is_specialized(qs_handle *h);
 /* 1 = config-specialised kernels, 0 = generic kernels with the reason written to why_out (NUL-terminated, at most cap bytes). */
 int qs_spec_status(qs_handle *h, char *why_out, int cap);

@@ -58,11 +58,15 @@ enum { QS_XCHG_ERR_ACK_TIMEOUT = 1, QS_XCHG_ERR_ARRIVE_TIMEOUT = 2 };
 
 typedef struct qs_xchg qs_xchg;
 
-/* QS_XCHG_FENCED=1 in the environment when an endpoint is created selects the FENCED variant of the flag protocol for it: whoever stores a
- * flag first executes a system-scope release fence, whoever has seen one a system-scope acquire fence (one per launch and direction, on the
- * wave that handles the flags).  The default (relaxed flags behind write-through rows that were drained) is what every test here runs on one
- * GPU; the fenced form is the immediate fallback if a real multi-GPU node's verify() (parallel.ObsExchange.verify) disagrees - before the
- * window transports are given up for the RCCL all-gather. */
+/* The FENCED variant of the flag protocol: every producing workgroup executes a system-scope release fence between its drained rows and its
+ * ticket, whoever has seen a flag executes a system-scope acquire fence (once per launch, on the wave that polls).  The default (relaxed flags
+ * behind write-through rows that were drained) is what every test here runs on one GPU; the fenced form is the immediate fallback if a real
+ * multi-GPU node's verify() (parallel.ObsExchange.verify) disagrees - before the window transports are given up for the RCCL all-gather.
+ * Selected per endpoint with qs_xchg_set_fenced (any time between launches; all ranks of a group must agree), read back with
+ * qs_xchg_get_fenced (1 / 0; -1 for a null endpoint).  QS_XCHG_FENCED=<non-zero integer> in the environment only sets the initial value of
+ * endpoints created afterwards. */
+int qs_xchg_set_fenced(qs_xchg *x, int fenced);
+int qs_xchg_get_fenced(qs_xchg *x);
 /* One endpoint: `rows` observation rows of `cols` float32 columns per rank, `world` ranks, this one is `rank`.  Allocates on
  * HIP device `device`: the receive window [2 slots][world][rows][cols] of the wire type, the flag window, and two float32
  * staging buffers [rows][cols] the stepper can write its observations to (qs_set_obs_target, quadswarm.h) so that the push of

@@ -220,7 +220,19 @@ def run_case(name, cfg, steps, seed, action_fn=None, forces=None, with_extra=Tru
     tape_pos = [len(TAPE)]
     snaps0 = snapshot(env)
     rec = {k: [] for k in ("actions", "obs", "rew", "done", "rew_info", "unique_col", "new_pairs", "curr_pairs",
-                           "obst_new", "obst_hit", "counters", "room_new")}
+                           "obst_new", "obst_hit", "obst_hit_idx", "counters", "room_new")}
+    # Which obstacle each drone hit (obstacles/utils.py:31-43: obstacles in index order, the first one within reach wins, `break`):
+    # quadrotor_multi.py:463 keeps the {drone: obstacle} dict of MultiObstacles.collision_detection in a local, so the call is recorded.
+    hit_pairs = []
+    if cfg["use_obstacles"]:   # (on the class: reset() builds a new MultiObstacles for every episode, quadrotor_multi.py:349)
+        from gym_art.quadrotor_multi.obstacles.obstacles import MultiObstacles
+        inner_detect = _ORIG.setdefault("collision_detection", MultiObstacles.collision_detection)
+
+        def recording_detect(self, pos_quads):
+            ids, pair = inner_detect(self, pos_quads=pos_quads)
+            hit_pairs.append({int(k): int(v) for k, v in pair.items()})
+            return ids, pair
+        MultiObstacles.collision_detection = recording_detect
     snaps = {k: [] for k in snaps0}
     force_steps, force_state = [], {k: [] for k in ("pos", "vel", "rot", "omega")}
     ep_stats = []
@@ -239,8 +251,11 @@ def run_case(name, cfg, steps, seed, action_fn=None, forces=None, with_extra=Tru
         else:
             act = np.asarray(action_fn(t, env, arng), dtype=np.float64)
         prev_pairs = np.array(env.prev_drone_collisions, dtype=np.int64).reshape(-1, 2)
+        del hit_pairs[:]
         obs, rew, done, infos = env.step([a for a in act])
         tape_pos.append(len(TAPE))
+        assert len(hit_pairs) == (1 if cfg["use_obstacles"] else 0)   # one detection pass per step (quadrotor_multi.py:463)
+        rec["obst_hit_idx"].append(np.array([hit_pairs[0].get(i, -1) if hit_pairs else -1 for i in range(n)], dtype=np.int32))
         rec["actions"].append(act)
         rec["obs"].append(np.asarray(obs, dtype=np.float64))
         rec["rew"].append(np.asarray(rew, dtype=np.float64))
@@ -575,6 +590,25 @@ _scen_case("e_n17_kall_obst", 50, 80, quads_mode="o_random", ep_time=0.4, **dict
 _scen_case("x_n40_obst", 45, 81, quads_mode="o_random", ep_time=0.4, **dict(OBST, num_agents=40, neighbor_visible_num=6))
 _scen_case("e_n2_k1_swap", 60, 82, quads_mode="swap_goals", ep_time=0.5, num_agents=2, neighbor_visible_num=1)
 _scen_case("e_n1_obst", 50, 83, quads_mode="o_static_same_goal", ep_time=0.3, **dict(OBST, num_agents=1, neighbor_visible_num=0, neighbor_obs_type="none"))
+
+
+def force_between_obstacles(env):
+    # Every drone halfway between two ADJACENT obstacles (1 m apart, radius 0.475: both within reach), a centimetre nearer to one of them -
+    # alternately the lower- and the higher-numbered one: obstacles/utils.py:31-43 reports the LOWER index either way (index order + break).
+    op = np.array(env.obstacles.pos_arr)[:, :2]
+    pairs = [(a, b) for a in range(len(op)) for b in range(a + 1, len(op)) if abs(np.linalg.norm(op[a] - op[b]) - 1.0) < 1e-9]
+    for i in range(len(env.envs)):
+        a, b = pairs[(i * 7 + 3) % len(pairs)]
+        mid, off = 0.5 * (op[a] + op[b]), (0.01 if i % 2 else -0.01) * (op[b] - op[a])
+        set_dyn(env, i, pos=[mid[0] + off[0], mid[1] + off[1], 1.0 + 0.4 * i], vel=[0.1 * (i - 4), 0.05 * i, 0.0])
+
+
+@case
+def x_obst_first_hit():
+    # 51 obstacles of 0.95 m: which obstacle a drone hit when two are within reach, on consecutive steps (new-vs-previous bookkeeping) and again later
+    cfg = default_cfg(quads_mode="o_random", ep_time=0.5, **dict(OBST, obst_density=0.8, obst_size=0.95))
+    run_case("x_obst_first_hit", cfg, steps=60, seed=84, action_fn=hover_actions,
+             forces={3: force_between_obstacles, 4: force_between_obstacles, 9: force_between_obstacles, 30: force_between_obstacles})
 
 
 if __name__ == "__main__":

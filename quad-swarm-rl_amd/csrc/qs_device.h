@@ -18,8 +18,10 @@ enum : uint32_t {
     F_REACHED = 1u << 8, F_COL_AGENT_OK = 1u << 9, F_COL_OBST_OK = 1u << 10,
     F_IN_COL = 1u << 11,   // this drone's id was in a colliding pair last step (prev_ids of quadrotor_multi.py:440)
     // bookkeeping rows that are only touched when they matter (DESIGN.md 4a "bytes"): the state of those rows in HBM is described by a flag
-    F_RING_LIVE = 1u << 12,   // dist_ring of this drone holds maintained values; clear = every entry counts as "far" (see goal_distance_log)
-    F_NEWPAIR_NZ = 1u << 13,  // the new_pair_mask word last stored for this drone was non-zero (clear = the word in HBM is 0: no store needed for a 0)
+    // dist_ring of this drone holds maintained values; clear = every entry counts as "far" (see goal_distance_log)
+    F_RING_LIVE = 1u << 12,
+    // the new_pair_mask word last stored for this drone was non-zero (clear = the word in HBM is 0: no store needed for a 0)
+    F_NEWPAIR_NZ = 1u << 13,
     F_SVD_SHIFT = 16, F_SVD_MASK = 0xffu << 16
 };
 
@@ -614,7 +616,8 @@ __device__ __forceinline__ void collide_room(const Consts<real> &c, const RngKey
     const bool tape = QS_ON_TAPE(key);
     real speed = norm3<real>(d.vel), dir[3], rs;
     uint32_t w[4] = {0, 0, 0, 0}, w1[4] = {0, 0, 0, 0};
-    if (tape) { rs = (real)tape_pop(key); for (int q = 0; q < 3; ++q) dir[q] = (real)tape_pop(key); }   // the reference's call order, room.py:10-41
+    // the reference's call order, room.py:10-41
+    if (tape) { rs = (real)tape_pop(key); for (int q = 0; q < 3; ++q) dir[q] = (real)tape_pop(key); }
     else {
         rng_words(key, site, 0, drone, 0, w);
         rs = (real)0.2 * speed + ((real)0.8 * speed - (real)0.2 * speed) * u01<real>(w[0]);
@@ -843,7 +846,7 @@ __device__ QS_COLD void svs_create_formations(const RngKey &key, const Formation
 // workgroup, 21.8 us kernel: profiles/r03c_wg_c4_steady_*.txt).  Same arithmetic per row, same summation order of the means, the same
 // draws (QS_SITE_SCEN_SHUFFLE slots) - results are bit-identical to the serial form.
 //   goals: LDS rows [>= 2N][3] of the environment (first N rows = result), scr: N ints of LDS scratch of the environment.
-//   Must be called by all lanes of the wave with `on` uniform per environment; needs N / 2 >= 3 (every formation has as many rows as drones).
+// Must be called by all lanes of the wave with `on` uniform per environment; needs N / 2 >= 3 (every formation has as many rows as drones).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
 __device__ __forceinline__ void goal_row(const Formation<real> &F, int n, int fd, const real center[3], int i, real g[3], bool &needs_mean) {
@@ -921,7 +924,9 @@ __device__ __forceinline__ void formation_rows_wave(const RngKey &key, const For
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (on && do_shuffle) {
         int pos = li;
-        for (int k0 = 1; k0 < n; k0 += 8) {   // eight swap partners per LDS round trip (a lone wave pays ~130 cycles per dependent LDS read: 15 of them were 2 k cycles of the goal swap)
+        // eight swap partners per LDS round trip (a lone wave pays ~130 cycles per dependent LDS read: 15 of them were 2 k cycles of the
+        // goal swap)
+        for (int k0 = 1; k0 < n; k0 += 8) {
             int jj[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) jj[u] = scr[r0 + ((k0 + u < n) ? k0 + u : n - 1)];

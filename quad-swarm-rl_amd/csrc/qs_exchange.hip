@@ -116,10 +116,10 @@ __global__ void __launch_bounds__(256) qs_xchg_push_kernel(PushArgs a) {
     wt_drain();                                                       // this thread's (write-through) rows have reached their window ...
     __syncthreads();
     if (threadIdx.x == 0) {
+        fence_release_sys(a.fenced);                                  // fenced protocol: every workgroup, before its ticket (qs_xchg_dev.h)
         const unsigned int t = atomicAdd(&a.loc->ticket[d], 1u);
         if (t == gridDim.x - 1) {                                     // ... and this is the last workgroup of destination d
             a.loc->ticket[d] = 0;
-            fence_release_sys(a.fenced);
             st_sys(&a.flag_win[d]->arrive[slot][a.rank], seq);
             const unsigned int g = atomicAdd(&a.loc->ticket_all, 1u);
             if (g == gridDim.y - 1) { a.loc->ticket_all = 0; __threadfence(); a.loc->push_seq = seq; }
@@ -135,7 +135,8 @@ __global__ void __launch_bounds__(64) qs_xchg_wait_kernel(FlagWin *mine, Release
     const int slot = (int)(seq & 1), r = threadIdx.x;
     bool ok = true;
     if (r < a.world) ok = poll_ge(&mine->arrive[slot][r], seq, timeout_ticks);
-    fence_acquire_sys(a.fenced);   // (the readers of the rows are later launches on this stream: the invalidate is in place before they start)
+    // (the readers of the rows are later launches on this stream: the invalidate is in place before they start)
+    fence_acquire_sys(a.fenced);
     if (__any(!ok) && r == 0) atomicOr(&a.loc->status, (unsigned int)QS_XCHG_ERR_ARRIVE_TIMEOUT);
     if (release && r < a.world) st_sys(&a.flag_win[r]->ack[a.rank], seq);
     if (r == 0) { a.loc->wait_seq = seq; if (release) a.loc->release_seq = seq; }
@@ -177,7 +178,8 @@ struct Blob { hipIpcMemHandle_t data, flags; int32_t pid, device; int32_t pad[2]
 static_assert(sizeof(hipIpcMemHandle_t) == QS_XCHG_HANDLE_BYTES, "handle size");
 static_assert(sizeof(Blob) == QS_XCHG_EXPORT_BYTES, "blob size");
 
-int grid_parts(long long n) {   // workgroups per destination: enough 16-byte stores in flight per link, few enough to leave the CUs to the step kernel
+// workgroups per destination: enough 16-byte stores in flight per link, few enough to leave the CUs to the step kernel
+int grid_parts(long long n) {
     const long long nvec = n >> 3;
     long long parts = (nvec + 2047) / 2048;   // >= 2048 vectors (32 KB of bf16) per workgroup
     if (parts < 1) parts = 1;
@@ -281,6 +283,14 @@ static int xchg_create(int device, int world, int rank, int64_t rows, int32_t co
     *out = x;
     return 0;
 }
+
+// the flag protocol of this endpoint (quadswarm_exchange.h): every launch reads x->fenced when it is enqueued
+int qs_xchg_set_fenced(qs_xchg *x, int fenced) {
+    if (!x) return fail(-1, "qs_xchg_set_fenced: null endpoint");
+    x->fenced = fenced ? 1 : 0;
+    return 0;
+}
+int qs_xchg_get_fenced(qs_xchg *x) { return x ? x->fenced : -1; }
 
 int qs_xchg_destroy(qs_xchg *x) {
     if (!x) return 0;
@@ -416,7 +426,8 @@ void *qs_xchg_fused_desc(qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *
     return x->desc;
 }
 
-// library-internal (qs_set_obs_exchange): does the endpoint carry `cols`-column rows in wire `wire` and, for QS_WIRE_Q8, the block [q0, q1)?
+// library-internal (qs_set_obs_exchange): does the endpoint carry `cols`-column rows in wire `wire` and, for QS_WIRE_Q8, the block [q0,
+// q1)?
 int qs_xchg_row_layout_is(qs_xchg *x, int32_t cols, int32_t q0, int32_t q1) {
     if (!x) return 0;
     if (x->cols != cols) return 0;

@@ -42,8 +42,8 @@ using namespace qs;
 //                   clocks and its stores in 250 instead of 400 (same microbenchmark); C2 7.82 -> 7.64 us per step.
 // pos .. pair are byte offsets of an array INSIDE a block (the same for both orders); the per-step outputs (newpair, reward, done, ohit)
 // stay flat component-major arrays behind the blocks (absolute offsets) - their consumers read them as plain vectors.
-// bytes of one state block: 40 x 64 reals (pos 3, vel 3, rot 9, omega 3, rot_damp 4, cmds_damp 4, ou 4, goal 3, ring 4, sums 3), 64 flag words
-// (u32), 64 pair masks (u64) - create_typed (quadswarm_hip.hip) lays the arrays out and checks this figure
+// bytes of one state block: 40 x 64 reals (pos 3, vel 3, rot 9, omega 3, rot_damp 4, cmds_damp 4, ou 4, goal 3, ring 4, sums 3), 64 flag
+// words (u32), 64 pair masks (u64) - create_typed (quadswarm_hip.hip) lays the arrays out and checks this figure
 static inline int qs_block_bytes(int real_size) { return 40 * 64 * real_size + 64 * 4 + 64 * 8; }
 // byte offsets of the arrays inside a state block, in the order create_typed lays them out (it checks them)
 template <typename real> struct BlkOff {
@@ -54,7 +54,8 @@ template <typename real> struct BlkOff {
 // components per drone of the blocked arrays (the lane pitch inside an array, in elements)
 namespace blkc { constexpr int pos = 3, vel = 3, rot = 9, omega = 3, rot_damp = 4, cmds_damp = 4, ou = 4, goal = 3, ring = 4, sums = 3, flags = 1, pair = 1; }
 struct StateBlk { char *base; uint32_t bytes, block_bytes, epb, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit, lane_major; };
-// element (component q of drone i of env e) of a blocked array of `comps` components, for the code outside the step kernels' buffer-resource views
+// element (component q of drone i of env e) of a blocked array of `comps` components, for the code outside the step kernels'
+// buffer-resource views
 template <typename TT> __device__ __forceinline__ TT &blk_at(const StateBlk &b, uint32_t arr, int comps, int q, int e, int i, int N) {
     const int blk = e / (int)b.epb, lane = (e - blk * (int)b.epb) * N + i;
     return *(TT *)(b.base + (size_t)blk * b.block_bytes + arr + (b.lane_major ? (size_t)lane * comps + q : (size_t)q * 64 + lane) * sizeof(TT));
@@ -164,9 +165,8 @@ template <typename T> struct BufRow {
 };
 #define QS_BUF_RSRC(p) __builtin_amdgcn_make_buffer_rsrc((void *)(p).blk.base, 0, (p).blk.bytes, 0x00020000)
 // blocked state array: the workgroup's block (blockIdx.x: one block = the environments of one workgroup), lane = position inside the wave;
-// component offsets are compile-time constants next to the scalar block offset.  QS_LM: the element order of the handle's blocks - a literal
-// in a config-specialised object (lane-major <=> the 8-wave team kernels), the handle's flag in the generic kernels
-// (QS_BLK: the state block a workgroup is working on - blockIdx.x, or the loop variable of the persistent form of the single-wave step kernel)
+// component offsets are compile-time constants next to the scalar block offset.  QS_LM: the element order of the handle's blocks - a
+// literal in a config-specialised object (lane-major <=> the 8-wave team kernels), the handle's flag in the generic kernels
 #define QS_BLK blockIdx.x
 #if defined(QS_SPEC_TEAM)
 #define QS_LM(p) (QS_SPEC_TEAM == 8)
@@ -191,6 +191,70 @@ __device__ __forceinline__ unsigned long long nbr_key(float m, int idx) {
 template <typename real> __device__ __forceinline__ real nbr_metric(const real rp[3], const real rv[3]) {
     const real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
     return rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) * M<real>::rcp(rd);
+}
+// Team kernels, N <= 8: the neighbour-observation columns (neighborhood_indices quadrotor_multi.py:247-274, extend_obs_space :233-245) and
+// the SDF cells (obstacles/utils.py:5-27) of lane i's row by helper wave `hw` of HW, from the published positions / velocities.  Every wave
+// computes all (at most 8) metrics of its drone in registers - no metric matrix in LDS, no barrier between "metrics" and "ranks" - and
+// ranks the partners j = hw, hw + HW, ... by counting: rank = position in the stable ascending argsort; the K lowest go to row slot `rank`.
+// Slots are a permutation of the partners, so the waves never write the same word.
+template <typename real, int HW>
+__device__ __forceinline__ void team_rows_small(const Consts<real> &c, int N, int K, bool ranked, int i, int base, int B, int tid, int hw, int le, int M_,
+                                                const real *s_pos, const real *s_vel, const real *s_obst, real *myobs, real obst_size) {
+    real *o = myobs + c.self_dim;
+    if (K > 0) {
+        real mpos[3], mvel[3], mk[8];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { mpos[q] = s_pos[q * B + tid]; mvel[q] = s_vel[q * B + tid]; }
+        if (ranked) {
+            real rp[8][3], rv[8][3];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {   // all LDS reads in front of the first use: one round trip
+                const int j = (u < N) ? u : N - 1;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mpos[a]; rv[u][a] = s_vel[a * B + base + j] - mvel[a]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mk[u] = (u < N && u != i) ? nbr_metric<real>(rp[u], rv[u]) : (real)3.4e38;
+        }
+        for (int j = hw; j < N; j += HW) {
+            if (j == i) continue;
+            int rank = (j < i) ? j : j - 1;   // K == N-1: all others in index order (:253-254)
+            if (ranked) {
+                real mj = mk[0];
+#pragma unroll
+                for (int u = 1; u < 8; ++u) mj = (u == j) ? mk[u] : mj;
+                rank = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += (int)((u < N) & ((mk[u] < mj) | ((mk[u] == mj) & (u < j))));
+            }
+            if (rank < K) {
+                real *oo = o + rank * 6;
+                real vals[6];   // all six LDS reads before the first LDS write (the compiler must assume they alias)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { vals[a] = s_pos[a * B + base + j]; vals[3 + a] = s_vel[a * B + base + j]; }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    oo[a] = clipr<real>(vals[a] - mpos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
+                    oo[3 + a] = clipr<real>(vals[3 + a] - mvel[a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
+                }
+            }
+        }
+    }
+    if (c.use_obstacles) {   // the 9 cells striped over the helper waves; one square root per cell (sdf_obs)
+        const real *ox = s_obst + (le * 2 + 0) * M_, *oy = s_obst + (le * 2 + 1) * M_;
+        const real px = s_pos[0 * B + tid], py = s_pos[1 * B + tid];
+        real *os = o + 6 * K;
+        for (int q = hw; q < 9; q += HW) {
+            const int a = q / 3, b = q - a * 3;
+            const real gx = px + (real)0.1 * (real)(a - 1), gy = py + (real)0.1 * (real)(b - 1);
+            real mind2 = (real)10000;
+            for (int k = 0; k < M_; ++k) {
+                real dx = gx - ox[k], dy = gy - oy[k], d2 = dx * dx + dy * dy;
+                mind2 = d2 < mind2 ? d2 : mind2;
+            }
+            os[q] = M<real>::sqrt(mind2) - (c.dr_on ? (real)0.5 * obst_size : c.obst_radius);
+        }
+    }
 }
 // (metric, index) with the order "smaller metric first, lower index first" = position in the stable argsort
 template <typename real> struct NbrKey;
@@ -219,7 +283,8 @@ template <> struct NbrKey<double> {
 #define QS_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.timing[k] = clock64(); } while (0)
 // helper waves of the team kernels: stamp k of wave w (1..3) lands in timing[32*w + k]
 #define QS_STAMPW(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x >= 64) p.timing[32 * (threadIdx.x >> 6) + (k)] = clock64(); } while (0)
-// start / end of EVERY workgroup (wave 0; s_memtime and the constant 100 MHz wall clock) and where it ran: HW_ID (gfx9: wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) and XCC_ID
+// start / end of EVERY workgroup (wave 0; s_memtime and the constant 100 MHz wall clock) and where it ran: HW_ID (gfx9: wave 3:0, simd 5:4,
+// pipe 7:6, cu 11:8, sh 12, se 15:13) and XCC_ID
 #define QS_WG_STRIDE 16
 #define QS_STAMP_WG(k) do { if (threadIdx.x == 0) { p.timing[128 + QS_WG_STRIDE * blockIdx.x + (k)] = clock64(); p.timing[128 + QS_WG_STRIDE * blockIdx.x + 4 + (k)] = wall_clock64(); \
         if ((k) == 0) { p.timing[128 + QS_WG_STRIDE * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); \
@@ -233,13 +298,42 @@ template <> struct NbrKey<double> {
 #define QS_STAMP_WGK(k) do { } while (0)
 #endif
 
+// Debug builds (QS_SPEC_EXTRA_FLAGS="-DQS_POISON_IDLE=1|2 [-DQS_POISON_PARTS=mask]"; tests/test_object_identity_gpu.py): the lanes of a
+// wave that own no drone - 64 % N of them, and every lane past the batch's last environment - start from garbage instead of a copy of drone
+// 0 (1: NaN, 2: 3e30 in every float; all ones in flags and masks), and the dynamic LDS is filled with the same pattern before its first
+// use.  Results must be bit-identical to the plain build's: nothing an active lane computes may depend on an idle lane's registers or on an
+// LDS word that nobody wrote in this launch.  QS_POISON_PARTS (default: everything) picks what is poisoned, for bisecting: 1 drone state, 2
+// flags / pair mask, 4 LDS, 8 actions, 16 goal / distance sums / ring.
+#ifdef QS_POISON_IDLE
+#ifndef QS_POISON_PARTS
+#define QS_POISON_PARTS 31
+#endif
+__device__ __forceinline__ uint32_t qs_poison_bits() { uint32_t u = QS_POISON_IDLE == 1 ? 0x7fc0deadu : 0x7217e7d5u; asm volatile("" : "+v"(u)); return u; }   // (opaque: fast-math would fold a literal NaN away)
+template <typename real> __device__ __forceinline__ real qs_poison() { return (real)__builtin_bit_cast(float, qs_poison_bits()); }
+#define QS_POISON_LDS(total_bytes, nthreads) do { if (QS_POISON_PARTS & 4) { for (int w_ = threadIdx.x; w_ < (total_bytes) / 4; w_ += (nthreads)) ((uint32_t *)smem)[w_] = qs_poison_bits(); __syncthreads(); } } while (0)
+#define QS_POISON_ARR_(a, n) do { if (!active) { _Pragma("unroll") for (int q_ = 0; q_ < (n); ++q_) (a)[q_] = qs_poison<real>(); } } while (0)
+#define QS_POISON_ARR(a, n, part) do { if (QS_POISON_PARTS & (part)) QS_POISON_ARR_(a, n); } while (0)
+#define QS_POISON_DRONE(d) do { if (QS_POISON_PARTS & 1) { QS_POISON_ARR_((d).pos, 3); QS_POISON_ARR_((d).vel, 3); QS_POISON_ARR_((d).rot, 9); QS_POISON_ARR_((d).omega, 3); \
+                                QS_POISON_ARR_((d).rot_damp, 4); QS_POISON_ARR_((d).cmds_damp, 4); QS_POISON_ARR_((d).ou, 4); } if ((QS_POISON_PARTS & 2) && !active) (d).flags = ~0u; } while (0)
+#define QS_POISON_U64(x) do { if ((QS_POISON_PARTS & 2) && !active) (x) = ~0ull; } while (0)
+#else
+#define QS_POISON_LDS(total_bytes, nthreads) do { } while (0)
+#define QS_POISON_ARR(a, n, part) do { } while (0)
+#define QS_POISON_DRONE(d) do { } while (0)
+#define QS_POISON_U64(x) do { } while (0)
+#endif
+
 struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
                    int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit;
-                   int off_t_ri;                            // team kernels: the step's 17 reward terms + the done flag, for the wave that keeps the episode sums
-                   int off_t_near, off_topk, off_t_redo;   // team kernels, N > 8 (pair-once scan): proximity masks, per-wave top-8 lists, per-env "velocities changed" flags
+                   // team kernels: the step's 17 reward terms + the done flag, for the wave that keeps the episode sums
+                   int off_t_ri;
+                   // team kernels, N > 8 (pair-once scan): proximity masks, per-wave top-8 lists, per-env "velocities changed" flags
+                   int off_t_near, off_topk, off_t_redo;
                    int off_self, off_rows, rows_per_pass, scr_cap;   // single-wave kernels: observation output (see obs_copy_rows)
                    int off_cur; };   // QS_TAPE kernels: per-env tape cursor
-#define QS_NV_MAX 57   // neighbour + SDF columns a lane can keep in registers between the row passes (K <= 8)   // single-wave kernels: observation columns staged per pass (see obs_flush)
+// neighbour + SDF columns a lane can keep in registers between the row passes (K <= 8)   // single-wave kernels: observation columns staged
+// per pass (see obs_flush)
+#define QS_NV_MAX 57
 #define QS_RESET_SCRATCH_INTS 160   // per env, full scenario set: virtual-pool index/value lists (2x64) + two DP rows (2x16)
 
 // Observation rows leave through LDS so that they reach HBM as whole, aligned cache lines (a first version wrote column
@@ -267,7 +361,8 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     L.off_si = o; o += full ? 4 * SI_COUNT * epb : 0;
     L.off_sr = o; o += full ? real_size * SR_COUNT * epb : 0;
     o = (o + 15) & ~15;
-    L.off_envflag = o; o += 4 * ((3 * epb + 3) & ~3);   // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods + [epb] obstacle-size choice
+    // [epb] have-spawn-points flags + [epb] swarm_vs_swarm periods + [epb] obstacle-size choice
+    L.off_envflag = o; o += 4 * ((3 * epb + 3) & ~3);
 #ifdef QS_TAPE
     L.off_cur = o; o += 4 * ((epb + 3) & ~3);
 #endif
@@ -625,8 +720,8 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
     const real res = (real)0.1;
     real gx[3] = {px - res, px, px + res}, gy[3] = {py - res, py, py + res};
     // min over the obstacles of the SQUARED distance, one square root per cell at the end: the square root is monotone, so
-    // min_k sqrt(d2_k) == sqrt(min_k d2_k) - 9 instead of 9 * M quarter-rate v_sqrt_f32 per drone and step (the reference's start value 100.0,
-    // utils.py:17, is the cap 100^2 on the squared side)
+    // min_k sqrt(d2_k) == sqrt(min_k d2_k) - 9 instead of 9 * M quarter-rate v_sqrt_f32 per drone and step (the reference's start value
+    // 100.0, utils.py:17, is the cap 100^2 on the squared side)
     real mind2[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) mind2[q] = (real)10000;
@@ -796,7 +891,8 @@ __device__ __forceinline__ void team_rank_local(int N, int i, int base, int B, i
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        if (q >= C) NbrKey<real>::st(s_topk, SL, (wv - 1) * 8 + q, B, tid, NbrKey<real>::make((real)3.4e38, 0x7fffff00 + q));   // fewer candidates than slots
+        // fewer candidates than slots
+        if (q >= C) NbrKey<real>::st(s_topk, SL, (wv - 1) * 8 + q, B, tid, NbrKey<real>::make((real)3.4e38, 0x7fffff00 + q));
     }
 }
 
@@ -863,7 +959,7 @@ __device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLay
 template <typename real, bool FULL, bool TEAM = false, bool STREAM = false>
 __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem, int epb, const RngKey &key,
                                         bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3], int blk = -1) {
-    const int bidx = blk < 0 ? (int)blockIdx.x : blk;   // (the persistent form of the single-wave step kernel passes the block it is working on)
+    const int bidx = blk < 0 ? (int)blockIdx.x : blk;
     const Consts<real> &c = *cp;
     const Ptrs<real> &p = *pp;
     const LdsLayout &L = *Lp;
@@ -875,7 +971,8 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     uint32_t *s_envflag = (uint32_t *)(smem + L.off_envflag);
     const int tid = threadIdx.x, le = tid / N, i = tid - le * N, e = bidx * epb + le, base = le * N;
     const int M_ = c.num_obstacles;
-    real *myobs = STREAM ? (real *)(smem + L.off_self) + tid * c.self_dim : s_obs + tid * c.obs_dim;   // STREAM: dense self block + rows stage
+    // STREAM: dense self block + rows stage
+    real *myobs = STREAM ? (real *)(smem + L.off_self) + tid * c.self_dim : s_obs + tid * c.obs_dim;
     int *tidx = (int *)(smem + L.off_scratch) + le * (2 * L.scr_cap + 32), *tval = tidx + L.scr_cap, *prev_row = tidx + 2 * L.scr_cap, *cur_row = prev_row + 16;
 
 #ifdef QS_TAPE
@@ -893,7 +990,9 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         if (FULL) for (int q = 0; q < 4; ++q) ((uint64_t *)(smem + L.off_omap))[le * 4 + q] = 0;
         int Me = M_;   // obstacles of this episode
         if (c.use_obstacles) {
-            if (c.dr_on) {   // --quads_domain_random: this episode's density / size (quad_experience_replay.py:106-118,:191-206 -> reset(obst_density, obst_size))
+            // --quads_domain_random: this episode's density / size (quad_experience_replay.py:106-118,:191-206 -> reset(obst_density,
+            // obst_size))
+            if (c.dr_on) {
                 if (c.dr_num_density > 0) {
                     const int k = rng_index<real>(key, QS_SITE_REPLAY, 2, c.dr_num_density);
                     Me = p.dr_count[k];
@@ -972,7 +1071,8 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
                 s_spawn[1 * B + base + k] = (real)jj + (real)0.5 - (real)(W / 2);
                 if (!on_tape) s_spawn[2 * B + base + k] = rng_uniform1<real>(key, QS_SITE_SCEN, 96 + k, 0, 0, (real)1, (real)3);
             }
-            if (on_tape) for (int k = 0; k < N; ++k) s_spawn[2 * B + base + k] = (real)tape_pop(key);   // the N heights follow the N ids (o_base.py:69-81)
+            // the N heights follow the N ids (o_base.py:69-81)
+            if (on_tape) for (int k = 0; k < N; ++k) s_spawn[2 * B + base + k] = (real)tape_pop(key);
             have_spawn = 1;
             // max_square_area_center o_base.py:124-153 (two-row dynamic programme)
             int max_size = 0, cx = 0, cy = 0;
@@ -995,7 +1095,8 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             int index = cx + W * cy, ii = index / W, jj = (W - 1) - (index - ii * W);
             real end[3] = {(real)ii + (real)0.5 - (real)(Lr / 2), (real)jj + (real)0.5 - (real)(W / 2), 0};
             end[2] = rng_uniform1<real>(key, QS_SITE_SCEN, 9, 0, 0, (real)1.5, (real)3);
-            if (on_tape) tape_skip(key, 3);   // update_formation_and_relate_param (:41): formation index, size, layer distance - unused here
+            // update_formation_and_relate_param (:41): formation index, size, layer distance - unused here
+            if (on_tape) tape_skip(key, 3);
             for (int k = 0; k < N; ++k) for (int q = 0; q < 3; ++q) goals[k * 3 + q] = end[q];
         } else {
             // swarm_vs_swarm.py:80-94 (reset) + :17-50 (formation_centers) + scenarios/utils.py:170-181 (get_z_value)
@@ -1061,7 +1162,8 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         self_obs<real>(c, sn, d, goal, myobs);
     };
 #ifdef QS_TAPE
-    if (QS_ON_TAPE(key)) {   // the reference resets the drones one after the other (spawn draw, yaw rejection loop, sensor noise): take turns
+    // the reference resets the drones one after the other (spawn draw, yaw rejection loop, sensor noise): take turns
+    if (QS_ON_TAPE(key)) {
         for (int turn = 0; turn < N; ++turn) {
             if (do_reset && i == turn) { *key.cur = s_cur[le]; per_drone(); s_cur[le] = *key.cur; }
             __syncthreads();
@@ -1138,7 +1240,8 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
 #pragma unroll
         for (int q = 0; q < 4; ++q) { QS_BLK_AT(real, p.blk, rot_damp, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, cmds_damp, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, ring, q, e, i, N) = 0; }
 #pragma unroll
-        for (int q = 0; q < 3; ++q) QS_BLK_AT(real, p.blk, sums, q, e, i, N) = 0;   // the step kernels leave the sums alone until the episode's 5-s window opens (qs_step_sem.h)
+        // the step kernels leave the sums alone until the episode's 5-s window opens (qs_step_sem.h)
+        for (int q = 0; q < 3; ++q) QS_BLK_AT(real, p.blk, sums, q, e, i, N) = 0;
         QS_BLK_AT(uint32_t, p.blk, flags, 0, e, i, N) = d.flags;
         QS_BLK_AT(uint64_t, p.blk, pair, 0, e, i, N) = 0;
         p.new_pair_mask[g] = 0;
@@ -1285,10 +1388,12 @@ __global__ void __launch_bounds__(QS_WAVE) qs_reset_kernel(const Consts<real> c,
 // A snapshot = every per-drone / per-env array of one environment (the list of qs_snapshot_*), packed array after array.
 // ------------------------------------------------------------------------------------------------
 #define QS_REPLAY_MAX_ARR 40
-struct ReplayArr { char *base; uint32_t elem, comps, per_env, off; uint64_t comp_stride; uint32_t group, group_stride; };   // strides / counts in elements, off in bytes; group > 0: wave-blocked array (envs per block, bytes between blocks)
+// strides / counts in elements, off in bytes; group > 0: wave-blocked array (envs per block, bytes between blocks)
+struct ReplayArr { char *base; uint32_t elem, comps, per_env, off; uint64_t comp_stride; uint32_t group, group_stride; };
 struct ReplayParams {
     ReplayArr arr[QS_REPLAY_MAX_ARR];
-    int32_t narr, N, E, use_obstacles, cp_every, grace_ticks, min_gap, obs_arr, tick_arr, ep_len;   // obs_arr / tick_arr: index of that array in arr[]
+    // obs_arr / tick_arr: index of that array in arr[]
+    int32_t narr, N, E, use_obstacles, cp_every, grace_ticks, min_gap, obs_arr, tick_arr, ep_len;
     uint32_t snap_bytes, seed_lo, seed_hi;
     int32_t env_id_offset;
     float sample_prob;
@@ -1304,7 +1409,8 @@ struct ReplayParams {
     int32_t *ev_len, *ev_idx, *ev_replayed;      // event buffer: entries, buffer_idx, num_replayed [QS_REPLAY_EVENTS][E]
     int32_t *ev_slot;                            // [QS_REPLAY_EVENTS][E]: pool slot of the k-th event (the deque order of the reference)
     int32_t *episodes, *replayed, *errors;
-    int32_t *start_tick, *last_steps;            // tick the running episode started at (a replayed one: its checkpoint's); control steps of the last finished one
+    // tick the running episode started at (a replayed one: its checkpoint's); control steps of the last finished one
+    int32_t *start_tick, *last_steps;
 };
 
 __device__ __forceinline__ void replay_copy(const ReplayParams &P, int e, char *snap, bool save, int lane) {

@@ -25,9 +25,6 @@
 
 #include <string>
 
-#ifdef ENC_EXP_NO_BARRIER   // timing experiment: no workgroup barriers (results are wrong)
-#define __syncthreads() do { } while (0)
-#endif
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -39,7 +36,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define ENC_NH (ENC_MAX_NBR / 2)   // neighbour row tiles per pass of the neighbour MLP
 #endif
 #ifndef ENC_WAVES
-#define ENC_WAVES 8   // 2 waves per SIMD: the layer chain of one workgroup is latency-bound, a second wave hides part of it (49 -> 40 us at 8192 agents)
+// 2 waves per SIMD: the layer chain of one workgroup is latency-bound, a second wave hides part of it (49 -> 40 us at 8192 agents)
+#define ENC_WAVES 8
 #endif
 #ifndef ENC_OCC
 #define ENC_OCC 4     // waves per SIMD the register budget is set for: two workgroups per CU (<= 128 VGPRs)
@@ -57,7 +55,8 @@ struct EncParams {
     int32_t self_dim, nbr_dim, num_nbr, obst_dim, obs_dim;
     int32_t nbr_encoder;        // ENC_NBR_*: mean_embed (:22-43), attention (:46-101), mlp (:104-122), no_encoder (:289-291); ENC_MODEL_MHA
     EncLayer s1, s2;            // self encoder        :303-309
-    EncLayer n1, n2, n3;        // neighbour embedding :29-34 (input = neighbour obs) / :52-57 (attention: input = [self obs | neighbour obs])
+    // neighbour embedding :29-34 (input = neighbour obs) / :52-57 (attention: input = [self obs | neighbour obs])
+    EncLayer n1, n2, n3;
                                 // / :110-117 (mlp: input = all neighbour obs of the agent, three layers)
     EncLayer o1, o2;            // obstacle encoder    :315-322
     EncLayer v1, v2;            // attention: value MLP :60-65
@@ -86,8 +85,8 @@ struct EncParams {
     float *act_out;                 // fp32 [B, head_dim]
     const uint32_t *sample_counter;
     uint32_t sample_seed_lo, sample_seed_hi;
-    // optional trajectory copy (rollout segments): the first kernel of a forward pass also copies the reward and the done flag of every agent
-    // of its workgroup - the outputs of the environment step that produced THESE observations - to traj_rew_dst / traj_done_dst
+    // optional trajectory copy (rollout segments): the first kernel of a forward pass also copies the reward and the done flag of every
+    // agent of its workgroup - the outputs of the environment step that produced THESE observations - to traj_rew_dst / traj_done_dst
     const float *traj_rew_src;
     float *traj_rew_dst;
     const uint8_t *traj_done_src;
@@ -137,9 +136,6 @@ __device__ __forceinline__ float sample_action(const EncParams &P, int a, int h,
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }   // in a scalar register
 
 __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1); v_exp_f32 + v_rcp_f32
-#ifdef ENC_EXP_NO_TANH   // timing experiment
-    return x;
-#endif
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x): one multiply, v_exp_f32
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
@@ -174,20 +170,12 @@ __device__ __forceinline__ float obs_at(__amdgpu_buffer_rsrc_t rs, bool valid, u
 // MFMA group has just consumed is refilled with the fragment of K-step ks + ENC_PD); the activation fragment of a row tile is
 // re-read from LDS for K-step ks + 1 as soon as its MFMAs of K-step ks are issued.
 #define ENC_PD 4
-#ifdef ENC_EXP_NO_WLOAD   // timing experiment: no weight traffic
-#define ENC_WLOAD(x) (bf16x8){}
-#else
 #define ENC_WLOAD(x) (x)
-#endif
 template <int MT, int NT>
 __device__ __forceinline__ void mfma_tile(const bf16x8 (&a)[MT], const bf16x8 &b, f32x4 (&acc)[MT][NT], int nt) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
-#ifndef ENC_EXP_NO_MFMA   // timing experiment
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
-#else
-        acc[mt][nt][0] += (float)a[mt][0] * (float)b[0];
-#endif
 }
 
 template <int MT, int NT>
@@ -199,11 +187,7 @@ __device__ __forceinline__ void gemm_tiles(const EncLayer &L, int mtile0, const 
     const uint32_t voff = lane * 16;
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, L.M * L.K * 2, 0x00020000);
 #define ENC_WFRAG(mt, ks) ENC_WLOAD(__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, ((mtile0 + (mt)) * ksteps + (ks)) * 1024, 0)))
-#ifdef ENC_EXP_NO_BREAD   // timing experiment: one activation fragment per row tile and layer instead of one per K-step
-#define ENC_XFRAG(nt, ks) (*(const bf16x8 *)(xrow + (nt) * 16 * xstride + (ks) * 0))
-#else
 #define ENC_XFRAG(nt, ks) (*(const bf16x8 *)(xrow + (nt) * 16 * xstride + (ks) * 32))
-#endif
     if (ksteps & (ENC_PD - 1)) {   // the 32- and 64-wide input layers: one or two K-steps, nothing to pipeline
         for (int ks = 0; ks < ksteps; ++ks) {
             bf16x8 a[MT];
@@ -381,7 +365,8 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 #pragma unroll 4
     for (int idx = tid; idx < NB * ENC_TA * 32; idx += 64 * ENC_WAVES) {
         const int row = idx >> 5, c = idx & 31, k = row >> 4, a = row & 15, ga = a0 + a;
-        const uint32_t i_self = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB) * (uint32_t)D + c;   // self_obs.repeat(K, 1)  (:84)
+        // self_obs.repeat(K, 1)  (:84)
+        const uint32_t i_self = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB) * (uint32_t)D + c;
         const uint32_t i_nbr = (uint32_t)ga * (uint32_t)D + P.self_dim + k * P.nbr_dim + (c - P.self_dim);
         const float v = obs_at(ors, ga < B && c < P.self_dim + P.nbr_dim, c < P.self_dim ? i_self : i_nbr);
         x_in[row * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
@@ -522,7 +507,8 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_obst = x_self + ENC_TA * ENC_XS;                      // [16][XS]
     uint16_t *buf_a = x_obst + ENC_TA * ENC_XS;                       // [ANH*16][YS]  e_i of the group, later the second score layer
-    uint16_t *buf_h = buf_a + ENC_ANH * ENC_TA * ENC_YS;              // [ANH*16][YS]  hidden layers; first the self / obstacle MLPs' (one tile)
+    // [ANH*16][YS]  hidden layers; first the self / obstacle MLPs' (one tile)
+    uint16_t *buf_h = buf_a + ENC_ANH * ENC_TA * ENC_YS;
     uint16_t *cat = buf_h + ENC_ANH * ENC_TA * ENC_YS;                // [16][CS]: self | neighbourhood | obstacles
     float *s_alpha = (float *)(cat + ENC_TA * ENC_CS);                // [8 waves][ANH][16] partial scores of the group
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
@@ -636,7 +622,8 @@ __device__ __forceinline__ void mha_body(const float *__restrict__ obs, int B, c
     const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT, nbw = P.nbr_dim * NB;
     traj_copy(P, a0, ENC_TA, B);
 
-    for (int idx = tid; idx < ENC_TA * 128; idx += 64 * ENC_WAVES) {   // columns as bf16, zero padded: [self 32 | obstacle 32 | neighbours 64]
+    // columns as bf16, zero padded: [self 32 | obstacle 32 | neighbours 64]
+    for (int idx = tid; idx < ENC_TA * 128; idx += 64 * ENC_WAVES) {
         const int a = idx >> 7, c = idx & 127, ga = a0 + a;
         int col = -1;
         uint16_t *dst;
@@ -815,7 +802,8 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim;
     const int mode = P.nbr_encoder;
-    const bool nbr_enc = NB > 0 && mode != ENC_NBR_NONE;   // no_encoder: the neighbour columns are in the row but nothing reads them (:289-291)
+    // no_encoder: the neighbour columns are in the row but nothing reads them (:289-291)
+    const bool nbr_enc = NB > 0 && mode != ENC_NBR_NONE;
     const int col_nbr = ENC_H, col_obst = ENC_H * (nbr_enc ? 2 : 1);   // column blocks of `cat` in the order of the reference's torch.cat
     const int mt0 = wave * ENC_MT;   // first of this wave's 16-feature tiles of a 256-wide layer
 
@@ -827,7 +815,8 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     {
         uint32_t *z = (uint32_t *)x_self;   // x_self, x_nbr, x_obst are contiguous: clear the padding first
         for (int idx = tid; idx < (2 + ENC_MAX_NBR) * ENC_TA * ENC_XS / 2; idx += 64 * ENC_WAVES) z[idx] = 0;
-        constexpr int PER = (ENC_TA * (32 + 32 * ENC_MAX_NBR + 32) + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);   // upper bound on elements per thread
+        // upper bound on elements per thread
+        constexpr int PER = (ENC_TA * (32 + 32 * ENC_MAX_NBR + 32) + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);
         const int total = ENC_TA * D;
         const size_t first = (size_t)a0 * D;
         const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
@@ -924,7 +913,8 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 #define ENC_WSLOTS (ENC_MAX_NBR + 1)   // neighbour slots in the staging rows: ceil(8 / 3) * 3
 struct WRing { bf16x8 a[ENC_WPD][ENC_MT]; };
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t layer_rsrc(const EncLayer &L) {   // a layer without weights (w == nullptr, M == 0): every load is out of range and returns zero
+// a layer without weights (w == nullptr, M == 0): every load is out of range and returns zero
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t layer_rsrc(const EncLayer &L) {
     return __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, L.M * L.K * 2, 0x00020000);
 }
 #define ENC_RFRAG(rs, mtile, kst, mt, ks) ENC_WLOAD(__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (((mtile) + (mt)) * (kst) + (ks)) * 1024, 0)))
@@ -936,7 +926,8 @@ __device__ __forceinline__ void ring_fill(WRing &R, const EncLayer &L, int mtile
 #pragma unroll
     for (int s = 0; s < ENC_WPD; ++s)
 #pragma unroll
-        for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rs, mtile0, kst, mt, s);   // K-steps past a short layer: in-range junk nobody multiplies
+        // K-steps past a short layer: in-range junk nobody multiplies
+        for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rs, mtile0, kst, mt, s);
 }
 
 // acc (+)= L[features of (wave, mt)] x X[row tiles]; the ring holds L's first ENC_WPD K-steps on entry and Ln's on exit.
@@ -978,7 +969,8 @@ __device__ __forceinline__ void gemm_ring(WRing &R, const EncLayer &L, int mtile
                 }
 #pragma unroll
                 for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rs, mtile0, KS, mt, ks0 + s + ENC_WPD);
-                __builtin_amdgcn_sched_barrier(0);   // keep the K-steps in program order: hoisted LDS reads of later K-steps cost 4 VGPRs per tile each
+                // keep the K-steps in program order: hoisted LDS reads of later K-steps cost 4 VGPRs per tile each
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -1244,9 +1236,11 @@ __device__ __forceinline__ void embed_wide_body(const float *__restrict__ obs, i
         const float invB = 1.0f / (float)B;
         const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
 #pragma unroll 6
-        for (int idx = tid; idx < ENC_WSLOTS * ENC_WA * 32; idx += 64 * ENC_WAVES) {   // 18 iterations; neighbour slots past NB are zero rows
+        // 18 iterations; neighbour slots past NB are zero rows
+        for (int idx = tid; idx < ENC_WSLOTS * ENC_WA * 32; idx += 64 * ENC_WAVES) {
             const int row = idx >> 5, c = idx & 31, k = row / ENC_WA, a = row % ENC_WA, ga = a0 + a;
-            const uint32_t i_self = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB) * (uint32_t)D + c;   // self_obs.repeat(K, 1)  (:84)
+            // self_obs.repeat(K, 1)  (:84)
+            const uint32_t i_self = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB) * (uint32_t)D + c;
             const uint32_t i_nbr = (uint32_t)ga * (uint32_t)D + P.self_dim + k * P.nbr_dim + (c - P.self_dim);
             const float v = obs_at(ors, ga < B && k < NB && c < P.self_dim + P.nbr_dim, c < P.self_dim ? i_self : i_nbr);
             x_in[row * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
@@ -1374,7 +1368,8 @@ __device__ __forceinline__ void attn_wide_body(const float *__restrict__ obs, in
         for (int nt = 0; nt < NT; ++nt) {
             const int k = t0 + nt / ENC_AT, ga = a0 + (nt % ENC_AT) * 16 + (lane & 15);
             const uint32_t j = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB);
-            const uint32_t off = (ga < B && k < NB) ? j * (ENC_H * 4) + (lane >> 4) * 16 : 0xffffffffu;   // padding rows: out of range, reads zero
+            // padding rows: out of range, reads zero
+            const uint32_t off = (ga < B && k < NB) ? j * (ENC_H * 4) + (lane >> 4) * 16 : 0xffffffffu;
 #pragma unroll
             for (int mt = 0; mt < ENC_MT; ++mt) acc[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, (mt0 + mt) * 64, 0));
         }
@@ -1551,7 +1546,8 @@ static int wide_min_agents(int dev) {
     if (!cus[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; } cus[dev] = n; }
     return ENC_TA * cus[dev] + 1;
 }
-int32_t qs_enc_set_wide_min(int32_t agents) { const int prev = g_wide_min; if (agents >= -1) g_wide_min = agents; return prev; }   // -1: the default rule; < -1: read only
+// -1: the default rule; < -1: read only
+int32_t qs_enc_set_wide_min(int32_t agents) { const int prev = g_wide_min; if (agents >= -1) g_wide_min = agents; return prev; }
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
 size_t qs_enc_lds_bytes(void) { return lds_main(0); }
 // LDS request of the kernel that serves `model` (QS_ENC_NBR_* / QS_ENC_MODEL_*): the multi-head and Sim2Real kernels ask for more than
@@ -1563,7 +1559,8 @@ size_t qs_enc_lds_bytes_of(int32_t model) {
     return lds_main(0);
 }
 
-// out[B, 512] (ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are device pointers
+// out[B, 512] (ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are
+// device pointers
 int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *out, void *stream) {
     if (!obs || !params || B < 0) { g_enc_error = "bad argument"; return -1; }
     const EncParams &P = *params;

@@ -421,7 +421,8 @@ __device__ QS_COLD void scenario_step_local(const Consts<real> &c, const RngKey 
                 real u[6];
                 for (int k = 0; k < 6; ++k) { int ax = k % 3; u[k] = rng_uniform1<real>(key, QS_SITE_SCEN, 300 + 8 * it + k, 0, 0, -high[ax], high[ax]); }
                 int lo_i = (int)floorf((float)min_dist), hi_i = (int)max_dist + 1;   // np.random.randint truncates a float low
-                int r = (QS_ON_TAPE(key) ? 0 : lo_i) + rng_index<real>(key, QS_SITE_SCEN, 300 + 8 * it + 6, hi_i - lo_i);   // (tape: the randint value itself)
+                // (tape: the randint value itself)
+                int r = (QS_ON_TAPE(key) ? 0 : lo_i) + rng_index<real>(key, QS_SITE_SCEN, 300 + 8 * it + 6, hi_i - lo_i);
                 bool ok = true;
                 for (int col = 0; col < 2; ++col) {
                     real v[3] = {u[0 + col], u[2 + col], u[4 + col]}, n = norm3<real>(v);

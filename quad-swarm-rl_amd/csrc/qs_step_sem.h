@@ -67,7 +67,8 @@ __device__ __forceinline__ void main_reward(const Consts<real> &c, const real *r
     ri[QS_RI_REW_QUADCOL_OBST] = 0; ri[QS_RI_RAW_QUADCOL_OBST] = 0;
 }
 
-// first obstacle hit of this drone -> event bits (quadrotor_multi.py:462-470: a hit counts as NEW when the drone was not in contact the step before)
+// first obstacle hit of this drone -> event bits (quadrotor_multi.py:462-470: a hit counts as NEW when the drone was not in contact the
+// step before)
 __device__ __forceinline__ void obstacle_hit_bits(int obst_idx, uint32_t &flags, uint32_t &bits) {
     if (obst_idx >= 0) { bits |= B_OBST_HIT; if (!(flags & F_PREV_OBST)) bits |= B_OBST_NEW; flags |= F_PREV_OBST; }
     else flags &= ~F_PREV_OBST;
@@ -156,7 +157,8 @@ __device__ __forceinline__ void collision_rewards(const Consts<real> &c, const r
 // wave-uniformly; the others keep the same representation so that every kernel of a handle reads what any other wrote):
 //  * dist_ring (the last 4 distances; reached_goal = mean of 5 < metric * dt, i.e. within millimetres of the goal): a mean of five
 //    non-negative values is below x only if every one of them is below 5 x, so a logged value >= 5.5 * metric * dt can never be part of a
-//    triggering window (the logged value is the raw position cost, control_dt * distance: "near" means within 2.75 * metric metres).  Such entries are not maintained: the ring of a drone is valid only while F_RING_LIVE says so (set while the
+// triggering window (the logged value is the raw position cost, control_dt * distance: "near" means within 2.75 * metric metres).  Such
+// entries are not maintained: the ring of a drone is valid only while F_RING_LIVE says so (set while the
 //    ring holds at least one "near" entry and the goal has not been reached); otherwise every entry stands for "far" (1e30).  The
 //    decisions are the reference's exactly - a window that contains a far entry gives false in both forms, with a margin of 10 %.
 //  * dist_sums (sums of the last 1 / 3 / 5 s): zero in HBM from the reset until the 5-s window of the episode opens (they used to be
@@ -177,7 +179,8 @@ __device__ __forceinline__ bool ring_needed(const Consts<real> &c, real metric, 
 template <typename real, bool LAZY>
 __device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real metric, int tick, bool done, uint32_t &flags, real ring[4], real sums[3], const real *ri, real eps_dist[3]) {
     const real dnow = -ri[QS_RI_RAW_POS];
-    if (!(flags & F_RING_LIVE)) { ring[0] = ring[1] = ring[2] = ring[3] = (real)1e30; }   // not maintained = far (also: whatever the row holds after a reset)
+    // not maintained = far (also: whatever the row holds after a reset)
+    if (!(flags & F_RING_LIVE)) { ring[0] = ring[1] = ring[2] = ring[3] = (real)1e30; }
     if (tick >= 5 && !(flags & F_REACHED)) {
         real mean5 = ((((ring[3] + ring[2]) + ring[1]) + ring[0]) + dnow) * (real)0.2;
         if (mean5 * c.inv_dt < metric) flags |= F_REACHED;
@@ -190,7 +193,8 @@ __device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real me
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
         const int win = (w == 0 ? 1 : (w == 1 ? 3 : 5)) * c.control_freq;
-        real sum = (tick == 1 || (LAZY && !sums_window_open<real>(c, tick))) ? (real)0 : sums[w];   // (not LAZY: the row holds zeros outside the window anyway)
+        // (not LAZY: the row holds zeros outside the window anyway)
+        real sum = (tick == 1 || (LAZY && !sums_window_open<real>(c, tick))) ? (real)0 : sums[w];
         if (tick > total - win) sum += dnow;
         eps_dist[w] = c.inv_dt * (sum * c.inv_win[w]);
         sums[w] = done ? (real)0 : sum;
@@ -315,7 +319,8 @@ __device__ __forceinline__ void pair_responses(const RngKey &key, Drone<real> &d
     }
 }
 
-// 3) obstacle response, 4) wall then ceiling (:565-587).  s_ox / s_oy: the env's obstacle positions in LDS; obst_size_env: the env's obstacle size of the running episode.
+// 3) obstacle response, 4) wall then ceiling (:565-587).  s_ox / s_oy: the env's obstacle positions in LDS; obst_size_env: the env's
+// obstacle size of the running episode.
 template <typename real, typename Sync>
 __device__ __forceinline__ void room_obstacle_phase(const Consts<real> *cp, const RngKey &key, Drone<real> &d, bool active, int N, int i, uint32_t bits, int obst_idx,
                                                     const real *s_ox, const real *s_oy, const real *obst_size_env, int *s_cur_env, Sync sync) {

@@ -33,11 +33,13 @@ struct XchgDev {
     long long n;                // elements per rank (rows * cols)
     long long slot_bytes;
     int world, rank, wire;
-    int auto_ack;               // 1: the launch that pushed sequence number s also waits for s from every rank and releases it (no in-place reader)
+    // 1: the launch that pushed sequence number s also waits for s from every rank and releases it (no in-place reader)
+    int auto_ack;
     unsigned int blocks;        // workgroups of one step launch (set by qs_set_obs_exchange)
     unsigned long long timeout_ticks;
     Q8Dev q8;                   // wire == QS_WIRE_Q8
-    int fenced;                 // QS_XCHG_FENCED=1: a system-scope release fence in front of every flag store, an acquire fence behind every flag wait
+    // QS_XCHG_FENCED=1: a system-scope release fence in front of every flag store, an acquire fence behind every flag wait
+    int fenced;
 };
 
 struct PushArgs {
@@ -61,8 +63,9 @@ __device__ __forceinline__ unsigned int f32_to_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
-// (every layout value by VALUE: with the struct passed by reference the compiler turns the select over its adjacent scale fields into an indexed
-//  load, which pins the whole struct in scratch memory - 28-48 bytes of private segment and ~10 us per C4 step in the fused epilogue)
+// (every layout value by VALUE: with the struct passed by reference the compiler turns the select over its adjacent scale fields into an
+// indexed load, which pins the whole struct in scratch memory - 28-48 bytes of private segment and ~10 us per C4 step in the fused
+// epilogue)
 __device__ __forceinline__ float q8_scale_of(int a, float s0, float s1, float s2, float s3, float s4, float s5) {
     float sc = s0;
     sc = a == 1 ? s1 : sc; sc = a == 2 ? s2 : sc; sc = a == 3 ? s3 : sc; sc = a == 4 ? s4 : sc; sc = a == 5 ? s5 : sc;
@@ -72,7 +75,8 @@ __device__ __forceinline__ float q8_scale(const Q8Dev &q, int a) { return q8_sca
 // QS_WIRE_Q8: 4-byte word j of the wire row of the float32 row `row` (LDS or global memory)
 __device__ __forceinline__ unsigned int q8_byte(float x, float scale) {
     const float v = __builtin_rintf(x * scale);                       // round half to even (v_rndne_f32)
-    const int q = (int)__builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);   // (NaN -> -127 by the min / max order: not a value the env produces)
+    // (NaN -> -127 by the min / max order: not a value the env produces)
+    const int q = (int)__builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);
     return (unsigned int)q & 0xffu;
 }
 __device__ __forceinline__ unsigned int q8_row_word_v(const float *row, int D, int q0, int q1, int w16, float s0, float s1, float s2, float s3, float s4, float s5, int j) {
@@ -84,7 +88,8 @@ __device__ __forceinline__ unsigned int q8_row_word_v(const float *row, int D, i
         return lo | (hi << 16);
     }
     const int m = 4 * (j - w16);
-    const int a0 = m % 6;   // = 0, 4 or 2: the column kind (3 relative-position, 3 relative-velocity columns per neighbour) of the word's first byte
+    // = 0, 4 or 2: the column kind (3 relative-position, 3 relative-velocity columns per neighbour) of the word's first byte
+    const int a0 = m % 6;
     unsigned int o = 0;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -107,10 +112,12 @@ __device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8De
 __device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// The FENCED variant of the protocol (endpoints created under QS_XCHG_FENCED=1; opt-in fallback if ObsExchange.verify() ever fails on a real
-// xGMI node, before giving the transport up for RCCL): whoever stores a flag first executes a system-scope RELEASE fence (buffer_wbl2 sc0 sc1 +
-// wait: everything this XCD's L2 still holds goes out), whoever has seen a flag executes a system-scope ACQUIRE fence (buffer_inv sc0 sc1).
-// One fence per launch and direction - on the wave that stores / polls the flags - not one per workgroup (that form cost ~20 us per step).
+// The FENCED variant of the protocol (qs_xchg_set_fenced, or endpoints created under QS_XCHG_FENCED=1; the fallback if ObsExchange.verify()
+// ever fails on a real xGMI node, before giving the transport up for RCCL).  Producer: EVERY workgroup executes a system-scope RELEASE
+// fence (buffer_wbl2 sc0 sc1 + wait) behind its drained rows and in front of its ticket - a release writes back the L2 of the XCD it runs
+// on, so the fence of the last workgroup alone (round 5) would have covered only the rows produced on that one XCD; ~20 us per
+// step when it was measured in round 3, acceptable on a fallback.  Consumer: whoever has seen a flag executes a system-scope ACQUIRE fence
+// (buffer_inv sc0 sc1), once per launch, on the wave that polls.
 __device__ __forceinline__ void fence_release_sys(int fenced) { if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); }
 __device__ __forceinline__ void fence_acquire_sys(int fenced) { if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); }
 
@@ -149,9 +156,12 @@ struct Gate {   // (sequence numbers: control steps since the gate was created, 
     char *act_ring;                      // [ring_len][T][4] real: the action batch of sequence number s is slot (s - 1) % ring_len
     unsigned long long act_stride;       // bytes of one batch
     unsigned int ring_len, groups, wg_per_group, blocks;
-    unsigned int status, pad;            // status bits: 1 = an action wait timed out (the launch then stopped waiting), 2 = a producer wait timed out
-    unsigned long long *act_flag;        // [groups]  producer -> stepper: the actions of sequence number <= act_flag[g] for the workgroups of group g are in the ring
-    unsigned long long *done_flag;       // [blocks]  stepper -> consumers: obs / reward / done of sequence number done_flag[w] of workgroup w's environments are in HBM
+    // status bits: 1 = an action wait timed out (the launch then stopped waiting), 2 = a producer wait timed out
+    unsigned int status, pad;
+    // [groups]  producer -> stepper: the actions of sequence number <= act_flag[g] for the workgroups of group g are in the ring
+    unsigned long long *act_flag;
+    // [blocks]  stepper -> consumers: obs / reward / done of sequence number done_flag[w] of workgroup w's environments are in HBM
+    unsigned long long *done_flag;
 };
 // (the gate's ring and sequence words live in fine-grained, uncached device memory - qs_gate_create - like the exchange's flag windows;
 // relaxed system-scope accesses go straight to it)
@@ -167,11 +177,11 @@ __device__ __forceinline__ bool poll_ge_agent(const unsigned long long *p, unsig
     return ld_agent(p) >= want;
 }
 // Data handed between concurrently running kernels.  Stepper -> consumer (observation rows, reward, done, masks; ordinary coarse-grained
-// device memory): SYSTEM-scope write-through stores (`sc0 sc1`, like the producer's ring writes: with `sc1` alone a flag was seen to overtake
-// its batch), drained (s_waitcnt vmcnt(0)) before done_flag is raised.  A consumer that has seen done_flag >= s executes an agent-scope
-// acquire (`buffer_inv sc1` = __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")) before it reads the rows: its own XCD's L2 may still hold
-// the rows of step s - 1 (include/quadswarm.h; tests/test_gated_gpu.py runs such a consumer against a resident launch).
-// Producer -> stepper (the action ring, uncached memory): `sc0 sc1` loads.
+// device memory): SYSTEM-scope write-through stores (`sc0 sc1`, like the producer's ring writes: with `sc1` alone a flag was seen to
+// overtake its batch), drained (s_waitcnt vmcnt(0)) before done_flag is raised.  A consumer that has seen done_flag >= s executes an
+// agent-scope acquire (`buffer_inv sc1` = __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")) before it reads the rows: its own XCD's L2 may
+// still hold the rows of step s - 1 (include/quadswarm.h; tests/test_gated_gpu.py runs such a consumer against a resident
+// launch). Producer -> stepper (the action ring, uncached memory): `sc0 sc1` loads.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4_t ld16_sc1(const void *p) { u32x4_t v; asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
 __device__ __forceinline__ unsigned int ld4_sc1(const void *p) { unsigned int v; asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }

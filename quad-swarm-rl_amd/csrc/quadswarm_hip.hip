@@ -11,6 +11,7 @@
 // order of operations that the step kernel follows.
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -43,17 +44,20 @@ struct qs_handle {
     int obs_dim = 0, epb = 1, blocks = 0;
     LdsLayout lds;
     bool full = false;     // scenario outside the fast set => kernels compiled with QS_SCEN_FULL
-    int cus = 256, persist_per_cu = 0;   // QS_PERSIST: workgroups per CU of the persistent single-wave step kernel (0 = off)
-    int team = 0;          // waves per workgroup of the team kernels (qs_step_team.inc): 4 generic, 8 (or 4) specialised; 0 = single-wave kernels
+    int cus = 256;
+    // waves per workgroup of the team kernels (qs_step_team.inc): 4 generic, 8 (or 4) specialised; 0 = single-wave kernels
+    int team = 0;
     // config-specialised code object (qs_spec_kernels.hip), when one is cached / could be built
     // environment snapshots (qs_snapshot_*): `snap_slots` packed copies of one environment's complete state
-    struct SnapArray { char *base; size_t elem, comps, comp_stride, per_env; int kind; size_t group, group_stride; };   // strides / counts in elements; kind: 1 = obs, 2 = episode sums; group > 0: wave-blocked (envs per block, bytes between blocks)
+    // strides / counts in elements; kind: 1 = obs, 2 = episode sums; group > 0: wave-blocked (envs per block, bytes between blocks)
+    struct SnapArray { char *base; size_t elem, comps, comp_stride, per_env; int kind; size_t group, group_stride; };
     std::vector<SnapArray> snap_arrays;
     size_t snap_bytes = 0;
     char *snap_pool = nullptr;
     int32_t snap_slots = 0;
     hipModule_t spec_mod = nullptr;
-    hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr, spec_gated = nullptr;   // (spec_gated: team objects only)
+    // (spec_gated: team objects only)
+    hipFunction_t spec_step = nullptr, spec_rollout = nullptr, spec_reset = nullptr, spec_gated = nullptr;
     std::string spec_note;   // why the handle runs the generic kernels (empty when it runs a config-specialised code object)
     Consts<float> kf;    // kernel constants, passed by value in the kernarg segment
     Consts<double> kd;
@@ -72,7 +76,8 @@ struct qs_handle {
     uint8_t *h_mask = nullptr;   // pinned staging for qs_reset masks
     // batched experience replay (qs_replay_enable)
     bool replay_on = false;
-    bool replay_stepped = false;   // a step was taken since qs_replay_enable: an explicit reset from now on is recorded by the wrapper state
+    // a step was taken since qs_replay_enable: an explicit reset from now on is recorded by the wrapper state
+    bool replay_stepped = false;
     ReplayParams rp;
     // noise tape (qs_set_noise_tape): device copy [E][tape_len] + per-env cursor; while set, reset / step run the tape kernels
     double *d_tape = nullptr;
@@ -81,7 +86,8 @@ struct qs_handle {
     // resident-state stepping (qs_gate_create / qs_step_gated): device descriptor + action ring + sequence flags, one allocation
     qsx::Gate *d_gate = nullptr;
     qsx::Gate gate_host = {};
-    unsigned long long gate_step_seq = 0, gate_prod_seq = 0;   // control steps launched so far by qs_step_gated / fed so far by qs_gate_produce
+    // control steps launched so far by qs_step_gated / fed so far by qs_gate_produce
+    unsigned long long gate_step_seq = 0, gate_prod_seq = 0;
     // The gated launch must be RESIDENT while its producer runs: two streams of one process may share a hardware queue (the runtime maps
     // streams onto a few HSA queues per priority level), and a queue runs its kernels one after the other - the producer behind a stepper
     // that waits for it would be a bounded deadlock (seen: 500 ms per launch in one of two otherwise identical bench runs).  The gated
@@ -222,25 +228,25 @@ static const char *const kSpecFlags = "--genco --offload-arch=gfx950 -O3 -std=c+
 // instantiation and the generic library keep strict IEEE semantics.
 static const char *const kSpecFlagsF32 = "-ffast-math -fno-slp-vectorize";
 // team objects only (one wave per SIMD, a budget of 256 - 512 VGPRs it does not need for occupancy): the machine scheduler's max-ILP
-// strategy instead of the occupancy-first default.  Same box, us per step: C4 13.58 -> 12.98, C3 8.39 -> 8.17, C2 7.86 -> 7.84, mix 11.95 ->
-// 11.76; the single-wave throughput kernels lose 1 % with it and keep the default (profiles/r03_sched_max_ilp_ab.txt).  Instruction order
+// strategy instead of the occupancy-first default.  Same box, us per step: C4 13.58 -> 12.98, C3 8.39 -> 8.17, C2 7.86 -> 7.84, mix 11.95
+// -> 11.76; the single-wave throughput kernels lose 1 % with it and keep the default (profiles/r03_sched_max_ilp_ab.txt).  Instruction
+// order
 // only: results are bit-identical.  If the compiler fails on an object with it, the object is built without.
 static const char *const kSpecFlagsTeam = "-mllvm -amdgpu-sched-strategy=max-ilp";
-// 8-wave team objects (N <= 8) only: without the post-RA scheduler on top.  Round 5's scheduler sweeps (tools/sched_sweep.py, profiles/r05s_ /
-// r05t_sched_sweep.txt; same box, us per step): C2 7.65 -> 7.43-7.46, C3 8.01 -> 8.01, while the 4-wave C4 object loses with it (12.65 -> 13.3)
-// and keeps the flag above; every other knob of the sweep (clustering, reschedule stages, RP trackers, scheduling direction) stayed inside
-// +- 0.03 of these.  Instruction order only: results are bit-identical.
+// 8-wave team objects (N <= 8) only: without the post-RA scheduler on top.  Round 5's scheduler sweeps (tools/sched_sweep.py,
+// profiles/r05s_ / r05t_sched_sweep.txt; same box, us per step): C2 7.65 -> 7.43-7.46, C3 8.01 -> 8.01, while the 4-wave C4 object loses
+// with it (12.65 -> 13.3) and keeps the flag above; every other knob of the sweep (clustering, reschedule stages, RP trackers, scheduling
+// direction) stayed inside +- 0.03 of these.  Instruction order only: results are bit-identical.
 static const char *const kSpecFlagsTeam8 = "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0";
-// (QS_SPEC_TEAM_FLAGS in the environment replaces both - part of the cache key like QS_SPEC_EXTRA_FLAGS: the sweeps of tools/sched_sweep.py)
-// single-wave objects (the throughput kernels, capped at 128 registers): built with the compiler's default scheduler settings.  Experiment, NOT
-// taken: the scheduler's AMDGPU-specific register-pressure trackers (`-mllvm -amdgpu-use-amdgpu-trackers`; QS_SPEC_SINGLE_FLAGS sets it).  Round 5's
-// sweeps 4 / 5 (profiles/r05z_sched_sweep.txt, r05z5_sched_sweep.txt; 2^20 drones, same box, us per step): the C3 shape 118.6 -> 109.2,
-// 119.7 -> 114.0, 112.6 -> 108.2 (three interleaved pairs on two boxes: - 4 to - 8 %; 44 -> 12 bytes of scratch per lane), the C2 and C4 shapes
-// inside their run-to-run noise - but with the flag as the default one float32 parity case of the single-wave kernels failed
-// (test_teacher_forced_f32_single_wave_kernels[e_n17_kall_obst], profiles/r05zz_single_wave_f32_parity.txt: 17 passed, 1 failed) in the last
-// GPU call of the round, with no budget left to find out why.  A flag that is supposed to change instruction order only and fails a parity
-// test is not shipped on a hunch: the default stays what the whole suite ran on.
-static const char *const kSpecFlagsSingleF32 = "";
+// (QS_SPEC_TEAM_FLAGS in the environment replaces both - part of the cache key like QS_SPEC_EXTRA_FLAGS: the sweeps of
+// tools/sched_sweep.py) single-wave float32 objects (the throughput kernels, capped at 128 registers): the scheduler's AMDGPU-specific
+// register-pressure trackers. Round 5's sweeps (profiles/r05z_sched_sweep.txt, r05z5_sched_sweep.txt; 2^20 drones, same box, us per step):
+// the C3 shape 118.6 -> 109.2, 119.7 -> 114.0, 112.6 -> 108.2 (44 -> 12 bytes of scratch per lane), the C2 and C4 shapes inside their
+// run-to-run noise.  Round 5 did not ship it because one parity case failed with it (e_n17_kall_obst); round 6 found why - a spill the
+// register allocator put in front of an exec restore, a compiler defect that any object can carry, with or without this flag
+// (spec_verify_file above) - and every object is now checked for it whatever its flags.  Instruction order only: results are
+// bit-identical (tests/test_object_identity_gpu.py).
+static const char *const kSpecFlagsSingleF32 = "-mllvm -amdgpu-use-amdgpu-trackers";
 static const char *spec_team_flags(int team) { const char *ev = getenv("QS_SPEC_TEAM_FLAGS"); return ev ? ev : (team == 8 ? kSpecFlagsTeam8 : kSpecFlagsTeam); }
 static const char *spec_sched_flags(int team, int precision) {
     if (team > 0) return spec_team_flags(team);
@@ -253,7 +259,8 @@ static bool spec_key(const std::string &header, std::string &key) {
     uint64_t h = fnv1a(14695981039346656037ull, header);
     h = fnv1a(h, kSpecFlags);
     h = fnv1a(h, kSpecFlagsF32);
-    h = fnv1a(h, spec_team_flags(4)); h = fnv1a(h, spec_team_flags(8)); h = fnv1a(h, spec_sched_flags(0, QS_PRECISION_F32));   // (the header carries team width and precision: all strings, whichever applies)
+    // (the header carries team width and precision: all strings, whichever applies)
+    h = fnv1a(h, spec_team_flags(4)); h = fnv1a(h, spec_team_flags(8)); h = fnv1a(h, spec_sched_flags(0, QS_PRECISION_F32));
     if (const char *xf = getenv("QS_SPEC_EXTRA_FLAGS")) h = fnv1a(h, xf);   // e.g. -DQS_TIMING for tools/phase_timing.py
     const std::string dir = lib_dir();
     for (const char *src : kSpecSources) {
@@ -277,13 +284,274 @@ static std::string spec_cache_dir() {
 }
 static bool file_exists(const std::string &path) { struct stat st; return stat(path.c_str(), &st) == 0 && st.st_size > 0; }
 
+// ---- code-object verification ------------------------------------------------------------------------------------------
+// ROCm 7.2's register allocator can place a VGPR spill, reload, copy or rematerialised constant at the top of a control-flow JOIN block in
+// front of the instruction that restores exec there (`s_or_b64 exec, exec, s[a:b]`): the scalar allocator, which runs first, puts its own
+// spills / copies at the very top of the block (they do not depend on exec), and the vector allocator's "skip the block prologue" stops at
+// the first of those that is not a spill.  A wave that reaches the join through the branch that skipped the `then` side arrives with
+// exec == 0: the spill stores nothing and the later reload returns stale scratch memory.  That is what round 5's unexplained parity
+// failure was (single-wave N = 17 object with the RP-tracker flag: the environment index came back as a float, the counter loads faulted),
+// and the default objects only differed from it by luck: 18 of 269 cached objects carried the pattern somewhere.  Every specialised object
+// is therefore disassembled and scanned before it is used; an object with the pattern is rebuilt with other scheduler settings (instruction
+// order and register assignment change, results do not) and, if none is clean, not used at all (generic kernels, loudly).
+static std::string llvm_bin() { const char *ev = getenv("QS_LLVM_BIN"); return (ev && ev[0]) ? ev : "/opt/rocm/lib/llvm/bin"; }
+static bool starts_with(const std::string &t, const char *p) { return t.compare(0, strlen(p), p) == 0; }
+// instructions of a block prologue that do not depend on exec (SGPR spills to VGPR lanes, scalar moves / adds, waits)
+static bool hz_silent(const std::string &t) {
+    static const char *const k[] = {"v_writelane_b32", "v_readlane_b32", "s_nop", "s_waitcnt", "s_mov_b32", "s_mov_b64", "s_add_i32", "s_add_u32", "s_addk_i32"};
+    for (const char *q : k) if (starts_with(t, q)) return t.find("exec") == std::string::npos;
+    return false;
+}
+// ... and those that do: what the vector register allocator inserts (spill, reload, copy, rematerialised constant, AGPR copy)
+static bool hz_exec_dependent(const std::string &t) {
+    return starts_with(t, "scratch_load_") || starts_with(t, "scratch_store_") || starts_with(t, "v_mov_b32") || starts_with(t, "v_mov_b64") || starts_with(t, "v_accvgpr_");
+}
+// the exec restore of a join / else block: s_or_b64 exec, exec, s[..] | s_xor_b64 exec, exec, s[..] | s_or_saveexec_b64 s[..], s[..]  (NOT
+// `, -1`: whole-wave mode)
+static bool hz_restore(const std::string &t) {
+    if (starts_with(t, "s_or_b64 exec, exec, s[") || starts_with(t, "s_xor_b64 exec, exec, s[")) return true;
+    return starts_with(t, "s_or_saveexec_b64 s[") && t.find("], s[") != std::string::npos;
+}
+// One hazard: the block prologue (instructions + encodings) in front of a misplaced exec restore, the restore itself, what follows it.
+struct SpecHazard { std::string kernel, label; std::vector<std::string> ins, raw; std::string restore, restore_raw; std::vector<std::string> after; };
+static std::string hz_describe(const SpecHazard &h) {
+    std::string o = h.kernel + " <" + h.label + ">:";
+    for (const std::string &t : h.ins) o += " " + t + " ;";
+    return o + " " + h.restore;
+}
+// Scan `llvm-objdump -d --symbolize-operands` text (instruction, then `// address: encoding dwords`).
+static void spec_scan_disassembly(FILE *f, std::vector<SpecHazard> &out) {
+    char line[1024];
+    std::string kernel = "?";
+    SpecHazard cur;
+    bool scanning = false, dependent = false;
+    int follow = 0;   // instructions still to record behind the last hazard's restore
+    while (fgets(line, sizeof line, f)) {
+        std::string t(line);
+        while (!t.empty() && (t.back() == '\n' || t.back() == '\r' || t.back() == ' ' || t.back() == '\t')) t.pop_back();
+        const size_t lt = t.find(" <"), gt = t.rfind(">:");
+        if (!t.empty() && isxdigit((unsigned char)t[0]) && lt != std::string::npos && gt == t.size() - 2) {   // "0000000000002b60 <L14>:"
+            const std::string label = t.substr(lt + 2, gt - lt - 2);
+            if (!(label.size() > 1 && label[0] == 'L' && isdigit((unsigned char)label[1]))) kernel = label;
+            cur = SpecHazard(); cur.kernel = kernel; cur.label = label;
+            scanning = true; dependent = false; follow = 0;
+            continue;
+        }
+        const size_t cm = t.find("//");
+        if (cm == std::string::npos) continue;
+        std::string raw;   // the encoding as bytes (little-endian dwords)
+        {
+            const size_t colon = t.find(':', cm);
+            if (colon != std::string::npos) {
+                const char *q = t.c_str() + colon + 1;
+                while (*q) {
+                    while (*q == ' ') ++q;
+                    if (!isxdigit((unsigned char)*q)) break;
+                    char *e = nullptr;
+                    const unsigned long w = strtoul(q, &e, 16);
+                    if (e - q != 8) break;
+                    for (int b = 0; b < 4; ++b) raw.push_back((char)((w >> (8 * b)) & 0xff));
+                    q = e;
+                }
+            }
+        }
+        t.resize(cm);
+        size_t b = 0;
+        while (b < t.size() && (t[b] == ' ' || t[b] == '\t')) ++b;
+        t = t.substr(b);
+        while (!t.empty() && (t.back() == ' ' || t.back() == '\t')) t.pop_back();
+        if (t.empty()) continue;
+        if (follow > 0) { out.back().after.push_back(t); --follow; }
+        if (!scanning) continue;
+        if (hz_restore(t)) {
+            if (dependent) { cur.restore = t; cur.restore_raw = raw; out.push_back(cur); follow = 3; }
+            scanning = false;
+        } else if (hz_exec_dependent(t)) { dependent = true; cur.ins.push_back(t); cur.raw.push_back(raw); }
+        else if (hz_silent(t)) { cur.ins.push_back(t); cur.raw.push_back(raw); }
+        else scanning = false;
+    }
+}
+// the plain gfx950 code objects inside `path` - a bundle (hipcc --genco), a plain object, or a shared library whose .hip_fatbin section
+// holds one bundle per translation unit - written to temporary files (the caller unlinks them)
+static int spec_extract_elfs(const std::string &path, std::vector<std::string> &elfs, std::string &why) {
+    static int serial = 0;
+    char tag[96];
+    snprintf(tag, sizeof tag, "/tmp/qs_verify_%ld_%d", (long)getpid(), serial++);
+    const std::string base = tag, bin = llvm_bin();
+    std::string blob;
+    if (path.size() > 3 && path.compare(path.size() - 3, 3, ".so") == 0) {
+        const std::string fat = base + ".fatbin";
+        const std::string cmd = "'" + bin + "/llvm-objcopy' --dump-section '.hip_fatbin=" + fat + "' '" + path + "' '" + base + ".copy' > /dev/null 2>&1";
+        const int rc = system(cmd.c_str());
+        unlink((base + ".copy").c_str());
+        const bool ok = rc == 0 && read_file(fat, blob);
+        unlink(fat.c_str());
+        if (!ok) { why = "cannot extract .hip_fatbin from " + path + " (QS_LLVM_BIN=" + bin + ")"; return -1; }
+    } else if (!read_file(path, blob)) { why = "cannot read " + path; return -1; }
+    const std::string magic = "__CLANG_OFFLOAD_BUNDLE__";
+    int k = 0;
+    for (size_t at = blob.find(magic); at != std::string::npos; ++k) {
+        const size_t next = blob.find(magic, at + magic.size());
+        const std::string part = base + "." + std::to_string(k) + ".bundle", elf = base + "." + std::to_string(k) + ".elf";
+        FILE *f = fopen(part.c_str(), "wb");
+        if (!f) { why = "cannot write " + part; return -1; }
+        fwrite(blob.data() + at, 1, (next == std::string::npos ? blob.size() : next) - at, f);
+        fclose(f);
+        const std::string unb = "'" + bin + "/clang-offload-bundler' --unbundle --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 '--input=" + part + "' '--output=" + elf + "' > /dev/null 2>&1";
+        const bool ok = system(unb.c_str()) == 0 && file_exists(elf);
+        unlink(part.c_str());
+        if (ok) elfs.push_back(elf); else unlink(elf.c_str());
+        at = next;
+    }
+    if (k == 0) {   // not a bundle: a plain code object (copied, so that the caller can unlink uniformly)
+        const std::string elf = base + ".plain.elf";
+        FILE *f = fopen(elf.c_str(), "wb");
+        if (!f) { why = "cannot write " + elf; return -1; }
+        fwrite(blob.data(), 1, blob.size(), f);
+        fclose(f);
+        elfs.push_back(elf);
+    }
+    if (elfs.empty()) { why = "no gfx950 code object in " + path; return -1; }
+    return 0;
+}
+static int spec_find_hazards(const std::string &path, std::vector<SpecHazard> &hz, std::string &why) {
+    std::vector<std::string> elfs;
+    if (spec_extract_elfs(path, elfs, why) != 0) { for (const std::string &e : elfs) unlink(e.c_str()); return -1; }
+    int rc = 0;
+    for (const std::string &elf : elfs) {
+        const std::string cmd = "'" + llvm_bin() + "/llvm-objdump' -d --symbolize-operands '" + elf + "' 2> /dev/null";
+        FILE *f = rc == 0 ? popen(cmd.c_str(), "r") : nullptr;
+        if (f) { spec_scan_disassembly(f, hz); if (pclose(f) != 0) { rc = -1; why = "llvm-objdump failed on " + path + " (QS_LLVM_BIN=" + llvm_bin() + ")"; } }
+        else if (rc == 0) { rc = -1; why = "cannot run " + llvm_bin() + "/llvm-objdump"; }
+        unlink(elf.c_str());
+    }
+    return rc;
+}
+// 0 = clean, 1 = the pattern is there (report: one line per place), < 0 = could not be checked (tools missing, not a code object)
+static int spec_verify_file(const std::string &path, std::string &report) {
+    std::vector<SpecHazard> hz;
+    if (spec_find_hazards(path, hz, report) != 0) return -1;
+    for (const SpecHazard &h : hz) report += hz_describe(h) + "\n";
+    return hz.empty() ? 0 : 1;
+}
+// scalar registers named in an operand text: "s5" -> {5}, "s[4:7]" -> {4..7}
+static void hz_sregs(const std::string &t, std::vector<int> &regs) {
+    for (size_t k = 0; k < t.size(); ++k) {
+        if (t[k] != 's' || (k > 0 && (isalnum((unsigned char)t[k - 1]) || t[k - 1] == '_'))) continue;
+        if (k + 1 < t.size() && t[k + 1] == '[') {
+            int lo = 0, hi = 0;
+            if (sscanf(t.c_str() + k, "s[%d:%d]", &lo, &hi) == 2) for (int r = lo; r <= hi; ++r) regs.push_back(r);
+        } else if (k + 1 < t.size() && isdigit((unsigned char)t[k + 1])) regs.push_back(atoi(t.c_str() + k + 1));
+    }
+}
+// REPAIR: the exec restore moves to the front of its block prologue (as far forward as the definition of the mask it reads allows) -
+// straight-line code that nobody jumps into; every other instruction keeps its place relative to the others.  Made only where it provably
+// changes nothing else:
+//   * no exec-dependent instruction sits in front of a prologue instruction that writes the SGPR pair the restore reads;
+// * none of the last five prologue instructions is a v_readlane (VALU-writes-SGPR -> VMEM-reads-it needs 5 wait states, and the restore was
+//     one of them); the first two instructions behind the restore are neither DPP nor lane operations (VALU-write -> DPP wait states);
+//   * the byte sequence occurs in the file exactly as often as the scan reports it.
+// Returns the number of places repaired (file rewritten in place), `left` = the ones that were not, with the reason; < 0 on errors.
+static int spec_repair_file(const std::string &path, std::string &left) {
+    std::vector<SpecHazard> hz;
+    std::string why;
+    if (spec_find_hazards(path, hz, why) != 0) { left = why; return -1; }
+    if (hz.empty()) return 0;
+    std::string blob;
+    if (!read_file(path, blob)) { left = "cannot read " + path; return -1; }
+    int repaired = 0;
+    std::vector<bool> done(hz.size(), false);
+    for (size_t a = 0; a < hz.size(); ++a) {
+        if (done[a]) continue;
+        const SpecHazard &h = hz[a];
+        std::string old_bytes;
+        for (const std::string &r : h.raw) old_bytes += r;
+        old_bytes += h.restore_raw;
+        int same = 0;   // hazards with the identical byte sequence (the same code in two kernels)
+        for (size_t b = a; b < hz.size(); ++b) {
+            std::string ob;
+            for (const std::string &r : hz[b].raw) ob += r;
+            ob += hz[b].restore_raw;
+            if (ob == old_bytes) { done[b] = true; ++same; }
+        }
+        // what the restore reads (and, for s_or_saveexec, also writes)
+        std::vector<int> need;
+        const size_t c1 = h.restore.find(',');
+        hz_sregs(starts_with(h.restore, "s_or_saveexec") ? h.restore.substr(h.restore.find(' ')) : h.restore.substr(h.restore.find(',', c1 + 1)), need);
+        size_t pos = 0;
+        for (size_t k = 0; k < h.ins.size(); ++k) {
+            const std::string &t = h.ins[k];
+            if (!hz_silent(t) || starts_with(t, "s_nop") || starts_with(t, "s_waitcnt") || starts_with(t, "v_writelane")) continue;
+            std::vector<int> wr;
+            const size_t sp = t.find(' ');
+            hz_sregs(t.substr(sp == std::string::npos ? 0 : sp, t.find(',') == std::string::npos ? std::string::npos : t.find(',') - sp), wr);
+            for (int w : wr) for (int n : need) if (w == n) pos = k + 1;
+        }
+        std::string reason;
+        for (size_t k = 0; k < pos; ++k) if (hz_exec_dependent(h.ins[k])) reason = "an exec-dependent instruction sits in front of the definition of the saved mask";
+        for (size_t k = h.ins.size() >= 5 ? h.ins.size() - 5 : 0; k < h.ins.size(); ++k) if (starts_with(h.ins[k], "v_readlane")) reason = "v_readlane among the last five prologue instructions";
+        for (size_t k = 0; k < h.after.size() && k < 2; ++k)
+            if (h.after[k].find("dpp") != std::string::npos || starts_with(h.after[k], "v_readlane") || starts_with(h.after[k], "v_writelane") || starts_with(h.after[k], "v_readfirstlane")) reason = "DPP / lane operation right behind the restore";
+        if (h.restore_raw.empty() || old_bytes.size() < 8) reason = "no encoding in the disassembly";
+        if (reason.empty()) {
+            size_t count = 0;
+            for (size_t at = blob.find(old_bytes); at != std::string::npos; at = blob.find(old_bytes, at + 1)) ++count;
+            if ((int)count != same) reason = "byte sequence found " + std::to_string(count) + " times in the file, " + std::to_string(same) + " expected";
+        }
+        if (!reason.empty()) { left += hz_describe(h) + "   [" + reason + "]\n"; continue; }
+        std::string new_bytes;
+        for (size_t k = 0; k < pos; ++k) new_bytes += h.raw[k];
+        new_bytes += h.restore_raw;
+        for (size_t k = pos; k < h.ins.size(); ++k) new_bytes += h.raw[k];
+        for (size_t at = blob.find(old_bytes); at != std::string::npos; at = blob.find(old_bytes, at + new_bytes.size())) blob.replace(at, old_bytes.size(), new_bytes);
+        repaired += same;
+    }
+    if (repaired > 0) {
+        struct stat st;
+        const std::string tmp = path + ".repair.tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) { left = "cannot write " + tmp; return -1; }
+        fwrite(blob.data(), 1, blob.size(), f);
+        fclose(f);
+        if (stat(path.c_str(), &st) == 0) chmod(tmp.c_str(), st.st_mode);
+        if (rename(tmp.c_str(), path.c_str()) != 0) { unlink(tmp.c_str()); left = "cannot replace " + path; return -1; }
+    }
+    return repaired;
+}
+extern "C" int qs_spec_repair(const char *path, char *left_out, int cap) {
+    if (!path) return fail(QS_ERR_INVALID, "null argument");
+    std::string left;
+    const int rc = spec_repair_file(path, left);
+    if (left_out && cap > 0) { const size_t n = left.size() < (size_t)cap - 1 ? left.size() : (size_t)cap - 1; memcpy(left_out, left.data(), n); left_out[n] = 0; }
+    if (rc < 0) return fail(QS_ERR_UNSUPPORTED, left);
+    return rc;
+}
+extern "C" int qs_spec_verify(const char *path, char *report_out, int cap) {
+    if (!path) return fail(QS_ERR_INVALID, "null argument");
+    std::string report;
+    const int rc = spec_verify_file(path, report);
+    if (report_out && cap > 0) { const size_t n = report.size() < (size_t)cap - 1 ? report.size() : (size_t)cap - 1; memcpy(report_out, report.data(), n); report_out[n] = 0; }
+    if (rc < 0) return fail(QS_ERR_UNSUPPORTED, report);
+    return rc;
+}
+
 // build <cache>/qs_<key>.hsaco if it is missing; returns its path or "" (reason in g_last_error)
 static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     const std::string header = spec_header_text(cfg, team);
     std::string key;
     if (!spec_key(header, key)) { g_last_error = "kernel sources not found next to the library"; return ""; }
-    const std::string dir = spec_cache_dir(), out = dir + "/qs_" + key + ".hsaco";
-    if (file_exists(out)) return out;
+    const std::string dir = spec_cache_dir(), out = dir + "/qs_" + key + ".hsaco", stamp = dir + "/qs_" + key + ".ok";
+    // QS_SPEC_VERIFY=0: tools that WANT a flagged object (tools/flag_diff.py)
+    const bool verify = !(getenv("QS_SPEC_VERIFY") && atoi(getenv("QS_SPEC_VERIFY")) == 0);
+    if (file_exists(out)) {
+        if (!verify || file_exists(stamp)) return out;
+        std::string report, left;   // an object without its stamp (an older cache): checked now, repaired if that is all it needs
+        int v = spec_verify_file(out, report);
+        if (v == 1 && spec_repair_file(out, left) > 0) { report.clear(); v = spec_verify_file(out, report); }
+        if (v == 0) { FILE *f = fopen(stamp.c_str(), "wb"); if (f) { fputs("verified: no VGPR spill / copy in front of an exec restore\n", f); fclose(f); } return out; }
+        if (v < 0) { g_last_error = "cached code object cannot be verified: " + report; return ""; }
+        unlink(out.c_str());   // the pattern is there and cannot be repaired: rebuilt below with other settings
+    }
     if (!build) { g_last_error = "no cached code object for this configuration"; return ""; }
     mkdir(dir.c_str(), 0755);
     char tag[64];
@@ -298,15 +566,45 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     }
     const char *cc = getenv("HIPCC");
     const std::string src = lib_dir();
-    auto command = [&](bool team_flags) {
-        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + (team_flags ? spec_sched_flags(team, cfg->precision) : "") + " " +
+    auto command = [&](const std::string &sched) {
+        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + sched + " " +
                (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src + "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
     };
-    const bool sched_flags = spec_sched_flags(team, cfg->precision)[0] != 0;   // (if the compiler fails on an object with them, the object is built without)
-    int rc = system(command(sched_flags).c_str());
-    if ((rc != 0 || !file_exists(tmp)) && sched_flags) { unlink(tmp.c_str()); rc = system(command(false).c_str()); }
-    if (rc != 0 || !file_exists(tmp)) { unlink(tmp.c_str()); g_last_error = "specialised kernel build failed, see " + log; return ""; }
+    // The configured scheduler settings first.  An object that carries a spill in front of an exec restore (spec_verify_file) is repaired
+    // in place
+    // (spec_repair_file) and checked again; if the compiler fails, or a place cannot be repaired, the alternatives follow - each only moves
+    // instructions and registers around, the arithmetic is the same (tested: tests/test_object_identity_gpu.py).  Single-wave objects end
+    // with the register cap lifted (no spills at all: 3 instead of 4 waves per SIMD).
+    std::vector<std::string> tries = {spec_sched_flags(team, cfg->precision)};
+    const char *const alt_team[] = {"", "-mllvm -amdgpu-sched-strategy=max-ilp", "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0", "-mllvm -amdgpu-use-amdgpu-trackers"};
+    const char *const alt_single[] = {"", "-mllvm -amdgpu-use-amdgpu-trackers", "-mllvm -enable-post-misched=0", "-DQS_WAVES_PER_EU=0"};
+    for (const char *a : team > 0 ? alt_team : alt_single) { bool seen = false; for (const std::string &t : tries) seen |= t == a; if (!seen) tries.push_back(a); }
+    std::string why = "specialised kernel build failed, see " + log, used;
+    bool ok = false;
+    for (const std::string &sched : tries) {
+        unlink(tmp.c_str());
+        const int rc = system(command(sched).c_str());
+        if (rc != 0 || !file_exists(tmp)) continue;
+        if (!verify) { ok = true; used = sched; break; }
+        std::string report, left;
+        int v = spec_verify_file(tmp, report);
+        // the exec restores moved in front of the spills (spec_repair_file): checked again
+        if (v == 1 && spec_repair_file(tmp, left) > 0) {
+            report.clear();
+            v = spec_verify_file(tmp, report);
+            if (v == 0) { ok = true; used = sched + "' + exec restores moved to the front of their block prologues '"; break; }
+        }
+        if (v == 0) { ok = true; used = sched; break; }
+        why = v < 0 ? "specialised object cannot be verified: " + report
+                    : "every build of this configuration's object has a VGPR spill / copy in front of an exec restore (DESIGN.md 5.3); last one: " + report;
+        if (v < 0) break;
+    }
+    if (!ok) { unlink(tmp.c_str()); g_last_error = why; return ""; }
     if (rename(tmp.c_str(), out.c_str()) != 0) { unlink(tmp.c_str()); g_last_error = "cannot move code object into the cache"; return ""; }
+    if (verify) {
+        FILE *f = fopen(stamp.c_str(), "wb");
+        if (f) { fprintf(f, "verified: no VGPR spill / copy in front of an exec restore; scheduler flags: '%s'%s\n", used.c_str(), used.compare(0, tries[0].size() + 1, tries[0] + "'") == 0 || used == tries[0] ? "" : " (the configured ones were rejected)"); fclose(f); }
+    }
     return out;
 }
 
@@ -397,7 +695,8 @@ template <typename real> static int create_typed(qs_handle *h) {
         if ((rc = dalloc(h, &blk, off)) != QS_OK) return rc;
         p.blk = {blk, (uint32_t)off, (uint32_t)block_bytes, (uint32_t)EPB, (uint32_t)o_pos, (uint32_t)o_vel, (uint32_t)o_rot, (uint32_t)o_omega, (uint32_t)o_rd, (uint32_t)o_cd,
                  (uint32_t)o_ou, (uint32_t)o_goal, (uint32_t)o_ring, (uint32_t)o_sums, (uint32_t)o_flags, (uint32_t)o_pair, (uint32_t)o_newpair, (uint32_t)o_reward,
-                 (uint32_t)o_done, (uint32_t)o_ohit, (uint32_t)(h->team == 8 ? 1 : 0)};   // lane-major <=> the specialised 8-wave team kernels step this handle
+                 // lane-major <=> the specialised 8-wave team kernels step this handle
+                 (uint32_t)o_done, (uint32_t)o_ohit, (uint32_t)(h->team == 8 ? 1 : 0)};
         // block 0's first row of each blocked array (what qs_buffers hands out; layout in include/quadswarm.h)
         p.pos = (real *)(blk + o_pos); p.vel = (real *)(blk + o_vel); p.rot = (real *)(blk + o_rot); p.omega = (real *)(blk + o_omega);
         p.rot_damp = (real *)(blk + o_rd); p.cmds_damp = (real *)(blk + o_cd); p.ou = (real *)(blk + o_ou); p.goal = (real *)(blk + o_goal);
@@ -428,7 +727,8 @@ template <typename real> static int create_typed(qs_handle *h) {
         HIP_TRY(hipMemcpy(p.obst_density_env, dn.data(), E * sizeof(real), hipMemcpyHostToDevice));
     }
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
-    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128 + 16 * NBLK);   // QS_TIMING builds: phase stamps of workgroup 0, then {start, end, HW_ID, XCC_ID, wall start, wall end} of every workgroup
+    // QS_TIMING builds: phase stamps of workgroup 0, then {start, end, HW_ID, XCC_ID, wall start, wall end} of every workgroup
+    DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128 + 16 * NBLK);
 #undef DA
     {   // run-time reward coefficients (+ proximity slope), read by every launch
         real *rw = nullptr;
@@ -464,7 +764,8 @@ template <typename real> static int create_typed(qs_handle *h) {
     auto &sa = h->snap_arrays;
     sa.clear();
 #define SNAP_T(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), T, N, 0, 0, 0})
-    // wave-blocked state array: `comps` rows of 64 elements, or (lane-major) the N drones of an env as ONE contiguous piece of N * comps elements
+    // wave-blocked state array: `comps` rows of 64 elements, or (lane-major) the N drones of an env as ONE contiguous piece of N * comps
+    // elements
 #define SNAP_B(field, comps) sa.push_back(p.blk.lane_major ? qs_handle::SnapArray{(char *)p.field, sizeof(*p.field), 1, 64 * (size_t)(comps), N * (size_t)(comps), 0, EPB, (size_t)p.blk.block_bytes} \
                                                            : qs_handle::SnapArray{(char *)p.field, sizeof(*p.field), (size_t)(comps), 64, N, 0, EPB, (size_t)p.blk.block_bytes})
 #define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1, 0, 0, 0})
@@ -559,8 +860,6 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         h->team = team_default(h->blocks, cus, cfg->num_agents) ? QS_TEAM_WAVES : 0;
         h->cus = cus;
-        // experiment: only objects built with -DQS_PERSIST_LOOP (QS_SPEC_EXTRA_FLAGS) walk over several state blocks per workgroup
-        if (const char *ev = getenv("QS_PERSIST")) { const char *xf = getenv("QS_SPEC_EXTRA_FLAGS"); if (xf && strstr(xf, "QS_PERSIST_LOOP")) h->persist_per_cu = atoi(ev); }
         const char *ev = getenv("QS_TEAM");
         if (ev && ev[0] == '0') h->team = 0;
         else if (ev && (ev[0] == '1' || ev[0] == '4' || ev[0] == '8')) h->team = QS_TEAM_WAVES;
@@ -711,7 +1010,8 @@ int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream) {
     const int E = h->cfg.num_envs;
     for (int e = 0; e < E; ++e) h->h_mask[e] = env_mask_host ? (env_mask_host[e] ? 1 : 0) : 1;
     HIP_TRY(hipMemcpyAsync(h->pf.reset_mask, h->h_mask, (size_t)E, hipMemcpyHostToDevice, s));
-    if (h->replay_on && h->replay_stepped) {   // the replay wrapper's bookkeeping of an explicit reset (before the reset kernel zeroes the running
+    // the replay wrapper's bookkeeping of an explicit reset (before the reset kernel zeroes the running
+    if (h->replay_on && h->replay_stepped) {
         // sums); the reset that starts the very first episode is already in the history (qs_replay_enable)
         hipLaunchKernelGGL(qs_replay_reset_kernel, dim3((E + QS_WAVE - 1) / QS_WAVE), dim3(QS_WAVE), 0, s, h->rp, (const uint8_t *)h->pf.reset_mask);
         HIP_TRY(hipGetLastError());
@@ -749,13 +1049,12 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     // the fused exchange epilogue exists in the one-step kernels only: a multi-step launch would advance the environments without sending
     // their rows and desynchronise push / wait sequence numbers (qs_step_many splits into single steps while an exchange is set)
     if (pf.xchg != nullptr && ksteps > 1) return fail(QS_ERR_UNSUPPORTED, "multi-step launches do not exchange observation rows: qs_set_obs_exchange is active");
-    if (gated) pf.xchg = (const qsx::XchgDev *)h->d_gate;   // the multi-step team kernels read the exchange slot as their gate (qs_step_team.inc)
+    // the multi-step team kernels read the exchange slot as their gate (qs_step_team.inc)
+    if (gated) pf.xchg = (const qsx::XchgDev *)h->d_gate;
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
         void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
-        // persistent form of the single-wave step kernel (QS_PERSIST = workgroups per CU, 0 = one workgroup per state block)
-        int grid = h->blocks;
-        if (!h->team && ksteps == 1 && !gated && h->persist_per_cu > 0 && (long)h->persist_per_cu * h->cus < (long)h->blocks) grid = h->persist_per_cu * h->cus;
+        const int grid = h->blocks;
         if (gated && !h->spec_gated) return fail(QS_ERR_UNSUPPORTED, "the specialised code object of this handle has no resident-state kernel");
         HIP_TRY(hipModuleLaunchKernel(gated ? h->spec_gated : (ksteps == 1 ? h->spec_step : h->spec_rollout), grid, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
@@ -806,7 +1105,8 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
     HIP_TRY(hipSetDevice(h->device));
     if (h->gate_pending) { if (int jr = gate_join_stream(h, (hipStream_t)stream)) return jr; }
     const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * h->real_size;
-    if (h->profiling || h->replay_on || h->pf.xchg) {   // per-step HIP events / the replay kernel behind every step / the fused exchange epilogue: one launch per control step
+    // per-step HIP events / the replay kernel behind every step / the fused exchange epilogue: one launch per control step
+    if (h->profiling || h->replay_on || h->pf.xchg) {
         for (int32_t t = 0; t < k; ++t) {
             int rc = launch_step(h, (const char *)actions_dev + stride * t, (hipStream_t)stream, 1);
             if (rc == QS_OK && h->replay_on) { rc = launch_replay(h, (hipStream_t)stream); h->replay_stepped = true; }
@@ -829,10 +1129,10 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
 // the benchmark's / the tests' producer: per control step it (closed_loop: waits until the outputs of the previous step of ITS workgroups
 // are published, else: only until the ring slot is free), copies the group's share of the next action batch from a table resident in HBM
 // into the ring - written through the L2 - and raises the group's sequence word
-// `sums` (qs_gate_produce_verify, closed loop only): the kernel is also a CONSUMER of the stepper's outputs the way the protocol describes one -
-// having seen done_flag >= s for its workgroups it executes an agent-scope acquire and reads the observation rows and rewards of step s with
-// plain loads - and records a checksum (the sum of their 32-bit words) per step and group, WHILE the gated launch is resident and working on
-// step s + 1.  tests/test_gated_gpu.py compares the sums with those of a one-launch-per-step twin.
+// `sums` (qs_gate_produce_verify, closed loop only): the kernel is also a CONSUMER of the stepper's outputs the way the protocol describes
+// one - having seen done_flag >= s for its workgroups it executes an agent-scope acquire and reads the observation rows and rewards of step
+// s with plain loads - and records a checksum (the sum of their 32-bit words) per step and group, WHILE the gated launch is resident and
+// working on step s + 1.  tests/test_gated_gpu.py compares the sums with those of a one-launch-per-step twin.
 __global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, const char *src, unsigned int n_src, unsigned long long seq0, int k, int closed_loop,
                                                                 unsigned long long wg_bytes, unsigned long long batch_bytes,
                                                                 unsigned long long *sums, const unsigned int *obs_words, const unsigned int *rew_words,
@@ -853,7 +1153,8 @@ __global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, con
                 if (!qsx::poll_ge_agent(&G->done_flag[w], need, G->timeout_ticks)) { dead = 1; atomicOr(&G->status, 2u); break; }
         }
         __syncthreads();
-        if (sums != nullptr && t >= 1) {   // the outputs of sequence number seq - 1 (a step of THIS call), read the way a policy would read them
+        // the outputs of sequence number seq - 1 (a step of THIS call), read the way a policy would read them
+        if (sums != nullptr && t >= 1) {
             if (threadIdx.x == 0) acc = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this XCD's L2 may hold the rows of the step before
             __syncthreads();
@@ -870,8 +1171,8 @@ __global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, con
         if (t == k) break;
         const char *from = src + ((seq - 1) % n_src) * batch_bytes;
         char *to = G->act_ring + ((seq - 1) % G->ring_len) * G->act_stride;
-        // system-scope write-through: the flag below must not become visible before the batch (`sc1` alone was seen to let it: one run in three
-        // of the run-ahead parity test read a stale batch)
+        // system-scope write-through: the flag below must not become visible before the batch (`sc1` alone was seen to let it: one run in
+        // three of the run-ahead parity test read a stale batch)
         for (unsigned long long off = lo + 16ull * threadIdx.x; off < hi; off += 16ull * 256) qsx::st16_wt(to + off, *(const qsx::u32x4_t *)(from + off));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -935,8 +1236,8 @@ int qs_step_gated(qs_handle *h, int32_t k, void *stream) {
     if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
     if (h->profiling || h->replay_on || h->d_tape || h->pf.xchg) return fail(QS_ERR_UNSUPPORTED, "qs_step_gated: not available with per-launch profiling, the replay wrapper, a noise tape or the fused exchange");
     HIP_TRY(hipSetDevice(h->device));
-    // stream-ordered behind everything on the caller's stream, and the caller's stream behind the launch - but the kernel itself sits in the
-    // library's high-priority queue (see qs_handle::gate_stream)
+    // stream-ordered behind everything on the caller's stream, and the caller's stream behind the launch - but the kernel itself sits in
+    // the library's high-priority queue (see qs_handle::gate_stream)
     HIP_TRY(hipEventRecord(h->gate_ev_in, (hipStream_t)stream));
     HIP_TRY(hipStreamWaitEvent(h->gate_stream, h->gate_ev_in, 0));
     // the kernel's action-pointer argument carries the sequence base of this launch (qs_step_team.inc)
@@ -1136,8 +1437,8 @@ int qs_state_array_copy(qs_handle *h, void *host, void *dev_array, int32_t elem,
         }
         return QS_OK;
     }
-    // lane-major: per block 64 lanes x comps adjacent components (lane = local env * N + drone); host: [comps][E * N].  Through a staging copy of
-    // the blocks' pieces of this array (a debugging / test path: one strided copy and a transposition on the host)
+    // lane-major: per block 64 lanes x comps adjacent components (lane = local env * N + drone); host: [comps][E * N].  Through a staging
+    // copy of the blocks' pieces of this array (a debugging / test path: one strided copy and a transposition on the host)
     const size_t nblk = (E + epb - 1) / epb, lanes = epb * N, width = lanes * comps * elem;
     std::vector<char> stage(nblk * width);
     if (!to_device || E % epb)   // (a partial last block: keep what its idle lanes hold)
@@ -1332,7 +1633,9 @@ int qs_debug_lds_bytes(const qs_config *cfg, int team, int spec) {
                       scenario_is_full(cfg->scenario), cfg->scenario, spec ? spec_rows_per_pass(cfg, team) : QS_WAVE).total;
 }
 
-int qs_debug_wg_times(qs_handle *h, unsigned long long *out, int32_t max_blocks) {   // [blocks][16]: start, end (s_memtime), HW_ID, XCC_ID, start, end (100 MHz wall clock), then s_memtime at 10 phase boundaries of wave 0 of every workgroup
+// [blocks][16]: start, end (s_memtime), HW_ID, XCC_ID, start, end (100 MHz wall clock), then s_memtime at 10 phase boundaries of wave 0 of
+// every workgroup
+int qs_debug_wg_times(qs_handle *h, unsigned long long *out, int32_t max_blocks) {
     if (!h || !out) return fail(QS_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -1351,7 +1654,8 @@ int qs_debug_timing(qs_handle *h, unsigned long long *out128) {   // [4 waves][3
 int qs_check_errors(qs_handle *h) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    if (int jr = gate_join_host(h)) return jr;   // the gated kernel's stream is non-blocking: a null-stream copy does not wait for it by itself
+    // the gated kernel's stream is non-blocking: a null-stream copy does not wait for it by itself
+    if (int jr = gate_join_host(h)) return jr;
     uint32_t f = 0;
     HIP_TRY(hipMemcpy(&f, h->pf.error_flag, sizeof f, hipMemcpyDeviceToHost));
     if (f) return fail(QS_ERR_NAN_REWARD, "QuadEnv: reward is Nan");

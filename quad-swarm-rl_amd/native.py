@@ -59,7 +59,27 @@ def build(force=False, verbose=False):
     subprocess.check_call(cmds[-1])
     for o in objs:
         os.remove(o)
+    finish_library(LIB_PATH, verbose)
     return LIB_PATH
+
+
+def finish_library(path, verbose=False):
+    """Every freshly built library goes through the code-object check of include/quadswarm.h: exec restores that the compiler
+    placed behind a VGPR spill / copy at a join block are moved in front of it (qs_spec_repair), and a library that still shows the pattern
+    afterwards is not kept.  (The checker lives in libquadswarm_hip.so itself - host code; when that library is the one being built, it is
+    loaded from the file just written.)"""
+    checker = C.CDLL(LIB_PATH)
+    buf = C.create_string_buffer(1 << 16)
+    checker.qs_spec_repair.argtypes = checker.qs_spec_verify.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    fixed = checker.qs_spec_repair(path.encode(), buf, len(buf))
+    left = buf.value.decode()
+    if verbose or fixed or left:
+        print(f"{os.path.basename(path)}: {fixed} misplaced exec restore(s) repaired" + (f"; left:\n{left}" if left else ""))
+    rc = checker.qs_spec_verify(path.encode(), buf, len(buf))
+    if rc != 0:
+        os.replace(path, path + ".rejected")
+        raise RuntimeError(f"{path}: VGPR spill / copy in front of an exec restore that could not be repaired, or the check could not run "
+                           f"(kept as .rejected):\n{buf.value.decode()}\n{left}")
 
 
 _lib = None
@@ -143,6 +163,8 @@ def lib():
         L.qs_set_profiling.argtypes = [vp, C.c_int32]
         L.qs_get_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.qs_spec_build.argtypes = [C.POINTER(qcfg.QsConfig), C.c_int, C.c_char_p, C.c_int]
+        L.qs_spec_verify.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.qs_spec_repair.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.qs_is_specialized.argtypes = [vp]
         L.qs_spec_status.argtypes = [vp, C.c_char_p, C.c_int]
         L.qs_kernel_flavor.argtypes = [vp]
@@ -195,7 +217,7 @@ def lib():
     return _lib
 
 
-EXPORTED_SYMBOLS = ["qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
+EXPORTED_SYMBOLS = ["qs_spec_verify", "qs_spec_repair", "qs_version", "qs_sizeof_config", "qs_last_error", "qs_default_config", "qs_obs_dim", "qs_create",
                     "qs_destroy", "qs_reset", "qs_step", "qs_step_many", "qs_sync", "qs_get_buffers", "qs_set_reward_coeffs",
                     "qs_get_state", "qs_set_state", "qs_memcpy_d2h", "qs_memcpy_h2d", "qs_state_array_copy", "qs_check_errors", "qs_set_profiling",
                     "qs_get_kernel_time", "qs_spec_build", "qs_is_specialized", "qs_spec_status", "qs_kernel_flavor",
@@ -209,6 +231,24 @@ EXCHANGE_SYMBOLS = ["qs_xchg_create", "qs_xchg_destroy", "qs_xchg_export", "qs_x
 
 class QsError(RuntimeError):
     pass
+
+
+def spec_verify(path):
+    """(0 | 1, report): include/quadswarm.h qs_spec_verify - 1 = the code object / library has a VGPR spill or copy in front of an exec restore"""
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib().qs_spec_verify(str(path).encode(), buf, len(buf))
+    if rc < 0:
+        raise QsError(lib().qs_last_error().decode())
+    return rc, buf.value.decode()
+
+
+def spec_repair(path):
+    """(places repaired, report of the ones left): include/quadswarm.h qs_spec_repair"""
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib().qs_spec_repair(str(path).encode(), buf, len(buf))
+    if rc < 0:
+        raise QsError(lib().qs_last_error().decode())
+    return rc, buf.value.decode()
 
 
 def spec_build(cfg, team=-1):

@@ -134,19 +134,10 @@ class PeerExchange:
         variant of the flag protocol (include/quadswarm_exchange.h, QS_XCHG_FENCED), None = whatever the environment says"""
         self.rows, self.cols, self.world, self.rank, self.device, self.wire, self.q8 = rows, cols, world, rank, device, wire, q8
         self._x = C.c_void_p()
-        import os
-        saved = os.environ.get("QS_XCHG_FENCED")
-        if fenced is not None:   # (the library reads the switch when it creates the endpoint)
-            os.environ["QS_XCHG_FENCED"] = "1" if fenced else "0"
-        self.fenced = os.environ.get("QS_XCHG_FENCED", "0") not in ("", "0")
-        try:
-            self._create(device, world, rank, rows, cols, wire, q8)
-        finally:
-            if fenced is not None:
-                if saved is None:
-                    os.environ.pop("QS_XCHG_FENCED", None)
-                else:
-                    os.environ["QS_XCHG_FENCED"] = saved
+        self._create(device, world, rank, rows, cols, wire, q8)
+        if fenced is not None:   # explicit, through the C ABI (round 5 toggled the process-wide environment variable around the create call)
+            _xcheck(native.lib().qs_xchg_set_fenced(self._x, 1 if fenced else 0))
+        self.fenced = bool(native.lib().qs_xchg_get_fenced(self._x))   # the library's own value, not a second parse of QS_XCHG_FENCED
         self.row_bytes = wire_row_bytes(cols, wire, q8)
         self._views = {}
 

@@ -26,6 +26,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    native.finish_library(ENC_LIB_PATH, verbose)   # the code-object check every library goes through
     return ENC_LIB_PATH
 
 

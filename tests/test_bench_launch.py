@@ -56,7 +56,7 @@ def test_dry_run_at_world_size_8_shards_and_wires():
     assert len(lines) == 1, r.stdout
     rec = lines[0]
     assert rec["n_gpus"] == 8 and rec["config"]["ranks_seen_by_process_group"] == 8 and rec["config"]["workload"] == "c4"
-    assert rec["wire"] == "bf16"                           # the headline wire is the one the Sample Factory env defaults to; q8 is an opt-in
+    assert rec["wire"] == "f32"                            # the headline wire is the bit-exact one (the reference's float observations); bf16 / q8 are labelled lossy variants
     shards = sorted(rec["config"]["shards"], key=lambda d: d["rank"])
     assert [d["rank"] for d in shards] == list(range(8))
     assert [d["envs"] for d in shards] == [[512 * k, 512 * (k + 1)] for k in range(8)]      # BASELINE configs[3]: 4096 envs, contiguous shards

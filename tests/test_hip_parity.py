@@ -354,10 +354,12 @@ def test_teacher_forced_f32(case):
     teacher_forced_f32(case, E, steps, tol)
 
 
-def teacher_forced_f32(case, E, steps, tol, expect_team=None):
+def teacher_forced_f32(case, E, steps, tol, expect_team=None, expect_specialized=False):
     pr = Pair(case, E, "f32")
     if expect_team is not None:
         assert bool(pr.hip.team) == expect_team
+    if expect_specialized:
+        assert pr.hip.specialized, pr.hip.spec_note
     rng = np.random.RandomState(9)
     oobs, hobs = pr.reset()
     tolr.check(f"{case} f32", "obs_reset", hobs, oobs, tolr.allowed_obs(oobs, tol, *pr.obs_layout), "after reset")
@@ -470,6 +472,16 @@ def test_full_size_against_the_oracle(case, E):
     environment's observations, rewards and state within the per-quantity 1e-8, done / tick / flags / pair masks / unique-id sets / obstacle and
     room masks / counters / obstacle-hit indices / episode statistics exact, for all E environments (8192 / 8192 / 16384 drones)."""
     rollout_f64(case, E, 36, 1e-8, ep_time=0.3)
+
+
+@pytest.mark.parametrize("case,E", [("c2_n8_dw", 1024), ("c3_n8_obst", 1024), ("c4_n32_svs", 512)])
+def test_full_size_f32_production_objects_against_the_oracle(case, E):
+    """The float32 PRODUCTION objects (config-specialised team kernels, fast-math, Philox) at the full batch sizes of BASELINE configs[1] / [2]
+    and of configs[3]'s per-GPU shard, teacher-forced from the oracle before every one of 34 control steps (round 5 met the oracle with these
+    objects at 7 environments only): EVERY environment's observations, rewards, reward terms and post-step state inside the per-quantity 1e-5
+    of tests/tolerances.py, done / tick / flags / masks / counters / obstacle-hit indices exact - 8192 / 8192 / 16384 drones per step, the
+    crafted collision, `.any()`-quirk, wall / ceiling / floor and obstacle events included."""
+    teacher_forced_f32(case, E, 34, 1e-5, expect_team=True, expect_specialized=True)
 
 
 @pytest.mark.parametrize("case,E", [("c2_n8_dw", 1024), ("c3_n8_obst", 1024), ("c4_n32_svs", 512)])

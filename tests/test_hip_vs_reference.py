@@ -15,7 +15,7 @@ import pytest
 
 from quad_swarm_rl_amd import config as qcfg
 from tests import golden_util as gu
-from tests.test_oracle_vs_reference import CASES, EDGE_CASES, SCEN_CASES
+from tests.test_oracle_vs_reference import CASES, CASES_FIRST_HIT, EDGE_CASES, SCEN_CASES
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-9
@@ -53,7 +53,7 @@ def check_episode_stats(st, eps, cnt, n, use_obstacles):
         assert cnt[9] == st["num_collisions_obst_quad_3_5"] and cnt[10] == st["num_collisions_obst_quad_5"]
 
 
-@pytest.mark.parametrize("name", CASES + EDGE_CASES + SCEN_CASES)
+@pytest.mark.parametrize("name", CASES + EDGE_CASES + SCEN_CASES + CASES_FIRST_HIT)
 def test_reference_fixture_through_hip(name, monkeypatch):
     from quad_swarm_rl_amd import native
     # a handle with a noise tape only ever launches the tape kernels of the library (launch_reset / launch_step, quadswarm_hip.hip): the
@@ -134,6 +134,8 @@ def test_reference_fixture_through_hip(name, monkeypatch):
                 if cfgd["use_obstacles"]:
                     assert mask_of(ohi[e] >= 0) == int(g["obst_hit"][t])
                 assert int(rn[e]) == int(g["room_new"][t]), f"room collisions step {t}"
+            if cfgd["use_obstacles"] and not done[e].any():   # WHICH obstacle (obstacles/utils.py:31-43: index order, first within reach, break)
+                np.testing.assert_array_equal(ohi[e], g["obst_hit_idx"][t], err_msg=f"first-hit obstacle index step {t}")
             np.testing.assert_array_equal(cnt[:, e], g["counters"][t], err_msg=f"counters step {t}")
             if done[e].any():  # episode stats (quadrotor_multi.py:626-718)
                 check_episode_stats(ep_stats[t], eps[e], epc[:, e], n, cfgd["use_obstacles"])

@@ -22,7 +22,7 @@ import pytest
 
 from tests import golden_util as gu
 from tests import tolerances as tolr
-from tests.test_oracle_vs_reference import CASES, EDGE_CASES, SCEN_CASES
+from tests.test_oracle_vs_reference import CASES, CASES_FIRST_HIT, EDGE_CASES, SCEN_CASES
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -50,7 +50,7 @@ def fp32_boundary(s, cfg):
     return bool(hover.any() or wall.any() or same_height or near_goal.any())
 
 
-@pytest.mark.parametrize("name", CASES + EDGE_CASES + SCEN_CASES)
+@pytest.mark.parametrize("name", CASES + EDGE_CASES + SCEN_CASES + CASES_FIRST_HIT)
 def test_reference_fixture_teacher_forced_through_f32(name, monkeypatch):
     from quad_swarm_rl_amd import native
     monkeypatch.setenv("QS_SPEC", "off")   # tape handles launch the library's tape kernels only: no per-configuration code object to compile

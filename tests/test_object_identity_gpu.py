@@ -1,0 +1,118 @@
+"""Two code objects of the same configuration must produce the same BITS.
+
+(1) Idle lanes.  A wave holds floor(64 / N) whole environments; with N = 17 that leaves 13 of 64 lanes without a drone, and the last
+    workgroup of a batch may have whole environments missing.  The debug build `-DQS_POISON_IDLE=1|2` (qs_kernels.h) starts those lanes
+    from NaN / 3e30 / all-ones instead of a copy of drone 0 and fills the dynamic LDS with the same pattern before its first use.  If any
+    active lane's result depended on an idle lane's registers or on an LDS word nobody wrote, the two builds would differ.
+(2) Scheduling flags.  A compiler flag that is only supposed to reorder instructions (register-pressure trackers, post-RA scheduler,
+    max-ILP strategy) is admitted only on exact equality with the default build: round 5 had one float32 parity case fail with
+    `-amdgpu-use-amdgpu-trackers` on the single-wave objects and could not say why (DESIGN.md 5.3 has the answer).
+
+Both run free from identical states with identical Philox streams, crafted events included (the same ones as tests/test_hip_parity.py), and
+compare every output and state array bit for bit after every control step.  (2) runs the float32 production objects: scheduler settings do not
+touch the IR, so fast-math reassociates the same way in both builds.  (1) runs the float64 objects (strict IEEE): the poison build's extra selects
+change what fast-math does with the float32 expressions around them by an ulp here and there (measured: tools/flag_diff.py,
+profiles/r06b_flag_diff_*.txt), which says nothing about idle lanes.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from quad_swarm_rl_amd import config as qcfg
+from tests import test_hip_parity as thp
+
+pytestmark = pytest.mark.gpu
+
+ARRAYS = ["obs", "reward", "done", "rew_info", "pos", "vel", "rot", "omega", "goal", "thrust_rot_damp", "thrust_cmds_damp", "ou_state", "flags",
+          "col_pair_mask", "new_pair_mask", "obst_hit_idx", "counters", "tick", "unique_col_mask", "obst_new_mask", "room_new_mask",
+          "ep_stats", "ep_counters"]
+POISON_CASES = ["e_n17_kall_obst", "e_n33_k8", "c2_n5_kall_short", "c4_n12_svs_short", "s_mix_obst", "c3_n8_obst_short"]
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view({1: np.uint8, 4: np.uint32, 8: np.uint64}[a.dtype.itemsize])
+
+
+def make_pair(case, E, var, value, precision="f32", seed=77):
+    """(plain handle, handle built with `var=value` in the environment) of one parity case"""
+    from quad_swarm_rl_amd import native
+    cfg = qcfg.make_config(num_envs=E, seed=seed, env_id_offset=2, precision=precision, **thp.CASES[case])
+    old = os.environ.pop(var, None)
+    try:
+        a = native.Stepper(cfg, device=0)
+        os.environ[var] = value
+        b = native.Stepper(cfg, device=0)
+    finally:
+        os.environ.pop(var, None)
+        if old is not None:
+            os.environ[var] = old
+    assert a.specialized and b.specialized, (a.spec_note, b.spec_note)
+    return cfg, a, b
+
+
+def identical_rollout(case, E, steps, var, value, expect_team=None, precision="f32"):
+    cfg, a, b = make_pair(case, E, var, value, precision=precision)
+    if expect_team is not None:
+        assert bool(a.team) == expect_team and bool(b.team) == expect_team
+    N = cfg.num_agents
+    a.reset(); b.reset()
+    rng = np.random.RandomState(3)
+    M = cfg.num_obstacles
+    for t in range(-1, steps):
+        if t >= 0:
+            for e in range(E):   # the crafted collision / wall / ceiling / floor / obstacle states of the parity suite, applied to both
+                s, tick = a.get_state(e)
+                oxy = None
+                if cfg.use_obstacles:
+                    op = a.to_host("obst_pos")
+                    oxy = np.stack([op[0, e * M:(e + 1) * M], op[1, e * M:(e + 1) * M]], axis=1).astype(np.float64)
+                if thp.force_events(t, e, s, N, oxy, cfg.obst_size / 2):
+                    a.set_state(e, s, tick); b.set_state(e, s, tick)
+            gentle = (t // 10) % 2 == 1
+            act = rng.uniform(-1, 1, size=(E * N, 4)) if not gentle else 0.06 + rng.uniform(-0.05, 0.05, size=(E * N, 4))
+            for st in (a, b):
+                st.from_host("actions", act)
+                st.step()
+                st.sync()
+        for nm in ARRAYS:
+            xa, xb = a.to_host(nm), b.to_host(nm)
+            ne = np.argwhere(_bits(xa) != _bits(xb))
+            if len(ne):
+                i = tuple(int(v) for v in ne[0])
+                raise AssertionError(f"{case} {var}={value}: `{nm}` differs after step {t} at {i} ({len(ne)} words): {xa[i]!r} vs {xb[i]!r}; "
+                                     f"drone index {i[-1] % N if nm != 'obs' else i[0] % N}, env {(i[-1] if nm != 'obs' else i[0]) // N if xa.shape[-1] != E else i[-1]}")
+    a.check_errors(); b.check_errors()
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("case", POISON_CASES)
+def test_single_wave_kernels_ignore_idle_lanes(case, mode, monkeypatch):
+    monkeypatch.setenv("QS_TEAM", "0")
+    identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", f"-DQS_POISON_IDLE={mode}", expect_team=False, precision="f64")
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("case", POISON_CASES)
+def test_team_kernels_ignore_idle_lanes(case, mode, monkeypatch):
+    monkeypatch.setenv("QS_TEAM", "1")
+    identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", f"-DQS_POISON_IDLE={mode}", expect_team=True, precision="f64")
+
+
+SCHED_SINGLE = ["e_n17_kall_obst", "c3_n8_obst", "c2_n8_dw", "c4_n32_svs", "x_n40_obst"]
+
+
+@pytest.mark.parametrize("case", SCHED_SINGLE)
+def test_single_wave_objects_are_schedule_independent(case, monkeypatch):
+    """the register-pressure trackers on the single-wave objects (the flag of round 5's unexplained failure): same bits"""
+    monkeypatch.setenv("QS_TEAM", "0")
+    identical_rollout(case, 7, 45, "QS_SPEC_SINGLE_FLAGS", "-mllvm -amdgpu-use-amdgpu-trackers", expect_team=False)
+
+
+@pytest.mark.parametrize("case", ["c2_n8_dw", "c3_n8_obst", "c4_n32_svs"])
+def test_team_objects_are_schedule_independent(case, monkeypatch):
+    """the team objects' scheduler settings against the compiler's defaults (no max-ILP strategy, post-RA scheduler on): same bits"""
+    monkeypatch.setenv("QS_TEAM", "1")
+    identical_rollout(case, 7, 45, "QS_SPEC_TEAM_FLAGS", "", expect_team=True)

@@ -20,6 +20,8 @@ SCEN_CASES = ["s_static_diff_goal", "s_dynamic_same_goal", "s_dynamic_diff_goal"
 # size edges / configuration corners, the configurations tests/test_hip_parity.py runs on the GPU (e_*, x_*)
 EDGE_CASES = ["e_n64_k20", "e_n33_k8_numpy_wall", "e_n40_kall_svs", "x_n8_blind", "x_no_noise", "x_dense_obst", "x_small_room", "x_ep_len2",
               "x_hitbox", "x_svs_odd", "e_n17_kall_obst", "x_n40_obst", "e_n2_k1_swap", "e_n1_obst"]
+# two obstacles within reach at once (51 obstacles of 0.95 m; full state recorded): the first-hit INDEX
+CASES_FIRST_HIT = ["x_obst_first_hit"]
 CASES = ["c1_single_numpy", "c1_single_numba", "c2_n8_random", "c2_n8_hover_svd", "c2_n8_events", "c2_n8_episode",
          "c2_n8_k2_numpy", "c2_n8_kall", "c3_n8_obst", "c3_n8_obst_episode", "c4_n32_svs", "c4_n6_svs_switch",
          "c4_svs_resets",
@@ -60,7 +62,7 @@ def check_episode_stats(st, info, n, use_obstacles):
         assert cnt[9] == st["num_collisions_obst_quad_3_5"] and cnt[10] == st["num_collisions_obst_quad_5"]
 
 
-@pytest.mark.parametrize("name", CASES + SCEN_CASES + EDGE_CASES + QUIRK_CASES)
+@pytest.mark.parametrize("name", CASES + SCEN_CASES + EDGE_CASES + QUIRK_CASES + CASES_FIRST_HIT)
 def test_replay(name, quirk=None):
     g, cfgd = gu.load(name)
     cfg = gu.config_from_golden(cfgd)
@@ -121,6 +123,8 @@ def test_replay(name, quirk=None):
             assert info.obst_hit_mask == int(g["obst_hit"][t])
             assert info.room_new_mask == int(g["room_new"][t]), f"room collisions step {t}"
             np.testing.assert_allclose(np.array(info.acc)[:n], g["s_acc"][t], atol=1e-7)
+        if cfgd["use_obstacles"] and not done.any():   # WHICH obstacle each drone hit (obstacles/utils.py:31-43: lowest index wins), -1 = none
+            np.testing.assert_array_equal(np.array(info.obst_hit_idx[:n]), g["obst_hit_idx"][t], err_msg=f"first-hit obstacle index step {t}")
         np.testing.assert_array_equal(np.array(info.counters), g["counters"][t], err_msg=f"counters step {t}")
         if done.any():  # episode stats (quadrotor_multi.py:626-718)
             check_episode_stats(ep_stats[t], info, n, cfgd["use_obstacles"])

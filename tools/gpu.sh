@@ -14,6 +14,9 @@
 #   abtree[:wls]     same-box A/B of the step kernels against another tree in build_exp/old (tools/ab_tree.sh)         -> gpurun_out/<tag>_ab_tree.txt
 #   c5[:iters[:batch]]  the in-tree PPO harness on BASELINE config 5 (tools/ppo_c5.py), learning curve                 -> gpurun_out/<tag>_ppo_c5.txt
 #   gather           bench.py --workload c4 --force-gather: the exchange at world size 1, every wire                   -> gpurun_out/<tag>_bench_c4_gather_w1.json
+#   diff:<case>[:var:flags]  two code objects of one parity case side by side, bit for bit + against the oracle (tools/flag_diff.py; QS_SPEC_VERIFY=0:
+#                    the flagged object as the compiler delivers it)                                                      -> gpurun_out/<tag>_flag_diff_<case>.txt
+#   gdb:<case>[:var:flags]   the same under rocgdb with precise memory faults: faulting instruction, registers            -> gpurun_out/<tag>_rocgdb_<case>.txt
 #   sweep:<n>        scheduler / switch sweep <n> of tools/sched_sweep.py (objects prebuilt with `SWEEP=<n> python tools/sched_sweep.py build`)  -> gpurun_out/<tag>_sched_sweep.txt
 tag=$1; shift
 mkdir -p gpurun_out
@@ -71,6 +74,17 @@ PY
     gather)
       timeout 300 python bench.py --workload c4 --force-gather --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train > gpurun_out/${tag}_bench_c4_gather_w1.json 2> gpurun_out/${tag}_bench_c4_gather_w1.err
       python -c "import json; d=json.loads(open('gpurun_out/${tag}_bench_c4_gather_w1.json').read().strip().splitlines()[-1]); print({w: (round(v['ms_per_step']*1e3,2), v['verified_against_rccl_gather_after']) for w, v in d['config']['exchange_per_wire'].items()})" ;;
+    diff:*|gdb:*)
+      IFS=: read -r kind case var flags <<< "$task"
+      var=${var:-QS_SPEC_SINGLE_FLAGS}; flags=${flags:--mllvm -amdgpu-use-amdgpu-trackers}
+      if [ $kind = diff ]; then
+        ( QS_SPEC_VERIFY=0 QS_TEAM=${QS_TEAM:-0} FLAGS_VAR="$var" FLAGS_B="$flags" timeout 300 python -u tools/flag_diff.py $case 7 40 ) > gpurun_out/${tag}_flag_diff_$case.txt 2>&1
+        grep -v "^A \|^B " gpurun_out/${tag}_flag_diff_$case.txt | tail -6 | cut -c1-300
+      else
+        ( QS_SPEC_VERIFY=0 QS_TEAM=${QS_TEAM:-0} FLAGS_VAR="$var" FLAGS_B="$flags" timeout 300 rocgdb -batch -ex "set pagination off" -ex "set confirm off" -ex "set amdgpu precise-memory on" -ex run \
+            -ex "info threads" -ex "x/40i \$pc-120" -ex "info registers" --args python -u tools/flag_diff.py $case 7 40 ) > gpurun_out/${tag}_rocgdb_$case.txt 2>&1
+        grep -n "received signal\|=> " gpurun_out/${tag}_rocgdb_$case.txt | head -4
+      fi ;;
     sweep:*) SWEEP=${task#sweep:} SWEEP_TAG=$tag python tools/sched_sweep.py run 2 2>&1 | tail -30 ;;
     run:*) sc=${task#run:}; timeout 900 python $sc > gpurun_out/${tag}_$(basename $sc .py).txt 2>&1; tail -25 gpurun_out/${tag}_$(basename $sc .py).txt ;;
     *) echo "unknown task $task" ;;
