@@ -420,8 +420,8 @@ int qs_spec_build(const qs_config *cfg, int team, char *path_out, int cap);
 int qs_spec_verify(const char *path, char *report_out, int cap);
 /* The repair qs_create() / qs_spec_build() apply to an object that shows the pattern (and the Python build applies to the two libraries): the exec
  * restore is moved to the front of its block prologue - straight-line code nobody jumps into, all other instructions keep their relative order -
- * where that provably changes nothing else (no prologue instruction in front of it defines the mask it reads, no v_readlane among the last five
- * prologue instructions, no DPP / lane operation right behind it, the byte sequence unique in the file).  Rewrites `path` in place; returns the
+ * where that provably changes nothing else (no prologue instruction in front of it defines the mask it reads, no v_readlane near the prologue's
+ * end feeding a memory / lane instruction right behind it, no DPP / lane operation right behind it, the byte sequence unique in the file).  Rewrites `path` in place; returns the
  * number of places repaired, the ones left (with the reason) in left_out; < 0 on errors.  Callers verify again afterwards. */
 int qs_spec_repair(const char *path, char *left_out, int cap);
 int qs_is_specialized(qs_handle *h);

@@ -192,70 +192,6 @@ template <typename real> __device__ __forceinline__ real nbr_metric(const real r
     const real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
     return rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) * M<real>::rcp(rd);
 }
-// Team kernels, N <= 8: the neighbour-observation columns (neighborhood_indices quadrotor_multi.py:247-274, extend_obs_space :233-245) and
-// the SDF cells (obstacles/utils.py:5-27) of lane i's row by helper wave `hw` of HW, from the published positions / velocities.  Every wave
-// computes all (at most 8) metrics of its drone in registers - no metric matrix in LDS, no barrier between "metrics" and "ranks" - and
-// ranks the partners j = hw, hw + HW, ... by counting: rank = position in the stable ascending argsort; the K lowest go to row slot `rank`.
-// Slots are a permutation of the partners, so the waves never write the same word.
-template <typename real, int HW>
-__device__ __forceinline__ void team_rows_small(const Consts<real> &c, int N, int K, bool ranked, int i, int base, int B, int tid, int hw, int le, int M_,
-                                                const real *s_pos, const real *s_vel, const real *s_obst, real *myobs, real obst_size) {
-    real *o = myobs + c.self_dim;
-    if (K > 0) {
-        real mpos[3], mvel[3], mk[8];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { mpos[q] = s_pos[q * B + tid]; mvel[q] = s_vel[q * B + tid]; }
-        if (ranked) {
-            real rp[8][3], rv[8][3];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {   // all LDS reads in front of the first use: one round trip
-                const int j = (u < N) ? u : N - 1;
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mpos[a]; rv[u][a] = s_vel[a * B + base + j] - mvel[a]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) mk[u] = (u < N && u != i) ? nbr_metric<real>(rp[u], rv[u]) : (real)3.4e38;
-        }
-        for (int j = hw; j < N; j += HW) {
-            if (j == i) continue;
-            int rank = (j < i) ? j : j - 1;   // K == N-1: all others in index order (:253-254)
-            if (ranked) {
-                real mj = mk[0];
-#pragma unroll
-                for (int u = 1; u < 8; ++u) mj = (u == j) ? mk[u] : mj;
-                rank = 0;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) rank += (int)((u < N) & ((mk[u] < mj) | ((mk[u] == mj) & (u < j))));
-            }
-            if (rank < K) {
-                real *oo = o + rank * 6;
-                real vals[6];   // all six LDS reads before the first LDS write (the compiler must assume they alias)
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { vals[a] = s_pos[a * B + base + j]; vals[3 + a] = s_vel[a * B + base + j]; }
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    oo[a] = clipr<real>(vals[a] - mpos[a], -c.nbr_clip_pos[a], c.nbr_clip_pos[a]);
-                    oo[3 + a] = clipr<real>(vals[3 + a] - mvel[a], -c.nbr_clip_vel[a], c.nbr_clip_vel[a]);
-                }
-            }
-        }
-    }
-    if (c.use_obstacles) {   // the 9 cells striped over the helper waves; one square root per cell (sdf_obs)
-        const real *ox = s_obst + (le * 2 + 0) * M_, *oy = s_obst + (le * 2 + 1) * M_;
-        const real px = s_pos[0 * B + tid], py = s_pos[1 * B + tid];
-        real *os = o + 6 * K;
-        for (int q = hw; q < 9; q += HW) {
-            const int a = q / 3, b = q - a * 3;
-            const real gx = px + (real)0.1 * (real)(a - 1), gy = py + (real)0.1 * (real)(b - 1);
-            real mind2 = (real)10000;
-            for (int k = 0; k < M_; ++k) {
-                real dx = gx - ox[k], dy = gy - oy[k], d2 = dx * dx + dy * dy;
-                mind2 = d2 < mind2 ? d2 : mind2;
-            }
-            os[q] = M<real>::sqrt(mind2) - (c.dr_on ? (real)0.5 * obst_size : c.obst_radius);
-        }
-    }
-}
 // (metric, index) with the order "smaller metric first, lower index first" = position in the stable argsort
 template <typename real> struct NbrKey;
 template <> struct NbrKey<float> {

@@ -364,7 +364,7 @@ static void spec_scan_disassembly(FILE *f, std::vector<SpecHazard> &out) {
         if (follow > 0) { out.back().after.push_back(t); --follow; }
         if (!scanning) continue;
         if (hz_restore(t)) {
-            if (dependent) { cur.restore = t; cur.restore_raw = raw; out.push_back(cur); follow = 3; }
+            if (dependent) { cur.restore = t; cur.restore_raw = raw; out.push_back(cur); follow = 6; }
             scanning = false;
         } else if (hz_exec_dependent(t)) { dependent = true; cur.ins.push_back(t); cur.raw.push_back(raw); }
         else if (hz_silent(t)) { cur.ins.push_back(t); cur.raw.push_back(raw); }
@@ -489,7 +489,20 @@ static int spec_repair_file(const std::string &path, std::string &left) {
         }
         std::string reason;
         for (size_t k = 0; k < pos; ++k) if (hz_exec_dependent(h.ins[k])) reason = "an exec-dependent instruction sits in front of the definition of the saved mask";
-        for (size_t k = h.ins.size() >= 5 ? h.ins.size() - 5 : 0; k < h.ins.size(); ++k) if (starts_with(h.ins[k], "v_readlane")) reason = "v_readlane among the last five prologue instructions";
+        // VALU writes an SGPR (v_readlane) -> a VMEM instruction / a lane select reads it: 5 wait states, and the restore was one of them
+        for (size_t k = h.ins.size() >= 5 ? h.ins.size() - 5 : 0; k < h.ins.size(); ++k) {
+            if (!starts_with(h.ins[k], "v_readlane")) continue;
+            std::vector<int> wr;
+            hz_sregs(h.ins[k].substr(0, h.ins[k].find(',')), wr);
+            for (size_t a2 = 0; a2 < h.after.size() && a2 < 5; ++a2) {
+                const std::string &u = h.after[a2];
+                const bool vmem = starts_with(u, "buffer_") || starts_with(u, "global_") || starts_with(u, "flat_") || starts_with(u, "scratch_") || starts_with(u, "v_readlane") || starts_with(u, "v_writelane");
+                if (!vmem) continue;
+                std::vector<int> rd;
+                hz_sregs(u, rd);
+                for (int w : wr) for (int r : rd) if (w == r) reason = "a v_readlane near the end of the prologue feeds a memory / lane instruction right behind the restore";
+            }
+        }
         for (size_t k = 0; k < h.after.size() && k < 2; ++k)
             if (h.after[k].find("dpp") != std::string::npos || starts_with(h.after[k], "v_readlane") || starts_with(h.after[k], "v_writelane") || starts_with(h.after[k], "v_readfirstlane")) reason = "DPP / lane operation right behind the restore";
         if (h.restore_raw.empty() || old_bytes.size() < 8) reason = "no encoding in the disassembly";
@@ -727,6 +740,12 @@ template <typename real> static int create_typed(qs_handle *h) {
         HIP_TRY(hipMemcpy(p.obst_density_env, dn.data(), E * sizeof(real), hipMemcpyHostToDevice));
     }
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
+    {   // the running episode's scenario: the resets of the full scenario set (mix: a new one per episode) keep it up to date; the three scenarios of
+        // the fast set never change it, so it is filled here (it stayed 0 = static_same_goal for o_static_same_goal / swarm_vs_swarm until round 5:
+        // the per-scenario reward keys of the Sample Factory env carried the wrong name - found by tests/test_sf_env_vs_reference_gpu.py)
+        std::vector<int32_t> sid(E, c.scenario);
+        HIP_TRY(hipMemcpy(p.scenario_id, sid.data(), E * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     // QS_TIMING builds: phase stamps of workgroup 0, then {start, end, HW_ID, XCC_ID, wall start, wall end} of every workgroup
     DA(error_flag, 1); DA(reset_mask, E); DA(timing, 128 + 16 * NBLK);
 #undef DA

@@ -226,7 +226,7 @@ EXPORTED_SYMBOLS = ["qs_spec_verify", "qs_spec_repair", "qs_version", "qs_sizeof
 # include/quadswarm_exchange.h
 EXCHANGE_SYMBOLS = ["qs_xchg_create", "qs_xchg_destroy", "qs_xchg_export", "qs_xchg_attach", "qs_xchg_attach_local", "qs_xchg_staging",
                     "qs_xchg_gathered", "qs_xchg_push", "qs_xchg_wait", "qs_xchg_release", "qs_xchg_wait_release", "qs_xchg_fused_desc", "qs_xchg_status", "qs_obs_pack", "qs_xchg_last_error",
-                    "qs_xchg_create_q8", "qs_wire_row_bytes", "qs_obs_pack_rows", "qs_obs_unpack_rows"]
+                    "qs_xchg_create_q8", "qs_wire_row_bytes", "qs_obs_pack_rows", "qs_obs_unpack_rows", "qs_xchg_set_fenced", "qs_xchg_get_fenced"]
 
 
 class QsError(RuntimeError):

@@ -373,9 +373,12 @@ class FusedQuadEncoder:
         P.self_dim, P.nbr_dim, P.num_nbr, P.obst_dim = module.self_dim, module.nbr_dim, module.num_nbr, module.obst_dim
         P.obs_dim = module.self_dim + module.nbr_dim * module.num_nbr + module.obst_dim
 
+        self._packed, self._raw = [], []   # what refresh() re-reads: (nn.Linear, cols, packed weights, bias) / (source getter, device tensor)
+
         def layer(linear, cols=None):
             w, b, M, K = pack_linear(linear, self.device, cols)
             self._keep += [w, b]
+            self._packed.append((linear, cols, w, b))
             return EncLayer(w.data_ptr(), b.data_ptr(), M, K)
 
         P.nbr_encoder = MODELS.index(getattr(module, "nbr_encoder", "mean_embed"))
@@ -398,6 +401,7 @@ class FusedQuadEncoder:
             P.mq, P.mk, P.mv, P.mfc = layer(att.w_qs), layer(att.w_ks), layer(att.w_vs), layer(att.fc)
             ln = [att.layer_norm.weight.detach().float().to(self.device).contiguous(), att.layer_norm.bias.detach().float().to(self.device).contiguous()]
             self._keep += ln
+            self._raw += [(lambda: att.layer_norm.weight, ln[0]), (lambda: att.layer_norm.bias, ln[1])]
             P.ln_w, P.ln_b = ln[0].data_ptr(), ln[1].data_ptr()
         self.attention = P.nbr_encoder == 1
         if P.nbr_encoder == 2:
@@ -413,6 +417,8 @@ class FusedQuadEncoder:
             a3 = module.attention_mlp[4]   # 256 -> 1: reduced from the second score layer's accumulators, fp32 weights
             a3w = a3.weight.detach().float().reshape(-1).to(self.device).contiguous()
             self._keep.append(a3w)
+            self._raw.append((lambda: a3.weight.reshape(-1), a3w))
+            self._a3 = a3
             P.a3w, P.a3b = a3w.data_ptr(), float(a3.bias.detach().float().item())
         self._scratch_rows = 0
         P.f = layer(module.feed_forward[0])
@@ -421,6 +427,22 @@ class FusedQuadEncoder:
             raise ValueError("the fused encoder is built for hidden size 256")
         self.params = P
         lib()
+
+    def refresh(self):
+        """Re-read the module's weights (an optimiser moved them) INTO the buffers the kernels - and any captured HIP graph - already point at.
+        One attention-score bias lives in the parameter struct (a3b): a graph that was captured before keeps the old value of that one scalar
+        until it is recaptured; everything else is picked up by replays."""
+        for linear, cols, w, b in self._packed:
+            nw, nb, _, _ = pack_linear(linear, self.device, cols)
+            w.copy_(nw)
+            b.copy_(nb)
+        for src, dst in self._raw:
+            dst.copy_(src().detach().float().reshape(dst.shape))
+        if getattr(self, "_a3", None) is not None:
+            self.params.a3b = float(self._a3.bias.detach().float().item())
+        if getattr(self, "_head_src", None) is not None:
+            self._head[0].copy_(self._head_src[0].detach().float())
+            self._head[1].copy_(self._head_src[1].detach().float())
 
     def forward(self, obs, out=None):
         torch = self._torch
@@ -438,11 +460,11 @@ class FusedQuadEncoder:
     def set_head(self, weight, bias):
         """Linear head on the 512 features (SF's action-parameter / value layer), evaluated in the encoder's epilogue by forward_head."""
         torch = self._torch
-        w = weight.detach().to(self.device, torch.float32).contiguous()
-        b = bias.detach().to(self.device, torch.float32).contiguous()
+        w = weight.detach().to(self.device, torch.float32).clone().contiguous()   # (own copies: refresh() writes into them)
+        b = bias.detach().to(self.device, torch.float32).clone().contiguous()
         if w.dim() != 2 or w.shape[1] != self.out_dim or not 1 <= w.shape[0] <= 8 or b.shape != (w.shape[0],):
             raise ValueError(f"head: weight [h, {self.out_dim}] with 1 <= h <= 8, bias [h]")
-        self._head = (w, b)
+        self._head, self._head_src = (w, b), (weight, bias)
 
     def forward_head(self, obs, head_out=None, features=None, sample=None, traj=None):
         """head(encoder(obs)) -> [B, h] float32; the [B, 512] features are written only if a `features` tensor is passed.

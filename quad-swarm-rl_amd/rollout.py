@@ -7,7 +7,7 @@ segment.  This is the device-resident counterpart of a Sample Factory rollout wo
 environments from `swarm_rl/train.py` through SF's sampler); it needs no part of SF.
 
     seg = GraphedRollout(env, encoder, head, steps=32)
-    out = seg.run()          # dict of device tensors: obs[T, A, D], actions[T, A, 4], rewards[T, A], dones[T, A], last_obs[A, D]
+    out = seg.run()          # dict of device tensors: obs[T, A, D], actions[T, A, 4], means[T, A, 4], rewards[T, A], dones[T, A], last_obs[A, D]
 """
 from . import native
 
@@ -47,10 +47,12 @@ class GraphedRollout:
         samples the action into actions[t] (qs_enc_params.sample_*); the step writes its observation rows straight into obs[t + 1]
         (qs_set_obs_target); its rewards / done flags are copied into rewards[t] / dones[t] by the first kernel of the NEXT step's forward pass
         (qs_enc_params.traj_*; round 5 - a launch of its own, qs_rollout_post, until round 4 and still for the segment's last step).
-        2 (attention: 3) dependent graph nodes per control step, and no observation copy.  (Tried and measured, C2 with
-        mean_embed, us per control step: this 32.9 (two glue launches per step: 34.3); the copy on a second stream as a parallel graph branch 46.3 - a fork / join costs
-        more than the launch it hides; the copy inside the next forward pass's first launch 33.2; rewards / done redirected inside the
-        step kernel 31.8, but + 0.08 us on every step of every user of the headline kernel - not taken.)"""
+        2 (attention: 3) dependent graph nodes per control step, and no observation copy.  Measured on C2, us per control step
+        (profiles/r05h_bench_rollout.txt): mean_embed 31.5, attention 82.5; with a copy launch of its own per step 33.0 (round 4); the copy on a
+        second stream as a parallel graph branch 46.3 - a fork / join costs more than the launch it hides; rewards / done redirected inside the
+        step kernel 31.8, but + 0.08 us on every step of every user of the headline kernel - not taken.
+        `means[t]` keeps the action head's output of every step - the mean of the Gaussian the action was drawn from - so that a learner has the
+        behaviour policy's log-probabilities without a second forward pass (tools/ppo_c5.py)."""
         import torch
         if not torch.cuda.is_available():
             raise native.QsError("GraphedRollout needs a GPU")
@@ -69,7 +71,7 @@ class GraphedRollout:
         self._glue = False
         if self._fused_head:   # the Linear runs in the encoder's epilogue: the [A, 512] features are never written
             encoder.set_head(head.weight, head.bias)
-            self._mean = torch.empty((A, 4), device=dev)
+            self.means = torch.empty((steps, A, 4), device=dev)   # the action head's output per step
             # ... and with the library's head so do sampling and the trajectory writes (no copy / sampling kernels between the steps)
             self._glue = isinstance(head, GaussianActionHead) and self.dones.dtype == torch.uint8 and self._done.dtype == torch.uint8
             # (the device-side replay wrapper restores observations into the library's buffer and reads its done flags: a handle with
@@ -89,10 +91,21 @@ class GraphedRollout:
                 with torch.cuda.stream(side):
                     self._segment(1)     # one step, eagerly: library warm-up outside the capture
                 torch.cuda.current_stream(dev).wait_stream(side)
-                torch.cuda.synchronize(dev)
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self._segment(steps)
+                self.recapture()
+        finally:
+            self._restore_targets()
+
+    def recapture(self):
+        """Record the segment again.  Needed when something that travels in LAUNCH ARGUMENTS changed - the attention encoder's score bias after
+        FusedQuadEncoder.refresh(), the head's sampling switch; weights, log-std, reward coefficients live in device memory and are picked up
+        by replays of the old graph.  Capturing runs nothing: the environments stay where they are."""
+        import torch
+        dev = self._obs.device
+        torch.cuda.synchronize(dev)
+        try:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._segment(self.steps)
         finally:
             self._restore_targets()
 
@@ -126,7 +139,7 @@ class GraphedRollout:
                 # control step (three with `attention`) instead of three (four); only the LAST step of the segment needs a copy launch of its own
                 traj = (self._rew, self.rewards[t - 1], self._done, self.dones[t - 1]) if t > 0 else None
                 if self.head.sample:
-                    self.encoder.forward_head(self.obs[t], head_out=self._mean, sample=(self.head.log_std, self.actions[t], self._counter, t, self._seed), traj=traj)
+                    self.encoder.forward_head(self.obs[t], head_out=self.means[t], sample=(self.head.log_std, self.actions[t], self._counter, t, self._seed), traj=traj)
                 else:   # deterministic policy: the head's output IS the action
                     self.encoder.forward_head(self.obs[t], head_out=self.actions[t], traj=traj)
                 # step t: observation rows -> obs[t + 1] (the last step: the library's buffer, where the next segment starts)
@@ -153,9 +166,9 @@ class GraphedRollout:
         L = policy.lib()
         stream = C.c_void_p(self._torch_stream().cuda_stream)
         A = self._obs.shape[0]
-        self.encoder.forward_head(self._obs, head_out=self._mean)
+        self.encoder.forward_head(self._obs, head_out=self.means[t])
         log_std = C.c_void_p(self.head.log_std.data_ptr()) if self.head.sample else None
-        rc = L.qs_rollout_pre(C.c_void_p(self._obs.data_ptr()), C.c_void_p(self.obs[t].data_ptr()), self._obs.numel(), C.c_void_p(self._mean.data_ptr()), log_std,
+        rc = L.qs_rollout_pre(C.c_void_p(self._obs.data_ptr()), C.c_void_p(self.obs[t].data_ptr()), self._obs.numel(), C.c_void_p(self.means[t].data_ptr()), log_std,
                               C.c_void_p(self.actions[t].data_ptr()), A, C.c_uint64(self._seed), C.c_void_p(self._counter.data_ptr()), stream)
         if rc != 0:
             raise native.QsError(f"qs_rollout_pre failed ({rc})")
@@ -168,8 +181,8 @@ class GraphedRollout:
     def _step(self, t):
         self.obs[t].copy_(self._obs)
         if self._fused_head:
-            self.encoder.forward_head(self._obs, head_out=self._mean)
-            self.actions[t].copy_(self.head.from_mean(self._mean))
+            self.encoder.forward_head(self._obs, head_out=self.means[t])
+            self.actions[t].copy_(self.head.from_mean(self.means[t]))
         else:
             self.encoder(self._obs, out=self._feat)
             self.actions[t].copy_(self.head(self._feat))
@@ -187,4 +200,7 @@ class GraphedRollout:
                 self._segment(self.steps)
             finally:
                 self._restore_targets()
-        return {"obs": self.obs, "actions": self.actions, "rewards": self.rewards, "dones": self.dones, "last_obs": self._obs}
+        out = {"obs": self.obs, "actions": self.actions, "rewards": self.rewards, "dones": self.dones, "last_obs": self._obs}
+        if self._fused_head:
+            out["means"] = self.means if getattr(self.head, "sample", True) else self.actions
+        return out

@@ -487,6 +487,34 @@ class BatchedQuadSwarm:
             self._steps_to_done = int(self._ep_steps - st.to_host("tick").max())
         return {"obs": obs}, rew, self._terminated, self._truncated, infos
 
+    # ---- rollout segments recorded into a HIP graph (rollout.GraphedRollout over self.vec): the host duties of step(), per SEGMENT ----
+    def segment_begin(self):
+        """Before a captured segment runs: what step() does on the host before the kernel - the shaping scheme pushed into the env's
+        coefficients (reward_shaping.py:55-61), the coefficients pushed to the device (the kernels read them from device memory on every
+        launch, so replays of a graph that was captured earlier see them)."""
+        if self.reward_shaping_updated:
+            for key, weight in self.reward_shaping_scheme["quad_rewards"].items():
+                if key in self.rew_coeff:
+                    self.rew_coeff[key] = weight
+            self.reward_shaping_updated = False
+        self.vec._sync_rew_coeff()
+
+    def segment_end(self, dones):
+        """After a captured segment of T control steps (dones: its [T, E*N] done flags): what step() does on the host behind the kernel, for
+        all steps of the segment at once - the episode-end `infos` of every environment whose episode ended inside the segment (the sums of a
+        finished episode stay in the device buffers until the environment's NEXT episode ends: segments are far shorter than episodes) and the
+        annealing of the collision coefficients (reward_shaping.py:111-118), which therefore takes effect at the next segment instead of the
+        next step.  Returns the EpisodeInfos (or [])."""
+        torch = self._torch
+        st, n = self.vec.stepper, self.agents_per_env
+        self.check_exchange()
+        ended = dones.reshape(dones.shape[0], self.num_envs, n)[:, :, 0].any(dim=0)
+        finished = torch.nonzero(ended).reshape(-1).cpu().numpy()
+        infos = self._episode_infos(finished) if len(finished) else []
+        self.vec._sync_rew_coeff()
+        self._steps_to_done = int(self._ep_steps - st.to_host("tick").max())
+        return infos
+
     def _episode_infos(self, finished):
         """What the wrapper stack attaches at an episode end - the env's own episode_extra_stats (quadrotor_multi.py:626-718, or
         the two `*_replay` counters of a replayed episode, :629-633), the replay wrapper's statistics

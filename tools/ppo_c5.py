@@ -64,6 +64,11 @@ def make_parser():
     p.add_argument("--graph_update", type=lambda v: str(v).lower() in ("1", "true", "yes"), default=True,
                    help="record the minibatch step (forward, losses, backward, gradient clipping, Adam) once into a HIP graph and replay it per minibatch "
                         "(same arithmetic, no per-kernel launch cost); falls back to eager steps where capture is not available")
+    p.add_argument("--fused_sampler", type=lambda v: str(v).lower() in ("1", "true", "yes"), default=True,
+                   help="collect the rollouts on the product's closed loop - the fused MFMA policy encoder + action head + step kernel recorded into ONE HIP "
+                        "graph per rollout (rollout.GraphedRollout over the env's stepper; bf16 encoder) - instead of stepping the torch actor eagerly; the "
+                        "behaviour policy's log-probabilities come from the action means the segment records, the values from the float32 critic in "
+                        "one batched pass.  Falls back to the eager sampler where the fused kernels do not apply (CPU stand-in envs, float64, widths)")
     sf_env.add_quadrotors_env_args(None, p)
     p.set_defaults(quads_num_envs=1024)
     return p
@@ -151,8 +156,59 @@ class Learner:
         self.episodes = 0
         self.terms = None       # [17] means of the per-step reward terms over the last rollout (config.REW_INFO_KEYS order)
         self._rew_info = getattr(getattr(env, "vec", None), "reward_info", None)
+        self.segment, self.sampler_note = None, "eager torch actor"
+        if bool(getattr(cfg, "fused_sampler", False)) and self.device.type == "cuda":
+            self._make_segment()
+
+    def _make_segment(self):
+        """the product's closed loop as the sampler: fused encoder (the actor's weights, bf16) + Gaussian head + step kernel, one HIP graph per rollout"""
+        torch, cfg = self.torch, self.cfg
+        try:
+            from quad_swarm_rl_amd import policy, rollout
+            self.fused = policy.FusedQuadEncoder(self.ac.actor_encoder, device=self.device.index or 0)
+            self.head = rollout.GaussianActionHead(in_features=self.fused.out_dim, device=self.device.index or 0, seed=cfg.seed, sample=True)
+            self.head.weight, self.head.bias = self.ac.action_mean.weight, self.ac.action_mean.bias   # set_head copies them; refresh() follows them
+            self.head.log_std = self.ac.log_std.detach().clone()
+            self.segment = rollout.GraphedRollout(self.env.vec, self.fused, self.head, steps=cfg.rollout)
+            self.sampler_note = f"fused encoder + head + step, one HIP graph of {cfg.rollout} control steps (rollout.GraphedRollout)"
+        except Exception as exc:   # noqa: BLE001 - the eager sampler is always there
+            self.segment, self.sampler_note = None, f"eager torch actor (fused sampler unavailable: {type(exc).__name__}: {exc})"
+
+    def collect_fused(self):
+        """one rollout = one replay of the captured segment; then, in batched float32 passes: log-probabilities of the recorded actions under the
+        recorded means (the behaviour policy as it really sampled), values of all T + 1 observation sets from the critic"""
+        torch, cfg, seg = self.torch, self.cfg, self.segment
+        T = cfg.rollout
+        with torch.no_grad():
+            self.fused.refresh()                                  # the weights the last update left, into the buffers the graph points at
+            self.head.log_std.copy_(self.ac.log_std.detach())
+            if self.fused.attention:
+                seg.recapture()                                   # (the attention score bias travels in the launch arguments)
+            self.env.set_training_info({"approx_total_training_steps": self.agent_steps})
+            self.env.segment_begin()
+            st = self.env.vec.stepper
+            run_before = st.tensor("run_sums")[:17].clone()       # the step kernel's running per-episode sums of the 17 reward terms (episode_sums)
+            out = seg.run()
+            self.obs[:T].copy_(out["obs"]); self.obs[T].copy_(out["last_obs"])
+            self.act.copy_(out["actions"]); self.rew.copy_(out["rewards"]); self.done.copy_(out["dones"])
+            self.logp.copy_(gaussian_logp(out["means"], self.head.log_std, out["actions"]))
+            flat = self.obs.reshape((T + 1) * self.A, self.D)
+            vals = self.val.reshape(-1)
+            for s0 in range(0, flat.shape[0], 65536):
+                vals[s0:s0 + 65536] = self.ac.values(flat[s0:s0 + 65536])
+            infos = self.env.segment_end(out["dones"])
+            if infos:
+                self.episodes += len(infos.finished_agents())
+            self.agent_steps += T * self.A
+            # means of the per-step reward terms over the rollout, from the running sums: end - start, plus the finished episode's total
+            # for the agents whose episode ended (and restarted the running sum) inside the segment
+            ended = out["dones"].any(dim=0).float()
+            total = st.tensor("run_sums")[:17] - run_before + ended[None, :] * st.tensor("ep_sums")[:17]
+            self.terms = total.float().mean(dim=1) / T
 
     def collect(self):
+        if self.segment is not None:
+            return self.collect_fused()
         torch, cfg = self.torch, self.cfg
         T = cfg.rollout
         term_sum = None
@@ -318,7 +374,8 @@ def train(cfg, env=None, log=None):
     total = time.time() - t_start
     summary = dict(c5="ran (in-tree PPO harness: Sample Factory is not installed)", iterations=iters, agent_steps=lr.agent_steps,
                    seconds=round(total, 2), fps=round(lr.agent_steps / total, 1), agents=lr.A, rollout=cfg.rollout, batch_size=cfg.batch_size,
-                   first=_brief(recs[0]), last=_brief(recs[-1]), graph_update=bool(recs[-1].get("graph_update")), graph_error=lr._graph_error)
+                   first=_brief(recs[0]), last=_brief(recs[-1]), graph_update=bool(recs[-1].get("graph_update")), graph_error=lr._graph_error,
+                   sampler=lr.sampler_note)
     if own:
         env.close()
     return recs, summary
