@@ -11,7 +11,7 @@
 Both run from identical states with identical Philox streams, crafted events included (the same ones as tests/test_hip_parity.py).  (2) compares
 every output and state array BIT FOR BIT after every control step of a free-running rollout: scheduler settings do not touch the IR.  (1) cannot
 be bit-exact - the poison build's extra selects change which multiply-adds the compiler fuses, an ulp here and there even in float64 (measured:
-profiles/r06b_flag_diff_*.txt, profiles/r06i_poison_f64_first_differences.txt) - so the poisoned handle restarts every step from the plain
+profiles/r06b_flag_diff_all_variants.txt, profiles/r06i_poison_f64_first_differences.txt) - so the poisoned handle restarts every step from the plain
 handle's state, floats may differ by a few ulps of one step, and everything discrete must be identical.
 """
 import os

@@ -34,7 +34,7 @@ for task in "$@"; do
   echo "== $task"
   case $task in
     suite)
-      ( timeout 1700 python -m pytest tests -m gpu -q --durations=25 --maxfail=20 --timeout=900 -p no:cacheprovider 2>&1 | tail -70 ) > gpurun_out/${tag}_pytest.txt
+      ( timeout 1700 python -m pytest tests -m gpu -q -rf --tb=line --durations=25 --maxfail=40 --timeout=900 -p no:cacheprovider 2>&1 | tail -120 ) > gpurun_out/${tag}_pytest.txt
       tail -4 gpurun_out/${tag}_pytest.txt
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ;;
     quick)
