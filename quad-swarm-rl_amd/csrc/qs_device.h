@@ -96,12 +96,14 @@ __device__ __forceinline__ bool not_finite(double x) {
     return ((unsigned long long)__double_as_longlong(x) & 0x7ff0000000000000ull) == 0x7ff0000000000000ull || fabs(x) > 3.0e38;
 }
 __device__ __forceinline__ bool bits_differ(float a, float b) { return __builtin_bit_cast(uint32_t, a) != __builtin_bit_cast(uint32_t, b); }
-__device__ __forceinline__ bool bits_differ(double a, double b) { return __builtin_bit_cast(uint64_t, a) != __builtin_bit_cast(uint64_t, b); }
+__device__ __forceinline__ bool bits_differ(double a,
+    double b) { return __builtin_bit_cast(uint64_t, a) != __builtin_bit_cast(uint64_t, b); }
 template <typename real> __device__ __forceinline__ real clipr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
 // fp32: one v_med3_f32 instead of two compare + select pairs (identical for every non-NaN x when lo <= hi)
 template <> __device__ __forceinline__ float clipr<float>(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 template <typename real> __device__ __forceinline__ real norm3(const real v[3]) { return M<real>::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
-template <typename real> __device__ __forceinline__ real dot3(const real a[3], const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename real> __device__ __forceinline__ real dot3(const real a[3],
+    const real b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10, the stream specified in include/quadswarm.h
@@ -184,7 +186,8 @@ template <typename real, int NN> __device__ __forceinline__ void rng_normal(cons
     }
 }
 // NN <= 4 draws of normal(0, scale): scale * z from the stream, the recorded value from a tape
-template <typename real, int NN> __device__ __forceinline__ void rng_normal_s(const RngKey &k, int site, int slot, int i, int j, real scale, real out[NN]) {
+template <typename real,
+    int NN> __device__ __forceinline__ void rng_normal_s(const RngKey &k, int site, int slot, int i, int j, real scale, real out[NN]) {
     rng_normal<real, NN>(k, site, slot, i, j, out);
     if (!QS_ON_TAPE(k)) {
 #pragma unroll
@@ -199,7 +202,8 @@ template <typename real> __device__ __forceinline__ void box_muller4(const uint3
     z[0] = r0 * c0; z[1] = r0 * s0; z[2] = r1 * c1; z[3] = r1 * s1;
 }
 
-template <typename real, int NN> __device__ __forceinline__ void rng_uniform(const RngKey &k, int site, int slot, int i, int j, real lo, real hi, real u[NN]) {
+template <typename real,
+    int NN> __device__ __forceinline__ void rng_uniform(const RngKey &k, int site, int slot, int i, int j, real lo, real hi, real u[NN]) {
     if (QS_ON_TAPE(k)) {
 #pragma unroll
         for (int q = 0; q < NN; ++q) u[q] = (real)tape_pop(k);
@@ -503,16 +507,22 @@ __device__ __forceinline__ void step_noise_draw(const Consts<real> &c, const Rng
     for (int q = 0; q < 3; ++q) { n.w[q] = c.gyro_noise_density * z[q]; n.th[q] = 0; }
     if (c.pos_unif_range != (real)0 || c.vel_unif_range != (real)0 || c.quat_norm_std != (real)0 || c.quat_unif_range != (real)0) {
         real u[3];   // non-default sensor model: the extra terms one group at a time
-        if (c.pos_unif_range != (real)0) { rng_uniform<real, 3>(key, QS_SITE_SENS_POS_U, 0, drone, 0, -c.pos_unif_range, c.pos_unif_range, u); for (int q = 0; q < 3; ++q) n.p[q] += u[q]; }
-        if (c.vel_unif_range != (real)0) { rng_uniform<real, 3>(key, QS_SITE_SENS_VEL_U, 0, drone, 0, -c.vel_unif_range, c.vel_unif_range, u); for (int q = 0; q < 3; ++q) n.v[q] += u[q]; }
-        if (c.quat_norm_std != (real)0) { rng_normal<real, 3>(key, QS_SITE_SENS_THETA_N, 0, drone, 0, z); for (int q = 0; q < 3; ++q) n.th[q] = c.quat_norm_std * z[q]; }
-        if (c.quat_unif_range != (real)0) { rng_uniform<real, 3>(key, QS_SITE_SENS_THETA_U, 0, drone, 0, -c.quat_unif_range, c.quat_unif_range, u); for (int q = 0; q < 3; ++q) n.th[q] += u[q]; }
+        if (c.pos_unif_range != (real)0) { rng_uniform<real,
+            3>(key, QS_SITE_SENS_POS_U, 0, drone, 0, -c.pos_unif_range, c.pos_unif_range, u); for (int q = 0; q < 3; ++q) n.p[q] += u[q]; }
+        if (c.vel_unif_range != (real)0) { rng_uniform<real,
+            3>(key, QS_SITE_SENS_VEL_U, 0, drone, 0, -c.vel_unif_range, c.vel_unif_range, u); for (int q = 0; q < 3; ++q) n.v[q] += u[q]; }
+        if (c.quat_norm_std != (real)0) { rng_normal<real, 3>(key, QS_SITE_SENS_THETA_N, 0, drone, 0, z);
+            for (int q = 0; q < 3; ++q) n.th[q] = c.quat_norm_std * z[q]; }
+        if (c.quat_unif_range != (real)0) { rng_uniform<real,
+            3>(key, QS_SITE_SENS_THETA_U, 0, drone, 0, -c.quat_unif_range, c.quat_unif_range, u);
+        for (int q = 0; q < 3; ++q) n.th[q] += u[q]; }
     }
 }
 
 // Self observation: get_state.py:6-72 + sensor_noise.py:112-218.  Writes self_dim values to o[] (LDS row).
 template <typename real>
-__device__ __forceinline__ void self_obs(const Consts<real> &c, const SensNoise<real> &n, const Drone<real> &d, const real goal[3], real *o) {
+__device__ __forceinline__ void self_obs(const Consts<real> &c, const SensNoise<real> &n, const Drone<real> &d, const real goal[3],
+    real *o) {
     real p[3], v[3], w[3], R[9];
     if (!c.sense_noise) {
 #pragma unroll
@@ -535,8 +545,10 @@ __device__ __forceinline__ void self_obs(const Consts<real> &c, const SensNoise<
         if (c.quat_norm_std != (real)0 || c.quat_unif_range != (real)0) {
             const real *th = n.th;
             real nt = norm3<real>(th), qsq = nt * nt / (real)4, qt[4];
-            if (qsq < (real)1) { qt[0] = M<real>::sqrt((real)1 - qsq); qt[1] = th[0] * (real)0.5; qt[2] = th[1] * (real)0.5; qt[3] = th[2] * (real)0.5; }
-            else { real ww = (real)1 / M<real>::sqrt((real)1 + qsq), f = (real)0.5 * ww; qt[0] = ww; qt[1] = th[0] * f; qt[2] = th[1] * f; qt[3] = th[2] * f; }
+            if (qsq < (real)1) { qt[0] = M<real>::sqrt((real)1 - qsq); qt[1] = th[0] * (real)0.5; qt[2] = th[1] * (real)0.5;
+                qt[3] = th[2] * (real)0.5; }
+            else { real ww = (real)1 / M<real>::sqrt((real)1 + qsq), f = (real)0.5 * ww; qt[0] = ww; qt[1] = th[0] * f;
+                qt[2] = th[1] * f; qt[3] = th[2] * f; }
             real qn = M<real>::sqrt(qt[0] * qt[0] + qt[1] * qt[1] + qt[2] * qt[2] + qt[3] * qt[3]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) qt[k] /= qn;
@@ -557,7 +569,8 @@ __device__ __forceinline__ void self_obs(const Consts<real> &c, const SensNoise<
     if (c.obs_repr == QS_OBS_XYZ_VXYZ_R_OMEGA_FLOOR) o[18] = p[2];
     else if (c.obs_repr == QS_OBS_XYZ_VXYZ_R_OMEGA_WALL) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { o[18 + q] = clipr<real>(p[q] - c.room_lo[q], (real)0, (real)5); o[21 + q] = clipr<real>(c.room_hi[q] - p[q], (real)0, (real)5); }
+        for (int q = 0; q < 3; ++q) { o[18 + q] = clipr<real>(p[q] - c.room_lo[q], (real)0, (real)5);
+            o[21 + q] = clipr<real>(c.room_hi[q] - p[q], (real)0, (real)5); }
     }
 }
 
@@ -578,7 +591,8 @@ template <typename real> __device__ __forceinline__ void compute_new_omega(const
 
 // perform_collision_with_obstacle collisions/obstacles.py:23-50 (+ :9-20)
 template <typename real>
-__device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const RngKey &key, int drone, Drone<real> &d, real ox, real oy, real obst_size) {
+__device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const RngKey &key, int drone, Drone<real> &d, real ox, real oy,
+    real obst_size) {
     real n[3] = {d.pos[0] - ox, d.pos[1] - oy, 0};
     real mag = norm3<real>(n), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
     n[0] /= den; n[1] /= den;
@@ -601,7 +615,8 @@ __device__ __forceinline__ void collide_obstacle(const Consts<real> &c, const Rn
     if (QS_ON_TAPE(key)) { for (int q = 0; q < 4; ++q) u[q] = (real)tape_pop(key); }   // uniform(-1,1,3), uniform(pi/2, pi)
     else {
         uint32_t w[4]; rng_words(key, QS_SITE_OBST_W, 0, drone, 0, w);
-        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]); u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
+        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]);
+        u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
         u[3] = (real)(0.5 * QS_PI_D) + (real)(QS_PI_D - 0.5 * QS_PI_D) * u01<real>(w[3]);
     }
     real dw[3]; compute_new_omega<real>(u, dw);
@@ -640,7 +655,8 @@ __device__ __forceinline__ void collide_room(const Consts<real> &c, const RngKey
     if (tape) { for (int q = 0; q < 4; ++q) u[q] = (real)tape_pop(key); }
     else {
         rng_words(key, site, 2, drone, 0, w);
-        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]); u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
+        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]);
+        u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
         u[3] = (real)(10.0 * QS_PI_D) + (real)(10.0 * QS_PI_D) * u01<real>(w[3]);
     }
     real um = norm3<real>(u);
@@ -750,7 +766,8 @@ __device__ QS_COLD int generate_goals(const Formation<real> &F, int n, int fd, c
 // QUADS_PARAMS_DICT scenarios/utils.py:33-51: number of candidate formations and [low, high] formation size
 __device__ __forceinline__ void scen_params(int scen, int *nform, float *lo, float *hi) {
     *nform = 1; *lo = 0.f; *hi = 0.f;
-    if (scen == QS_SCENARIO_STATIC_DIFF_GOAL || scen == QS_SCENARIO_DYNAMIC_DIFF_GOAL || scen == QS_SCENARIO_SWARM_VS_SWARM || scen == QS_SCENARIO_RUN_AWAY) { *nform = 8; *lo = 0.25f; *hi = 0.5f; }
+    if (scen == QS_SCENARIO_STATIC_DIFF_GOAL || scen == QS_SCENARIO_DYNAMIC_DIFF_GOAL || scen == QS_SCENARIO_SWARM_VS_SWARM
+        || scen == QS_SCENARIO_RUN_AWAY) { *nform = 8; *lo = 0.25f; *hi = 0.5f; }
     else if (scen == QS_SCENARIO_SWAP_GOALS) { *nform = 8; *lo = 0.4f; *hi = 0.8f; }
     else if (scen == QS_SCENARIO_DYNAMIC_FORMATIONS) { *nform = 8; *lo = 0.f; *hi = 1.0f; }
     else if (scen == QS_SCENARIO_O_SWAP_GOALS) { *nform = 7; *lo = 0.4f; *hi = 0.8f; }
@@ -849,7 +866,8 @@ __device__ QS_COLD void svs_create_formations(const RngKey &key, const Formation
 // Must be called by all lanes of the wave with `on` uniform per environment; needs N / 2 >= 3 (every formation has as many rows as drones).
 // ------------------------------------------------------------------------------------------------
 template <typename real>
-__device__ __forceinline__ void goal_row(const Formation<real> &F, int n, int fd, const real center[3], int i, real g[3], bool &needs_mean) {
+__device__ __forceinline__ void goal_row(const Formation<real> &F, int n, int fd, const real center[3], int i, real g[3],
+    bool &needs_mean) {
     const int f = F.f, per = F.per_layer;
     const real size = F.size;
     needs_mean = false;
@@ -885,7 +903,8 @@ __device__ __forceinline__ void goal_row(const Formation<real> &F, int n, int fd
 // at row r0.  `build`, `do_shuffle`, `n`, `fd`, `cen`, `r0`, `slot_base` are uniform over the lanes of one formation; `on` is uniform per
 // environment; environments of one wave may differ in all of them (their lanes share no data).
 template <typename real>
-__device__ __forceinline__ void formation_rows_wave(const RngKey &key, const Formation<real> &F, bool build, int n, int fd, const real cen[3], int li, int r0,
+__device__ __forceinline__ void formation_rows_wave(const RngKey &key, const Formation<real> &F, bool build, int n, int fd,
+    const real cen[3], int li, int r0,
                                                     bool do_shuffle, int slot_base, real *goals, int *scr, int i, bool on) {
     real g[3] = {0, 0, 0};
     bool needs_mean = false;
@@ -948,11 +967,13 @@ __device__ __forceinline__ void formation_rows_wave(const RngKey &key, const For
 }
 
 template <typename real>
-__device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, const Formation<real> &F, int N, int fd0, int fd1, const real c1[3], const real c2[3],
+__device__ __forceinline__ void svs_create_formations_wave(const RngKey &key, const Formation<real> &F, int N, int fd0, int fd1,
+    const real c1[3], const real c2[3],
                                                            bool do_shuffle, real *goals, int *scr, int i, bool on) {
     const int n1 = N / 2, n2 = N - N / 2;
     const bool second = i >= n1;   // this lane's formation: rows, local row, first row
-    formation_rows_wave<real>(key, F, true, second ? n2 : n1, second ? fd1 : fd0, second ? c2 : c1, second ? i - n1 : i, second ? n1 : 0, do_shuffle,
+    formation_rows_wave<real>(key, F, true, second ? n2 : n1, second ? fd1 : fd0, second ? c2 : c1, second ? i - n1 : i, second ? n1 : 0,
+        do_shuffle,
                               second ? 256 : 0, goals, scr, i, on);
 }
 

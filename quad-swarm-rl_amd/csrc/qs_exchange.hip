@@ -32,12 +32,15 @@ int fail(int code, const std::string &m) { g_err = m; return code; }
 // copy / convert this workgroup's share (part of parts) of src[0, n) into dst (wire type).  Vector path: groups of 8 floats
 // (two 16-byte loads, one or two 16-byte stores per lane); pointers that are not 16-byte aligned (a row count that is not a
 // multiple of 8 puts rank r's rows at an odd offset) take the element-wise path.
-__device__ __forceinline__ void copy_range(const float *__restrict__ src, char *__restrict__ dst, long long n, int wire, int part, int parts) {
+__device__ __forceinline__ void copy_range(const float *__restrict__ src, char *__restrict__ dst, long long n, int wire, int part,
+    int parts) {
     const bool vec = ((((size_t)src) | ((size_t)dst)) & 15) == 0;
     if (!vec) {
         const long long per = (n + parts - 1) / parts, k0 = per * part, k1 = (k0 + per < n) ? k0 + per : n;
-        if (wire == QS_WIRE_BF16) { unsigned short *d2 = (unsigned short *)dst; for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) st2_wt(d2 + k, f32_to_bf16_rne(src[k])); }
-        else { float *d1 = (float *)dst; for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) st4_wt(d1 + k, __float_as_uint(src[k])); }
+        if (wire == QS_WIRE_BF16) { unsigned short *d2 = (unsigned short *)dst;
+            for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) st2_wt(d2 + k, f32_to_bf16_rne(src[k])); }
+        else { float *d1 = (float *)dst;
+            for (long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) st4_wt(d1 + k, __float_as_uint(src[k])); }
         return;
     }
     const long long nvec = n >> 3;                                   // groups of 8 floats
@@ -72,7 +75,8 @@ __device__ __forceinline__ void copy_range(const float *__restrict__ src, char *
 
 // QS_WIRE_Q8: this workgroup's share of `rows` float32 rows [rows][q.D] -> wire rows (q.row_words 4-byte words each), 16 bytes per store
 // where source share and destination are 16-byte aligned (always, for the row counts of whole wavefront blocks)
-__device__ __forceinline__ void copy_rows_q8(const float *__restrict__ src, char *__restrict__ dst, long long rows, const Q8Dev &q, int part, int parts) {
+__device__ __forceinline__ void copy_rows_q8(const float *__restrict__ src, char *__restrict__ dst, long long rows, const Q8Dev &q,
+    int part, int parts) {
     const long long words = rows * q.row_words;
     if ((((size_t)dst) & 15) == 0 && (words & 3) == 0) {
         const long long nvec = words >> 2, per = (nvec + parts - 1) / parts, v0 = per * part, v1 = (v0 + per < nvec) ? v0 + per : nvec;
@@ -149,8 +153,10 @@ __global__ void __launch_bounds__(64) qs_xchg_release_kernel(ReleaseArgs a) {
     if (r == 0) a.loc->release_seq = seq;
 }
 
-__global__ void __launch_bounds__(256) qs_obs_pack_kernel(const float *src, char *dst, long long n, int wire) { copy_range(src, dst, n, wire, blockIdx.x, gridDim.x); wt_drain(); }
-__global__ void __launch_bounds__(256) qs_obs_pack_q8_kernel(const float *src, char *dst, long long rows, Q8Dev q) { copy_rows_q8(src, dst, rows, q, blockIdx.x, gridDim.x); wt_drain(); }
+__global__ void __launch_bounds__(256) qs_obs_pack_kernel(const float *src, char *dst, long long n,
+    int wire) { copy_range(src, dst, n, wire, blockIdx.x, gridDim.x); wt_drain(); }
+__global__ void __launch_bounds__(256) qs_obs_pack_q8_kernel(const float *src, char *dst, long long rows,
+    Q8Dev q) { copy_rows_q8(src, dst, rows, q, blockIdx.x, gridDim.x); wt_drain(); }
 // wire rows -> float32 rows (one thread per element)
 __global__ void __launch_bounds__(256) qs_obs_unpack_kernel(const char *src, float *dst, long long rows, int cols, int wire, Q8Dev q) {
     const long long n = rows * cols;
@@ -274,9 +280,11 @@ static int xchg_create(int device, int world, int rank, int64_t rows, int32_t co
     XTRY(hipMemset(x->staging[0], 0, 2 * stage_bytes));
     XTRY(hipDeviceSynchronize());
     int khz = 100000;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) { (void)hipGetLastError();
+        khz = 100000; }
     x->timeout_ticks = (unsigned long long)khz * QS_XCHG_TIMEOUT_MS;
-    if (const char *ev = getenv("QS_XCHG_TIMEOUT_MS")) { const long v = atol(ev); if (v > 0) x->timeout_ticks = (unsigned long long)khz * (unsigned long long)v; }
+    if (const char *ev = getenv("QS_XCHG_TIMEOUT_MS")) { const long v = atol(ev);
+        if (v > 0) x->timeout_ticks = (unsigned long long)khz * (unsigned long long)v; }
     if (const char *ev = getenv("QS_XCHG_FENCED")) x->fenced = atoi(ev) != 0 ? 1 : 0;
     x->peer_data[rank] = x->data;
     x->peer_flags[rank] = x->flags;
@@ -342,12 +350,15 @@ int qs_xchg_attach(qs_xchg *x, const void *blobs) {
 }
 
 int qs_xchg_attach_local(qs_xchg *x, int peer_rank, qs_xchg *peer) {
-    if (!x || !peer || peer_rank < 0 || peer_rank >= x->world || peer_rank == x->rank) return fail(-1, "qs_xchg_attach_local: bad argument");
-    if (peer->world != x->world || peer->n != x->n || peer->wire != x->wire || peer->rank_bytes != x->rank_bytes || peer->rank != peer_rank) return fail(-1, "qs_xchg_attach_local: endpoints do not match");
+    if (!x || !peer || peer_rank < 0 || peer_rank >= x->world || peer_rank == x->rank) return fail(-1,
+        "qs_xchg_attach_local: bad argument");
+    if (peer->world != x->world || peer->n != x->n || peer->wire != x->wire || peer->rank_bytes != x->rank_bytes
+        || peer->rank != peer_rank) return fail(-1, "qs_xchg_attach_local: endpoints do not match");
     if (peer->device != x->device) {
         XTRY(hipSetDevice(x->device));
         hipError_t pe = hipDeviceEnablePeerAccess(peer->device, 0);
-        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(-2, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+        if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(-2,
+            std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
         (void)hipGetLastError();
     }
     x->peer_data[peer_rank] = peer->data; x->peer_flags[peer_rank] = peer->flags;
@@ -371,7 +382,8 @@ int qs_xchg_push(qs_xchg *x, const void *src_f32, void *stream) {
     memset(&a, 0, sizeof a);
     a.src = (const float *)src_f32; a.staging[0] = x->staging[0]; a.staging[1] = x->staging[1];
     for (int r = 0; r < x->world; ++r) { a.data_win[r] = x->peer_data[r]; a.flag_win[r] = x->peer_flags[r]; }
-    a.mine = x->flags; a.loc = x->loc; a.n = x->n; a.slot_bytes = (long long)x->slot_bytes; a.world = x->world; a.rank = x->rank; a.wire = x->wire;
+    a.mine = x->flags; a.loc = x->loc; a.n = x->n; a.slot_bytes = (long long)x->slot_bytes; a.world = x->world; a.rank = x->rank;
+    a.wire = x->wire;
     a.timeout_ticks = x->timeout_ticks; a.q8 = x->q8; a.rows = x->rows; a.fenced = x->fenced;
     hipLaunchKernelGGL(qs_xchg_push_kernel, dim3(grid_parts(x->n), x->world), dim3(256), 0, (hipStream_t)stream, a);
     XTRY(hipGetLastError());
@@ -418,10 +430,12 @@ void *qs_xchg_fused_desc(qs_xchg *x, int32_t blocks, int32_t auto_ack, int64_t *
     XchgDev d;
     memset(&d, 0, sizeof d);
     for (int r = 0; r < x->world; ++r) { d.data_win[r] = x->peer_data[r]; d.flag_win[r] = x->peer_flags[r]; }
-    d.mine = x->flags; d.loc = x->loc; d.n = x->n; d.slot_bytes = (long long)x->slot_bytes; d.world = x->world; d.rank = x->rank; d.wire = x->wire;
+    d.mine = x->flags; d.loc = x->loc; d.n = x->n; d.slot_bytes = (long long)x->slot_bytes; d.world = x->world; d.rank = x->rank;
+    d.wire = x->wire;
     d.auto_ack = auto_ack ? 1 : 0; d.blocks = (unsigned int)blocks; d.timeout_ticks = x->timeout_ticks; d.q8 = x->q8; d.fenced = x->fenced;
     if (!x->desc && hipMalloc((void **)&x->desc, sizeof d) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(x->desc, &d, sizeof d, hipMemcpyHostToDevice) != hipSuccess) { g_err = "descriptor upload failed"; return nullptr; }
+    if (hipDeviceSynchronize() != hipSuccess
+        || hipMemcpy(x->desc, &d, sizeof d, hipMemcpyHostToDevice) != hipSuccess) { g_err = "descriptor upload failed"; return nullptr; }
     if (n_out) *n_out = x->n;
     return x->desc;
 }
@@ -449,7 +463,8 @@ int qs_obs_pack(const void *src_f32, void *dst, int64_t n, int wire, void *strea
     if (n == 0) return 0;
     int parts = (int)(((n >> 3) + 1023) / 1024);
     parts = parts < 1 ? 1 : (parts > 1024 ? 1024 : parts);
-    hipLaunchKernelGGL(qs_obs_pack_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, (const float *)src_f32, (char *)dst, (long long)n, wire);
+    hipLaunchKernelGGL(qs_obs_pack_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, (const float *)src_f32, (char *)dst,
+        (long long)n, wire);
     XTRY(hipGetLastError());
     return 0;
 }
@@ -461,7 +476,8 @@ int qs_obs_pack_rows(const void *src_f32, void *dst, int64_t rows, int32_t cols,
     if (rows == 0) return 0;
     int parts = (int)((rows * q.row_words / 4 + 1023) / 1024);
     parts = parts < 1 ? 1 : (parts > 1024 ? 1024 : parts);
-    hipLaunchKernelGGL(qs_obs_pack_q8_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, (const float *)src_f32, (char *)dst, (long long)rows, q);
+    hipLaunchKernelGGL(qs_obs_pack_q8_kernel, dim3(parts), dim3(256), 0, (hipStream_t)stream, (const float *)src_f32, (char *)dst,
+        (long long)rows, q);
     XTRY(hipGetLastError());
     return 0;
 }
@@ -469,12 +485,14 @@ int qs_obs_pack_rows(const void *src_f32, void *dst, int64_t rows, int32_t cols,
 int qs_obs_unpack_rows(const void *src_wire, void *dst_f32, int64_t rows, int32_t cols, int wire, const qs_wire_q8 *layout, void *stream) {
     Q8Dev q;
     memset(&q, 0, sizeof q);
-    if (!src_wire || !dst_f32 || rows < 0 || cols < 1 || (wire != QS_WIRE_F32 && wire != QS_WIRE_BF16 && wire != QS_WIRE_Q8) || (wire == QS_WIRE_Q8 && !q8_dev(cols, layout, q)))
+    if (!src_wire || !dst_f32 || rows < 0 || cols < 1 || (wire != QS_WIRE_F32 && wire != QS_WIRE_BF16 && wire != QS_WIRE_Q8)
+        || (wire == QS_WIRE_Q8 && !q8_dev(cols, layout, q)))
         return fail(-1, "qs_obs_unpack_rows: bad argument");
     if (rows == 0) return 0;
     long long parts = (rows * cols + 2047) / 2048;
     parts = parts < 1 ? 1 : (parts > 2048 ? 2048 : parts);
-    hipLaunchKernelGGL(qs_obs_unpack_kernel, dim3((int)parts), dim3(256), 0, (hipStream_t)stream, (const char *)src_wire, (float *)dst_f32, (long long)rows, (int)cols, wire, q);
+    hipLaunchKernelGGL(qs_obs_unpack_kernel, dim3((int)parts), dim3(256), 0, (hipStream_t)stream, (const char *)src_wire,
+        (float *)dst_f32, (long long)rows, (int)cols, wire, q);
     XTRY(hipGetLastError());
     return 0;
 }

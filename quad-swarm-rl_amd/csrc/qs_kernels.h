@@ -48,17 +48,21 @@ static inline int qs_block_bytes(int real_size) { return 40 * 64 * real_size + 6
 // byte offsets of the arrays inside a state block, in the order create_typed lays them out (it checks them)
 template <typename real> struct BlkOff {
     static constexpr uint32_t row = 64 * sizeof(real);
-    static constexpr uint32_t pos = 0, vel = 3 * row, rot = 6 * row, omega = 15 * row, rot_damp = 18 * row, cmds_damp = 22 * row, ou = 26 * row, goal = 30 * row,
+    static constexpr uint32_t pos = 0, vel = 3 * row, rot = 6 * row, omega = 15 * row, rot_damp = 18 * row, cmds_damp = 22 * row,
+        ou = 26 * row, goal = 30 * row,
                               ring = 33 * row, sums = 37 * row, flags = 40 * row, pair = 40 * row + 256, bytes = 40 * row + 768;
 };
 // components per drone of the blocked arrays (the lane pitch inside an array, in elements)
-namespace blkc { constexpr int pos = 3, vel = 3, rot = 9, omega = 3, rot_damp = 4, cmds_damp = 4, ou = 4, goal = 3, ring = 4, sums = 3, flags = 1, pair = 1; }
-struct StateBlk { char *base; uint32_t bytes, block_bytes, epb, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags, pair, newpair, reward, done, ohit, lane_major; };
+namespace blkc { constexpr int pos = 3, vel = 3, rot = 9, omega = 3, rot_damp = 4, cmds_damp = 4, ou = 4, goal = 3, ring = 4, sums = 3,
+    flags = 1, pair = 1; }
+struct StateBlk { char *base; uint32_t bytes, block_bytes, epb, pos, vel, rot, omega, rot_damp, cmds_damp, ou, goal, ring, sums, flags,
+    pair, newpair, reward, done, ohit, lane_major; };
 // element (component q of drone i of env e) of a blocked array of `comps` components, for the code outside the step kernels'
 // buffer-resource views
 template <typename TT> __device__ __forceinline__ TT &blk_at(const StateBlk &b, uint32_t arr, int comps, int q, int e, int i, int N) {
     const int blk = e / (int)b.epb, lane = (e - blk * (int)b.epb) * N + i;
-    return *(TT *)(b.base + (size_t)blk * b.block_bytes + arr + (b.lane_major ? (size_t)lane * comps + q : (size_t)q * 64 + lane) * sizeof(TT));
+    return *(TT *)(b.base + (size_t)blk * b.block_bytes + arr + (b.lane_major
+        ? (size_t)lane * comps + q : (size_t)q * 64 + lane) * sizeof(TT));
 }
 #define QS_BLK_AT(TT, b, name, q, e, i, N) blk_at<TT>((b), (b).name, blkc::name, (q), (e), (i), (N))
 
@@ -110,24 +114,32 @@ template <typename T> struct BufRow {
     uint32_t off, comp_bytes, lane_off;
     bool wide;
     __device__ __forceinline__ T ld(int q = 0) const {
-        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + (uint32_t)q * comp_bytes, 0));
+        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T,
+            __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + (uint32_t)q * comp_bytes, 0));
         else return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, off + (uint32_t)q * comp_bytes, 0));
     }
     __device__ __forceinline__ void st(T v, int q = 0) const {
-        if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qs_u32x2, v), r, lane_off, off + (uint32_t)q * comp_bytes, 0);
-        else if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, lane_off, off + (uint32_t)q * comp_bytes, 0);
+        if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(qs_u32x2, v), r, lane_off,
+            off + (uint32_t)q * comp_bytes, 0);
+        else if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, lane_off,
+            off + (uint32_t)q * comp_bytes, 0);
         else __builtin_amdgcn_raw_buffer_store_b8((uint8_t)v, r, lane_off, off + (uint32_t)q * comp_bytes, 0);
     }
     // the D dwords from byte `at` of this lane's piece of a lane-major array, as the widest accesses that cover them (16, 12, 8, 4 bytes)
     template <int D> __device__ __forceinline__ void ld_dwords(uint32_t *w, uint32_t at) const {
-        if constexpr (D >= 4) { const qs_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, off + at, 0); w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; if constexpr (D > 4) ld_dwords<D - 4>(w + 4, at + 16); }
-        else if constexpr (D == 3) { const qs_u32x3 x = __builtin_amdgcn_raw_buffer_load_b96(r, lane_off, off + at, 0); w[0] = x.x; w[1] = x.y; w[2] = x.z; }
-        else if constexpr (D == 2) { const qs_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + at, 0); w[0] = x.x; w[1] = x.y; }
+        if constexpr (D >= 4) { const qs_u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, off + at, 0); w[0] = x.x;
+            w[1] = x.y; w[2] = x.z; w[3] = x.w; if constexpr (D > 4) ld_dwords<D - 4>(w + 4, at + 16); }
+        else if constexpr (D == 3) { const qs_u32x3 x = __builtin_amdgcn_raw_buffer_load_b96(r, lane_off, off + at, 0); w[0] = x.x;
+            w[1] = x.y; w[2] = x.z; }
+        else if constexpr (D == 2) { const qs_u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, off + at, 0); w[0] = x.x;
+            w[1] = x.y; }
         else w[0] = __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, off + at, 0);
     }
     template <int D> __device__ __forceinline__ void st_dwords(const uint32_t *w, uint32_t at) const {
-        if constexpr (D >= 4) { const qs_u32x4 x = {w[0], w[1], w[2], w[3]}; __builtin_amdgcn_raw_buffer_store_b128(x, r, lane_off, off + at, 0); if constexpr (D > 4) st_dwords<D - 4>(w + 4, at + 16); }
-        else if constexpr (D == 3) { const qs_u32x3 x = {w[0], w[1], w[2]}; __builtin_amdgcn_raw_buffer_store_b96(x, r, lane_off, off + at, 0); }
+        if constexpr (D >= 4) { const qs_u32x4 x = {w[0], w[1], w[2], w[3]};
+            __builtin_amdgcn_raw_buffer_store_b128(x, r, lane_off, off + at, 0); if constexpr (D > 4) st_dwords<D - 4>(w + 4, at + 16); }
+        else if constexpr (D == 3) { const qs_u32x3 x = {w[0], w[1], w[2]};
+            __builtin_amdgcn_raw_buffer_store_b96(x, r, lane_off, off + at, 0); }
         else if constexpr (D == 2) { const qs_u32x2 x = {w[0], w[1]}; __builtin_amdgcn_raw_buffer_store_b64(x, r, lane_off, off + at, 0); }
         else __builtin_amdgcn_raw_buffer_store_b32(w[0], r, lane_off, off + at, 0);
     }
@@ -157,7 +169,8 @@ template <typename T> struct BufRow {
         uint32_t w[D];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if constexpr (sizeof(T) == 8) { const uint64_t u = __builtin_bit_cast(uint64_t, src[k]); w[2 * k] = (uint32_t)u; w[2 * k + 1] = (uint32_t)(u >> 32); }
+            if constexpr (sizeof(T) == 8) { const uint64_t u = __builtin_bit_cast(uint64_t, src[k]); w[2 * k] = (uint32_t)u;
+                w[2 * k + 1] = (uint32_t)(u >> 32); }
             else w[k] = __builtin_bit_cast(uint32_t, src[k]);
         }
         st_dwords<D>(w, 0);
@@ -200,8 +213,10 @@ template <> struct NbrKey<float> {
     __device__ __forceinline__ bool less(const NbrKey &o) const { return k < o.k; }
     __device__ __forceinline__ int idx() const { return (int)(uint32_t)k; }
     // LDS list entry `slot` of lane tid: keys [slots][B]
-    static __device__ __forceinline__ void st(unsigned char *base, int slots, int slot, int B, int tid, const NbrKey &v) { ((unsigned long long *)base)[slot * B + tid] = v.k; }
-    static __device__ __forceinline__ NbrKey ld(const unsigned char *base, int slots, int slot, int B, int tid) { return {((const unsigned long long *)base)[slot * B + tid]}; }
+    static __device__ __forceinline__ void st(unsigned char *base, int slots, int slot, int B, int tid,
+        const NbrKey &v) { ((unsigned long long *)base)[slot * B + tid] = v.k; }
+    static __device__ __forceinline__ NbrKey ld(const unsigned char *base, int slots, int slot, int B,
+        int tid) { return {((const unsigned long long *)base)[slot * B + tid]}; }
 };
 template <> struct NbrKey<double> {
     double m; int j;
@@ -244,7 +259,9 @@ template <> struct NbrKey<double> {
 #ifndef QS_POISON_PARTS
 #define QS_POISON_PARTS 31
 #endif
-__device__ __forceinline__ uint32_t qs_poison_bits() { uint32_t u = QS_POISON_IDLE == 1 ? 0x7fc0deadu : 0x7217e7d5u; asm volatile("" : "+v"(u)); return u; }   // (opaque: fast-math would fold a literal NaN away)
+// (opaque: fast-math would fold a literal NaN away)
+__device__ __forceinline__ uint32_t qs_poison_bits() { uint32_t u = QS_POISON_IDLE == 1 ? 0x7fc0deadu : 0x7217e7d5u;
+    asm volatile("" : "+v"(u)); return u; }
 template <typename real> __device__ __forceinline__ real qs_poison() { return (real)__builtin_bit_cast(float, qs_poison_bits()); }
 #define QS_POISON_LDS(total_bytes, nthreads) do { if (QS_POISON_PARTS & 4) { for (int w_ = threadIdx.x; w_ < (total_bytes) / 4; w_ += (nthreads)) ((uint32_t *)smem)[w_] = qs_poison_bits(); __syncthreads(); } } while (0)
 #define QS_POISON_ARR_(a, n) do { if (!active) { _Pragma("unroll") for (int q_ = 0; q_ < (n); ++q_) (a)[q_] = qs_poison<real>(); } } while (0)
@@ -259,7 +276,8 @@ template <typename real> __device__ __forceinline__ real qs_poison() { return (r
 #define QS_POISON_U64(x) do { } while (0)
 #endif
 
-struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal, off_obst, off_metric, off_obs, goal_rows, total;
+struct LdsLayout { int off_mask, off_omap, off_si, off_sr, off_envflag, off_scratch, off_pos, off_vel, off_zax, off_om, off_goal,
+    off_obst, off_metric, off_obs, goal_rows, total;
                    int off_t_rot, off_t_goal, off_t_prox, off_t_col, off_t_dw, off_t_ohit;
                    // team kernels: the step's 17 reward terms + the done flag, for the wave that keeps the episode sums
                    int off_t_ri;
@@ -308,7 +326,9 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
     L.off_zax = o; o += real_size * 3 * B;            // body z axes (downwash); spawn points in the reset tail
     L.off_obst = o; o += real_size * 2 * (num_obst > 0 ? num_obst : 1) * epb;   // obstacle xy of the block's envs
     // neighbour metric rows [N][B]; team kernels with N > 8: one sorted top-8 list per wave, metrics [8W][B] + indices [8W][B]
-    L.off_metric = o; o += ((team ? K > 0 : K > 8) && K < N - 1) ? ((team && N > 8) ? ((real_size + 4) * 8 * team > real_size * N ? (real_size + 4) * 8 * team : real_size * N) * B : real_size * N * B) : 0;
+    L.off_metric = o; o += ((team ? K > 0 : K > 8) && K < N - 1)
+        ? ((team && N > 8) ? ((real_size + 4) * 8 * team > real_size * N
+        ? (real_size + 4) * 8 * team : real_size * N) * B : real_size * N * B) : 0;
     o = (o + 15) & ~15;
     if (team) {
         L.off_mask = o; o += 8 * B;                   // u64 per lane: new-pair masks for the serial response path
@@ -339,7 +359,8 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
         o = (o + 15) & ~15;
         // the rows stage and, in the same bytes, what only the rare paths touch: (a) collision responses: pair masks + angular
         // velocities, (b) scenario goal switch / reset: goal scratch rows + reset scratch
-        const int stage_bytes = real_size * extra * L.rows_per_pass, rare_a = 8 * B + real_size * 3 * B, rare_b = goal_bytes + scratch_bytes;
+        const int stage_bytes = real_size * extra * L.rows_per_pass, rare_a = 8 * B + real_size * 3 * B,
+            rare_b = goal_bytes + scratch_bytes;
         int u = stage_bytes > rare_a ? stage_bytes : rare_a;
         u = u > rare_b ? u : rare_b;
         L.off_rows = o; L.off_mask = o; L.off_om = o + 8 * B; L.off_goal = o; L.off_scratch = o + goal_bytes;
@@ -361,7 +382,8 @@ static LdsLayout lds_layout(int real_size, int B, int N, int epb, int obs_dim, i
 // compares); larger N with a streaming sorted top-K list (insertion by compare-exchange).  Both give the first K
 // entries of the stable ascending order of the metric = argsort.
 template <typename real>
-__device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
+__device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos,
+    const real *s_vel,
                                              real *s_metric, const real mypos[3], const real myvel[3], real *o) {
     const int K = c.num_neighbors;
     if (K <= 0) return;
@@ -374,7 +396,8 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
             for (int u = 0; u < 8; ++u) {        // 48 LDS reads issued before the first use: one round trip
                 const int j = (j0 + u < N) ? j0 + u : N - 1;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a];
+                    rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
             }
             if (all_others) {
 #pragma unroll
@@ -421,7 +444,8 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
             for (int u = 0; u < 4; ++u) {
                 const int j = (j0 + u < N) ? j0 + u : N - 1;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a];
+                    rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -446,7 +470,8 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
         for (int k = 0; k < 8; ++k) {
             if (k < K) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { vals[k][a] = s_pos[a * B + base + bi[k]] - mypos[a]; vals[k][3 + a] = s_vel[a * B + base + bi[k]] - myvel[a]; }
+                for (int a = 0; a < 3; ++a) { vals[k][a] = s_pos[a * B + base + bi[k]] - mypos[a];
+                    vals[k][3 + a] = s_vel[a * B + base + bi[k]] - myvel[a]; }
             }
         }
 #pragma unroll
@@ -503,12 +528,16 @@ __device__ __forceinline__ void neighbor_obs(const Consts<real> &c, int N, int i
 #endif
 typedef float qs_f32x2 __attribute__((ext_vector_type(2)));
 typedef float qs_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void obs_st2(float *dst, qs_f32x2 v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, (qs_f32x2 *)dst); else *(qs_f32x2 *)dst = v; }
-__device__ __forceinline__ void obs_st4(float *dst, qs_f32x4 v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, (qs_f32x4 *)dst); else *(qs_f32x4 *)dst = v; }
-template <typename real> __device__ __forceinline__ void obs_st1(real *dst, real v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, dst); else *dst = v; }
+__device__ __forceinline__ void obs_st2(float *dst, qs_f32x2 v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, (qs_f32x2 *)dst);
+    else *(qs_f32x2 *)dst = v; }
+__device__ __forceinline__ void obs_st4(float *dst, qs_f32x4 v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, (qs_f32x4 *)dst);
+    else *(qs_f32x4 *)dst = v; }
+template <typename real> __device__ __forceinline__ void obs_st1(real *dst, real v) { if (QS_NT_OBS) __builtin_nontemporal_store(v, dst);
+    else *dst = v; }
 
 template <typename real>
-__device__ __forceinline__ void obs_copy_rows(real *__restrict__ dst_block, const real *s_self, const real *s_rows, int S, int D, int r0, int nr, uint64_t rowmask, int tid) {
+__device__ __forceinline__ void obs_copy_rows(real *__restrict__ dst_block, const real *s_self, const real *s_rows, int S, int D, int r0,
+    int nr, uint64_t rowmask, int tid) {
 #ifdef QS_EXP_NOFLUSH   // experiment: how much of the step is the observation output path
     if (rowmask != 0x1234567ull) return;
 #endif
@@ -538,7 +567,8 @@ template <typename real> struct NbrSel {
     uint64_t taken;            // 8 < K < N-1: drones already emitted (arg-min rounds over the LDS metric column)
 };
 template <typename real>
-__device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
+__device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos,
+    const real *s_vel,
                                            real *s_metric, const real mypos[3], const real myvel[3], NbrSel<real> &S) {
     const int K = c.num_neighbors;
     S.taken = 1ull << i;
@@ -552,7 +582,8 @@ __device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, 
             for (int u = 0; u < 8; ++u) {        // 48 LDS reads issued before the first use: one round trip
                 const int j = (u < N) ? u : N - 1;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a];
+                    rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -585,7 +616,8 @@ __device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, 
             for (int u = 0; u < 4; ++u) {
                 const int j = (j0 + u < N) ? j0 + u : N - 1;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+                for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a];
+                    rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -617,8 +649,10 @@ __device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, 
 }
 // neighbours of ranks [k0, k1) -> o[(rank - k0) * 6 ..]   (o = this lane's dense stage row of (k1 - k0) * 6 columns)
 template <typename real>
-__device__ __forceinline__ void nbr_emit(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos, const real *s_vel,
-                                         const real *s_metric, const real mypos[3], const real myvel[3], NbrSel<real> &S, int k0, int k1, real *o) {
+__device__ __forceinline__ void nbr_emit(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos,
+    const real *s_vel,
+                                         const real *s_metric, const real mypos[3], const real myvel[3], NbrSel<real> &S, int k0, int k1,
+                                             real *o) {
     const int K = c.num_neighbors;
     for (int k = k0; k < k1; ++k) {
         int j;
@@ -652,7 +686,8 @@ __device__ __forceinline__ void nbr_emit(const Consts<real> &c, int N, int i, in
 
 // get_surround_sdfs obstacles/utils.py:5-27 (obstacle xy of the env in LDS)
 template <typename real>
-__device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o, real radius) {
+__device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, const real *oy, int M_, real px, real py, real *o,
+    real radius) {
     const real res = (real)0.1;
     real gx[3] = {px - res, px, px + res}, gy[3] = {py - res, py, py + res};
     // min over the obstacles of the SQUARED distance, one square root per cell at the end: the square root is monotone, so
@@ -680,8 +715,10 @@ __device__ __forceinline__ void sdf_obs(const Consts<real> &c, const real *ox, c
 // rare-path buffers: nothing of those may be live here; ends with the stage free again (RP < 64) or still being read (RP = 64:
 // the caller's next barrier).
 template <typename real>
-__device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayout &L, real *__restrict__ dst_block, const real *s_self, real *s_rows, int N, int i, int le, int base, int tid,
-                                            const real *s_pos, const real *s_vel, real *s_metric, const real *s_obst, const real mypos[3], const real myvel[3],
+__device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayout &L, real *__restrict__ dst_block, const real *s_self,
+    real *s_rows, int N, int i, int le, int base, int tid,
+                                            const real *s_pos, const real *s_vel, real *s_metric, const real *s_obst,
+                                                const real mypos[3], const real myvel[3],
                                             bool live, int nrows, uint64_t rowmask, real obst_radius) {
     const int B = QS_WAVE, K = c.num_neighbors, D = c.obs_dim, S = c.self_dim, X = D - S, M_ = c.num_obstacles, RP = L.rows_per_pass;
     NbrSel<real> sel;
@@ -691,7 +728,8 @@ __device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayo
         real nv[QS_NV_MAX];
         if (live) {
             nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel, 0, K, nv);
-            if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], nv + 6 * K, obst_radius);
+            if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1],
+                nv + 6 * K, obst_radius);
         }
         for (int r0 = 0; r0 < nrows; r0 += RP) {
             if (live && tid >= r0 && tid < r0 + RP) {
@@ -709,7 +747,8 @@ __device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayo
     if (live) {   // complete rows at once: straight into the stage
         real *o = s_rows + tid * X;
         nbr_emit<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, mypos, myvel, sel, 0, K, o);
-        if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], o + 6 * K, obst_radius);
+        if (c.use_obstacles) sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, mypos[0], mypos[1], o + 6 * K,
+            obst_radius);
     }
     __syncthreads();
     obs_copy_rows<real>(dst_block, s_self, s_rows, S, D, 0, nrows, rowmask, tid);
@@ -717,9 +756,11 @@ __device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayo
 
 // perform_collision_between_drones collisions/quadrotors.py:24-59 on LDS-resident vel/omega (serial per env)
 template <typename real>
-__device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int j, int base, int B, const real *s_pos, real *s_vel, real *s_om) {
+__device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int j, int base, int B, const real *s_pos, real *s_vel,
+    real *s_om) {
     real p1[3], p2[3], v1[3], v2[3];
-    for (int q = 0; q < 3; ++q) { p1[q] = s_pos[q * B + base + i]; p2[q] = s_pos[q * B + base + j]; v1[q] = s_vel[q * B + base + i]; v2[q] = s_vel[q * B + base + j]; }
+    for (int q = 0; q < 3; ++q) { p1[q] = s_pos[q * B + base + i]; p2[q] = s_pos[q * B + base + j]; v1[q] = s_vel[q * B + base + i];
+        v2[q] = s_vel[q * B + base + j]; }
     real n[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
     real mag = norm3<real>(n), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
     for (int q = 0; q < 3; ++q) n[q] /= den;
@@ -746,7 +787,8 @@ __device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int
     if (QS_ON_TAPE(key)) { for (int q = 0; q < 4; ++q) u[q] = (real)tape_pop(key); }   // uniform(-1,1,3), uniform(10 pi, 20 pi)
     else {
         uint32_t w[4]; rng_words(key, QS_SITE_DD_W, 0, i, j, w);
-        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]); u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
+        u[0] = (real)-1 + (real)2 * u01<real>(w[0]); u[1] = (real)-1 + (real)2 * u01<real>(w[1]);
+        u[2] = (real)-1 + (real)2 * u01<real>(w[2]);
         u[3] = (real)(10.0 * QS_PI_D) + (real)(20.0 * QS_PI_D - 10.0 * QS_PI_D) * u01<real>(w[3]);
     }
     real dw[3]; compute_new_omega<real>(u, dw);
@@ -758,7 +800,8 @@ __device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int
 
 // rare per-drone responses kept out of line so the hot path stays compact
 template <typename real>
-__device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, const RngKey &key, int i, uint32_t bits, real ox, real oy, real pos[3], real vel[3], real omega[3],
+__device__ __forceinline__ void room_obst_responses(const Consts<real> *cp, const RngKey &key, int i, uint32_t bits, real ox, real oy,
+    real pos[3], real vel[3], real omega[3],
                                                     real obst_size) {
     const Consts<real> &c = *cp;
     Drone<real> d;
@@ -834,7 +877,8 @@ __device__ __forceinline__ void team_rank_local(int N, int i, int base, int B, i
 
 // full-scenario kernels: per-env scenario state HBM <-> LDS (each drone of the env moves a strided part)
 template <typename real>
-__device__ __forceinline__ void scen_lds_load(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
+__device__ __forceinline__ void scen_lds_load(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i,
+    int N) {
     real *sr = (real *)(smem + L.off_sr) + le * SR_COUNT;
     int *si = (int *)(smem + L.off_si) + le * SI_COUNT;
     uint64_t *om = (uint64_t *)(smem + L.off_omap) + le * 4;
@@ -854,7 +898,8 @@ template <typename real>
 __device__ __forceinline__ void scen_regs_load(const Ptrs<real> &p, int E, int e, int i, ScenRegs<real> &v) {
     constexpr int N = QS_SPEC_N;
 #pragma unroll
-    for (int j = 0; j < (SR_COUNT + N - 1) / N; ++j) { const int k = i + j * N; v.r[j] = (k < SR_COUNT) ? p.scen_real[k * E + e] : (real)0; }
+    for (int j = 0; j < (SR_COUNT + N - 1) / N; ++j) { const int k = i + j * N; v.r[j] = (k < SR_COUNT)
+        ? p.scen_real[k * E + e] : (real)0; }
 #pragma unroll
     for (int j = 0; j < (SI_COUNT + N - 1) / N; ++j) { const int k = i + j * N; v.n[j] = (k < SI_COUNT) ? p.scen_int[k * E + e] : 0; }
 #pragma unroll
@@ -875,7 +920,8 @@ __device__ __forceinline__ void scen_regs_to_lds(const LdsLayout &L, unsigned ch
 }
 #endif
 template <typename real>
-__device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i, int N) {
+__device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLayout &L, unsigned char *smem, int E, int e, int le, int i,
+    int N) {
     const real *sr = (const real *)(smem + L.off_sr) + le * SR_COUNT;
     const int *si = (const int *)(smem + L.off_si) + le * SI_COUNT;
     const uint64_t *om = (const uint64_t *)(smem + L.off_omap) + le * 4;
@@ -893,7 +939,8 @@ __device__ __forceinline__ void scen_lds_store(const Ptrs<real> &p, const LdsLay
 // velocities: the first neighbour obs of an episode is computed from them (SURVEY App. A reset quirk).
 // ------------------------------------------------------------------------------------------------
 template <typename real, bool FULL, bool TEAM = false, bool STREAM = false>
-__device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem, int epb, const RngKey &key,
+__device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<real> *pp, const LdsLayout *Lp, unsigned char *smem,
+    int epb, const RngKey &key,
                                         bool do_reset, Drone<real> *dp, real goal[3], const real stale_vel[3], int blk = -1) {
     const int bidx = blk < 0 ? (int)blockIdx.x : blk;
     const Consts<real> &c = *cp;
@@ -909,7 +956,8 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
     const int M_ = c.num_obstacles;
     // STREAM: dense self block + rows stage
     real *myobs = STREAM ? (real *)(smem + L.off_self) + tid * c.self_dim : s_obs + tid * c.obs_dim;
-    int *tidx = (int *)(smem + L.off_scratch) + le * (2 * L.scr_cap + 32), *tval = tidx + L.scr_cap, *prev_row = tidx + 2 * L.scr_cap, *cur_row = prev_row + 16;
+    int *tidx = (int *)(smem + L.off_scratch) + le * (2 * L.scr_cap + 32), *tval = tidx + L.scr_cap, *prev_row = tidx + 2 * L.scr_cap,
+        *cur_row = prev_row + 16;
 
 #ifdef QS_TAPE
     int *s_cur = (int *)(smem + L.off_cur);
@@ -1045,7 +1093,8 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
             real z = rng_uniform1<real>(key, QS_SITE_SCEN, 10, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2, zlb = (real)0.25;
             const int f = F.f;
             if (f == 3 || f == 1 || f == 2) zlb = F.size + (real)0.25;
-            else if (f == 5 || f == 6) { int rn = N < F.per_layer ? N : F.per_layer, d1, d2; grid_dim(rn, &d1, &d2); zlb = (real)d1 * F.size + (real)0.25; }
+            else if (f == 5 || f == 6) { int rn = N < F.per_layer ? N : F.per_layer, d1, d2; grid_dim(rn, &d1, &d2);
+                zlb = (real)d1 * F.size + (real)0.25; }
             z = M<real>::fmax(zlb, z);
             real c1[3] = {xy[0], xy[1], z}, c2[3];
             real dist = rng_uniform1<real>(key, QS_SITE_SCEN, 11, 0, 0, box / (real)4, box);
@@ -1112,13 +1161,15 @@ __device__ __forceinline__ void reset_body(const Consts<real> *cp, const Ptrs<re
         const uint64_t rowmask = __ballot(do_reset);
         const int first_env = bidx * epb;
         int nenv = E - first_env; nenv = nenv < epb ? nenv : epb;
-        stream_rows<real>(c, L, p.obs + (size_t)first_env * N * c.obs_dim, (const real *)(smem + L.off_self), (real *)(smem + L.off_rows), N, i, le, base, tid,
+        stream_rows<real>(c, L, p.obs + (size_t)first_env * N * c.obs_dim, (const real *)(smem + L.off_self),
+            (real *)(smem + L.off_rows), N, i, le, base, tid,
                           s_pos, s_vel, s_metric, s_obst, d.pos, stale_vel, do_reset, nenv * N, rowmask,
                           c.dr_num_size > 0 ? (real)0.5 * p.dr_size[s_envflag[2 * epb + (le < epb ? le : 0)] & 7] : c.obst_radius);
     } else if (do_reset) {
         neighbor_obs<real>(c, N, i, base, B, tid, s_pos, s_vel, s_metric, d.pos, stale_vel, myobs + c.self_dim);
         if (c.use_obstacles)
-            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1], myobs + c.self_dim + 6 * c.num_neighbors,
+            sdf_obs<real>(c, s_obst + (le * 2 + 0) * M_, s_obst + (le * 2 + 1) * M_, M_, d.pos[0], d.pos[1],
+                myobs + c.self_dim + 6 * c.num_neighbors,
                           c.dr_num_size > 0 ? (real)0.5 * p.dr_size[s_envflag[2 * epb + le] & 7] : c.obst_radius);
     }
 }
@@ -1174,7 +1225,8 @@ __device__ __forceinline__ void qs_reset_impl(const Consts<real> &c, Ptrs<real> 
 #pragma unroll
         for (int q = 0; q < 9; ++q) QS_BLK_AT(real, p.blk, rot, q, e, i, N) = d.rot[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { QS_BLK_AT(real, p.blk, rot_damp, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, cmds_damp, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, ring, q, e, i, N) = 0; }
+        for (int q = 0; q < 4; ++q) { QS_BLK_AT(real, p.blk, rot_damp, q, e, i, N) = 0;
+            QS_BLK_AT(real, p.blk, cmds_damp, q, e, i, N) = 0; QS_BLK_AT(real, p.blk, ring, q, e, i, N) = 0; }
 #pragma unroll
         // the step kernels leave the sums alone until the episode's 5-s window opens (qs_step_sem.h)
         for (int q = 0; q < 3; ++q) QS_BLK_AT(real, p.blk, sums, q, e, i, N) = 0;
@@ -1471,7 +1523,8 @@ __global__ void __launch_bounds__(QS_WAVE) qs_replay_kernel(const ReplayParams P
     const int act = s_act[0];
     if (act == ACT_NONE) return;
     char *pool = P.pool + (size_t)e * SLOTS * P.snap_bytes;
-    if ((act & 15) == ACT_SAVE) { replay_copy(P, e, pool + (size_t)(s_act[2] & 255) * P.snap_bytes, true, lane); __threadfence_block(); __syncthreads(); }
+    if ((act & 15) == ACT_SAVE) { replay_copy(P, e, pool + (size_t)(s_act[2] & 255) * P.snap_bytes, true, lane); __threadfence_block();
+        __syncthreads(); }
     if ((act & 15) == ACT_FILE || (act >> 4) == ACT_FILE) {
         const char *src = pool + (size_t)((act & 15) == ACT_FILE ? s_act[1] : s_act[3]) * P.snap_bytes;
         char *dst = pool + (size_t)(s_act[2] >> 8) * P.snap_bytes;
@@ -1510,9 +1563,11 @@ __global__ void qs_state_kernel(Ptrs<real> p, int E, int N, int env, double *buf
         s[31] = (double)((f & F_SVD_MASK) >> F_SVD_SHIFT);
         if (i == 0) *tick_io = p.tick[env];
     } else {
-        for (int q = 0; q < 3; ++q) { QS_S(pos, q) = (real)s[q]; QS_S(vel, q) = (real)s[3 + q]; QS_S(omega, q) = (real)s[15 + q]; QS_S(goal, q) = (real)s[32 + q]; }
+        for (int q = 0; q < 3; ++q) { QS_S(pos, q) = (real)s[q]; QS_S(vel, q) = (real)s[3 + q]; QS_S(omega, q) = (real)s[15 + q];
+            QS_S(goal, q) = (real)s[32 + q]; }
         for (int q = 0; q < 9; ++q) QS_S(rot, q) = (real)s[6 + q];
-        for (int q = 0; q < 4; ++q) { QS_S(rot_damp, q) = (real)s[18 + q]; QS_S(cmds_damp, q) = (real)s[22 + q]; QS_S(ou, q) = (real)s[26 + q]; }
+        for (int q = 0; q < 4; ++q) { QS_S(rot_damp, q) = (real)s[18 + q]; QS_S(cmds_damp, q) = (real)s[22 + q];
+            QS_S(ou, q) = (real)s[26 + q]; }
         uint32_t f = QS_BLK_AT(uint32_t, B, flags, 0, env, i, N) & ~(F_ON_FLOOR | F_SVD_MASK);
         if (s[30] != 0.0) f |= F_ON_FLOOR;
         f |= ((uint32_t)s[31] & 0xffu) << F_SVD_SHIFT;

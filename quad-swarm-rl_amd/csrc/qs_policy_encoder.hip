@@ -110,7 +110,8 @@ __device__ unsigned long long enc_wg_times[2 * 8192];   // start / end of every 
 #define ENC_STAMP(k) do { } while (0)
 #endif
 
-__device__ __forceinline__ void glue_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+__device__ __forceinline__ void glue_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+    uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0, h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
@@ -126,7 +127,8 @@ __device__ __forceinline__ float sample_action(const EncParams &P, int a, int h,
     uint32_t w[4];
     glue_philox((uint32_t)a, *P.sample_counter + P.sample_step, 0x51u, (uint32_t)(h >> 2), P.sample_seed_lo, P.sample_seed_hi, w);
     const int pr = (h >> 1) & 1;
-    const float ua = ((float)(w[2 * pr] >> 9) + 0.5f) * (1.0f / 8388608.0f), ub = ((float)(w[2 * pr + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);
+    const float ua = ((float)(w[2 * pr] >> 9) + 0.5f) * (1.0f / 8388608.0f),
+        ub = ((float)(w[2 * pr + 1] >> 9) + 0.5f) * (1.0f / 8388608.0f);
     const float r = sqrtf(-2.0f * __logf(ua));
     float sn, cs;
     __sincosf(6.283185307179586f * ub, &sn, &cs);
@@ -254,7 +256,8 @@ __device__ __forceinline__ void store_tanh(const f32x4 (&acc)[MT][NT], int mtile
 }
 
 // one 16-row MLP: Y[:, col0:col0+256] = tanh(L2 tanh(L1 X)), hidden layer through `hid` (one barrier inside)
-__device__ __forceinline__ void mlp2_one_tile(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride, uint16_t *hid,
+__device__ __forceinline__ void mlp2_one_tile(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride,
+    uint16_t *hid,
                                               uint16_t *Y, int ystride, int col0) {
     f32x4 acc[ENC_MT][1];
     init_bias<ENC_MT, 1>(L1, mt0, acc);
@@ -330,7 +333,8 @@ __device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t 
 // attention, launch 1: e_i = embedding_mlp([self_obs[(a*K+k) mod B] | neighbour obs (a,k)]) -> ebuf;  g_a = W_m mean_k e_(a,k) -> gbuf
 // ------------------------------------------------------------------------------------------------
 template <int NTH>
-__device__ __forceinline__ void embed_pass(const EncParams &P, int B, int a0, int t0, bool first, const uint16_t *x_in, uint16_t *buf_a, f32x4 (&mean)[ENC_MT]) {
+__device__ __forceinline__ void embed_pass(const EncParams &P, int B, int a0, int t0, bool first, const uint16_t *x_in, uint16_t *buf_a,
+    f32x4 (&mean)[ENC_MT]) {
     const int wave = wave_id(), lane = threadIdx.x & 63, mt0 = wave * ENC_MT, NB = P.num_nbr;
     f32x4 acc[ENC_MT][NTH];
     init_bias<ENC_MT, NTH>(P.n1, mt0, acc);
@@ -352,7 +356,8 @@ __device__ __forceinline__ void embed_pass(const EncParams &P, int B, int a0, in
         }
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_embed_kernel(const float *__restrict__ obs, int B, EncParams P) {
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_embed_kernel(const float *__restrict__ obs, int B,
+    EncParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_in = (uint16_t *)smem;                                // [NBR*16][XS]
     uint16_t *buf_a = x_in + ENC_MAX_NBR * ENC_TA * ENC_XS;           // [NH*16][YS]
@@ -414,7 +419,8 @@ struct AttnState { f32x4 o[ENC_MT]; float mx, den; };
 template <int NTH>
 __device__ __forceinline__ void attn_load_e(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a) {
     // e_i rows in 16-byte chunks, coalesced; 32-bit offsets into a buffer resource (rows past the batch read as zero: out of range)
-    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)P.ebuf, 0, (uint32_t)B * (uint32_t)P.num_nbr * (ENC_H * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)P.ebuf, 0,
+        (uint32_t)B * (uint32_t)P.num_nbr * (ENC_H * 2), 0x00020000);
     for (int idx = threadIdx.x; idx < NTH * ENC_TA * (ENC_H / 8); idx += 64 * ENC_WAVES) {
         const int row = idx >> 5, ch = idx & 31, k = t0 + (row >> 4), ra = a0 + (row & 15);
         const uint32_t off = ra < B ? ((uint32_t)ra * (uint32_t)P.num_nbr + (uint32_t)k) * (ENC_H * 2) + ch * 16 : 0xffffffffu;
@@ -426,7 +432,8 @@ __device__ __forceinline__ void attn_load_e(const EncParams &P, int B, int a0, i
 // then the values from the same e_i tile, which go straight into the running sum - the h_i are never live together with another
 // layer's accumulators.  Four barriers per group.
 template <int NTH>
-__device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a, uint16_t *buf_h, float *s_alpha, AttnState &st) {
+__device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a, uint16_t *buf_h, float *s_alpha,
+    AttnState &st) {
     const int wave = wave_id(), lane = threadIdx.x & 63, mt0 = wave * ENC_MT;
     const int ga = a0 + (lane & 15);
     attn_load_e<NTH>(P, B, a0, t0, buf_a);
@@ -502,7 +509,8 @@ __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int
     st.mx = mx;
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_attn_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_attn_kernel(const float *__restrict__ obs, int B,
+    EncParams P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_obst = x_self + ENC_TA * ENC_XS;                      // [16][XS]
@@ -567,7 +575,8 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
 }
 // 16-row MLP like mlp2_one_tile, but the fp32 result also stays in registers (the attention block's residual)
-__device__ __forceinline__ void mlp2_keep(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride, uint16_t *hid, uint16_t *Y,
+__device__ __forceinline__ void mlp2_keep(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride, uint16_t *hid,
+    uint16_t *Y,
                                           f32x4 (&keep)[ENC_MT]) {
     const int lane = threadIdx.x & 63;
     f32x4 acc[ENC_MT][1];
@@ -588,7 +597,8 @@ __device__ __forceinline__ void mlp2_keep(const EncLayer &L1, const EncLayer &L2
 
 // one-layer embedding of 16 rows: Y[:, col..] = tanh(L X); KEEP: the fp32 result also stays in registers (the attention block's residual)
 template <bool KEEP>
-__device__ __forceinline__ void mlp1_keep(const EncLayer &L1, int mt0, const uint16_t *X, int xstride, uint16_t *Y, int ystride, f32x4 (&keep)[ENC_MT]) {
+__device__ __forceinline__ void mlp1_keep(const EncLayer &L1, int mt0, const uint16_t *X, int xstride, uint16_t *Y, int ystride,
+    f32x4 (&keep)[ENC_MT]) {
     const int lane = threadIdx.x & 63;
     f32x4 acc[ENC_MT][1];
     init_bias<ENC_MT, 1>(L1, mt0, acc);
@@ -742,7 +752,8 @@ __device__ __forceinline__ void mha_body(const float *__restrict__ obs, int B, c
             s1 += red_ln[((w * 2 + i) * 2 + 0) * 16 + (lane & 15)];
             s2 += red_ln[((w * 2 + i) * 2 + 1) * 16 + (lane & 15)];
         }
-        const float mean = s1 * (1.0f / ENC_H), var = fmaxf(s2 * (1.0f / ENC_H) - mean * mean, 0.0f), rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
+        const float mean = s1 * (1.0f / ENC_H), var = fmaxf(s2 * (1.0f / ENC_H) - mean * mean, 0.0f),
+            rstd = __builtin_amdgcn_rsqf(var + 1e-6f);
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) {
             const int f0 = (mt0 + mt) * 16 + (lane >> 4) * 4;
@@ -756,10 +767,12 @@ __device__ __forceinline__ void mha_body(const float *__restrict__ obs, int B, c
     __syncthreads();
     feed_forward<S2R ? ENC_MTF / 2 : ENC_MTF>(P, cat, a0, B, out, (float *)hid);
 }
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_kernel(const float *__restrict__ obs, int B, EncParams P,
+    float *__restrict__ out) {
     mha_body<false>(obs, B, P, out);
 }
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_s2r_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_s2r_kernel(const float *__restrict__ obs, int B, EncParams P,
+    float *__restrict__ out) {
     mha_body<true>(obs, B, P, out);
 }
 
@@ -790,7 +803,8 @@ __device__ __forceinline__ void mean_pass(const EncParams &P, int t0, const uint
             for (int r = 0; r < 4; ++r) mean[mt][r] += fast_tanh(acc[mt][nt][r]);
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_kernel(const float *__restrict__ obs, int B, EncParams P, float *__restrict__ out) {
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_kernel(const float *__restrict__ obs, int B,
+    EncParams P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_nbr = x_self + ENC_TA * ENC_XS;                       // [NBR*16][XS]
@@ -935,7 +949,8 @@ __device__ __forceinline__ void ring_fill(WRing &R, const EncLayer &L, int mtile
 // compiler no longer knows how many are in flight and waits for ALL of them (s_waitcnt vmcnt(0)) at the next use of any loaded
 // value - i.e. for the whole prefetched next layer at the end of every layer.
 template <int NT, int KS>
-__device__ __forceinline__ void gemm_ring(WRing &R, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n, const uint16_t *X, int xstride,
+__device__ __forceinline__ void gemm_ring(WRing &R, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n, const uint16_t *X,
+    int xstride,
                                           f32x4 (&acc)[ENC_MT][NT]) {
     const int lane = threadIdx.x & 63, kn = Ln.K >> 5;
     const uint16_t *xrow = X + (lane & 15) * xstride + 8 * (lane >> 4);
@@ -1006,7 +1021,8 @@ __device__ __forceinline__ void add_bias(f32x4 (&acc)[ENC_MT][NT], const Bias &b
 }
 // one layer of the chain: acc = L X + b (fp32, before the non-linearity)
 template <int NT, int KS>
-__device__ __forceinline__ void layer_ring(WRing &R, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n, const uint16_t *X, int xstride,
+__device__ __forceinline__ void layer_ring(WRing &R, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n, const uint16_t *X,
+    int xstride,
                                            f32x4 (&acc)[ENC_MT][NT]) {
     const Bias b = load_bias(L, mtile0);
     zero_acc<ENC_MT, NT>(acc);
@@ -1033,7 +1049,8 @@ __device__ __forceinline__ void store_tanh_wide(const f32x4 (&acc)[ENC_MT][NT], 
 }
 
 // observation rows of the workgroup's ENC_WA agents -> bf16 staging rows (self [WA][XS] | neighbours [(k*WA + a)][XS] | obstacles [WA][XS])
-__device__ __forceinline__ void stage_obs_wide(const float *__restrict__ obs, int B, const EncParams &P, int a0, uint16_t *x_self, uint16_t *x_nbr, uint16_t *x_obst) {
+__device__ __forceinline__ void stage_obs_wide(const float *__restrict__ obs, int B, const EncParams &P, int a0, uint16_t *x_self,
+    uint16_t *x_nbr, uint16_t *x_obst) {
     const int tid = threadIdx.x, D = P.obs_dim, NB = P.num_nbr;
     uint32_t *z = (uint32_t *)x_self;   // the three are contiguous: clear the padding first
     for (int idx = tid; idx < (2 + ENC_WSLOTS) * ENC_WA * ENC_XS / 2; idx += 64 * ENC_WAVES) z[idx] = 0;
@@ -1066,7 +1083,8 @@ __device__ __forceinline__ void stage_obs_wide(const float *__restrict__ obs, in
 
 // feed forward on the ring: the wave's 64 output features as two 32-feature halves over the same `cat` rows
 template <int KS>   // K-steps of the feed-forward layer: 16 ([self | neighbourhood]) or 24 (with obstacles)
-__device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, const uint16_t *cat, int a0, int B, float *__restrict__ out, float *red) {
+__device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, const uint16_t *cat, int a0, int B,
+    float *__restrict__ out, float *red) {
     const int wave = wave_id(), lane = threadIdx.x & 63, mf0 = wave * ENC_MTF;
     const EncLayer none = {nullptr, nullptr, 0, 0};
     f32x4 acc[2][ENC_MT][ENC_AT];
@@ -1121,7 +1139,8 @@ __device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, 
 // WNP is a template parameter picked per neighbour count at launch (one pass body, no run-time tile counts); a last pass that
 // runs past the neighbour count works on zero rows and is masked out of the mean.
 template <int WNP>
-__device__ __forceinline__ void mean_pass_wide(WRing &R, const EncParams &P, int t0, const EncLayer &after, int mt_after, const uint16_t *x_nbr, uint16_t *buf_a,
+__device__ __forceinline__ void mean_pass_wide(WRing &R, const EncParams &P, int t0, const EncLayer &after, int mt_after,
+    const uint16_t *x_nbr, uint16_t *buf_a,
                                                f32x4 (&mean)[ENC_MT][ENC_AT]) {
     constexpr int NT = WNP * ENC_AT;
     const int wave = wave_id(), mt0 = wave * ENC_MT;
@@ -1269,7 +1288,8 @@ __device__ __forceinline__ void embed_wide_body(const float *__restrict__ obs, i
             for (int mt = 0; mt < ENC_MT; ++mt) {
                 bf16x4 v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = fast_tanh(acc[mt][nt][r]); mean[mt][nt % ENC_AT][r] += live ? e : 0.0f; v[r] = (__bf16)e; }
+                for (int r = 0; r < 4; ++r) { const float e = fast_tanh(acc[mt][nt][r]); mean[mt][nt % ENC_AT][r] += live ? e : 0.0f;
+                    v[r] = (__bf16)e; }
                 if (live && ga < B) *(bf16x4 *)(P.ebuf + ((size_t)ga * NB + k) * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1356,7 +1376,8 @@ __device__ __forceinline__ void attn_wide_body(const float *__restrict__ obs, in
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) st.o[mt][h] = (f32x4){0, 0, 0, 0};
     }
-    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)P.ebuf, 0, (uint32_t)B * (uint32_t)NB * (ENC_H * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)P.ebuf, 0, (uint32_t)B * (uint32_t)NB * (ENC_H * 2),
+        0x00020000);
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void *)P.gbuf, 0, (uint32_t)B * (ENC_H * 4), 0x00020000);
 #pragma unroll 1
     for (int t0 = 0; t0 < NB; t0 += WNP) {
@@ -1371,7 +1392,8 @@ __device__ __forceinline__ void attn_wide_body(const float *__restrict__ obs, in
             // padding rows: out of range, reads zero
             const uint32_t off = (ga < B && k < NB) ? j * (ENC_H * 4) + (lane >> 4) * 16 : 0xffffffffu;
 #pragma unroll
-            for (int mt = 0; mt < ENC_MT; ++mt) acc[mt][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, off, (mt0 + mt) * 64, 0));
+            for (int mt = 0; mt < ENC_MT; ++mt) acc[mt][nt] = __builtin_bit_cast(f32x4,
+                __builtin_amdgcn_raw_buffer_load_b128(grs, off, (mt0 + mt) * 64, 0));
         }
         {   // e_i rows of the group in 16-byte chunks, coalesced
             constexpr int PER = NT * 16 * (ENC_H / 8) / (64 * ENC_WAVES);
@@ -1479,8 +1501,10 @@ ENC_WIDE_ATT_KERNELS(1) ENC_WIDE_ATT_KERNELS(2) ENC_WIDE_ATT_KERNELS(3)
 // copy, copy, copy) at 1.5 - 2 us each inside a HIP graph.  The noise is Philox4x32-10 keyed (seed, launch counter, agent); the
 // counter lives in device memory and is advanced by the second launch, so a captured graph draws fresh noise on every replay.
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256) qs_rollout_pre_kernel(const float *__restrict__ obs, float *__restrict__ obs_out, int n_obs, const float *__restrict__ mean,
-                                                                        const float *__restrict__ log_std, float *__restrict__ act_out, int A, uint32_t seed_lo,
+extern "C" __global__ void __launch_bounds__(256) qs_rollout_pre_kernel(const float *__restrict__ obs, float *__restrict__ obs_out,
+    int n_obs, const float *__restrict__ mean,
+                                                                        const float *__restrict__ log_std, float *__restrict__ act_out,
+                                                                            int A, uint32_t seed_lo,
                                                                         uint32_t seed_hi, const uint32_t *__restrict__ counter) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     // 16-byte copies when both rows are 16-byte aligned (a trajectory slot obs[t] of A * D floats is only when A * D % 4 == 0)
@@ -1505,11 +1529,14 @@ extern "C" __global__ void __launch_bounds__(256) qs_rollout_pre_kernel(const fl
             m[2] += __expf(log_std[2]) * r1 * c1; m[3] += __expf(log_std[3]) * r1 * s1;
         }
         if (act16) *(f32x4 *)(act_out + (size_t)a * 4) = m;
-        else { act_out[(size_t)a * 4] = m[0]; act_out[(size_t)a * 4 + 1] = m[1]; act_out[(size_t)a * 4 + 2] = m[2]; act_out[(size_t)a * 4 + 3] = m[3]; }
+        else { act_out[(size_t)a * 4] = m[0]; act_out[(size_t)a * 4 + 1] = m[1]; act_out[(size_t)a * 4 + 2] = m[2];
+            act_out[(size_t)a * 4 + 3] = m[3]; }
     }
 }
-extern "C" __global__ void __launch_bounds__(256) qs_rollout_post_kernel(const float *__restrict__ rew, float *__restrict__ rew_out, const uint8_t *__restrict__ done,
-                                                                         uint8_t *__restrict__ done_out, int A, uint32_t *__restrict__ counter) {
+extern "C" __global__ void __launch_bounds__(256) qs_rollout_post_kernel(const float *__restrict__ rew, float *__restrict__ rew_out,
+    const uint8_t *__restrict__ done,
+                                                                         uint8_t *__restrict__ done_out, int A,
+                                                                             uint32_t *__restrict__ counter) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     for (int a = tid; a < A; a += nthreads) { rew_out[a] = rew[a]; done_out[a] = done[a]; }
     if (tid == 0) *counter += 1u;
@@ -1543,7 +1570,9 @@ static int wide_min_agents(int dev) {
     if (g_wide_min >= 0) return g_wide_min;
     static int cus[64] = {0};
     if (dev < 0 || dev >= 64) return 4097;
-    if (!cus[dev]) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; } cus[dev] = n; }
+    if (!cus[dev]) { int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError();
+        n = 256; } cus[dev] = n; }
     return ENC_TA * cus[dev] + 1;
 }
 // -1: the default rule; < -1: read only
@@ -1569,8 +1598,10 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         g_enc_error = "bad argument";   // neither the features nor a head output requested, or an incomplete head
         return -1;
     }
-    const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, s2r = P.nbr_encoder == ENC_MODEL_S2R, mha = P.nbr_encoder == ENC_MODEL_MHA || s2r;
-    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0 || P.nbr_encoder > ENC_MODEL_S2R ||
+    const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, s2r = P.nbr_encoder == ENC_MODEL_S2R,
+        mha = P.nbr_encoder == ENC_MODEL_MHA || s2r;
+    if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0
+        || P.nbr_encoder > ENC_MODEL_S2R ||
         (att && P.self_dim + P.nbr_dim > 32) || ((P.nbr_encoder == ENC_NBR_MLP || mha) && P.nbr_dim * P.num_nbr > 64) ||
         (mha && (P.num_nbr < 1 || P.obst_dim < 1 || !P.ln_w || !P.ln_b))) {
         g_enc_error = "unsupported encoder shape (inputs wider than 32 - 64 for the mlp neighbour encoder - or more than 8 neighbours)";
@@ -1595,20 +1626,34 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         std::lock_guard<std::mutex> lock(attr_mutex);
         if (dev < 0 || dev >= 64) { g_enc_error = "device index out of range"; return -2; }
         if (!(attr_set >> dev & 1)) {
-            if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(0)) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_main(1)) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_s2r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mha()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_embed_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_embed_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_embed_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_attn_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_attn_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_attn_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attn_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
-                hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_embed()) != hipSuccess) {
+            if (hipFuncSetAttribute((const void *)qs_encoder_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (int)lds_main(0)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_main(1)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_mha_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_mha()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_s2r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_mha()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_embed_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_embed_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_embed_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_attn_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_attn_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_attn_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_wide1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_wide2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_embed()) != hipSuccess) {
                 g_enc_error = "cannot raise the dynamic LDS limit";
                 return -2;
             }
@@ -1640,26 +1685,34 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         else
             hipLaunchKernelGGL(qs_encoder_wide3_kernel, grid, block, lds_wide(), st, obs, B, P, out);
     } else if (s2r)
-        hipLaunchKernelGGL(qs_encoder_s2r_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);
+        hipLaunchKernelGGL(qs_encoder_s2r_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream,
+            obs, B, P, out);
     else if (mha)
-        hipLaunchKernelGGL(qs_encoder_mha_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream, obs, B, P, out);
+        hipLaunchKernelGGL(qs_encoder_mha_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_mha(), (hipStream_t)stream,
+            obs, B, P, out);
     else if (att) {
-        hipLaunchKernelGGL(qs_encoder_embed_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_embed(), (hipStream_t)stream, obs, B, P);
-        hipLaunchKernelGGL(qs_encoder_attn_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
+        hipLaunchKernelGGL(qs_encoder_embed_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds_embed(),
+            (hipStream_t)stream, obs, B, P);
+        hipLaunchKernelGGL(qs_encoder_attn_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs,
+            B, P, out);
     } else
-        hipLaunchKernelGGL(qs_encoder_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P, out);
+        hipLaunchKernelGGL(qs_encoder_kernel, dim3((B + ENC_TA - 1) / ENC_TA), dim3(64 * ENC_WAVES), lds, (hipStream_t)stream, obs, B, P,
+            out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_enc_error = hipGetErrorString(e); return -2; }
     return 0;
 }
 
 // rollout glue, see the kernels above: obs[n_obs] -> obs_out, act_out[A, 4] = mean[A, 4] (+ exp(log_std[4]) * N(0, 1) if log_std != NULL)
-int qs_rollout_pre(const float *obs, float *obs_out, int32_t n_obs, const float *mean, const float *log_std, float *act_out, int32_t A, uint64_t seed,
+int qs_rollout_pre(const float *obs, float *obs_out, int32_t n_obs, const float *mean, const float *log_std, float *act_out, int32_t A,
+    uint64_t seed,
                    const uint32_t *counter, void *stream) {
-    if ((n_obs > 0 && (!obs || !obs_out)) || !mean || !act_out || !counter || n_obs < 0 || A < 0) { g_enc_error = "bad argument"; return -1; }
+    if ((n_obs > 0 && (!obs || !obs_out)) || !mean || !act_out || !counter || n_obs < 0 || A < 0) { g_enc_error = "bad argument";
+        return -1; }
     if (A == 0 && n_obs == 0) return 0;
     const int work = (n_obs >> 2) > A ? (n_obs >> 2) : A, blocks = (work + 255) / 256 < 2048 ? (work + 255) / 256 : 2048;
-    hipLaunchKernelGGL(qs_rollout_pre_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, obs, obs_out, n_obs, mean, log_std, act_out, A,
+    hipLaunchKernelGGL(qs_rollout_pre_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, obs, obs_out, n_obs,
+        mean, log_std, act_out, A,
                        (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), counter);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_enc_error = hipGetErrorString(e); return -2; }
@@ -1668,15 +1721,18 @@ int qs_rollout_pre(const float *obs, float *obs_out, int32_t n_obs, const float 
 // rew[A] -> rew_out, done[A] -> done_out, *counter += 1 (the next qs_rollout_pre draws new noise)
 int qs_rollout_post(const float *rew, float *rew_out, const uint8_t *done, uint8_t *done_out, int32_t A, uint32_t *counter, void *stream) {
     if (!rew || !rew_out || !done || !done_out || !counter || A < 0) { g_enc_error = "bad argument"; return -1; }
-    hipLaunchKernelGGL(qs_rollout_post_kernel, dim3((A + 255) / 256 > 0 ? ((A + 255) / 256 < 2048 ? (A + 255) / 256 : 2048) : 1), dim3(256), 0, (hipStream_t)stream, rew, rew_out, done, done_out, A, counter);
+    hipLaunchKernelGGL(qs_rollout_post_kernel, dim3((A + 255) / 256 > 0 ? ((A + 255) / 256 < 2048 ? (A + 255) / 256 : 2048) : 1),
+        dim3(256), 0, (hipStream_t)stream, rew, rew_out, done, done_out, A, counter);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_enc_error = hipGetErrorString(e); return -2; }
     return 0;
 }
 
 #ifdef ENC_TIMING
-int qs_enc_stamps(unsigned long long *out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(enc_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2; }
-int qs_enc_wg_times(unsigned long long *out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(enc_wg_times), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -2; }
+int qs_enc_stamps(unsigned long long *out16) { return hipMemcpyFromSymbol(out16, HIP_SYMBOL(enc_stamps),
+    sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -2; }
+int qs_enc_wg_times(unsigned long long *out,
+    int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(enc_wg_times), sizeof(unsigned long long) * 2 * n) == hipSuccess ? 0 : -2; }
 #endif
 // `iters` back-to-back forward passes timed with HIP events on `stream` (no host work in between): average ms per pass
 int qs_enc_benchmark(const float *obs, int32_t B, const EncParams *params, float *out, void *stream, int32_t iters, double *avg_ms) {

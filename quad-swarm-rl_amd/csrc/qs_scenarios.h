@@ -25,10 +25,12 @@ template <typename real> struct ScenCtx {
 };
 
 template <typename real> __device__ __forceinline__ void load_formation(const ScenCtx<real> &x, Formation<real> &F) {
-    F.f = x.si[SI_FORM]; F.per_layer = x.si[SI_PER_LAYER]; F.lo = x.sr[SR_LO]; F.hi = x.sr[SR_HI]; F.size = x.sr[SR_SIZE]; F.layer_dist = x.sr[SR_LAYER];
+    F.f = x.si[SI_FORM]; F.per_layer = x.si[SI_PER_LAYER]; F.lo = x.sr[SR_LO]; F.hi = x.sr[SR_HI]; F.size = x.sr[SR_SIZE];
+    F.layer_dist = x.sr[SR_LAYER];
 }
 template <typename real> __device__ __forceinline__ void store_formation(const ScenCtx<real> &x, const Formation<real> &F) {
-    x.si[SI_FORM] = F.f; x.si[SI_PER_LAYER] = F.per_layer; x.sr[SR_LO] = F.lo; x.sr[SR_HI] = F.hi; x.sr[SR_SIZE] = F.size; x.sr[SR_LAYER] = F.layer_dist;
+    x.si[SI_FORM] = F.f; x.si[SI_PER_LAYER] = F.per_layer; x.sr[SR_LO] = F.lo; x.sr[SR_HI] = F.hi; x.sr[SR_SIZE] = F.size;
+    x.sr[SR_LAYER] = F.layer_dist;
 }
 
 // cell centre of grid cell (row x, col y): cell_centers[x + L*y] with the layout of obstacles/utils.py:47-58
@@ -49,7 +51,8 @@ __device__ __forceinline__ int kth_free_cell(const uint64_t *omap, int cells, in
 // held in `tidx/tval`, LDS scratch) + z ~ U(1,3).  out: rows of stride `ld` starting at out[0] (x,y,z consecutive) or the
 // component-major spawn array when `to_spawn`.
 template <typename real>
-__device__ QS_COLD void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *tidx, int *tval, int slot_choice, int slot_z,
+__device__ QS_COLD void pos_obst_map_2(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int *tidx, int *tval,
+    int slot_choice, int slot_z,
                                bool to_spawn) {
     // free cells = cells not in the obstacle map (the episode's obstacle count varies under --quads_domain_random)
     const int Lr = c.obst_area[0], W = c.obst_area[1], cells = Lr * W, nfree = cells - map_count(x.omap), N = x.N;
@@ -87,7 +90,8 @@ __device__ QS_COLD void pos_obst_map_1(const Consts<real> &c, const RngKey &key,
 }
 // Scenario_o_base.max_square_area_center o_base.py:124-153 (two-row dynamic programme in LDS scratch rows)
 template <typename real>
-__device__ QS_COLD void max_square_center(const Consts<real> &c, const RngKey &key, const uint64_t *omap, int *prev_row, int *cur_row, int slot_z, real out[3]) {
+__device__ QS_COLD void max_square_center(const Consts<real> &c, const RngKey &key, const uint64_t *omap, int *prev_row, int *cur_row,
+    int slot_z, real out[3]) {
     const int Lr = c.obst_area[0], W = c.obst_area[1];
     int max_size = 0, cx = 0, cy = 0;
     for (int q = 0; q < W; ++q) prev_row[q] = (int)(omap[q >> 6] >> (q & 63) & 1);
@@ -119,7 +123,8 @@ __device__ QS_COLD real get_z_value(const Consts<real> &c, const RngKey &key, co
     real z = rng_uniform1<real>(key, QS_SITE_SCEN, slot, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2, zlb = (real)0.25;
     const int f = F.f;
     if (f == 3 || f == 1 || f == 2) zlb = F.size + (real)0.25;
-    else if (f == 5 || f == 6) { int rn = N < F.per_layer ? N : F.per_layer, d1, d2; grid_dim(rn, &d1, &d2); zlb = (real)d1 * F.size + (real)0.25; }
+    else if (f == 5 || f == 6) { int rn = N < F.per_layer ? N : F.per_layer, d1, d2; grid_dim(rn, &d1, &d2);
+        zlb = (real)d1 * F.size + (real)0.25; }
     return M<real>::fmax(zlb, z);
 }
 
@@ -136,8 +141,10 @@ __device__ QS_COLD void standard_reset(const Consts<real> &c, const RngKey &key,
 
 // u < 0: -(k+1) encodes the list index k the reference drew (noise tape)
 __device__ __forceinline__ int mix_pick(int num_agents, bool use_obstacles, double u) {   // scenarios/mix.py:84-90 + utils.py:10-25
-    const int LIST_MULTI[9] = {QS_SCENARIO_STATIC_SAME_GOAL, QS_SCENARIO_STATIC_DIFF_GOAL, QS_SCENARIO_EP_LISSAJOUS3D, QS_SCENARIO_EP_RAND_BEZIER,
-                               QS_SCENARIO_DYNAMIC_SAME_GOAL, QS_SCENARIO_DYNAMIC_DIFF_GOAL, QS_SCENARIO_DYNAMIC_FORMATIONS, QS_SCENARIO_SWAP_GOALS,
+    const int LIST_MULTI[9] = {QS_SCENARIO_STATIC_SAME_GOAL, QS_SCENARIO_STATIC_DIFF_GOAL, QS_SCENARIO_EP_LISSAJOUS3D,
+        QS_SCENARIO_EP_RAND_BEZIER,
+                               QS_SCENARIO_DYNAMIC_SAME_GOAL, QS_SCENARIO_DYNAMIC_DIFF_GOAL, QS_SCENARIO_DYNAMIC_FORMATIONS,
+                                   QS_SCENARIO_SWAP_GOALS,
                                QS_SCENARIO_SWARM_VS_SWARM};
     int n, base_list;   // base_list 0: multi / single (a prefix of it), 1: obstacles
     if (num_agents == 1) { if (use_obstacles) { n = 1; base_list = 1; } else { n = 5; base_list = 0; } }
@@ -282,7 +289,8 @@ __device__ QS_COLD void scenario_reset_full(const Consts<real> &c, const RngKey 
 __device__ __forceinline__ bool scen_step_serial_needed(int sc, int period, int tick) {
     const bool at_period = period > 0 && tick > 0 && imod_small(tick, period) == 0;
     return sc == QS_SCENARIO_DYNAMIC_FORMATIONS ||
-           (at_period && (sc == QS_SCENARIO_SWARM_VS_SWARM || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS || sc == QS_SCENARIO_O_SWAP_GOALS ||
+           (at_period && (sc == QS_SCENARIO_SWARM_VS_SWARM || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS
+               || sc == QS_SCENARIO_O_SWAP_GOALS ||
                           sc == QS_SCENARIO_RUN_AWAY));
 }
 
@@ -320,7 +328,8 @@ __device__ QS_COLD void scenario_step_serial(const Consts<real> &c, const RngKey
         generate_goals<real>(F, N, c.cube_fd_all, ctr, x.goals, 3);
     } else if (sc == QS_SCENARIO_RUN_AWAY) {            // run_away.py:15-27: drones 0 and 1 get the goals of two random others
         const int on_tape = QS_ON_TAPE(key) ? 1 : 0;   // np.random.randint(low=1, high=N, size=2): a tape holds the values themselves
-        const int g0 = (1 - on_tape) + rng_index<real>(key, QS_SITE_SCEN, 44, N - 1), g1 = (1 - on_tape) + rng_index<real>(key, QS_SITE_SCEN, 45, N - 1);
+        const int g0 = (1 - on_tape) + rng_index<real>(key, QS_SITE_SCEN, 44, N - 1),
+            g1 = (1 - on_tape) + rng_index<real>(key, QS_SITE_SCEN, 45, N - 1);
         for (int q = 0; q < 3; ++q) x.goals[0 * 3 + q] = x.goals[g0 * 3 + q];
         for (int q = 0; q < 3; ++q) x.goals[1 * 3 + q] = x.goals[g1 * 3 + q];
     } else {                                            // swap_goals.py:13-24 / o_swap_goals.py:14-25
@@ -334,19 +343,22 @@ __device__ QS_COLD void scenario_step_serial(const Consts<real> &c, const RngKey
 // Fisher-Yates on every control step, and the slowest workgroup sets the duration of the launch (`mix`, 1024 x 8: 42 us per step with
 // the serial form against 8 us for the same shape on a static scenario; profiles/r03_final_batched_env_host.json).
 __device__ __forceinline__ bool scen_step_wave_ok(int sc, int N) {
-    return N >= 3 && (sc == QS_SCENARIO_DYNAMIC_FORMATIONS || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS || sc == QS_SCENARIO_O_SWAP_GOALS ||
+    return N >= 3 && (sc == QS_SCENARIO_DYNAMIC_FORMATIONS || sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL || sc == QS_SCENARIO_SWAP_GOALS
+        || sc == QS_SCENARIO_O_SWAP_GOALS ||
                       (sc == QS_SCENARIO_SWARM_VS_SWARM && N / 2 >= 3));
 }
 // Called by all lanes of a wave; `on` (uniform per environment): this environment takes the wave path at this tick.  scr: N ints of LDS.
 template <typename real>
-__device__ __forceinline__ void scenario_step_wave(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int *scr, int i, bool on) {
+__device__ __forceinline__ void scenario_step_wave(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int *scr,
+    int i, bool on) {
     const int N = x.N;
     Formation<real> F;
     F.f = 0; F.per_layer = 1; F.lo = F.hi = F.size = F.layer_dist = (real)0;
     real c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, speed = 0;
     int inc = 0;
     bool build = false, shuffle = false;
-    const bool svs = sc == QS_SCENARIO_SWARM_VS_SWARM, ddg = sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL, dyf = sc == QS_SCENARIO_DYNAMIC_FORMATIONS;
+    const bool svs = sc == QS_SCENARIO_SWARM_VS_SWARM, ddg = sc == QS_SCENARIO_DYNAMIC_DIFF_GOAL,
+        dyf = sc == QS_SCENARIO_DYNAMIC_FORMATIONS;
     if (on) {   // every lane of the environment derives the new scenario state (identical keys => identical values)
         if (svs) {                                         // swarm_vs_swarm.py:59-79
             for (int q = 0; q < 3; ++q) { c1[q] = x.sr[SR_C2 + q]; c2[q] = x.sr[SR_C1 + q]; }
@@ -389,13 +401,15 @@ __device__ __forceinline__ void scenario_step_wave(const Consts<real> &c, const 
 // lane-local part of scenario.step(): scenarios whose drones all share one goal, computed redundantly by every drone
 // of the env (identical RNG keys => identical values); `persist` (drone 0) writes the env's state back to LDS.
 template <typename real>
-__device__ QS_COLD void scenario_step_local(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int period, int tick, bool persist,
+__device__ QS_COLD void scenario_step_local(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, int sc, int period,
+    int tick, bool persist,
                                     real goal[3]) {
     if (sc == QS_SCENARIO_DYNAMIC_SAME_GOAL) {           // dynamic_same_goal.py:16-29 (formation size 0: every goal = the centre)
         if (period > 0 && tick > 0 && imod_small(tick, period) == 0) {
             real box = c.spawn_box, xy[2];
             rng_uniform<real, 2>(key, QS_SITE_SCEN, 40, 0, 0, -box, box, xy);
-            real z = M<real>::fmax((real)0.25, rng_uniform1<real>(key, QS_SITE_SCEN, 41, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2);
+            real z = M<real>::fmax((real)0.25,
+                rng_uniform1<real>(key, QS_SITE_SCEN, 41, 0, 0, (real)-0.5 * box, (real)0.5 * box) + (real)2);
             // generate_goals with size 0: goal = (0*cos, 0*sin, 0) + centre
             goal[0] = (real)0 + xy[0]; goal[1] = (real)0 + xy[1]; goal[2] = (real)0 + z;
             if (persist) { x.sr[SR_C1] = xy[0]; x.sr[SR_C1 + 1] = xy[1]; x.sr[SR_C1 + 2] = z; }
@@ -411,15 +425,18 @@ __device__ QS_COLD void scenario_step_local(const Consts<real> &c, const RngKey 
         const int control_steps = (obst ? 6 : 5) * c.control_freq, t = tick % control_steps;
         real fsz = x.sr[SR_SIZE];
         real room[3] = {c.room_hi[0] - c.room_lo[0] - fsz, c.room_hi[1] - c.room_lo[1] - fsz, c.room_hi[2] - c.room_lo[2] - fsz};
-        real mx = M<real>::fmax(room[0], M<real>::fmax(room[1], room[2])), max_dist = M<real>::fmin(obst ? (real)5 : (real)30, mx), min_dist = max_dist / (real)2;
+        real mx = M<real>::fmax(room[0], M<real>::fmax(room[1], room[2])), max_dist = M<real>::fmin(obst ? (real)5 : (real)30, mx),
+            min_dist = max_dist / (real)2;
         real bez[9];
         for (int q = 0; q < 9; ++q) bez[q] = x.sr[SR_BEZ + q];
         if (tick % control_steps == 0 || tick == 1) {
-            real low[3] = {-room[0] / (real)2, -room[1] / (real)2, obst ? (real)1.5 : (real)0}, high[3] = {room[0] / (real)2, room[1] / (real)2, obst ? (real)3 : room[2]};
+            real low[3] = {-room[0] / (real)2, -room[1] / (real)2, obst ? (real)1.5 : (real)0},
+                high[3] = {room[0] / (real)2, room[1] / (real)2, obst ? (real)3 : room[2]};
             real np_[3][2];
             for (int it = 0; it < 100000; ++it) {
                 real u[6];
-                for (int k = 0; k < 6; ++k) { int ax = k % 3; u[k] = rng_uniform1<real>(key, QS_SITE_SCEN, 300 + 8 * it + k, 0, 0, -high[ax], high[ax]); }
+                for (int k = 0; k < 6; ++k) { int ax = k % 3;
+                    u[k] = rng_uniform1<real>(key, QS_SITE_SCEN, 300 + 8 * it + k, 0, 0, -high[ax], high[ax]); }
                 int lo_i = (int)floorf((float)min_dist), hi_i = (int)max_dist + 1;   // np.random.randint truncates a float low
                 // (tape: the randint value itself)
                 int r = (QS_ON_TAPE(key) ? 0 : lo_i) + rng_index<real>(key, QS_SITE_SCEN, 300 + 8 * it + 6, hi_i - lo_i);

@@ -38,7 +38,8 @@ __device__ __forceinline__ void tape_cursor_out(const RngKey &key, int *slot) {
 // RawControl quadrotor_control.py:53-57 (clip to [-1, 1], map to [0, 1]) and the thrust-noise OU update quad_utils.py:275-279 with this
 // step's four normal draws
 template <typename real>
-__device__ __forceinline__ void control_and_thrust_noise(const Consts<real> &c, const real act[4], const real zou[4], Drone<real> &d, real cmds[4]) {
+__device__ __forceinline__ void control_and_thrust_noise(const Consts<real> &c, const real act[4], const real zou[4], Drone<real> &d,
+    real cmds[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         cmds[m] = (real)0.5 * (clipr<real>(act[m], (real)-1, (real)1) + (real)1);
@@ -50,7 +51,8 @@ __device__ __forceinline__ void control_and_thrust_noise(const Consts<real> &c, 
 // compute_reward_weighted quadrotor_single.py:34-92 on the post-step state: the five per-drone terms, their sum in the reference's
 // order, and the 12 info entries they feed (the obstacle entries start at zero)
 template <typename real>
-__device__ __forceinline__ void main_reward(const Consts<real> &c, const real *rewc, const Drone<real> &d, const real goal[3], const real act[4], real &rew, real *ri) {
+__device__ __forceinline__ void main_reward(const Consts<real> &c, const real *rewc, const Drone<real> &d, const real goal[3],
+    const real act[4], real &rew, real *ri) {
     const real dt = c.dt;
     real diff[3] = {goal[0] - d.pos[0], goal[1] - d.pos[1], goal[2] - d.pos[2]};
     real cpr = norm3<real>(diff), cpos = rewc[QS_REW_POS] * cpr;
@@ -100,7 +102,8 @@ struct EnvEvents {
 // quadrotor_multi.py:432-459, :462-488: id sets by wave ballots; updates the drone's F_IN_COL / F_COL_*_OK flags.
 // myobs: the drone's NOISY self observation (distance_to_goal_3_5 / _5 use its relative position, :474-478).
 template <typename real>
-__device__ __forceinline__ EnvEvents env_events(const Consts<real> &c, bool active, bool in_curr, uint64_t new_pair, uint32_t bits, uint32_t &flags, int base,
+__device__ __forceinline__ EnvEvents env_events(const Consts<real> &c, bool active, bool in_curr, uint64_t new_pair, uint32_t bits,
+    uint32_t &flags, int base,
                                                 uint64_t nmask, int i, int tick, int tick_before, const real *myobs) {
     EnvEvents ev;
     const bool was_in_col = active && (flags & F_IN_COL);
@@ -133,7 +136,8 @@ __device__ __forceinline__ EnvEvents env_events(const Consts<real> &c, bool acti
 
 // collision / proximity / obstacle terms of the reward (:499-546), added to `rew` in the reference's order
 template <typename real>
-__device__ __forceinline__ void collision_rewards(const Consts<real> &c, const real *rewc, const EnvEvents &ev, int i, uint32_t bits, real prox, real &rew, real *ri) {
+__device__ __forceinline__ void collision_rewards(const Consts<real> &c, const real *rewc, const EnvEvents &ev, int i, uint32_t bits,
+    real prox, real &rew, real *ri) {
     const bool any_nonzero_id = (ev.unique & ~1ull) != 0;   // `.any()` of the id array
     real raw = (any_nonzero_id && (ev.unique >> i & 1)) ? (real)-1 : (real)0;
     real rc = rewc[QS_REW_QUADCOL_BIN] * raw;
@@ -177,7 +181,8 @@ __device__ __forceinline__ bool ring_needed(const Consts<real> &c, real metric, 
 // on the physics wave's critical path are 0.1 us of an 8 us step - measured: profiles/r04g_ab_tree_vs_r03.txt) keep every entry exact and
 // simply mark the ring live while the goal is not reached; both forms read what the other wrote.
 template <typename real, bool LAZY>
-__device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real metric, int tick, bool done, uint32_t &flags, real ring[4], real sums[3], const real *ri, real eps_dist[3]) {
+__device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real metric, int tick, bool done, uint32_t &flags, real ring[4],
+    real sums[3], const real *ri, real eps_dist[3]) {
     const real dnow = -ri[QS_RI_RAW_POS];
     // not maintained = far (also: whatever the row holds after a reset)
     if (!(flags & F_RING_LIVE)) { ring[0] = ring[1] = ring[2] = ring[3] = (real)1e30; }
@@ -187,7 +192,8 @@ __device__ __forceinline__ void goal_distance_log(const Consts<real> &c, real me
     }
     ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = dnow;
     bool live = !(flags & F_REACHED);
-    if (LAZY) live = live && (ring_near<real>(c, metric, ring[0]) | ring_near<real>(c, metric, ring[1]) | ring_near<real>(c, metric, ring[2]) | ring_near<real>(c, metric, ring[3]));
+    if (LAZY) live = live && (ring_near<real>(c, metric, ring[0]) | ring_near<real>(c, metric, ring[1]) | ring_near<real>(c, metric,
+        ring[2]) | ring_near<real>(c, metric, ring[3]));
     flags = live ? (flags | F_RING_LIVE) : (flags & ~F_RING_LIVE);
     const int total = c.ep_len + 1;
 #pragma unroll
@@ -208,7 +214,8 @@ __device__ __forceinline__ void env_counters_add(const Consts<real> &c, int32_t 
     if (ev.col_tick > 0 && ev.settled) cnt[QS_CNT_COLLISIONS_AFTER_SETTLE] += ev.col_tick;
     if (ev.col_tick > 0 && ev.time_remain <= c.final_steps) cnt[QS_CNT_COLLISIONS_FINAL_5S] += ev.col_tick;
     cnt[QS_CNT_OBST] += ev.obst_cnt;
-    if (ev.obst_cnt > 0 && ev.settled) { cnt[QS_CNT_OBST_AFTER_SETTLE] += ev.obst_cnt; cnt[QS_CNT_OBST_DIST_3_5] += ev.n35; cnt[QS_CNT_OBST_DIST_5] += ev.n5; }
+    if (ev.obst_cnt > 0 && ev.settled) { cnt[QS_CNT_OBST_AFTER_SETTLE] += ev.obst_cnt; cnt[QS_CNT_OBST_DIST_3_5] += ev.n35;
+        cnt[QS_CNT_OBST_DIST_5] += ev.n5; }
     if (ev.settled) {
         cnt[QS_CNT_ROOM] += __popcll(ev.room); cnt[QS_CNT_FLOOR] += __popcll(ev.floor);
         cnt[QS_CNT_WALL] += __popcll(ev.wall); cnt[QS_CNT_CEILING] += __popcll(ev.ceil);
@@ -220,7 +227,8 @@ __device__ __forceinline__ void env_counters_add(const Consts<real> &c, int32_t 
 // ------------------------------------------------------------------------------------------------
 // 1) downwash aerodynamics/downwash.py:4-66: this lane is the LOWER drone, ii the upper one
 template <typename real>
-__device__ __forceinline__ void downwash_apply(const Consts<real> &c, Drone<real> &d, const real *s_pos, const real *s_zax, int B, int base, int ii, real ua, real uw,
+__device__ __forceinline__ void downwash_apply(const Consts<real> &c, Drone<real> &d, const real *s_pos, const real *s_zax, int B,
+    int base, int ii, real ua, real uw,
                                                const real vn[3], const real dirw[3], uint32_t &bits) {
     real rel[3] = {d.pos[0] - s_pos[0 * B + base + ii], d.pos[1] - s_pos[1 * B + base + ii], d.pos[2] - s_pos[2 * B + base + ii]};
     real zx[3] = {s_zax[0 * B + base + ii], s_zax[1 * B + base + ii], s_zax[2 * B + base + ii]};
@@ -244,8 +252,10 @@ __device__ __forceinline__ void downwash_apply(const Consts<real> &c, Drone<real
 // all upper drones of this lane (dw_mask: bit ii = drone ii hovers above me), ascending ii = the reference's outer-loop order.
 // s_cur / tape_env: the tape flavour's cursor slot of this env and its tape (unused otherwise).
 template <typename real, typename Sync>
-__device__ __forceinline__ void downwash_phase(const Consts<real> &c, const RngKey &key, Drone<real> &d, const real *s_pos, const real *s_zax, int B, int base, uint64_t nmask,
-                                               int N, int i, bool active, uint64_t dw_mask, uint32_t &bits, int *s_cur_env, const double *tape_env, Sync sync) {
+__device__ __forceinline__ void downwash_phase(const Consts<real> &c, const RngKey &key, Drone<real> &d, const real *s_pos,
+    const real *s_zax, int B, int base, uint64_t nmask,
+                                               int N, int i, bool active, uint64_t dw_mask, uint32_t &bits, int *s_cur_env,
+                                                   const double *tape_env, Sync sync) {
 #ifdef QS_TAPE
     if (c.use_downwash && QS_ON_TAPE(key)) {
         // downwash.py:30-62 on a tape: two draws per upper drone ii (always), then six per affected lower drone in ascending order:
@@ -292,7 +302,8 @@ __device__ __forceinline__ void downwash_phase(const Consts<real> &c, const RngK
 // 2) drone-drone responses for the NEW pairs in lexicographic order (collisions/quadrotors.py:24-59); order-dependent and rare: one
 //    lane per env walks the pair list on LDS-resident vel / omega.  s_mask: one uint64 per lane of LDS scratch.
 template <typename real, typename Sync>
-__device__ __forceinline__ void pair_responses(const RngKey &key, Drone<real> &d, const EnvEvents &ev, uint64_t new_pair, bool active, int N, int i, int tid, int base, int B,
+__device__ __forceinline__ void pair_responses(const RngKey &key, Drone<real> &d, const EnvEvents &ev, uint64_t new_pair, bool active,
+    int N, int i, int tid, int base, int B,
                                                const real *s_pos, real *s_vel, real *s_om, uint64_t *s_mask, int *s_cur_env, Sync sync) {
     if (__builtin_expect(ev.wave_newpair != 0, 0)) {
 #pragma unroll
@@ -322,8 +333,10 @@ __device__ __forceinline__ void pair_responses(const RngKey &key, Drone<real> &d
 // 3) obstacle response, 4) wall then ceiling (:565-587).  s_ox / s_oy: the env's obstacle positions in LDS; obst_size_env: the env's
 // obstacle size of the running episode.
 template <typename real, typename Sync>
-__device__ __forceinline__ void room_obstacle_phase(const Consts<real> *cp, const RngKey &key, Drone<real> &d, bool active, int N, int i, uint32_t bits, int obst_idx,
-                                                    const real *s_ox, const real *s_oy, const real *obst_size_env, int *s_cur_env, Sync sync) {
+__device__ __forceinline__ void room_obstacle_phase(const Consts<real> *cp, const RngKey &key, Drone<real> &d, bool active, int N, int i,
+    uint32_t bits, int obst_idx,
+                                                    const real *s_ox, const real *s_oy, const real *obst_size_env, int *s_cur_env,
+                                                        Sync sync) {
     const Consts<real> &c = *cp;
 #define QS_SEM_OSIZE (c.dr_on ? *obst_size_env : c.obst_size)   /* --quads_domain_random: the running episode's obstacle size */
 #ifdef QS_TAPE
@@ -361,7 +374,8 @@ __device__ __forceinline__ void room_obstacle_phase(const Consts<real> *cp, cons
 // ------------------------------------------------------------------------------------------------
 // the full scenario set (qs_scenarios.h); x: the env's scenario context (state in LDS), scr: N ints of LDS scratch of the env
 template <typename real, typename Sync>
-__device__ __forceinline__ void scenario_phase_full(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, bool active, int N, int i, int tick, real goal[3], int *scr,
+__device__ __forceinline__ void scenario_phase_full(const Consts<real> &c, const RngKey &key, const ScenCtx<real> &x, bool active, int N,
+    int i, int tick, real goal[3], int *scr,
                                                     int *s_cur_env, Sync sync) {
     const int sc = active ? x.si[SI_SCEN] : 0, period = active ? x.si[SI_PERIOD] : 0;
     const bool serial = active && scen_step_serial_needed(sc, period, tick);
@@ -409,7 +423,8 @@ __device__ __forceinline__ void scenario_phase_full(const Consts<real> &c, const
 // env_goals: the env's goal rows in LDS (>= 2N + 6 rows); the centres live in scen_real[0..5][e].
 template <typename real, typename Sync>
 // returns (wave-uniform) whether any environment of the wave got new goals on this step
-__device__ __forceinline__ bool svs_phase(const Consts<real> &c, const Ptrs<real> &p, const RngKey &key, bool active, int N, int E, int e, int i, int tick, int svs_period,
+__device__ __forceinline__ bool svs_phase(const Consts<real> &c, const Ptrs<real> &p, const RngKey &key, bool active, int N, int E,
+    int e, int i, int tick, int svs_period,
                                           real *env_goals, int *scr, real goal[3], int *s_cur_env, Sync sync) {
     if (c.scenario != QS_SCENARIO_SWARM_VS_SWARM) return false;
     const bool sw = active && svs_period > 0 && tick % svs_period == 0 && tick > 0;

@@ -13,13 +13,16 @@
 #include "qs_kernels.h"
 
 static LdsLayout tape_layout(const qs_config *cfg, int obs_dim, bool full, int real_size) {
-    return lds_layout(real_size, QS_WAVE, cfg->num_agents, QS_WAVE / cfg->num_agents, obs_dim, cfg->num_obstacles, cfg->num_neighbors, 0, full, cfg->scenario, QS_WAVE);
+    return lds_layout(real_size, QS_WAVE, cfg->num_agents, QS_WAVE / cfg->num_agents, obs_dim, cfg->num_obstacles, cfg->num_neighbors, 0,
+        full, cfg->scenario, QS_WAVE);
 }
 
-extern "C" int qs_tape_lds_bytes(const qs_config *cfg, int obs_dim, int full, int real_size) { return tape_layout(cfg, obs_dim, full != 0, real_size).total; }
+extern "C" int qs_tape_lds_bytes(const qs_config *cfg, int obs_dim, int full,
+    int real_size) { return tape_layout(cfg, obs_dim, full != 0, real_size).total; }
 
 template <typename real>
-static int tape_launch(int which, const qs_config *cfg, int obs_dim, int full, const void *consts, const void *ptrs, const void *actions, void *stream) {
+static int tape_launch(int which, const qs_config *cfg, int obs_dim, int full, const void *consts, const void *ptrs, const void *actions,
+    void *stream) {
     const LdsLayout L = tape_layout(cfg, obs_dim, full != 0, (int)sizeof(real));
     const int epb = QS_WAVE / cfg->num_agents, blocks = (cfg->num_envs + epb - 1) / epb;
     Consts<real> c;
@@ -39,14 +42,16 @@ static int tape_launch(int which, const qs_config *cfg, int obs_dim, int full, c
         if (full) hipLaunchKernelGGL((qs_tape_reset_kernel<real, true>), dim3(blocks), dim3(QS_WAVE), L.total, s, c, p, L, epb);
         else hipLaunchKernelGGL((qs_tape_reset_kernel<real, false>), dim3(blocks), dim3(QS_WAVE), L.total, s, c, p, L, epb);
     } else {
-        if (full) hipLaunchKernelGGL(qs_tape_step_kernel_full<real>, dim3(blocks), dim3(QS_WAVE), L.total, s, c, p, (const real *)actions, L, epb);
+        if (full) hipLaunchKernelGGL(qs_tape_step_kernel_full<real>, dim3(blocks), dim3(QS_WAVE), L.total, s, c, p,
+            (const real *)actions, L, epb);
         else hipLaunchKernelGGL(qs_tape_step_kernel<real>, dim3(blocks), dim3(QS_WAVE), L.total, s, c, p, (const real *)actions, L, epb);
     }
     return (int)hipGetLastError();
 }
 
 // which: 0 = reset kernel, 1 = step kernel; consts = Consts<float> / Consts<double> by real_size (4 / 8).  Returns a hipError_t.
-extern "C" int qs_tape_launch(int which, const qs_config *cfg, int obs_dim, int full, int real_size, const void *consts, const void *ptrs, const void *actions, void *stream) {
+extern "C" int qs_tape_launch(int which, const qs_config *cfg, int obs_dim, int full, int real_size, const void *consts,
+    const void *ptrs, const void *actions, void *stream) {
     return real_size == 8 ? tape_launch<double>(which, cfg, obs_dim, full, consts, ptrs, actions, stream)
                           : tape_launch<float>(which, cfg, obs_dim, full, consts, ptrs, actions, stream);
 }

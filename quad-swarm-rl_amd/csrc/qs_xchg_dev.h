@@ -79,7 +79,8 @@ __device__ __forceinline__ unsigned int q8_byte(float x, float scale) {
     const int q = (int)__builtin_fminf(__builtin_fmaxf(v, -127.0f), 127.0f);
     return (unsigned int)q & 0xffu;
 }
-__device__ __forceinline__ unsigned int q8_row_word_v(const float *row, int D, int q0, int q1, int w16, float s0, float s1, float s2, float s3, float s4, float s5, int j) {
+__device__ __forceinline__ unsigned int q8_row_word_v(const float *row, int D, int q0, int q1, int w16, float s0, float s1, float s2,
+    float s3, float s4, float s5, int j) {
     const int nq = q1 - q0;
     if (j < w16) {
         const int b0 = 2 * j, b1 = b0 + 1;
@@ -109,8 +110,10 @@ __device__ __forceinline__ unsigned int q8_row_word(const float *row, const Q8De
 // / writes back the whole L2 on this part).  What orders them against the rows: the rows are written through and drained
 // (s_waitcnt vmcnt(0)) before a workgroup takes its ticket, the flag is stored by whoever takes the last ticket; readers of the rows
 // are separate launches behind the wait (kernel-boundary acquire).
-__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_sys(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED,
+    __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(unsigned long long *p,
+    unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // The FENCED variant of the protocol (qs_xchg_set_fenced, or endpoints created under QS_XCHG_FENCED=1; the fallback if ObsExchange.verify()
 // ever fails on a real xGMI node, before giving the transport up for RCCL).  Producer: EVERY workgroup executes a system-scope RELEASE
@@ -126,9 +129,12 @@ __device__ __forceinline__ void fence_acquire_sys(int fenced) { if (fenced) __bu
 // fence per workgroup, which on this part writes the whole L2 back and cost ~20 us per step when 128-256 workgroups each issued one
 // (profiles/r03d_bench_lines.txt: 27.7 us per C2 step with the fences, 7.7 us without any exchange).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st16_wt(void *p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st4_wt(void *p, unsigned int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st2_wt(void *p, unsigned int v) { asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st16_wt(void *p,
+    u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st4_wt(void *p,
+    unsigned int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st2_wt(void *p,
+    unsigned int v) { asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ void wt_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // bounded poll: true when *p >= want before the deadline
@@ -165,8 +171,10 @@ struct Gate {   // (sequence numbers: control steps since the gate was created, 
 };
 // (the gate's ring and sequence words live in fine-grained, uncached device memory - qs_gate_create - like the exchange's flag windows;
 // relaxed system-scope accesses go straight to it)
-__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED,
+    __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_agent(unsigned long long *p,
+    unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ bool poll_ge_agent(const unsigned long long *p, unsigned long long want, unsigned long long timeout_ticks) {
     if (ld_agent(p) >= want) return true;
     const unsigned long long t0 = wall_clock64();
@@ -183,11 +191,17 @@ __device__ __forceinline__ bool poll_ge_agent(const unsigned long long *p, unsig
 // still hold the rows of step s - 1 (include/quadswarm.h; tests/test_gated_gpu.py runs such a consumer against a resident
 // launch). Producer -> stepper (the action ring, uncached memory): `sc0 sc1` loads.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t ld16_sc1(const void *p) { u32x4_t v; asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ unsigned int ld4_sc1(const void *p) { unsigned int v; asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
-__device__ __forceinline__ void st16_sc1(void *p, u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st8_sc1(void *p, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st4_sc1(void *p, unsigned int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st1_sc1(void *p, unsigned int v) { asm volatile("global_store_byte %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ u32x4_t ld16_sc1(const void *p) { u32x4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ unsigned int ld4_sc1(const void *p) { unsigned int v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+__device__ __forceinline__ void st16_sc1(void *p,
+    u32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8_sc1(void *p,
+    unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st4_sc1(void *p,
+    unsigned int v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st1_sc1(void *p,
+    unsigned int v) { asm volatile("global_store_byte %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
 
 }   // namespace qsx

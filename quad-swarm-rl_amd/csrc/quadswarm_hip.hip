@@ -32,7 +32,8 @@ extern "C" int qs_obs_dim(const qs_config *c);
 extern "C" int qs_destroy(struct qs_handle *h);
 // noise-tape flavour of the kernels (qs_tape_kernels.hip, compiled with QS_TAPE)
 extern "C" int qs_tape_lds_bytes(const qs_config *cfg, int obs_dim, int full, int real_size);
-extern "C" int qs_tape_launch(int which, const qs_config *cfg, int obs_dim, int full, int real_size, const void *consts, const void *ptrs, const void *actions, void *stream);
+extern "C" int qs_tape_launch(int which, const qs_config *cfg, int obs_dim, int full, int real_size, const void *consts,
+    const void *ptrs, const void *actions, void *stream);
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) { g_last_error = msg; return code; }
 #define HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return fail(QS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
@@ -104,11 +105,13 @@ struct qs_handle {
 
 template <typename real> static void fill_consts(const qs_config &c, Consts<real> &k) {
     memset(&k, 0, sizeof k);
-    for (int q = 0; q < 3; ++q) { k.inertia[q] = (real)c.inertia[q]; k.inv_inertia[q] = (real)(1.0 / c.inertia[q]); k.room_lo[q] = (real)c.room_lo[q]; k.room_hi[q] = (real)c.room_hi[q];
+    for (int q = 0; q < 3; ++q) { k.inertia[q] = (real)c.inertia[q]; k.inv_inertia[q] = (real)(1.0 / c.inertia[q]);
+        k.room_lo[q] = (real)c.room_lo[q]; k.room_hi[q] = (real)c.room_hi[q];
                                   k.nbr_clip_pos[q] = (real)c.nbr_clip_pos[q]; k.nbr_clip_vel[q] = (real)c.nbr_clip_vel[q]; }
     k.arm = (real)c.arm; k.mass = (real)c.mass; k.inv_mass = (real)(1.0 / c.mass);
     for (int m = 0; m < 4; ++m) { for (int q = 0; q < 3; ++q) k.prop_cross[m][q] = (real)c.prop_cross[m][q];
-                                  k.prop_ccw[m] = (real)c.prop_ccw[m]; k.thrust_max[m] = (real)c.thrust_max[m]; k.torque_max[m] = (real)c.torque_max[m]; }
+                                  k.prop_ccw[m] = (real)c.prop_ccw[m]; k.thrust_max[m] = (real)c.thrust_max[m];
+                                  k.torque_max[m] = (real)c.torque_max[m]; }
     k.motor_tau_up = (real)c.motor_tau_up; k.motor_tau_down = (real)c.motor_tau_down; k.motor_linearity = (real)c.motor_linearity;
     k.vel_damp = (real)c.vel_damp; k.damp_omega_quadratic = (real)c.damp_omega_quadratic; k.omega_max = (real)c.omega_max;
     k.thrust_noise_sigma = (real)c.thrust_noise_sigma; k.ou_theta = (real)c.ou_theta;
@@ -155,7 +158,8 @@ static int validate(const qs_config *c);
 // Config-specialised code objects: header text -> key -> <cache>/qs_<key>.hsaco (built with hipcc --genco)
 // ------------------------------------------------------------------------------------------------
 static bool scenario_is_full(int scenario) {
-    return !(scenario == QS_SCENARIO_STATIC_SAME_GOAL || scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || scenario == QS_SCENARIO_SWARM_VS_SWARM);
+    return !(scenario == QS_SCENARIO_STATIC_SAME_GOAL || scenario == QS_SCENARIO_O_STATIC_SAME_GOAL
+        || scenario == QS_SCENARIO_SWARM_VS_SWARM);
 }
 static int spec_team_waves(int num_agents);
 // Team kernels pay off while the whole batch still fits at <= 8 waves per CU (measured on MI355X, specialised fp32 kernels, us per
@@ -178,12 +182,15 @@ static int spec_rows_per_pass(const qs_config *cfg, int team) {
 
 static std::string spec_header_text(const qs_config *cfg, int team) {
     const int rs = cfg->precision == QS_PRECISION_F64 ? 8 : 4, epb = QS_WAVE / cfg->num_agents;
-    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team, scenario_is_full(cfg->scenario), cfg->scenario,
+    LdsLayout L = lds_layout(rs, QS_WAVE, cfg->num_agents, epb, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team,
+        scenario_is_full(cfg->scenario), cfg->scenario,
                              spec_rows_per_pass(cfg, team));
     std::vector<uint32_t> w;
-    if (rs == 8) { Consts<double> k; fill_consts<double>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0; k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
+    if (rs == 8) { Consts<double> k; fill_consts<double>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0;
+        k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
                    w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
-    else { Consts<float> k; fill_consts<float>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0; k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
+    else { Consts<float> k; fill_consts<float>(*cfg, k); memset(k.rew_coeff, 0, sizeof k.rew_coeff); k.prox_ratio = 0;
+        k.seed_lo = k.seed_hi = 0; k.env_id_offset = 0; k.num_envs = 0;
            w.resize(sizeof k / 4); memcpy(w.data(), &k, sizeof k); }
     std::string o = "// generated by quadswarm_hip (spec_header_text): configuration constants as literals\n";
     char t[256];
@@ -221,7 +228,8 @@ static bool read_file(const std::string &path, std::string &out) {
     fclose(f);
     return true;
 }
-static const char *const kSpecSources[] = {"qs_spec_kernels.hip", "qs_kernels.h", "qs_device.h", "qs_scenarios.h", "qs_step_sem.h", "qs_xchg_dev.h", "qs_step_kernel.inc", "qs_step_team.inc"};
+static const char *const kSpecSources[] = {"qs_spec_kernels.hip", "qs_kernels.h", "qs_device.h", "qs_scenarios.h", "qs_step_sem.h",
+    "qs_xchg_dev.h", "qs_step_kernel.inc", "qs_step_team.inc"};
 static const char *const kSpecFlags = "--genco --offload-arch=gfx950 -O3 -std=c++17";
 // fp32 objects only (the production precision, specified to 1e-5): reassociation / finite-math simplifications are worth ~8 %
 // of the step; the SLP vectoriser's v_pk_* pairs cost more register shuffling than they save on this code.  The f64 parity
@@ -247,7 +255,8 @@ static const char *const kSpecFlagsTeam8 = "-mllvm -amdgpu-sched-strategy=max-il
 // (spec_verify_file above) - and every object is now checked for it whatever its flags.  Instruction order only: results are
 // bit-identical (tests/test_object_identity_gpu.py).
 static const char *const kSpecFlagsSingleF32 = "-mllvm -amdgpu-use-amdgpu-trackers";
-static const char *spec_team_flags(int team) { const char *ev = getenv("QS_SPEC_TEAM_FLAGS"); return ev ? ev : (team == 8 ? kSpecFlagsTeam8 : kSpecFlagsTeam); }
+static const char *spec_team_flags(int team) { const char *ev = getenv("QS_SPEC_TEAM_FLAGS"); return ev
+    ? ev : (team == 8 ? kSpecFlagsTeam8 : kSpecFlagsTeam); }
 static const char *spec_sched_flags(int team, int precision) {
     if (team > 0) return spec_team_flags(team);
     if (const char *ev = getenv("QS_SPEC_SINGLE_FLAGS")) return ev;
@@ -298,13 +307,15 @@ static std::string llvm_bin() { const char *ev = getenv("QS_LLVM_BIN"); return (
 static bool starts_with(const std::string &t, const char *p) { return t.compare(0, strlen(p), p) == 0; }
 // instructions of a block prologue that do not depend on exec (SGPR spills to VGPR lanes, scalar moves / adds, waits)
 static bool hz_silent(const std::string &t) {
-    static const char *const k[] = {"v_writelane_b32", "v_readlane_b32", "s_nop", "s_waitcnt", "s_mov_b32", "s_mov_b64", "s_add_i32", "s_add_u32", "s_addk_i32"};
+    static const char *const k[] = {"v_writelane_b32", "v_readlane_b32", "s_nop", "s_waitcnt", "s_mov_b32", "s_mov_b64", "s_add_i32",
+        "s_add_u32", "s_addk_i32"};
     for (const char *q : k) if (starts_with(t, q)) return t.find("exec") == std::string::npos;
     return false;
 }
 // ... and those that do: what the vector register allocator inserts (spill, reload, copy, rematerialised constant, AGPR copy)
 static bool hz_exec_dependent(const std::string &t) {
-    return starts_with(t, "scratch_load_") || starts_with(t, "scratch_store_") || starts_with(t, "v_mov_b32") || starts_with(t, "v_mov_b64") || starts_with(t, "v_accvgpr_");
+    return starts_with(t, "scratch_load_") || starts_with(t, "scratch_store_") || starts_with(t, "v_mov_b32")
+        || starts_with(t, "v_mov_b64") || starts_with(t, "v_accvgpr_");
 }
 // the exec restore of a join / else block: s_or_b64 exec, exec, s[..] | s_xor_b64 exec, exec, s[..] | s_or_saveexec_b64 s[..], s[..]  (NOT
 // `, -1`: whole-wave mode)
@@ -313,7 +324,8 @@ static bool hz_restore(const std::string &t) {
     return starts_with(t, "s_or_saveexec_b64 s[") && t.find("], s[") != std::string::npos;
 }
 // One hazard: the block prologue (instructions + encodings) in front of a misplaced exec restore, the restore itself, what follows it.
-struct SpecHazard { std::string kernel, label; std::vector<std::string> ins, raw; std::string restore, restore_raw; std::vector<std::string> after; };
+struct SpecHazard { std::string kernel, label; std::vector<std::string> ins, raw; std::string restore, restore_raw;
+    std::vector<std::string> after; };
 static std::string hz_describe(const SpecHazard &h) {
     std::string o = h.kernel + " <" + h.label + ">:";
     for (const std::string &t : h.ins) o += " " + t + " ;";
@@ -421,7 +433,8 @@ static int spec_find_hazards(const std::string &path, std::vector<SpecHazard> &h
     for (const std::string &elf : elfs) {
         const std::string cmd = "'" + llvm_bin() + "/llvm-objdump' -d --symbolize-operands '" + elf + "' 2> /dev/null";
         FILE *f = rc == 0 ? popen(cmd.c_str(), "r") : nullptr;
-        if (f) { spec_scan_disassembly(f, hz); if (pclose(f) != 0) { rc = -1; why = "llvm-objdump failed on " + path + " (QS_LLVM_BIN=" + llvm_bin() + ")"; } }
+        if (f) { spec_scan_disassembly(f, hz);
+            if (pclose(f) != 0) { rc = -1; why = "llvm-objdump failed on " + path + " (QS_LLVM_BIN=" + llvm_bin() + ")"; } }
         else if (rc == 0) { rc = -1; why = "cannot run " + llvm_bin() + "/llvm-objdump"; }
         unlink(elf.c_str());
     }
@@ -477,14 +490,16 @@ static int spec_repair_file(const std::string &path, std::string &left) {
         // what the restore reads (and, for s_or_saveexec, also writes)
         std::vector<int> need;
         const size_t c1 = h.restore.find(',');
-        hz_sregs(starts_with(h.restore, "s_or_saveexec") ? h.restore.substr(h.restore.find(' ')) : h.restore.substr(h.restore.find(',', c1 + 1)), need);
+        hz_sregs(starts_with(h.restore, "s_or_saveexec")
+            ? h.restore.substr(h.restore.find(' ')) : h.restore.substr(h.restore.find(',', c1 + 1)), need);
         size_t pos = 0;
         for (size_t k = 0; k < h.ins.size(); ++k) {
             const std::string &t = h.ins[k];
             if (!hz_silent(t) || starts_with(t, "s_nop") || starts_with(t, "s_waitcnt") || starts_with(t, "v_writelane")) continue;
             std::vector<int> wr;
             const size_t sp = t.find(' ');
-            hz_sregs(t.substr(sp == std::string::npos ? 0 : sp, t.find(',') == std::string::npos ? std::string::npos : t.find(',') - sp), wr);
+            hz_sregs(t.substr(sp == std::string::npos ? 0 : sp, t.find(',') == std::string::npos ? std::string::npos : t.find(',') - sp),
+                wr);
             for (int w : wr) for (int n : need) if (w == n) pos = k + 1;
         }
         std::string reason;
@@ -496,7 +511,8 @@ static int spec_repair_file(const std::string &path, std::string &left) {
             hz_sregs(h.ins[k].substr(0, h.ins[k].find(',')), wr);
             for (size_t a2 = 0; a2 < h.after.size() && a2 < 5; ++a2) {
                 const std::string &u = h.after[a2];
-                const bool vmem = starts_with(u, "buffer_") || starts_with(u, "global_") || starts_with(u, "flat_") || starts_with(u, "scratch_") || starts_with(u, "v_readlane") || starts_with(u, "v_writelane");
+                const bool vmem = starts_with(u, "buffer_") || starts_with(u, "global_") || starts_with(u, "flat_")
+                    || starts_with(u, "scratch_") || starts_with(u, "v_readlane") || starts_with(u, "v_writelane");
                 if (!vmem) continue;
                 std::vector<int> rd;
                 hz_sregs(u, rd);
@@ -504,7 +520,9 @@ static int spec_repair_file(const std::string &path, std::string &left) {
             }
         }
         for (size_t k = 0; k < h.after.size() && k < 2; ++k)
-            if (h.after[k].find("dpp") != std::string::npos || starts_with(h.after[k], "v_readlane") || starts_with(h.after[k], "v_writelane") || starts_with(h.after[k], "v_readfirstlane")) reason = "DPP / lane operation right behind the restore";
+            if (h.after[k].find("dpp") != std::string::npos || starts_with(h.after[k], "v_readlane")
+                || starts_with(h.after[k], "v_writelane")
+                || starts_with(h.after[k], "v_readfirstlane")) reason = "DPP / lane operation right behind the restore";
         if (h.restore_raw.empty() || old_bytes.size() < 8) reason = "no encoding in the disassembly";
         if (reason.empty()) {
             size_t count = 0;
@@ -516,7 +534,8 @@ static int spec_repair_file(const std::string &path, std::string &left) {
         for (size_t k = 0; k < pos; ++k) new_bytes += h.raw[k];
         new_bytes += h.restore_raw;
         for (size_t k = pos; k < h.ins.size(); ++k) new_bytes += h.raw[k];
-        for (size_t at = blob.find(old_bytes); at != std::string::npos; at = blob.find(old_bytes, at + new_bytes.size())) blob.replace(at, old_bytes.size(), new_bytes);
+        for (size_t at = blob.find(old_bytes); at != std::string::npos;
+            at = blob.find(old_bytes, at + new_bytes.size())) blob.replace(at, old_bytes.size(), new_bytes);
         repaired += same;
     }
     if (repaired > 0) {
@@ -535,7 +554,8 @@ extern "C" int qs_spec_repair(const char *path, char *left_out, int cap) {
     if (!path) return fail(QS_ERR_INVALID, "null argument");
     std::string left;
     const int rc = spec_repair_file(path, left);
-    if (left_out && cap > 0) { const size_t n = left.size() < (size_t)cap - 1 ? left.size() : (size_t)cap - 1; memcpy(left_out, left.data(), n); left_out[n] = 0; }
+    if (left_out && cap > 0) { const size_t n = left.size() < (size_t)cap - 1 ? left.size() : (size_t)cap - 1;
+        memcpy(left_out, left.data(), n); left_out[n] = 0; }
     if (rc < 0) return fail(QS_ERR_UNSUPPORTED, left);
     return rc;
 }
@@ -543,7 +563,8 @@ extern "C" int qs_spec_verify(const char *path, char *report_out, int cap) {
     if (!path) return fail(QS_ERR_INVALID, "null argument");
     std::string report;
     const int rc = spec_verify_file(path, report);
-    if (report_out && cap > 0) { const size_t n = report.size() < (size_t)cap - 1 ? report.size() : (size_t)cap - 1; memcpy(report_out, report.data(), n); report_out[n] = 0; }
+    if (report_out && cap > 0) { const size_t n = report.size() < (size_t)cap - 1 ? report.size() : (size_t)cap - 1;
+        memcpy(report_out, report.data(), n); report_out[n] = 0; }
     if (rc < 0) return fail(QS_ERR_UNSUPPORTED, report);
     return rc;
 }
@@ -561,7 +582,8 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
         std::string report, left;   // an object without its stamp (an older cache): checked now, repaired if that is all it needs
         int v = spec_verify_file(out, report);
         if (v == 1 && spec_repair_file(out, left) > 0) { report.clear(); v = spec_verify_file(out, report); }
-        if (v == 0) { FILE *f = fopen(stamp.c_str(), "wb"); if (f) { fputs("verified: no VGPR spill / copy in front of an exec restore\n", f); fclose(f); } return out; }
+        if (v == 0) { FILE *f = fopen(stamp.c_str(), "wb");
+            if (f) { fputs("verified: no VGPR spill / copy in front of an exec restore\n", f); fclose(f); } return out; }
         if (v < 0) { g_last_error = "cached code object cannot be verified: " + report; return ""; }
         unlink(out.c_str());   // the pattern is there and cannot be repaired: rebuilt below with other settings
     }
@@ -580,7 +602,8 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     const char *cc = getenv("HIPCC");
     const std::string src = lib_dir();
     auto command = [&](const std::string &sched) {
-        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64 ? "" : kSpecFlagsF32) + " " + sched + " " +
+        return std::string(cc && cc[0] ? cc : "/opt/rocm/bin/hipcc") + " " + kSpecFlags + " " + (cfg->precision == QS_PRECISION_F64
+            ? "" : kSpecFlagsF32) + " " + sched + " " +
                (getenv("QS_SPEC_EXTRA_FLAGS") ? getenv("QS_SPEC_EXTRA_FLAGS") : "") + " -DQS_SPEC_FILE='\"" + hdr + "\"' '" + src + "/qs_spec_kernels.hip' -o '" + tmp + "' > '" + log + "' 2>&1";
     };
     // The configured scheduler settings first.  An object that carries a spill in front of an exec restore (spec_verify_file) is repaired
@@ -589,9 +612,11 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     // instructions and registers around, the arithmetic is the same (tested: tests/test_object_identity_gpu.py).  Single-wave objects end
     // with the register cap lifted (no spills at all: 3 instead of 4 waves per SIMD).
     std::vector<std::string> tries = {spec_sched_flags(team, cfg->precision)};
-    const char *const alt_team[] = {"", "-mllvm -amdgpu-sched-strategy=max-ilp", "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0", "-mllvm -amdgpu-use-amdgpu-trackers"};
+    const char *const alt_team[] = {"", "-mllvm -amdgpu-sched-strategy=max-ilp",
+        "-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -enable-post-misched=0", "-mllvm -amdgpu-use-amdgpu-trackers"};
     const char *const alt_single[] = {"", "-mllvm -amdgpu-use-amdgpu-trackers", "-mllvm -enable-post-misched=0", "-DQS_WAVES_PER_EU=0"};
-    for (const char *a : team > 0 ? alt_team : alt_single) { bool seen = false; for (const std::string &t : tries) seen |= t == a; if (!seen) tries.push_back(a); }
+    for (const char *a : team > 0 ? alt_team : alt_single) { bool seen = false; for (const std::string &t : tries) seen |= t == a;
+        if (!seen) tries.push_back(a); }
     std::string why = "specialised kernel build failed, see " + log, used;
     bool ok = false;
     for (const std::string &sched : tries) {
@@ -616,7 +641,9 @@ static std::string spec_ensure(const qs_config *cfg, int team, bool build) {
     if (rename(tmp.c_str(), out.c_str()) != 0) { unlink(tmp.c_str()); g_last_error = "cannot move code object into the cache"; return ""; }
     if (verify) {
         FILE *f = fopen(stamp.c_str(), "wb");
-        if (f) { fprintf(f, "verified: no VGPR spill / copy in front of an exec restore; scheduler flags: '%s'%s\n", used.c_str(), used.compare(0, tries[0].size() + 1, tries[0] + "'") == 0 || used == tries[0] ? "" : " (the configured ones were rejected)"); fclose(f); }
+        if (f) { fprintf(f, "verified: no VGPR spill / copy in front of an exec restore; scheduler flags: '%s'%s\n", used.c_str(),
+            used.compare(0, tries[0].size() + 1, tries[0] + "'") == 0 || used == tries[0] ? "" : " (the configured ones were rejected)");
+            fclose(f); }
     }
     return out;
 }
@@ -633,7 +660,8 @@ extern "C" int qs_spec_build(const qs_config *cfg, int team, char *path_out, int
     if (team != 0 && team != 4 && team != 8) return fail(QS_ERR_INVALID, "team must be -1, 0, 1, 4 or 8");
     std::string path = spec_ensure(cfg, team, true);
     if (path.empty()) return QS_ERR_UNSUPPORTED;
-    if (path_out) { if ((int)path.size() + 1 > cap) return fail(QS_ERR_INVALID, "buffer too small"); memcpy(path_out, path.c_str(), path.size() + 1); }
+    if (path_out) { if ((int)path.size() + 1 > cap) return fail(QS_ERR_INVALID, "buffer too small");
+        memcpy(path_out, path.c_str(), path.size() + 1); }
     return QS_OK;
 }
 
@@ -649,15 +677,20 @@ static int validate(const qs_config *c) {
         const bool o_scen = c->scenario == QS_SCENARIO_O_STATIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_RANDOM ||
                             c->scenario == QS_SCENARIO_O_DYNAMIC_SAME_GOAL || c->scenario == QS_SCENARIO_O_SWAP_GOALS ||
                             c->scenario == QS_SCENARIO_O_EP_RAND_BEZIER;
-        if (c->scenario != QS_SCENARIO_MIX && o_scen != (c->use_obstacles != 0)) return fail(QS_ERR_INVALID, "obstacle scenario <=> use_obstacles");
+        if (c->scenario != QS_SCENARIO_MIX && o_scen != (c->use_obstacles != 0)) return fail(QS_ERR_INVALID,
+            "obstacle scenario <=> use_obstacles");
     }
     if (c->use_obstacles) {
-        if (c->obst_area[0] < 1 || c->obst_area[1] < 1 || c->obst_area[0] > 16 || c->obst_area[1] > 16) return fail(QS_ERR_UNSUPPORTED, "obst_area must be within [1,16]x[1,16]");
-        if (c->num_obstacles < 1 || c->num_obstacles > QS_MAX_OBSTACLES || c->num_obstacles > c->obst_area[0] * c->obst_area[1]) return fail(QS_ERR_INVALID, "bad num_obstacles");
-        if (c->obst_area[0] * c->obst_area[1] - c->num_obstacles < c->num_agents) return fail(QS_ERR_INVALID, "not enough free cells to spawn the drones");
+        if (c->obst_area[0] < 1 || c->obst_area[1] < 1 || c->obst_area[0] > 16 || c->obst_area[1] > 16) return fail(QS_ERR_UNSUPPORTED,
+            "obst_area must be within [1,16]x[1,16]");
+        if (c->num_obstacles < 1 || c->num_obstacles > QS_MAX_OBSTACLES
+            || c->num_obstacles > c->obst_area[0] * c->obst_area[1]) return fail(QS_ERR_INVALID, "bad num_obstacles");
+        if (c->obst_area[0] * c->obst_area[1] - c->num_obstacles < c->num_agents) return fail(QS_ERR_INVALID,
+            "not enough free cells to spawn the drones");
     }
     {
-        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents, qs_obs_dim(c), c->num_obstacles, c->num_neighbors,
+        LdsLayout L = lds_layout(c->precision == QS_PRECISION_F64 ? 8 : 4, QS_WAVE, c->num_agents, QS_WAVE / c->num_agents,
+            qs_obs_dim(c), c->num_obstacles, c->num_neighbors,
                                  spec_team_waves(c->num_agents) /* the largest layout qs_create may pick */, scenario_is_full(c->scenario), c->scenario);
         if (L.total > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "observation staging does not fit the 160 KiB LDS of a CU");
     }
@@ -665,8 +698,10 @@ static int validate(const qs_config *c) {
         return fail(QS_ERR_INVALID, "bad number of domain-randomisation choices");
     if (c->use_obstacles)
         for (int q = 0; q < c->dr_num_density; ++q)
-            if (c->dr_obst_count[q] < 1 || c->dr_obst_count[q] > c->num_obstacles) return fail(QS_ERR_INVALID, "domain randomisation: obstacle counts must be in [1, num_obstacles]");
-    if (c->sim_steps < 1 || c->ep_len < 1 || c->svd_period < 1 || c->svd_period > 255) return fail(QS_ERR_INVALID, "bad sim_steps/ep_len/svd_period");
+            if (c->dr_obst_count[q] < 1 || c->dr_obst_count[q] > c->num_obstacles) return fail(QS_ERR_INVALID,
+                "domain randomisation: obstacle counts must be in [1, num_obstacles]");
+    if (c->sim_steps < 1 || c->ep_len < 1 || c->svd_period < 1 || c->svd_period > 255) return fail(QS_ERR_INVALID,
+        "bad sim_steps/ep_len/svd_period");
     return QS_OK;
 }
 
@@ -693,21 +728,27 @@ template <typename real> static int create_typed(qs_handle *h) {
         const size_t R = sizeof(real);
         size_t row = 0;   // inside a block: array after array, each 64 lanes x comps elements (component rows or lane-major: qs_kernels.h)
         auto rows = [&](size_t comps, size_t elem) { size_t o = row; row += comps * 64 * elem; return o; };
-        const size_t o_pos = rows(3, R), o_vel = rows(3, R), o_rot = rows(9, R), o_omega = rows(3, R), o_rd = rows(4, R), o_cd = rows(4, R), o_ou = rows(4, R),
+        const size_t o_pos = rows(3, R), o_vel = rows(3, R), o_rot = rows(9, R), o_omega = rows(3, R), o_rd = rows(4, R),
+            o_cd = rows(4, R), o_ou = rows(4, R),
                      o_goal = rows(3, R), o_ring = rows(4, R), o_sums = rows(3, R), o_flags = rows(1, 4), o_pair = rows(1, 8);
         const size_t block_bytes = row;
         typedef BlkOff<real> BO;
-        if ((int)block_bytes != qs_block_bytes((int)R) || block_bytes != BO::bytes || o_pos != BO::pos || o_vel != BO::vel || o_rot != BO::rot || o_omega != BO::omega || o_rd != BO::rot_damp ||
-            o_cd != BO::cmds_damp || o_ou != BO::ou || o_goal != BO::goal || o_ring != BO::ring || o_sums != BO::sums || o_flags != BO::flags || o_pair != BO::pair)
+        if ((int)block_bytes != qs_block_bytes((int)R) || block_bytes != BO::bytes || o_pos != BO::pos || o_vel != BO::vel
+            || o_rot != BO::rot || o_omega != BO::omega || o_rd != BO::rot_damp ||
+            o_cd != BO::cmds_damp || o_ou != BO::ou || o_goal != BO::goal || o_ring != BO::ring || o_sums != BO::sums
+                || o_flags != BO::flags || o_pair != BO::pair)
             return fail(QS_ERR_INVALID, "state block layout out of step with BlkOff / qs_block_bytes()");
         size_t off = NBLK * block_bytes;
         auto carve = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
         const size_t o_newpair = carve(T * 8), o_reward = carve(T * R), o_done = carve(T), o_ohit = carve(T * 4);
-        if (off >= ((size_t)1 << 32)) return fail(QS_ERR_UNSUPPORTED, "per-drone state exceeds the 4 GiB a buffer resource addresses: use fewer envs per handle");
+        if (off >= ((size_t)1 << 32)) return fail(QS_ERR_UNSUPPORTED,
+            "per-drone state exceeds the 4 GiB a buffer resource addresses: use fewer envs per handle");
         char *blk = nullptr;
         if ((rc = dalloc(h, &blk, off)) != QS_OK) return rc;
-        p.blk = {blk, (uint32_t)off, (uint32_t)block_bytes, (uint32_t)EPB, (uint32_t)o_pos, (uint32_t)o_vel, (uint32_t)o_rot, (uint32_t)o_omega, (uint32_t)o_rd, (uint32_t)o_cd,
-                 (uint32_t)o_ou, (uint32_t)o_goal, (uint32_t)o_ring, (uint32_t)o_sums, (uint32_t)o_flags, (uint32_t)o_pair, (uint32_t)o_newpair, (uint32_t)o_reward,
+        p.blk = {blk, (uint32_t)off, (uint32_t)block_bytes, (uint32_t)EPB, (uint32_t)o_pos, (uint32_t)o_vel, (uint32_t)o_rot,
+            (uint32_t)o_omega, (uint32_t)o_rd, (uint32_t)o_cd,
+                 (uint32_t)o_ou, (uint32_t)o_goal, (uint32_t)o_ring, (uint32_t)o_sums, (uint32_t)o_flags, (uint32_t)o_pair,
+                     (uint32_t)o_newpair, (uint32_t)o_reward,
                  // lane-major <=> the specialised 8-wave team kernels step this handle
                  (uint32_t)o_done, (uint32_t)o_ohit, (uint32_t)(h->team == 8 ? 1 : 0)};
         // block 0's first row of each blocked array (what qs_buffers hands out; layout in include/quadswarm.h)
@@ -724,7 +765,8 @@ template <typename real> static int create_typed(qs_handle *h) {
     DA(obst_count, E); DA(obst_size_env, E); DA(obst_density_env, E);
     {   // --quads_domain_random choice tables
         int32_t *dc = nullptr; real *dd = nullptr, *ds = nullptr;
-        if ((rc = dalloc(h, &dc, QS_MAX_DR_CHOICES)) != QS_OK || (rc = dalloc(h, &dd, QS_MAX_DR_CHOICES)) != QS_OK || (rc = dalloc(h, &ds, QS_MAX_DR_CHOICES)) != QS_OK) return rc;
+        if ((rc = dalloc(h, &dc, QS_MAX_DR_CHOICES)) != QS_OK || (rc = dalloc(h, &dd, QS_MAX_DR_CHOICES)) != QS_OK
+            || (rc = dalloc(h, &ds, QS_MAX_DR_CHOICES)) != QS_OK) return rc;
         real hd[QS_MAX_DR_CHOICES], hs[QS_MAX_DR_CHOICES];
         for (int q = 0; q < QS_MAX_DR_CHOICES; ++q) { hd[q] = (real)c.dr_density[q]; hs[q] = (real)c.dr_size[q]; }
         HIP_TRY(hipMemcpy(dc, c.dr_obst_count, sizeof c.dr_obst_count, hipMemcpyHostToDevice));
@@ -740,7 +782,8 @@ template <typename real> static int create_typed(qs_handle *h) {
         HIP_TRY(hipMemcpy(p.obst_density_env, dn.data(), E * sizeof(real), hipMemcpyHostToDevice));
     }
     DA(scen_real, SR_COUNT * E); DA(scen_int, SI_COUNT * E); DA(scen_omap, 4 * E); DA(scenario_id, E); DA(ep_scenario, E);
-    {   // the running episode's scenario: the resets of the full scenario set (mix: a new one per episode) keep it up to date; the three scenarios of
+    // the running episode's scenario: the resets of the full scenario set (mix: a new one per episode) keep it up to date; the three scenarios of
+    {
         // the fast set never change it, so it is filled here (it stayed 0 = static_same_goal for o_static_same_goal / swarm_vs_swarm until round 5:
         // the per-scenario reward keys of the Sample Factory env carried the wrong name - found by tests/test_sf_env_vs_reference_gpu.py)
         std::vector<int32_t> sid(E, c.scenario);
@@ -773,9 +816,11 @@ template <typename real> static int create_typed(qs_handle *h) {
     b.pos = p.pos; b.vel = p.vel; b.omega = p.omega; b.rot = p.rot; b.thrust_rot_damp = p.rot_damp; b.thrust_cmds_damp = p.cmds_damp;
     b.ou_state = p.ou; b.goal = p.goal; b.flags = p.flags; b.obst_hit_idx = p.obst_hit_idx; b.col_pair_mask = p.pair_mask;
     b.new_pair_mask = p.new_pair_mask; b.unique_col_mask = p.unique_col; b.obst_new_mask = p.obst_new; b.room_new_mask = p.room_new;
-    b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters; b.run_sums = p.run_sums; b.ep_sums = p.ep_sums;
+    b.counters = p.counters; b.tick = p.tick; b.obst_pos = p.obst_pos; b.ep_stats = p.ep_stats; b.ep_counters = p.ep_counters;
+    b.run_sums = p.run_sums; b.ep_sums = p.ep_sums;
     b.obst_count = p.obst_count; b.obst_size_env = p.obst_size_env; b.obst_density_env = p.obst_density_env;
-    b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim; b.real_size = sizeof(real);
+    b.error_flag = p.error_flag; b.scenario_id = p.scenario_id; b.ep_scenario = p.ep_scenario; b.obs_dim = h->obs_dim;
+    b.real_size = sizeof(real);
     b.state_block_bytes = (int32_t)p.blk.block_bytes; b.envs_per_block = (int32_t)EPB; b.state_lane_major = (int32_t)p.blk.lane_major;
     // what a deep copy of one reference env carries (quad_experience_replay.py:99-104 deep-copies the whole env): every
     // per-drone and per-env array except the noise-stream position (step_ctr: a restored env draws fresh noise, as the
@@ -788,7 +833,8 @@ template <typename real> static int create_typed(qs_handle *h) {
 #define SNAP_B(field, comps) sa.push_back(p.blk.lane_major ? qs_handle::SnapArray{(char *)p.field, sizeof(*p.field), 1, 64 * (size_t)(comps), N * (size_t)(comps), 0, EPB, (size_t)p.blk.block_bytes} \
                                                            : qs_handle::SnapArray{(char *)p.field, sizeof(*p.field), (size_t)(comps), 64, N, 0, EPB, (size_t)p.blk.block_bytes})
 #define SNAP_E(field, comps) sa.push_back({(char *)p.field, sizeof(*p.field), (size_t)(comps), E, 1, 0, 0, 0})
-    SNAP_B(pos, 3); SNAP_B(vel, 3); SNAP_B(rot, 9); SNAP_B(omega, 3); SNAP_B(rot_damp, 4); SNAP_B(cmds_damp, 4); SNAP_B(ou, 4); SNAP_B(goal, 3);
+    SNAP_B(pos, 3); SNAP_B(vel, 3); SNAP_B(rot, 9); SNAP_B(omega, 3); SNAP_B(rot_damp, 4); SNAP_B(cmds_damp, 4); SNAP_B(ou, 4);
+    SNAP_B(goal, 3);
     SNAP_B(flags, 1); SNAP_B(pair_mask, 1); SNAP_T(new_pair_mask, 1); SNAP_T(obst_hit_idx, 1); SNAP_B(dist_ring, 4); SNAP_B(dist_sums, 3);
     SNAP_T(run_sums, QS_SUM_COUNT); sa.back().kind = 2;
     sa.push_back({(char *)p.obs, sizeof(real), 1, T * D, N * D, 1, 0, 0});                     // the observation that goes with the state
@@ -890,7 +936,8 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         const char *ev = getenv("QS_SPEC"), *tv = getenv("QS_TEAM");
         const std::string mode = (ev && ev[0]) ? ev : "jit";
         const int spec_team = h->team ? ((tv && tv[0] == '4') ? 4 : ((tv && tv[0] == '8') ? 8 : spec_team_waves(cfg->num_agents))) : 0;
-        const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, spec_team, scenario_is_full(cfg->scenario), cfg->scenario,
+        const LdsLayout sl = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles,
+            cfg->num_neighbors, spec_team, scenario_is_full(cfg->scenario), cfg->scenario,
                                            spec_rows_per_pass(cfg, spec_team));
         const bool require = mode == "require";
         if (mode == "off" || mode == "0") h->spec_note = "QS_SPEC=off";
@@ -903,7 +950,8 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
                     hipModuleGetFunction(&h->spec_rollout, h->spec_mod, "qs_spec_rollout") == hipSuccess &&
                     hipModuleGetFunction(&h->spec_reset, h->spec_mod, "qs_spec_reset") == hipSuccess) {
                     h->team = spec_team;   // specialised kernels in use
-                    if (spec_team > 0 && hipModuleGetFunction(&h->spec_gated, h->spec_mod, "qs_spec_gated") != hipSuccess) { (void)hipGetLastError(); h->spec_gated = nullptr; }
+                    if (spec_team > 0 && hipModuleGetFunction(&h->spec_gated, h->spec_mod,
+                        "qs_spec_gated") != hipSuccess) { (void)hipGetLastError(); h->spec_gated = nullptr; }
                 } else {
                     (void)hipGetLastError();
                     if (h->spec_mod) { (void)hipModuleUnload(h->spec_mod); h->spec_mod = nullptr; }
@@ -917,11 +965,13 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
         // The fallback is LOUD: one line on stderr, the reason kept for qs_spec_status(), and QS_SPEC=require turns it into an error
         // (the generic kernels give the same results - tests/test_fp32_parity_gpu.py - at ~1.3x the step time).
         if (!h->spec_step && mode != "off" && mode != "0") {
-            if (require && sl.total <= 64 * 1024) { const std::string why = h->spec_note; delete h; return fail(QS_ERR_UNSUPPORTED, "QS_SPEC=require: no config-specialised kernels: " + why); }
+            if (require && sl.total <= 64 * 1024) { const std::string why = h->spec_note; delete h;
+                return fail(QS_ERR_UNSUPPORTED, "QS_SPEC=require: no config-specialised kernels: " + why); }
             fprintf(stderr, "quadswarm_hip: WARNING: running the GENERIC step kernels (%s)\n", h->spec_note.c_str());
         }
     }
-    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team, scenario_is_full(cfg->scenario), cfg->scenario,
+    h->lds = lds_layout(h->real_size, QS_WAVE, cfg->num_agents, h->epb, h->obs_dim, cfg->num_obstacles, cfg->num_neighbors, h->team,
+        scenario_is_full(cfg->scenario), cfg->scenario,
                         h->spec_step ? spec_rows_per_pass(cfg, h->team) : QS_WAVE);
     h->full = scenario_is_full(cfg->scenario);
     rc = (h->real_size == 8) ? create_typed<double>(h) : create_typed<float>(h);
@@ -933,11 +983,14 @@ int qs_create(const qs_config *cfg, int device, qs_handle **out) {
     }
     if (rc != QS_OK) { qs_destroy(h); return rc; }
     if (h->lds.total > 64 * 1024) {
-        const void *fns[] = {(const void *)qs_step_kernel<float>, (const void *)qs_step_kernel<double>, (const void *)qs_rollout_kernel<float>,
-                             (const void *)qs_rollout_kernel<double>, (const void *)qs_step_kernel_full<float>, (const void *)qs_step_kernel_full<double>,
+        const void *fns[] = {(const void *)qs_step_kernel<float>, (const void *)qs_step_kernel<double>,
+            (const void *)qs_rollout_kernel<float>,
+                             (const void *)qs_rollout_kernel<double>, (const void *)qs_step_kernel_full<float>,
+                                 (const void *)qs_step_kernel_full<double>,
                              (const void *)qs_rollout_kernel_full<float>, (const void *)qs_rollout_kernel_full<double>,
                              (const void *)qs_step_team<float>, (const void *)qs_step_team<double>, (const void *)qs_rollout_team<float>,
-                             (const void *)qs_rollout_team<double>, (const void *)qs_step_team_full<float>, (const void *)qs_step_team_full<double>,
+                             (const void *)qs_rollout_team<double>, (const void *)qs_step_team_full<float>,
+                                 (const void *)qs_step_team_full<double>,
                              (const void *)qs_rollout_team_full<float>, (const void *)qs_rollout_team_full<double>,
                              (const void *)qs_reset_kernel<float, false>, (const void *)qs_reset_kernel<double, false>,
                              (const void *)qs_reset_kernel<float, true>, (const void *)qs_reset_kernel<double, true>};
@@ -959,7 +1012,8 @@ int qs_spec_status(qs_handle *h, char *why_out, int cap) {
     return h->spec_step ? 1 : 0;
 }
 // bit 0: config-specialised code object, bit 1: team kernels, bit 2: full scenario set, bits 8..15: waves per workgroup
-int qs_kernel_flavor(qs_handle *h) { return h ? ((h->spec_step ? 1 : 0) | (h->team ? 2 : 0) | (h->full ? 4 : 0) | ((h->team ? h->team : 1) << 8)) : 0; }
+int qs_kernel_flavor(qs_handle *h) { return h
+    ? ((h->spec_step ? 1 : 0) | (h->team ? 2 : 0) | (h->full ? 4 : 0) | ((h->team ? h->team : 1) << 8)) : 0; }
 
 int qs_destroy(qs_handle *h) {
     if (!h) return QS_OK;
@@ -986,7 +1040,8 @@ int qs_destroy(qs_handle *h) {
 
 static int launch_reset(qs_handle *h, hipStream_t s) {
     if (h->d_tape) {
-        hipError_t e = (hipError_t)qs_tape_launch(0, &h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size, h->real_size == 8 ? (const void *)&h->kd : (const void *)&h->kf, &h->pf, nullptr, s);
+        hipError_t e = (hipError_t)qs_tape_launch(0, &h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size, h->real_size == 8
+            ? (const void *)&h->kd : (const void *)&h->kf, &h->pf, nullptr, s);
         if (e != hipSuccess) return fail(QS_ERR_HIP, std::string("tape reset kernel: ") + hipGetErrorString(e));
         return QS_OK;
     }
@@ -994,17 +1049,22 @@ static int launch_reset(qs_handle *h, hipStream_t s) {
     if (h->obs_target) pf.obs = (float *)h->obs_target;
     if (h->spec_reset) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
-        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, &h->lds, &h->epb};
+        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, &h->lds,
+            &h->epb};
         HIP_TRY(hipModuleLaunchKernel(h->spec_reset, h->blocks, 1, 1, QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         return QS_OK;
     }
     if (h->real_size == 8) {
         Ptrs<double> p; memcpy(&p, &pf, sizeof p);
-        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<double, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
-        else hipLaunchKernelGGL((qs_reset_kernel<double, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds, h->epb);
+        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<double, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p,
+            h->lds, h->epb);
+        else hipLaunchKernelGGL((qs_reset_kernel<double, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kd, p, h->lds,
+            h->epb);
     } else {
-        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<float, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, pf, h->lds, h->epb);
-        else hipLaunchKernelGGL((qs_reset_kernel<float, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, pf, h->lds, h->epb);
+        if (h->full) hipLaunchKernelGGL((qs_reset_kernel<float, true>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, pf,
+            h->lds, h->epb);
+        else hipLaunchKernelGGL((qs_reset_kernel<float, false>), dim3(h->blocks), dim3(QS_WAVE), h->lds.total, s, h->kf, pf, h->lds,
+            h->epb);
     }
     HIP_TRY(hipGetLastError());
     return QS_OK;
@@ -1032,7 +1092,8 @@ int qs_reset(qs_handle *h, const uint8_t *env_mask_host, void *stream) {
     // the replay wrapper's bookkeeping of an explicit reset (before the reset kernel zeroes the running
     if (h->replay_on && h->replay_stepped) {
         // sums); the reset that starts the very first episode is already in the history (qs_replay_enable)
-        hipLaunchKernelGGL(qs_replay_reset_kernel, dim3((E + QS_WAVE - 1) / QS_WAVE), dim3(QS_WAVE), 0, s, h->rp, (const uint8_t *)h->pf.reset_mask);
+        hipLaunchKernelGGL(qs_replay_reset_kernel, dim3((E + QS_WAVE - 1) / QS_WAVE), dim3(QS_WAVE), 0, s, h->rp,
+            (const uint8_t *)h->pf.reset_mask);
         HIP_TRY(hipGetLastError());
     }
     int rc = launch_reset(h, s);
@@ -1056,7 +1117,8 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     if (h->d_tape) {   // noise-tape flavour: one launch per control step
         const size_t stride = (size_t)h->cfg.num_envs * h->cfg.num_agents * 4 * (size_t)h->real_size;
         for (int t = 0; t < ksteps; ++t) {
-            hipError_t e = (hipError_t)qs_tape_launch(1, &h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size, h->real_size == 8 ? (const void *)&h->kd : (const void *)&h->kf, &h->pf,
+            hipError_t e = (hipError_t)qs_tape_launch(1, &h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size, h->real_size == 8
+                ? (const void *)&h->kd : (const void *)&h->kf, &h->pf,
                                                      (const char *)actions + stride * t, s);
             if (e != hipSuccess) return fail(QS_ERR_HIP, std::string("tape step kernel: ") + hipGetErrorString(e));
         }
@@ -1067,15 +1129,19 @@ static int launch_step(qs_handle *h, const void *actions, hipStream_t s, int kst
     if (h->obs_target) pf.obs = (float *)h->obs_target;
     // the fused exchange epilogue exists in the one-step kernels only: a multi-step launch would advance the environments without sending
     // their rows and desynchronise push / wait sequence numbers (qs_step_many splits into single steps while an exchange is set)
-    if (pf.xchg != nullptr && ksteps > 1) return fail(QS_ERR_UNSUPPORTED, "multi-step launches do not exchange observation rows: qs_set_obs_exchange is active");
+    if (pf.xchg != nullptr && ksteps > 1) return fail(QS_ERR_UNSUPPORTED,
+        "multi-step launches do not exchange observation rows: qs_set_obs_exchange is active");
     // the multi-step team kernels read the exchange slot as their gate (qs_step_team.inc)
     if (gated) pf.xchg = (const qsx::XchgDev *)h->d_gate;
     if (h->spec_step) {
         Ptrs<double> pd; memcpy(&pd, &pf, sizeof pd);
-        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf, (void *)&actions, &h->lds, &h->epb, &ksteps};
+        void *args[] = {h->real_size == 8 ? (void *)&h->kd : (void *)&h->kf, h->real_size == 8 ? (void *)&pd : (void *)&pf,
+            (void *)&actions, &h->lds, &h->epb, &ksteps};
         const int grid = h->blocks;
-        if (gated && !h->spec_gated) return fail(QS_ERR_UNSUPPORTED, "the specialised code object of this handle has no resident-state kernel");
-        HIP_TRY(hipModuleLaunchKernel(gated ? h->spec_gated : (ksteps == 1 ? h->spec_step : h->spec_rollout), grid, 1, 1, h->team ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
+        if (gated && !h->spec_gated) return fail(QS_ERR_UNSUPPORTED,
+            "the specialised code object of this handle has no resident-state kernel");
+        HIP_TRY(hipModuleLaunchKernel(gated ? h->spec_gated : (ksteps == 1 ? h->spec_step : h->spec_rollout), grid, 1, 1, h->team
+            ? QS_WAVE * h->team : QS_WAVE, 1, 1, h->lds.total, s, args, nullptr));
         if (h->profiling) HIP_TRY(hipEventRecord(e1, s));
         return QS_OK;
     }
@@ -1152,13 +1218,17 @@ int qs_step_many(qs_handle *h, const void *actions_dev, int32_t k, void *stream)
 // one - having seen done_flag >= s for its workgroups it executes an agent-scope acquire and reads the observation rows and rewards of step
 // s with plain loads - and records a checksum (the sum of their 32-bit words) per step and group, WHILE the gated launch is resident and
 // working on step s + 1.  tests/test_gated_gpu.py compares the sums with those of a one-launch-per-step twin.
-__global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, const char *src, unsigned int n_src, unsigned long long seq0, int k, int closed_loop,
+__global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, const char *src, unsigned int n_src,
+    unsigned long long seq0, int k, int closed_loop,
                                                                 unsigned long long wg_bytes, unsigned long long batch_bytes,
-                                                                unsigned long long *sums, const unsigned int *obs_words, const unsigned int *rew_words,
+                                                                unsigned long long *sums, const unsigned int *obs_words,
+                                                                    const unsigned int *rew_words,
                                                                 unsigned long long obs_words_per_wg, unsigned long long rew_words_per_wg,
                                                                 unsigned long long obs_words_total, unsigned long long rew_words_total) {
-    const unsigned int grp = blockIdx.x, w0 = grp * G->wg_per_group, w1 = (w0 + G->wg_per_group < G->blocks) ? w0 + G->wg_per_group : G->blocks;
-    const unsigned long long lo = (unsigned long long)w0 * wg_bytes, hi0 = (unsigned long long)w1 * wg_bytes, hi = hi0 < batch_bytes ? hi0 : batch_bytes;
+    const unsigned int grp = blockIdx.x, w0 = grp * G->wg_per_group, w1 = (w0 + G->wg_per_group < G->blocks)
+        ? w0 + G->wg_per_group : G->blocks;
+    const unsigned long long lo = (unsigned long long)w0 * wg_bytes, hi0 = (unsigned long long)w1 * wg_bytes, hi = hi0 < batch_bytes
+        ? hi0 : batch_bytes;
     __shared__ int dead;
     __shared__ unsigned long long acc;
     if (threadIdx.x == 0) dead = 0;
@@ -1178,9 +1248,11 @@ __global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, con
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // buffer_inv sc1: this XCD's L2 may hold the rows of the step before
             __syncthreads();
             unsigned long long part = 0;
-            const unsigned long long o0 = (unsigned long long)w0 * obs_words_per_wg, o1u = (unsigned long long)w1 * obs_words_per_wg, o1 = o1u < obs_words_total ? o1u : obs_words_total;
+            const unsigned long long o0 = (unsigned long long)w0 * obs_words_per_wg, o1u = (unsigned long long)w1 * obs_words_per_wg,
+                o1 = o1u < obs_words_total ? o1u : obs_words_total;
             for (unsigned long long j = o0 + threadIdx.x; j < o1; j += 256) part += obs_words[j];
-            const unsigned long long r0 = (unsigned long long)w0 * rew_words_per_wg, r1u = (unsigned long long)w1 * rew_words_per_wg, r1 = r1u < rew_words_total ? r1u : rew_words_total;
+            const unsigned long long r0 = (unsigned long long)w0 * rew_words_per_wg, r1u = (unsigned long long)w1 * rew_words_per_wg,
+                r1 = r1u < rew_words_total ? r1u : rew_words_total;
             for (unsigned long long j = r0 + threadIdx.x; j < r1; j += 256) part += rew_words[j];
             atomicAdd(&acc, part);
             __syncthreads();
@@ -1192,7 +1264,8 @@ __global__ void __launch_bounds__(256) qs_gate_producer_kernel(qsx::Gate *G, con
         char *to = G->act_ring + ((seq - 1) % G->ring_len) * G->act_stride;
         // system-scope write-through: the flag below must not become visible before the batch (`sc1` alone was seen to let it: one run in
         // three of the run-ahead parity test read a stale batch)
-        for (unsigned long long off = lo + 16ull * threadIdx.x; off < hi; off += 16ull * 256) qsx::st16_wt(to + off, *(const qsx::u32x4_t *)(from + off));
+        for (unsigned long long off = lo + 16ull * threadIdx.x; off < hi; off += 16ull * 256) qsx::st16_wt(to + off,
+            *(const qsx::u32x4_t *)(from + off));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) qsx::st_agent(&G->act_flag[grp], seq);
@@ -1203,11 +1276,13 @@ int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group) {
     if (!h || ring_len < 1 || ring_len > 65536 || wg_per_group < 1) return fail(QS_ERR_INVALID, "qs_gate_create: bad argument");
     if (h->d_gate) return fail(QS_ERR_INVALID, "qs_gate_create: the handle has a gate already");
     if (!h->team) return fail(QS_ERR_UNSUPPORTED, "resident-state stepping lives in the team kernels (batches up to ~8 waves per CU, see qs_kernel_flavor): larger batches are bandwidth-bound, not launch-bound");
-    if (h->replay_on || h->d_tape) return fail(QS_ERR_UNSUPPORTED, "resident-state stepping is not available with the device-side replay wrapper or a noise tape");
+    if (h->replay_on || h->d_tape) return fail(QS_ERR_UNSUPPORTED,
+        "resident-state stepping is not available with the device-side replay wrapper or a noise tape");
     HIP_TRY(hipSetDevice(h->device));
     const size_t T = (size_t)h->cfg.num_envs * h->cfg.num_agents, stride = (T * 4 * (size_t)h->real_size + 255) & ~(size_t)255;
     const unsigned int groups = (unsigned int)((h->blocks + wg_per_group - 1) / wg_per_group);
-    const size_t o_ring = 256, o_act = o_ring + stride * (size_t)ring_len, o_done = o_act + (((size_t)groups * 8 + 255) & ~(size_t)255), total = o_done + (((size_t)h->blocks * 8 + 255) & ~(size_t)255);
+    const size_t o_ring = 256, o_act = o_ring + stride * (size_t)ring_len, o_done = o_act + (((size_t)groups * 8 + 255) & ~(size_t)255),
+        total = o_done + (((size_t)h->blocks * 8 + 255) & ~(size_t)255);
     // Fine-grained (uncached) device memory: the ring and the sequence words are handed between kernels that run CONCURRENTLY, mostly on
     // different XCDs, whose L2s are not coherent with each other - an `sc1` load that hits a stale line of its own XCD's L2 is how a first
     // version of this took 7.8 ms per closed-loop step (profiles/r04c_bench_c2_default.json); uncached memory has no such line
@@ -1220,11 +1295,13 @@ int qs_gate_create(qs_handle *h, int32_t ring_len, int32_t wg_per_group) {
     qsx::Gate g;
     memset(&g, 0, sizeof g);
     int khz = 100000;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) { (void)hipGetLastError(); khz = 100000; }
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) != hipSuccess || khz <= 0) { (void)hipGetLastError();
+        khz = 100000; }
     long ms = 500;
     if (const char *ev = getenv("QS_GATE_TIMEOUT_MS")) { const long v = atol(ev); if (v > 0) ms = v; }
     g.timeout_ticks = (unsigned long long)khz * (unsigned long long)ms;
-    g.act_ring = base + o_ring; g.act_stride = stride; g.ring_len = (unsigned int)ring_len; g.groups = groups; g.wg_per_group = (unsigned int)wg_per_group; g.blocks = (unsigned int)h->blocks;
+    g.act_ring = base + o_ring; g.act_stride = stride; g.ring_len = (unsigned int)ring_len; g.groups = groups;
+    g.wg_per_group = (unsigned int)wg_per_group; g.blocks = (unsigned int)h->blocks;
     g.act_flag = (unsigned long long *)(base + o_act); g.done_flag = (unsigned long long *)(base + o_done);
     HIP_TRY(hipMemcpy(base, &g, sizeof g, hipMemcpyHostToDevice));
     HIP_TRY(hipDeviceSynchronize());
@@ -1245,7 +1322,8 @@ int qs_gate_info(qs_handle *h, qs_gate_info_t *out) {
     if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
     const qsx::Gate &g = h->gate_host;
     out->action_ring = g.act_ring; out->action_stride_bytes = (int64_t)g.act_stride; out->ring_len = (int32_t)g.ring_len;
-    out->act_flag = g.act_flag; out->done_flag = g.done_flag; out->groups = (int32_t)g.groups; out->wg_per_group = (int32_t)g.wg_per_group; out->workgroups = (int32_t)g.blocks;
+    out->act_flag = g.act_flag; out->done_flag = g.done_flag; out->groups = (int32_t)g.groups;
+    out->wg_per_group = (int32_t)g.wg_per_group; out->workgroups = (int32_t)g.blocks;
     out->envs_per_workgroup = h->epb; out->steps_launched = (int64_t)h->gate_step_seq; out->steps_fed = (int64_t)h->gate_prod_seq;
     return QS_OK;
 }
@@ -1253,7 +1331,8 @@ int qs_gate_info(qs_handle *h, qs_gate_info_t *out) {
 int qs_step_gated(qs_handle *h, int32_t k, void *stream) {
     if (!h || k < 1) return fail(QS_ERR_INVALID, "bad argument");
     if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
-    if (h->profiling || h->replay_on || h->d_tape || h->pf.xchg) return fail(QS_ERR_UNSUPPORTED, "qs_step_gated: not available with per-launch profiling, the replay wrapper, a noise tape or the fused exchange");
+    if (h->profiling || h->replay_on || h->d_tape || h->pf.xchg) return fail(QS_ERR_UNSUPPORTED,
+        "qs_step_gated: not available with per-launch profiling, the replay wrapper, a noise tape or the fused exchange");
     HIP_TRY(hipSetDevice(h->device));
     // stream-ordered behind everything on the caller's stream, and the caller's stream behind the launch - but the kernel itself sits in
     // the library's high-priority queue (see qs_handle::gate_stream)
@@ -1284,24 +1363,31 @@ int qs_gate_produce(qs_handle *h, const void *src_actions_dev, int32_t n_src, in
     if (((uintptr_t)src_actions_dev) & 15) return fail(QS_ERR_INVALID, "qs_gate_produce: the action table must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
     const unsigned long long T = (unsigned long long)h->cfg.num_envs * h->cfg.num_agents;
-    const unsigned long long wg_bytes = (unsigned long long)h->epb * h->cfg.num_agents * 4 * h->real_size, batch_bytes = T * 4 * h->real_size;
-    hipLaunchKernelGGL(qs_gate_producer_kernel, dim3(h->gate_host.groups), dim3(256), 0, (hipStream_t)stream, h->d_gate, (const char *)src_actions_dev, (unsigned int)n_src,
-                       h->gate_prod_seq, (int)k, (int)(closed_loop != 0), wg_bytes, batch_bytes, (unsigned long long *)nullptr, (const unsigned int *)nullptr,
+    const unsigned long long wg_bytes = (unsigned long long)h->epb * h->cfg.num_agents * 4 * h->real_size,
+        batch_bytes = T * 4 * h->real_size;
+    hipLaunchKernelGGL(qs_gate_producer_kernel, dim3(h->gate_host.groups), dim3(256), 0, (hipStream_t)stream, h->d_gate,
+        (const char *)src_actions_dev, (unsigned int)n_src,
+                       h->gate_prod_seq, (int)k, (int)(closed_loop != 0), wg_bytes, batch_bytes, (unsigned long long *)nullptr,
+                           (const unsigned int *)nullptr,
                        (const unsigned int *)nullptr, 0ull, 0ull, 0ull, 0ull);
     HIP_TRY(hipGetLastError());
     h->gate_prod_seq += (unsigned long long)k;
     return QS_OK;
 }
 
-int qs_gate_produce_verify(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, unsigned long long *sums_dev, void *stream) {
+int qs_gate_produce_verify(qs_handle *h, const void *src_actions_dev, int32_t n_src, int32_t k, unsigned long long *sums_dev,
+    void *stream) {
     if (!h || !src_actions_dev || !sums_dev || n_src < 1 || k < 1) return fail(QS_ERR_INVALID, "bad argument");
     if (!h->d_gate) return fail(QS_ERR_INVALID, "no gate: call qs_gate_create first");
     if (((uintptr_t)src_actions_dev) & 15) return fail(QS_ERR_INVALID, "qs_gate_produce_verify: the action table must be 16-byte aligned");
     HIP_TRY(hipSetDevice(h->device));
-    const unsigned long long T = (unsigned long long)h->cfg.num_envs * h->cfg.num_agents, rows_wg = (unsigned long long)h->epb * h->cfg.num_agents, wpr = h->real_size / 4;
+    const unsigned long long T = (unsigned long long)h->cfg.num_envs * h->cfg.num_agents,
+        rows_wg = (unsigned long long)h->epb * h->cfg.num_agents, wpr = h->real_size / 4;
     const unsigned long long wg_bytes = rows_wg * 4 * h->real_size, batch_bytes = T * 4 * h->real_size;
-    hipLaunchKernelGGL(qs_gate_producer_kernel, dim3(h->gate_host.groups), dim3(256), 0, (hipStream_t)stream, h->d_gate, (const char *)src_actions_dev, (unsigned int)n_src,
-                       h->gate_prod_seq, (int)k, 1, wg_bytes, batch_bytes, sums_dev, (const unsigned int *)h->pf.obs, (const unsigned int *)h->pf.reward,
+    hipLaunchKernelGGL(qs_gate_producer_kernel, dim3(h->gate_host.groups), dim3(256), 0, (hipStream_t)stream, h->d_gate,
+        (const char *)src_actions_dev, (unsigned int)n_src,
+                       h->gate_prod_seq, (int)k, 1, wg_bytes, batch_bytes, sums_dev, (const unsigned int *)h->pf.obs,
+                           (const unsigned int *)h->pf.reward,
                        rows_wg * h->obs_dim * wpr, rows_wg * wpr, T * h->obs_dim * wpr, T * wpr);
     HIP_TRY(hipGetLastError());
     h->gate_prod_seq += (unsigned long long)k;
@@ -1341,7 +1427,8 @@ int qs_get_buffers(qs_handle *h, qs_buffers *out) {
 
 int qs_set_obs_target(qs_handle *h, void *obs_dev) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
-    if (obs_dev && h->replay_on) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_target: the device-side replay wrapper restores observations into qs_buffers.obs");
+    if (obs_dev && h->replay_on) return fail(QS_ERR_UNSUPPORTED,
+        "qs_set_obs_target: the device-side replay wrapper restores observations into qs_buffers.obs");
     if (obs_dev && h->d_tape) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_target: not available while a noise tape is set");
     h->obs_target = obs_dev;
     return QS_OK;
@@ -1353,13 +1440,15 @@ extern "C" int qs_xchg_row_layout_is(struct qs_xchg *x, int32_t cols, int32_t q0
 int qs_set_obs_exchange(qs_handle *h, struct qs_xchg *xchg, int32_t auto_ack) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     if (!xchg) { h->pf.xchg = nullptr; return QS_OK; }
-    if (!h->team || h->real_size != 4) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_exchange: the fused exchange lives in the float32 team kernels (small batches); use qs_xchg_push for this handle");
+    if (!h->team || h->real_size != 4) return fail(QS_ERR_UNSUPPORTED,
+        "qs_set_obs_exchange: the fused exchange lives in the float32 team kernels (small batches); use qs_xchg_push for this handle");
     if (h->d_tape) return fail(QS_ERR_UNSUPPORTED, "qs_set_obs_exchange: not available while a noise tape is set");
     HIP_TRY(hipSetDevice(h->device));
     int64_t n = 0;
     void *desc = qs_xchg_fused_desc(xchg, h->blocks, auto_ack, &n);
     if (!desc) return fail(QS_ERR_INVALID, std::string("qs_set_obs_exchange: ") + qs_xchg_last_error());
-    if (n != (int64_t)h->cfg.num_envs * h->cfg.num_agents * h->obs_dim) return fail(QS_ERR_INVALID, "qs_set_obs_exchange: the endpoint's rows * cols must be E*N * obs_dim");
+    if (n != (int64_t)h->cfg.num_envs * h->cfg.num_agents * h->obs_dim) return fail(QS_ERR_INVALID,
+        "qs_set_obs_exchange: the endpoint's rows * cols must be E*N * obs_dim");
     {   // the kernels rebuild a QS_WIRE_Q8 layout from their own constants: the neighbour block behind the self observation
         const int self_dim = h->cfg.obs_repr == 0 ? 18 : (h->cfg.obs_repr == 1 ? 19 : 24);
         if (!qs_xchg_row_layout_is(xchg, h->obs_dim, self_dim, self_dim + 6 * h->cfg.num_neighbors))
@@ -1404,8 +1493,10 @@ static int state_io(qs_handle *h, int32_t env, double *host, int32_t *tick, int 
         HIP_TRY(hipMemcpy(h->d_tick_io, &t, sizeof t, hipMemcpyHostToDevice));
     }
     if (h->real_size == 8) { Ptrs<double> p; memcpy(&p, &h->pf, sizeof p);
-        hipLaunchKernelGGL(qs_state_kernel<double>, dim3(1), dim3(QS_WAVE), 0, 0, p, h->cfg.num_envs, N, env, h->d_state_buf, h->d_tick_io, set); }
-    else hipLaunchKernelGGL(qs_state_kernel<float>, dim3(1), dim3(QS_WAVE), 0, 0, h->pf, h->cfg.num_envs, N, env, h->d_state_buf, h->d_tick_io, set);
+        hipLaunchKernelGGL(qs_state_kernel<double>, dim3(1), dim3(QS_WAVE), 0, 0, p, h->cfg.num_envs, N, env, h->d_state_buf,
+            h->d_tick_io, set); }
+    else hipLaunchKernelGGL(qs_state_kernel<float>, dim3(1), dim3(QS_WAVE), 0, 0, h->pf, h->cfg.num_envs, N, env, h->d_state_buf,
+        h->d_tick_io, set);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (!set) {
@@ -1417,7 +1508,8 @@ static int state_io(qs_handle *h, int32_t env, double *host, int32_t *tick, int 
 }
 
 int qs_get_state(qs_handle *h, int32_t env, double *state_host, int32_t *tick) { return state_io(h, env, state_host, tick, 0); }
-int qs_set_state(qs_handle *h, int32_t env, const double *state_host, int32_t tick) { int32_t t = tick; return state_io(h, env, (double *)state_host, &t, 1); }
+int qs_set_state(qs_handle *h, int32_t env, const double *state_host, int32_t tick) { int32_t t = tick;
+    return state_io(h, env, (double *)state_host, &t, 1); }
 
 int qs_memcpy_d2h(qs_handle *h, void *host_dst, const void *dev_src, size_t bytes) {
     if (!h || !host_dst || !dev_src) return fail(QS_ERR_INVALID, "null argument");
@@ -1503,9 +1595,11 @@ static int snapshot_io(qs_handle *h, int32_t env, int32_t slot, bool save, hipSt
     return QS_OK;
 }
 int qs_snapshot_save(qs_handle *h, int32_t env, int32_t slot, void *stream) { return snapshot_io(h, env, slot, true, (hipStream_t)stream); }
-int qs_snapshot_load(qs_handle *h, int32_t slot, int32_t env, void *stream) { return snapshot_io(h, env, slot, false, (hipStream_t)stream); }
+int qs_snapshot_load(qs_handle *h, int32_t slot, int32_t env,
+    void *stream) { return snapshot_io(h, env, slot, false, (hipStream_t)stream); }
 int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *stream) {
-    if (!h || src_slot < 0 || dst_slot < 0 || src_slot >= h->snap_slots || dst_slot >= h->snap_slots) return fail(QS_ERR_INVALID, "snapshot slot out of range");
+    if (!h || src_slot < 0 || dst_slot < 0 || src_slot >= h->snap_slots || dst_slot >= h->snap_slots) return fail(QS_ERR_INVALID,
+        "snapshot slot out of range");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipMemcpyAsync(h->snap_pool + h->snap_bytes * (size_t)dst_slot, h->snap_pool + h->snap_bytes * (size_t)src_slot, h->snap_bytes,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1516,8 +1610,10 @@ int qs_snapshot_copy(qs_handle *h, int32_t src_slot, int32_t dst_slot, void *str
 int qs_replay_enable(qs_handle *h, double sample_prob) {
     if (!h) return fail(QS_ERR_INVALID, "null handle");
     if (h->replay_on) return fail(QS_ERR_INVALID, "replay is already enabled on this handle");
-    if (h->obs_target) return fail(QS_ERR_UNSUPPORTED, "qs_replay_enable: the replay wrapper restores observations into qs_buffers.obs (reset qs_set_obs_target first)");
-    if (!h->cfg.episode_sums) return fail(QS_ERR_INVALID, "qs_replay_enable needs a handle created with episode_sums = 1 (per-episode crash reward)");
+    if (h->obs_target) return fail(QS_ERR_UNSUPPORTED,
+        "qs_replay_enable: the replay wrapper restores observations into qs_buffers.obs (reset qs_set_obs_target first)");
+    if (!h->cfg.episode_sums) return fail(QS_ERR_INVALID,
+        "qs_replay_enable needs a handle created with episode_sums = 1 (per-episode crash reward)");
     if (!(sample_prob >= 0.0 && sample_prob <= 1.0)) return fail(QS_ERR_INVALID, "sample_prob must be in [0, 1]");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
@@ -1530,7 +1626,8 @@ int qs_replay_enable(qs_handle *h, double sample_prob) {
         if (P.narr == QS_REPLAY_MAX_ARR) return fail(QS_ERR_UNSUPPORTED, "too many snapshot arrays");
         if (a.kind == 1) P.obs_arr = P.narr;
         if (a.base == (char *)h->pf.tick) P.tick_arr = P.narr;
-        P.arr[P.narr++] = {a.base, (uint32_t)a.elem, (uint32_t)a.comps, (uint32_t)a.per_env, off, (uint64_t)a.comp_stride, (uint32_t)a.group, (uint32_t)a.group_stride};
+        P.arr[P.narr++] = {a.base, (uint32_t)a.elem, (uint32_t)a.comps, (uint32_t)a.per_env, off, (uint64_t)a.comp_stride,
+            (uint32_t)a.group, (uint32_t)a.group_stride};
         off += (uint32_t)((a.elem * a.comps * a.per_env + 15) & ~(size_t)15);
     }
     P.snap_bytes = off;
@@ -1544,15 +1641,20 @@ int qs_replay_enable(qs_handle *h, double sample_prob) {
     P.env_id_offset = h->cfg.env_id_offset;
     P.sample_prob = (float)sample_prob;
     P.done = h->pf.done; P.tick = h->pf.tick; P.step_ctr = h->pf.step_ctr; P.unique_col = h->pf.unique_col; P.obst_new = h->pf.obst_new;
-    P.counters = h->pf.counters; P.ep_sums = h->pf.ep_sums; P.run_sums = h->pf.run_sums; P.real_size = h->real_size; P.T = (int32_t)(E * h->cfg.num_agents);
+    P.counters = h->pf.counters; P.ep_sums = h->pf.ep_sums; P.run_sums = h->pf.run_sums; P.real_size = h->real_size;
+    P.T = (int32_t)(E * h->cfg.num_agents);
     int rc;
     if ((rc = dalloc(h, &P.pool, (size_t)P.snap_bytes * (QS_REPLAY_RING + QS_REPLAY_EVENTS) * E)) != QS_OK) return rc;
-    if ((rc = dalloc(h, &P.active, E)) != QS_OK || (rc = dalloc(h, &P.saved, E)) != QS_OK || (rc = dalloc(h, &P.ep_saved, E)) != QS_OK || (rc = dalloc(h, &P.crash_hist, 100 * E)) != QS_OK ||
-        (rc = dalloc(h, &P.crash_n, E)) != QS_OK || (rc = dalloc(h, &P.crash_pos, E)) != QS_OK || (rc = dalloc(h, &P.ck_count, E)) != QS_OK ||
-        (rc = dalloc(h, &P.ck_head, E)) != QS_OK || (rc = dalloc(h, &P.last_added, E)) != QS_OK || (rc = dalloc(h, &P.ev_len, E)) != QS_OK ||
+    if ((rc = dalloc(h, &P.active, E)) != QS_OK || (rc = dalloc(h, &P.saved, E)) != QS_OK || (rc = dalloc(h, &P.ep_saved, E)) != QS_OK
+        || (rc = dalloc(h, &P.crash_hist, 100 * E)) != QS_OK ||
+        (rc = dalloc(h, &P.crash_n, E)) != QS_OK || (rc = dalloc(h, &P.crash_pos, E)) != QS_OK
+            || (rc = dalloc(h, &P.ck_count, E)) != QS_OK ||
+        (rc = dalloc(h, &P.ck_head, E)) != QS_OK || (rc = dalloc(h, &P.last_added, E)) != QS_OK
+            || (rc = dalloc(h, &P.ev_len, E)) != QS_OK ||
         (rc = dalloc(h, &P.ev_idx, E)) != QS_OK || (rc = dalloc(h, &P.ev_replayed, QS_REPLAY_EVENTS * E)) != QS_OK ||
         (rc = dalloc(h, &P.ev_slot, QS_REPLAY_EVENTS * E)) != QS_OK || (rc = dalloc(h, &P.episodes, E)) != QS_OK ||
-        (rc = dalloc(h, &P.replayed, E)) != QS_OK || (rc = dalloc(h, &P.errors, E)) != QS_OK || (rc = dalloc(h, &P.start_tick, E)) != QS_OK ||
+        (rc = dalloc(h, &P.replayed, E)) != QS_OK || (rc = dalloc(h, &P.errors, E)) != QS_OK
+            || (rc = dalloc(h, &P.start_tick, E)) != QS_OK ||
         (rc = dalloc(h, &P.last_steps, E)) != QS_OK) return rc;
     {   // the reset() that starts the first episode records crashes_last_episode = 0 (quadrotor_multi.py:356-359); last_added = -1e9
         std::vector<int32_t> ones(E, 1), neg(E, -1000000000);
@@ -1613,7 +1715,8 @@ int qs_set_noise_tape(qs_handle *h, const double *tape_host, int64_t len_per_env
     h->pf.tape = nullptr; h->pf.tape_pos = nullptr; h->pf.tape_len = 0;
     if (!tape_host || len_per_env <= 0) return QS_OK;   // back to the counter-based stream
     if (len_per_env > 0x7fffff00ll) return fail(QS_ERR_INVALID, "tape too long");
-    if (qs_tape_lds_bytes(&h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size) > 160 * 1024) return fail(QS_ERR_UNSUPPORTED, "noise tape: the single-wave layout does not fit the LDS");
+    if (qs_tape_lds_bytes(&h->cfg, h->obs_dim, h->full ? 1 : 0, h->real_size) > 160 * 1024) return fail(QS_ERR_UNSUPPORTED,
+        "noise tape: the single-wave layout does not fit the LDS");
     const size_t E = h->cfg.num_envs, bytes = E * (size_t)len_per_env * sizeof(double);
     HIP_TRY(hipMalloc((void **)&h->d_tape, bytes));
     HIP_TRY(hipMalloc((void **)&h->d_tape_pos, E * sizeof(int32_t)));
@@ -1627,7 +1730,8 @@ int qs_set_noise_tape(qs_handle *h, const double *tape_host, int64_t len_per_env
 int qs_set_tape_pos(qs_handle *h, const int32_t *pos_host) {
     if (!h || !pos_host) return fail(QS_ERR_INVALID, "null argument");
     if (!h->d_tape) return fail(QS_ERR_INVALID, "no noise tape set");
-    for (int e = 0; e < h->cfg.num_envs; ++e) if (pos_host[e] < 0 || pos_host[e] > h->tape_len) return fail(QS_ERR_INVALID, "tape position out of range");
+    for (int e = 0; e < h->cfg.num_envs; ++e) if (pos_host[e] < 0 || pos_host[e] > h->tape_len) return fail(QS_ERR_INVALID,
+        "tape position out of range");
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(h->d_tape_pos, pos_host, (size_t)h->cfg.num_envs * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1648,7 +1752,8 @@ int qs_get_tape_pos(qs_handle *h, int32_t *pos_host) {
 int qs_debug_lds_bytes(const qs_config *cfg, int team, int spec) {
     if (!cfg) return -1;
     const int rs = cfg->precision == QS_PRECISION_F64 ? 8 : 4;
-    return lds_layout(rs, QS_WAVE, cfg->num_agents, QS_WAVE / cfg->num_agents, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors, team,
+    return lds_layout(rs, QS_WAVE, cfg->num_agents, QS_WAVE / cfg->num_agents, qs_obs_dim(cfg), cfg->num_obstacles, cfg->num_neighbors,
+        team,
                       scenario_is_full(cfg->scenario), cfg->scenario, spec ? spec_rows_per_pass(cfg, team) : QS_WAVE).total;
 }
 
