@@ -17,6 +17,8 @@
 #   diff:<case>[:var:flags]  two code objects of one parity case side by side, bit for bit + against the oracle (tools/flag_diff.py; QS_SPEC_VERIFY=0:
 #                    the flagged object as the compiler delivers it)                                                      -> gpurun_out/<tag>_flag_diff_<case>.txt
 #   gdb:<case>[:var:flags]   the same under rocgdb with precise memory faults: faulting instruction, registers            -> gpurun_out/<tag>_rocgdb_<case>.txt
+#   noise[:shapes]   what the random draws cost at run time: the throughput shapes with the sensor + thrust noise configured off (27 + 4 normal draws per
+#                    drone-step not made) beside the default, same box, interleaved                                      -> gpurun_out/<tag>_noise_share.txt
 #   sweep:<n>        scheduler / switch sweep <n> of tools/sched_sweep.py (objects prebuilt with `SWEEP=<n> python tools/sched_sweep.py build`)  -> gpurun_out/<tag>_sched_sweep.txt
 tag=$1; shift
 mkdir -p gpurun_out
@@ -85,6 +87,15 @@ PY
             -ex "info threads" -ex "x/40i \$pc-120" -ex "info registers" --args python -u tools/flag_diff.py $case 7 40 ) > gpurun_out/${tag}_rocgdb_$case.txt 2>&1
         grep -n "received signal\|=> " gpurun_out/${tag}_rocgdb_$case.txt | head -4
       fi ;;
+    noise*)
+      shapes=${task#noise}; shapes=${shapes#:}; shapes=${shapes:-$BIG}
+      out=gpurun_out/${tag}_noise_share.txt
+      echo "# bench.py --steps 400, us per step: default configuration / sense_noise=None + thrust_noise_ratio=0 (no Philox + Box-Muller draws on the per-drone path)" > $out
+      for rep in 1 2; do for we in ${shapes//,/ }; do for v in default nonoise; do
+        extra=""; [ $v = nonoise ] && extra="--set sense_noise=None --set thrust_noise_ratio=0.0"
+        us=$(timeout 300 python bench.py --workload ${we%%:*} --envs-per-gpu ${we##*:} --steps 400 --warmup 50 --prewarm 200 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train $extra 2>>gpurun_out/${tag}_err.txt | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.3f' % (1e3*d['ms_per_step']))")
+        echo "$we rep $rep $v: $us" | tee -a $out
+      done; done; done ;;
     sweep:*) SWEEP=${task#sweep:} SWEEP_TAG=$tag python tools/sched_sweep.py run 2 2>&1 | tail -30 ;;
     run:*) sc=${task#run:}; timeout 900 python $sc > gpurun_out/${tag}_$(basename $sc .py).txt 2>&1; tail -25 gpurun_out/${tag}_$(basename $sc .py).txt ;;
     *) echo "unknown task $task" ;;
