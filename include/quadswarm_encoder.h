@@ -12,6 +12,15 @@
  *   layer with torch weight W[M_real, K_real], bias b[M_real]  ->  M = ceil16(M_real), K = ceil32(K_real), zero padded,
  *   w[((mt * (K/32) + ks) * 64 + lane) * 8 + j] = bf16(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),  b as fp32[M].
  * (quad-swarm-rl_amd/policy.py does the packing from a torch module.)  All pointers are device pointers.
+ *
+ * Reference precision (qs_enc_params.precision = 1).  The reference's modules run in fp32; with bf16 operands the features come out
+ * ~1e-2 away from them.  For a sampler whose learner is fp32 every GEMM operand - weight or activation - can instead be a PAIR of fp16
+ * numbers, x = h + l / 2048 (h = fp16(x), 0 below 2^-14; l = fp16((x - h) * 2048)): three v_mfma_f32_16x16x32_f16 per product, fp32
+ * accumulation, ~2^-22 relative per product; features within 1e-5 of the fp32 module (tests/test_policy_encoder_gpu.py).  Weights are then
+ * packed as two 1 KiB planes per fragment:
+ *   w[(((mt * (K/32) + ks) * 2 + plane) * 64 + lane) * 8 + j] = (plane ? l : h)(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),
+ * `ebuf` rows are the two planes [2][256], and the 16-agent kernels run with one workgroup per CU (two LDS planes).  Built for
+ * QuadMultiEncoder's four neighbour encoders; the two multi-head classes return -4.
  */
 #ifndef QUADSWARM_ENCODER_H
 #define QUADSWARM_ENCODER_H
@@ -41,8 +50,8 @@ typedef struct qs_enc_params {
     qs_enc_layer a2;       /* attention: attention_mlp[2] */
     const float *a3w;      /* attention: attention_mlp[4] (256 -> 1): fp32 weight row [256] ... */
     float a3b;             /* ... and bias */
-    int32_t pad0;
-    uint16_t *ebuf;        /* attention scratch, device, bf16 [B * num_nbr, 256] */
+    int32_t precision;     /* 0: bf16 operands; 1: reference precision (fp16 pairs, see the top of this file) */
+    uint16_t *ebuf;        /* attention scratch, device, bf16 [B * num_nbr, 256]; precision 1: fp16 [B * num_nbr, 2, 256] */
     float *gbuf;           /* attention scratch, device, fp32 [B, 256] */
     qs_enc_layer f;        /* feed forward      (:329-332): K = 256 * (1 + (neighbour encoder present) + (obst_dim > 0)), M = 512 */
     /* QS_ENC_MODEL_MHA only (quad_multi_model.py:124-196, --quads_encoder_type=attention; needs num_nbr >= 1, obst_dim >= 1):
@@ -84,6 +93,8 @@ size_t qs_enc_lds_bytes(void);
 /* dynamic LDS the kernel of `model` (QS_ENC_NBR_* / QS_ENC_MODEL_*) requests.  QS_ENC_MODEL_MHA / _S2R: more than half of a CU's
  * 160 KiB, i.e. one workgroup per CU by construction. */
 size_t qs_enc_lds_bytes_of(int32_t model);
+/* ... of the reference-precision kernels (attention != 0: the second launch of the attention encoder). */
+size_t qs_enc_lds_bytes_split(int32_t attention);
 const char *qs_enc_last_error(void);
 
 /* out[B, 512] (QS_ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]) on `stream` (out may be NULL when params->head_dim > 0).  0 on success, < 0 on error

@@ -28,6 +28,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 
 #define ENC_H 256            // hidden size of every MLP (rnn_size = neighbor_hidden_size = obst_hidden_size = 256)
 #define ENC_TA 16            // agents per workgroup = one 16-row tile
@@ -63,7 +65,7 @@ struct EncParams {
     EncLayer a1e, a1m, a2;      // attention: score MLP :68-75; its first layer split into the e_i half (with the bias) and the e_mean half
     const float *a3w;           // attention: last score layer 256 -> 1, fp32 weight row [256] ...
     float a3b;                  // ... and bias
-    int32_t pad0;
+    int32_t precision;          // 0: bf16 operands; 1: reference precision - every operand as a pair of fp16 (see "Reference precision" below)
     uint16_t *ebuf;             // attention scratch: e_i of every (agent, neighbour) row, bf16 [B*num_nbr, 256]
     float *gbuf;                // attention scratch: W_m e_mean of every agent, fp32 [B, 256]
     EncLayer f;                 // feed forward        :329-332
@@ -142,6 +144,50 @@ __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Reference precision (qs_enc_params.precision = 1; template parameter SP of the 16-agent kernels).  The reference's modules run in
+// fp32 (quad_multi_model.py:250-350); bf16 operands leave the fused features ~1e-2 away from them.  Here every operand of every GEMM -
+// weight or activation - is the pair x = h + l / 2048 of fp16 numbers: h = fp16(x) carries 11 significant bits, l = fp16((x - h) * 2048)
+// the next 11 (x - h is exact in fp32; the scale keeps l a normal fp16 number whatever the size of x).  A product becomes three
+// v_mfma_f32_16x16x32_f16 - h.h into the accumulator, h.l and l.h into a second one that is folded in, times 1 / 2048, behind the K loop;
+// the dropped l.l term and the roundings of the l halves are <= 2^-22 relative per product, i.e. fp32-grade.  Weights arrive split from
+// the host (two 1 KiB planes per fragment), activations are kept as two planes ENC_SPLANE elements apart in LDS (and in `ebuf`).  The
+// matrix cores do three times the work of the bf16 kernels, at a sixteenth of the price of the fp32 MFMA (v_mfma_f32_16x16x4_f32).
+// Values below the smallest normal fp16 go into l alone (h = 0: no subnormal operand), values beyond +-65504 (no observation is) clamp.
+// ------------------------------------------------------------------------------------------------
+#define ENC_SPLANE 39936   // elements between the h and the l plane of an LDS buffer: the largest 16-agent layout (qs_encoder_kernel's)
+#define ENC_SPLIT_SCALE 2048.0f
+__device__ __forceinline__ void split2(float x, _Float16 &h, _Float16 &l) {
+    x = __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+    h = __builtin_fabsf(x) < 6.103515625e-05f ? (_Float16)0.0f : (_Float16)x;
+    l = (_Float16)((x - (float)h) * ENC_SPLIT_SCALE);
+}
+// one activation / four consecutive ones -> LDS (or `ebuf`): bf16, or the two fp16 planes `plane` elements apart
+template <bool SP>
+__device__ __forceinline__ void put1(uint16_t *p, float v) {
+    if constexpr (SP) {
+        _Float16 h, l;
+        split2(v, h, l);
+        p[0] = __builtin_bit_cast(uint16_t, h);
+        p[ENC_SPLANE] = __builtin_bit_cast(uint16_t, l);
+    } else p[0] = __builtin_bit_cast(uint16_t, (__bf16)v);
+}
+template <bool SP>
+__device__ __forceinline__ void put4(uint16_t *p, const f32x4 &x, int plane = ENC_SPLANE) {
+    if constexpr (SP) {
+        f16x4 vh, vl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { _Float16 h, l; split2(x[r], h, l); vh[r] = h; vl[r] = l; }
+        *(f16x4 *)p = vh;
+        *(f16x4 *)(p + plane) = vl;
+    } else {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (__bf16)x[r];
+        *(bf16x4 *)p = v;
+    }
+}
+
 // floor(n / d) for small operands (n * d < 2^32) from m = ceil(2^32 / d), computed once per thread: integer division by a
 // run-time divisor is ~40 instructions, and the staging loops did two per element
 __device__ __forceinline__ uint32_t div_magic(uint32_t d) { return 0xffffffffu / d + 1u; }
@@ -180,8 +226,81 @@ __device__ __forceinline__ void mfma_tile(const bf16x8 (&a)[MT], const bf16x8 &b
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b, acc[mt][nt], 0, 0, 0);
 }
 
+// reference precision (see split2): A fragments in two planes per (tile, K-step), B fragments in two LDS planes, three MFMAs per product
 template <int MT, int NT>
+__device__ __forceinline__ void gemm_tiles_split(const EncLayer &L, int mtile0, const uint16_t *X, int xstride, f32x4 (&acc)[MT][NT]) {
+    const int lane = threadIdx.x & 63, ksteps = L.K >> 5;
+    const uint16_t *xrow = X + (lane & 15) * xstride + 8 * (lane >> 4);
+    const uint32_t voff = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, L.M * L.K * 4, 0x00020000);
+#define ENC_SW(mt, ks, pl) __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, (((mtile0 + (mt)) * ksteps + (ks)) * 2 + (pl)) * 1024, 0))
+#define ENC_SX(nt, ks, pl) (*(const f16x8 *)(xrow + (pl) * ENC_SPLANE + (nt) * 16 * xstride + (ks) * 32))
+    f32x4 lo[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) lo[mt][nt] = (f32x4){0, 0, 0, 0};
+    // one K-step of every tile: h.h for all tiles first, then the two cross terms - consecutive MFMAs never share an accumulator
+#define ENC_SSTEP(AH, AL, BH, BL)                                                                                        \
+    do {                                                                                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16((AH)[mt], (BH)[nt], acc[mt][nt], 0, 0, 0);           \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
+                lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16((AH)[mt], (BL)[nt], lo[mt][nt], 0, 0, 0);             \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                             \
+                lo[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16((AL)[mt], (BH)[nt], lo[mt][nt], 0, 0, 0);             \
+    } while (0)
+    f16x8 bh[NT], bl[NT];
+    if (ksteps & (ENC_PD - 1)) {   // the 32- and 64-wide input layers
+        for (int ks = 0; ks < ksteps; ++ks) {
+            f16x8 ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { ah[mt] = ENC_SW(mt, ks, 0); al[mt] = ENC_SW(mt, ks, 1); }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bh[nt] = ENC_SX(nt, ks, 0); bl[nt] = ENC_SX(nt, ks, 1); }
+            ENC_SSTEP(ah, al, bh, bl);
+        }
+    } else {
+        f16x8 ah[ENC_PD][MT], al[ENC_PD][MT];   // weight ring, ENC_PD K-steps ahead (as in gemm_tiles)
+#pragma unroll
+        for (int s = 0; s < ENC_PD; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) { ah[s][mt] = ENC_SW(mt, s, 0); al[s][mt] = ENC_SW(mt, s, 1); }
+        int ks0 = 0;
+        for (; ks0 + ENC_PD < ksteps; ks0 += ENC_PD) {
+#pragma unroll
+            for (int s = 0; s < ENC_PD; ++s) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { bh[nt] = ENC_SX(nt, ks0 + s, 0); bl[nt] = ENC_SX(nt, ks0 + s, 1); }
+                ENC_SSTEP(ah[s], al[s], bh, bl);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { ah[s][mt] = ENC_SW(mt, ks0 + s + ENC_PD, 0); al[s][mt] = ENC_SW(mt, ks0 + s + ENC_PD, 1); }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < ENC_PD; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { bh[nt] = ENC_SX(nt, ks0 + s, 0); bl[nt] = ENC_SX(nt, ks0 + s, 1); }
+            ENC_SSTEP(ah[s], al[s], bh, bl);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][nt][r] += lo[mt][nt][r] * (1.0f / ENC_SPLIT_SCALE);
+#undef ENC_SSTEP
+#undef ENC_SX
+#undef ENC_SW
+}
+
+template <int MT, int NT, bool SP = false>
 __device__ __forceinline__ void gemm_tiles(const EncLayer &L, int mtile0, const uint16_t *X, int xstride, f32x4 (&acc)[MT][NT]) {
+    if constexpr (SP) { gemm_tiles_split<MT, NT>(L, mtile0, X, xstride, acc); return; }
     const int lane = threadIdx.x & 63, ksteps = L.K >> 5;
     const uint16_t *xrow = X + (lane & 15) * xstride + 8 * (lane >> 4);
     // fragment address = buffer resource of the layer (scalar registers) + wave-uniform scalar offset (mtile0 is uniform) + one
@@ -241,32 +360,33 @@ __device__ __forceinline__ void init_bias(const EncLayer &L, int mtile0, f32x4 (
 }
 
 // tanh, bf16, store: lane holds features f0..f0+3 of row (nt*16 + lane&15)
-template <int MT, int NT>
+template <int MT, int NT, bool SP = false>
 __device__ __forceinline__ void store_tanh(const f32x4 (&acc)[MT][NT], int mtile0, uint16_t *Y, int ystride, int col0 = 0) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            bf16x4 v;
+            f32x4 t;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)fast_tanh(acc[mt][nt][r]);
-            *(bf16x4 *)(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4) = v;
+            for (int r = 0; r < 4; ++r) t[r] = fast_tanh(acc[mt][nt][r]);
+            put4<SP>(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4, t);
         }
 }
 
 // one 16-row MLP: Y[:, col0:col0+256] = tanh(L2 tanh(L1 X)), hidden layer through `hid` (one barrier inside)
+template <bool SP = false>
 __device__ __forceinline__ void mlp2_one_tile(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride,
     uint16_t *hid,
                                               uint16_t *Y, int ystride, int col0) {
     f32x4 acc[ENC_MT][1];
     init_bias<ENC_MT, 1>(L1, mt0, acc);
-    gemm_tiles<ENC_MT, 1>(L1, mt0, X, xstride, acc);
-    store_tanh<ENC_MT, 1>(acc, mt0, hid, ENC_YS);
+    gemm_tiles<ENC_MT, 1, SP>(L1, mt0, X, xstride, acc);
+    store_tanh<ENC_MT, 1, SP>(acc, mt0, hid, ENC_YS);
     __syncthreads();
     init_bias<ENC_MT, 1>(L2, mt0, acc);
-    gemm_tiles<ENC_MT, 1>(L2, mt0, hid, ENC_YS, acc);
-    store_tanh<ENC_MT, 1>(acc, mt0, Y, ystride, col0);
+    gemm_tiles<ENC_MT, 1, SP>(L2, mt0, hid, ENC_YS, acc);
+    store_tanh<ENC_MT, 1, SP>(acc, mt0, Y, ystride, col0);
 }
 
 __device__ __forceinline__ float lane_groups_sum(float v) {   // sum over the 4 lane groups that hold the same row (lane & 15)
@@ -279,14 +399,14 @@ __device__ __forceinline__ float lane_groups_sum(float v) {   // sum over the 4 
 // head on it (Sample Factory's action-parameter or value layer, 512 -> head_dim <= 8) so that a rollout does not have to write
 // and re-read the features: per-lane partial dot products, two shuffles over the lane groups, the eight waves through `red`
 // (LDS scratch, >= ENC_WAVES * 8 * 16 floats in a buffer nobody reads any more and that is not `cat`).
-template <int MTF = ENC_MTF>   // 16-feature tiles per wave: 512 outputs = 32 tiles; the Sim2Real encoder's 256 = 16 tiles
+template <int MTF = ENC_MTF, bool SP = false>   // 16-feature tiles per wave: 512 outputs = 32 tiles; the Sim2Real encoder's 256 = 16 tiles
 __device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t *cat, int a0, int B, float *__restrict__ out, float *red) {
     const int wave = wave_id(), lane = threadIdx.x & 63;
     constexpr int OUT = MTF * ENC_WAVES * 16;
     f32x4 acc[MTF][1];
     const int mf0 = wave * MTF;
     init_bias<MTF, 1>(P.f, mf0, acc);
-    gemm_tiles<MTF, 1>(P.f, mf0, cat, ENC_CS, acc);
+    gemm_tiles<MTF, 1, SP>(P.f, mf0, cat, ENC_CS, acc);
     ENC_STAMP(8);
     const int ga = a0 + (lane & 15);
     f32x4 v[MTF];
@@ -332,32 +452,33 @@ __device__ __forceinline__ void feed_forward(const EncParams &P, const uint16_t 
 // ------------------------------------------------------------------------------------------------
 // attention, launch 1: e_i = embedding_mlp([self_obs[(a*K+k) mod B] | neighbour obs (a,k)]) -> ebuf;  g_a = W_m mean_k e_(a,k) -> gbuf
 // ------------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, bool SP = false>
 __device__ __forceinline__ void embed_pass(const EncParams &P, int B, int a0, int t0, bool first, const uint16_t *x_in, uint16_t *buf_a,
     f32x4 (&mean)[ENC_MT]) {
     const int wave = wave_id(), lane = threadIdx.x & 63, mt0 = wave * ENC_MT, NB = P.num_nbr;
     f32x4 acc[ENC_MT][NTH];
     init_bias<ENC_MT, NTH>(P.n1, mt0, acc);
-    gemm_tiles<ENC_MT, NTH>(P.n1, mt0, x_in + t0 * ENC_TA * ENC_XS, ENC_XS, acc);
+    gemm_tiles<ENC_MT, NTH, SP>(P.n1, mt0, x_in + t0 * ENC_TA * ENC_XS, ENC_XS, acc);
     if (!first) __syncthreads();   // the previous pass is done reading buf_a
-    store_tanh<ENC_MT, NTH>(acc, mt0, buf_a, ENC_YS);
+    store_tanh<ENC_MT, NTH, SP>(acc, mt0, buf_a, ENC_YS);
     __syncthreads();
     init_bias<ENC_MT, NTH>(P.n2, mt0, acc);
-    gemm_tiles<ENC_MT, NTH>(P.n2, mt0, buf_a, ENC_YS, acc);
+    gemm_tiles<ENC_MT, NTH, SP>(P.n2, mt0, buf_a, ENC_YS, acc);
     const int ga = a0 + (lane & 15);
+    constexpr int ES = SP ? 2 * ENC_H : ENC_H;   // ebuf row: bf16 [256], or the two fp16 planes [2][256]
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTH; ++nt) {
-            bf16x4 v;
+            f32x4 e;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = fast_tanh(acc[mt][nt][r]); mean[mt][r] += e; v[r] = (__bf16)e; }
-            if (ga < B) *(bf16x4 *)(P.ebuf + ((size_t)ga * NB + (t0 + nt)) * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+            for (int r = 0; r < 4; ++r) { e[r] = fast_tanh(acc[mt][nt][r]); mean[mt][r] += e[r]; }
+            if (ga < B) put4<SP>(P.ebuf + ((size_t)ga * NB + (t0 + nt)) * ES + (mt0 + mt) * 16 + (lane >> 4) * 4, e, ENC_H);
         }
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_embed_kernel(const float *__restrict__ obs, int B,
-    EncParams P) {
+template <bool SP>
+__device__ __forceinline__ void embed_body(const float *__restrict__ obs, int B, const EncParams &P) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_in = (uint16_t *)smem;                                // [NBR*16][XS]
     uint16_t *buf_a = x_in + ENC_MAX_NBR * ENC_TA * ENC_XS;           // [NH*16][YS]
@@ -374,35 +495,43 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
         const uint32_t i_self = mod_batch((uint32_t)ga * (uint32_t)NB + (uint32_t)k, (uint32_t)B, invB) * (uint32_t)D + c;
         const uint32_t i_nbr = (uint32_t)ga * (uint32_t)D + P.self_dim + k * P.nbr_dim + (c - P.self_dim);
         const float v = obs_at(ors, ga < B && c < P.self_dim + P.nbr_dim, c < P.self_dim ? i_self : i_nbr);
-        x_in[row * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        put1<SP>(x_in + row * ENC_XS + c, v);
     }
     __syncthreads();
     f32x4 mean[ENC_MT];
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
     for (int t0 = 0; t0 < NB; t0 += ENC_NH) {
-#define ENC_CALL(n) embed_pass<n>(P, B, a0, t0, t0 == 0, x_in, buf_a, mean)
+#define ENC_CALL(n) embed_pass<n, SP>(P, B, a0, t0, t0 == 0, x_in, buf_a, mean)
         ENC_DISPATCH_NT(NB - t0, ENC_NH, ENC_CALL)
 #undef ENC_CALL
     }
     const float inv = 1.0f / (float)NB;   // e_mean (:90-91), then its half of the score MLP's first layer once per agent
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) {
-        bf16x4 v;
+        f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(mean[mt][r] * inv);
-        *(bf16x4 *)(emean + (lane & 15) * ENC_YS + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        for (int r = 0; r < 4; ++r) v[r] = mean[mt][r] * inv;
+        put4<SP>(emean + (lane & 15) * ENC_YS + (mt0 + mt) * 16 + (lane >> 4) * 4, v);
     }
     __syncthreads();
     f32x4 g[ENC_MT][1];
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) g[mt][0] = (f32x4){0, 0, 0, 0};
-    gemm_tiles<ENC_MT, 1>(P.a1m, mt0, emean, ENC_YS, g);
+    gemm_tiles<ENC_MT, 1, SP>(P.a1m, mt0, emean, ENC_YS, g);
     const int ga = a0 + (lane & 15);
     if (ga < B) {
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) *(f32x4 *)(P.gbuf + (size_t)ga * ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = g[mt][0];
     }
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_embed_kernel(const float *__restrict__ obs, int B,
+    EncParams P) {
+    embed_body<false>(obs, B, P);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_embed_split_kernel(const float *__restrict__ obs, int B,
+    EncParams P) {
+    embed_body<true>(obs, B, P);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,27 +545,28 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 #endif
 struct AttnState { f32x4 o[ENC_MT]; float mx, den; };
 
-template <int NTH>
+template <int NTH, bool SP = false>
 __device__ __forceinline__ void attn_load_e(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a) {
     // e_i rows in 16-byte chunks, coalesced; 32-bit offsets into a buffer resource (rows past the batch read as zero: out of range)
+    constexpr int PL = SP ? 2 : 1;   // reference precision: a row of ebuf is the two fp16 planes [2][256]
     const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc((void *)P.ebuf, 0,
-        (uint32_t)B * (uint32_t)P.num_nbr * (ENC_H * 2), 0x00020000);
-    for (int idx = threadIdx.x; idx < NTH * ENC_TA * (ENC_H / 8); idx += 64 * ENC_WAVES) {
-        const int row = idx >> 5, ch = idx & 31, k = t0 + (row >> 4), ra = a0 + (row & 15);
-        const uint32_t off = ra < B ? ((uint32_t)ra * (uint32_t)P.num_nbr + (uint32_t)k) * (ENC_H * 2) + ch * 16 : 0xffffffffu;
-        *(bf16x8 *)(buf_a + row * ENC_YS + ch * 8) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ers, off, 0, 0));
+        (uint32_t)B * (uint32_t)P.num_nbr * (ENC_H * 2 * PL), 0x00020000);
+    for (int idx = threadIdx.x; idx < NTH * ENC_TA * (ENC_H / 8) * PL; idx += 64 * ENC_WAVES) {
+        const int row = idx / (32 * PL), pl = (idx >> 5) & (PL - 1), ch = idx & 31, k = t0 + (row >> 4), ra = a0 + (row & 15);
+        const uint32_t off = ra < B ? (((uint32_t)ra * (uint32_t)P.num_nbr + (uint32_t)k) * PL + pl) * (ENC_H * 2) + ch * 16 : 0xffffffffu;
+        *(bf16x8 *)(buf_a + pl * ENC_SPLANE + row * ENC_YS + ch * 8) = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ers, off, 0, 0));
     }
 }
 
 // One group of NTH neighbour row tiles: scores first (the 256 -> 1 layer is reduced from the accumulators of the layer before it),
 // then the values from the same e_i tile, which go straight into the running sum - the h_i are never live together with another
 // layer's accumulators.  Four barriers per group.
-template <int NTH>
+template <int NTH, bool SP = false>
 __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int t0, uint16_t *buf_a, uint16_t *buf_h, float *s_alpha,
     AttnState &st) {
     const int wave = wave_id(), lane = threadIdx.x & 63, mt0 = wave * ENC_MT;
     const int ga = a0 + (lane & 15);
-    attn_load_e<NTH>(P, B, a0, t0, buf_a);
+    attn_load_e<NTH, SP>(P, B, a0, t0, buf_a);
     f32x4 acc[ENC_MT][NTH];
     // score MLP, first layer on [e_i | e_mean.repeat(K, 1)]: W_e e_i + b + g[(a*K + k) mod B]   (:92-94)
     init_bias<ENC_MT, NTH>(P.a1e, mt0, acc);
@@ -455,11 +585,11 @@ __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int
         }
     }
     __syncthreads();   // e_i is in buf_a; the previous group's value layers are done with buf_h
-    gemm_tiles<ENC_MT, NTH>(P.a1e, mt0, buf_a, ENC_YS, acc);
-    store_tanh<ENC_MT, NTH>(acc, mt0, buf_h, ENC_YS);
+    gemm_tiles<ENC_MT, NTH, SP>(P.a1e, mt0, buf_a, ENC_YS, acc);
+    store_tanh<ENC_MT, NTH, SP>(acc, mt0, buf_h, ENC_YS);
     __syncthreads();
     init_bias<ENC_MT, NTH>(P.a2, mt0, acc);
-    gemm_tiles<ENC_MT, NTH>(P.a2, mt0, buf_h, ENC_YS, acc);
+    gemm_tiles<ENC_MT, NTH, SP>(P.a2, mt0, buf_h, ENC_YS, acc);
     // last score layer 256 -> 1 straight from the accumulators: per-lane partial dot product with the fp32 weight row, two shuffles
     // over the lane groups, the eight waves' partials through LDS - no activation store, no extra MFMA pass, and e_i stays in buf_a
 #pragma unroll
@@ -477,11 +607,11 @@ __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int
     __syncthreads();   // partial scores visible; every wave is done reading buf_h (second score layer)
     // h_i = neighbor_value_mlp(e_i)   (:88)
     init_bias<ENC_MT, NTH>(P.v1, mt0, acc);
-    gemm_tiles<ENC_MT, NTH>(P.v1, mt0, buf_a, ENC_YS, acc);
-    store_tanh<ENC_MT, NTH>(acc, mt0, buf_h, ENC_YS);
+    gemm_tiles<ENC_MT, NTH, SP>(P.v1, mt0, buf_a, ENC_YS, acc);
+    store_tanh<ENC_MT, NTH, SP>(acc, mt0, buf_h, ENC_YS);
     __syncthreads();
     init_bias<ENC_MT, NTH>(P.v2, mt0, acc);
-    gemm_tiles<ENC_MT, NTH>(P.v2, mt0, buf_h, ENC_YS, acc);
+    gemm_tiles<ENC_MT, NTH, SP>(P.v2, mt0, buf_h, ENC_YS, acc);
     // online softmax over the neighbours of agent (lane & 15)   (:95-100)
     float al[NTH], mx = st.mx;
 #pragma unroll
@@ -509,8 +639,8 @@ __device__ __forceinline__ void attn_pass(const EncParams &P, int B, int a0, int
     st.mx = mx;
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_attn_kernel(const float *__restrict__ obs, int B,
-    EncParams P, float *__restrict__ out) {
+template <bool SP>
+__device__ __forceinline__ void attn_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_obst = x_self + ENC_TA * ENC_XS;                      // [16][XS]
@@ -518,7 +648,7 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     // [ANH*16][YS]  hidden layers; first the self / obstacle MLPs' (one tile)
     uint16_t *buf_h = buf_a + ENC_ANH * ENC_TA * ENC_YS;
     uint16_t *cat = buf_h + ENC_ANH * ENC_TA * ENC_YS;                // [16][CS]: self | neighbourhood | obstacles
-    float *s_alpha = (float *)(cat + ENC_TA * ENC_CS);                // [8 waves][ANH][16] partial scores of the group
+    float *s_alpha = (float *)(SP ? (uint16_t *)smem + 2 * ENC_SPLANE : cat + ENC_TA * ENC_CS);   // [8 waves][ANH][16] partial scores of the group
     const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
     const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT;
     const int col_nbr = ENC_H, col_obst = 2 * ENC_H;
@@ -527,13 +657,13 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
         const int which = idx >> 9, a = (idx >> 5) & 15, c = idx & 31, ga = a0 + a;
         const int dim = which ? P.obst_dim : P.self_dim, col = which ? P.self_dim + P.nbr_dim * NB : 0;
         const float v = obs_at(obs_rsrc(obs, B, D), ga < B && c < dim, (uint32_t)ga * (uint32_t)D + col + c);
-        (which ? x_obst : x_self)[a * ENC_XS + c] = __builtin_bit_cast(uint16_t, (__bf16)v);
+        put1<SP>((which ? x_obst : x_self) + a * ENC_XS + c, v);
     }
     __syncthreads();
-    mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, buf_h, cat, ENC_CS, 0);
+    mlp2_one_tile<SP>(P.s1, P.s2, mt0, x_self, ENC_XS, buf_h, cat, ENC_CS, 0);
     if (P.obst_dim > 0) {
         __syncthreads();
-        mlp2_one_tile(P.o1, P.o2, mt0, x_obst, ENC_XS, buf_h, cat, ENC_CS, col_obst);
+        mlp2_one_tile<SP>(P.o1, P.o2, mt0, x_obst, ENC_XS, buf_h, cat, ENC_CS, col_obst);
     }
     __syncthreads();
 
@@ -542,20 +672,28 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) st.o[mt] = (f32x4){0, 0, 0, 0};
     for (int t0 = 0; t0 < NB; t0 += ENC_ANH) {
-#define ENC_CALL(n) attn_pass<n>(P, B, a0, t0, buf_a, buf_h, s_alpha, st)
+#define ENC_CALL(n) attn_pass<n, SP>(P, B, a0, t0, buf_a, buf_h, s_alpha, st)
         ENC_DISPATCH_NT(NB - t0, ENC_ANH, ENC_CALL)
 #undef ENC_CALL
     }
     const float rden = 1.0f / st.den;
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) {
-        bf16x4 v;
+        f32x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (__bf16)(st.o[mt][r] * rden);
-        *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        for (int r = 0; r < 4; ++r) v[r] = st.o[mt][r] * rden;
+        put4<SP>(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4, v);
     }
     __syncthreads();
-    feed_forward(P, cat, a0, B, out, (float *)buf_a);
+    feed_forward<ENC_MTF, SP>(P, cat, a0, B, out, (float *)buf_a);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_attn_kernel(const float *__restrict__ obs, int B,
+    EncParams P, float *__restrict__ out) {
+    attn_body<false>(obs, B, P, out);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_attn_split_kernel(const float *__restrict__ obs, int B,
+    EncParams P, float *__restrict__ out) {
+    attn_body<true>(obs, B, P, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -780,19 +918,19 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_s2r_k
 // ------------------------------------------------------------------------------------------------
 // mean_embed / mlp / no_encoder: one launch
 // ------------------------------------------------------------------------------------------------
-template <int NTH>
+template <int NTH, bool SP = false>
 __device__ __forceinline__ void mean_pass(const EncParams &P, int t0, const uint16_t *x_nbr, uint16_t *buf_a, f32x4 (&mean)[ENC_MT]) {
     const int wave = wave_id(), mt0 = wave * ENC_MT;
     f32x4 acc[ENC_MT][NTH];
     init_bias<ENC_MT, NTH>(P.n1, mt0, acc);
-    gemm_tiles<ENC_MT, NTH>(P.n1, mt0, x_nbr + t0 * ENC_TA * ENC_XS, ENC_XS, acc);
+    gemm_tiles<ENC_MT, NTH, SP>(P.n1, mt0, x_nbr + t0 * ENC_TA * ENC_XS, ENC_XS, acc);
     ENC_STAMP(4);
     if (t0) __syncthreads();   // the previous pass's second layer is done reading buf_a
-    store_tanh<ENC_MT, NTH>(acc, mt0, buf_a, ENC_YS);
+    store_tanh<ENC_MT, NTH, SP>(acc, mt0, buf_a, ENC_YS);
     __syncthreads();
     ENC_STAMP(5);
     init_bias<ENC_MT, NTH>(P.n2, mt0, acc);
-    gemm_tiles<ENC_MT, NTH>(P.n2, mt0, buf_a, ENC_YS, acc);
+    gemm_tiles<ENC_MT, NTH, SP>(P.n2, mt0, buf_a, ENC_YS, acc);
     ENC_STAMP(6);
     // e_i = tanh(.); the mean over neighbours is a sum over the row tiles (same lane, same register)
 #pragma unroll
@@ -803,8 +941,8 @@ __device__ __forceinline__ void mean_pass(const EncParams &P, int t0, const uint
             for (int r = 0; r < 4; ++r) mean[mt][r] += fast_tanh(acc[mt][nt][r]);
 }
 
-extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_kernel(const float *__restrict__ obs, int B,
-    EncParams P, float *__restrict__ out) {
+template <bool SP>
+__device__ __forceinline__ void main_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
     extern __shared__ __align__(16) unsigned char smem[];
     uint16_t *x_self = (uint16_t *)smem;                              // [16][XS]
     uint16_t *x_nbr = x_self + ENC_TA * ENC_XS;                       // [NBR*16][XS]
@@ -828,7 +966,10 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
     // then scatter each element to its slot of the self / neighbour / obstacle staging rows.
     {
         uint32_t *z = (uint32_t *)x_self;   // x_self, x_nbr, x_obst are contiguous: clear the padding first
-        for (int idx = tid; idx < (2 + ENC_MAX_NBR) * ENC_TA * ENC_XS / 2; idx += 64 * ENC_WAVES) z[idx] = 0;
+        for (int idx = tid; idx < (2 + ENC_MAX_NBR) * ENC_TA * ENC_XS / 2; idx += 64 * ENC_WAVES) {
+            z[idx] = 0;
+            if constexpr (SP) z[ENC_SPLANE / 2 + idx] = 0;
+        }
         // upper bound on elements per thread
         constexpr int PER = (ENC_TA * (32 + 32 * ENC_MAX_NBR + 32) + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);
         const int total = ENC_TA * D;
@@ -847,24 +988,24 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
             const int idx = tid + it * 64 * ENC_WAVES;
             if (idx < total) {
                 const int a = div_by(idx, mD), cidx = idx - a * D;
-                const uint16_t h = __builtin_bit_cast(uint16_t, (__bf16)v[it]);
-                if (cidx < P.self_dim) x_self[a * ENC_XS + cidx] = h;
+                uint16_t *dst;
+                if (cidx < P.self_dim) dst = x_self + a * ENC_XS + cidx;
                 else if (cidx < P.self_dim + P.nbr_dim * NB) {
                     const int q = cidx - P.self_dim, nb = div_by(q, mN), j = q - nb * P.nbr_dim;
-                    if (mode == ENC_NBR_MLP) x_nbr[a * ENC_XW + q] = h;
-                    else x_nbr[(nb * ENC_TA + a) * ENC_XS + j] = h;
-                } else x_obst[a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB)] = h;
+                    dst = mode == ENC_NBR_MLP ? x_nbr + a * ENC_XW + q : x_nbr + (nb * ENC_TA + a) * ENC_XS + j;
+                } else dst = x_obst + a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB);
+                put1<SP>(dst, v[it]);
             }
         }
     }
     __syncthreads();
 
     ENC_STAMP(1);
-    mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, buf_b, cat, ENC_CS, 0);                      // self encoder -> cat[:, 0:256]
+    mlp2_one_tile<SP>(P.s1, P.s2, mt0, x_self, ENC_XS, buf_b, cat, ENC_CS, 0);                  // self encoder -> cat[:, 0:256]
     ENC_STAMP(2);
     if (P.obst_dim > 0) {
         __syncthreads();
-        mlp2_one_tile(P.o1, P.o2, mt0, x_obst, ENC_XS, buf_b, cat, ENC_CS, col_obst);           // obstacle encoder -> cat[:, 512:768]
+        mlp2_one_tile<SP>(P.o1, P.o2, mt0, x_obst, ENC_XS, buf_b, cat, ENC_CS, col_obst);       // obstacle encoder -> cat[:, 512:768]
     }
     __syncthreads();
 
@@ -874,10 +1015,10 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
         // mlp neighbour encoder (:104-122): three layers on the concatenated neighbour observations of the agent
         f32x4 acc[ENC_MT][1];
         init_bias<ENC_MT, 1>(P.n1, mt0, acc);
-        gemm_tiles<ENC_MT, 1>(P.n1, mt0, x_nbr, ENC_XW, acc);
-        store_tanh<ENC_MT, 1>(acc, mt0, buf_a, ENC_YS);
+        gemm_tiles<ENC_MT, 1, SP>(P.n1, mt0, x_nbr, ENC_XW, acc);
+        store_tanh<ENC_MT, 1, SP>(acc, mt0, buf_a, ENC_YS);
         __syncthreads();
-        mlp2_one_tile(P.n2, P.n3, mt0, buf_a, ENC_YS, buf_a + ENC_TA * ENC_YS, cat, ENC_CS, col_nbr);
+        mlp2_one_tile<SP>(P.n2, P.n3, mt0, buf_a, ENC_YS, buf_a + ENC_TA * ENC_YS, cat, ENC_CS, col_nbr);
     } else if (nbr_enc) {
         // mean_embed (:22-43) in passes of up to ENC_NH neighbour tiles: the hidden layer of the neighbour MLP is the largest LDS
         // buffer, and at half its size two workgroups fit one CU (the layer chain of one workgroup is latency-bound, a second overlaps it)
@@ -885,24 +1026,32 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) mean[mt] = (f32x4){0, 0, 0, 0};
         for (int t0 = 0; t0 < NB; t0 += ENC_NH) {
-#define ENC_CALL(n) mean_pass<n>(P, t0, x_nbr, buf_a, mean)
+#define ENC_CALL(n) mean_pass<n, SP>(P, t0, x_nbr, buf_a, mean)
             ENC_DISPATCH_NT(NB - t0, ENC_NH, ENC_CALL)
 #undef ENC_CALL
         }
         const float inv = 1.0f / (float)NB;   // torch.mean(neighbor_embeds, dim=1) (:41-42)
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) {
-            bf16x4 v;
+            f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)(mean[mt][r] * inv);
-            *(bf16x4 *)(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+            for (int r = 0; r < 4; ++r) v[r] = mean[mt][r] * inv;
+            put4<SP>(cat + (lane & 15) * ENC_CS + col_nbr + (mt0 + mt) * 16 + (lane >> 4) * 4, v);
         }
     }
     __syncthreads();
 
     ENC_STAMP(7);
-    feed_forward(P, cat, a0, B, out, (float *)buf_a);
+    feed_forward<ENC_MTF, SP>(P, cat, a0, B, out, (float *)buf_a);
     ENC_STAMP(9);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, ENC_OCC) qs_encoder_kernel(const float *__restrict__ obs, int B,
+    EncParams P, float *__restrict__ out) {
+    main_body<false>(obs, B, P, out);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_split_kernel(const float *__restrict__ obs, int B,
+    EncParams P, float *__restrict__ out) {
+    main_body<true>(obs, B, P, out);
 }
 
 
@@ -1555,6 +1704,13 @@ static size_t lds_main(int attention) {
     if (attention) return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + 2 * ENC_ANH * ENC_TA * ENC_YS + ENC_TA * ENC_CS) + sizeof(float) * ENC_WAVES * ENC_ANH * 16;
     return sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS);
 }
+// reference precision: both planes of the largest 16-agent layout (+ the attention kernel's partial scores behind them)
+static size_t lds_split(int attention) { return sizeof(uint16_t) * 2 * ENC_SPLANE + (attention ? sizeof(float) * ENC_WAVES * ENC_ANH * 16 : 0); }
+static_assert(sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS + ENC_TA * ENC_CS) <=
+                  sizeof(uint16_t) * ENC_SPLANE &&
+              sizeof(uint16_t) * (ENC_TA * ENC_XS * 2 + 2 * ENC_ANH * ENC_TA * ENC_YS + ENC_TA * ENC_CS) <= sizeof(uint16_t) * ENC_SPLANE,
+              "ENC_SPLANE holds one plane of every 16-agent layout");
+static_assert(sizeof(uint16_t) * 2 * ENC_SPLANE + sizeof(float) * ENC_WAVES * ENC_ANH * 16 <= 160 * 1024, "two planes fit a CU's LDS");
 static size_t lds_mha(void) {
     return sizeof(uint16_t) * (2 * ENC_TA * ENC_XS + ENC_TA * ENC_XW + 3 * ENC_TA * ENC_YS + 2 * ENC_TA * ENC_OS + ENC_TA * ENC_CS) + sizeof(float) * (4 * 2 * 4 * 16 + ENC_WAVES * 2 * 2 * 16);
 }
@@ -1587,6 +1743,7 @@ size_t qs_enc_lds_bytes_of(int32_t model) {
     if (model == ENC_NBR_ATTENTION) return lds_embed() > lds_main(0) ? lds_embed() : lds_main(0);
     return lds_main(0);
 }
+size_t qs_enc_lds_bytes_split(int32_t attention) { return lds_split(attention); }
 
 // out[B, 512] (ENC_MODEL_S2R: [B, 256]) = encoder(obs[B, obs_dim]); all pointers (obs, out, the weights / biases inside `params`) are
 // device pointers
@@ -1599,7 +1756,9 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         return -1;
     }
     const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, s2r = P.nbr_encoder == ENC_MODEL_S2R,
-        mha = P.nbr_encoder == ENC_MODEL_MHA || s2r;
+        mha = P.nbr_encoder == ENC_MODEL_MHA || s2r, sp = P.precision == 1;
+    if (P.precision != 0 && P.precision != 1) { g_enc_error = "precision: 0 (bf16) or 1 (reference precision, fp16 pairs)"; return -1; }
+    if (sp && mha) { g_enc_error = "reference precision is built for QuadMultiEncoder (mean_embed, attention, mlp, no_encoder), not for the multi-head encoders"; return -4; }
     if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0
         || P.nbr_encoder > ENC_MODEL_S2R ||
         (att && P.self_dim + P.nbr_dim > 32) || ((P.nbr_encoder == ENC_NBR_MLP || mha) && P.nbr_dim * P.num_nbr > 64) ||
@@ -1609,7 +1768,7 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
     }
     if (att && !P.a3w) { g_enc_error = "the attention neighbour encoder needs the last score layer's weight row (a3w)"; return -1; }
     if (att && (!P.ebuf || !P.gbuf)) { g_enc_error = "the attention neighbour encoder needs the ebuf / gbuf scratch buffers"; return -1; }
-    if (att && (int64_t)B * P.num_nbr * (ENC_H * 2) > 0x7fffffffll) { g_enc_error = "attention: batch x neighbours too large for 32-bit scratch offsets"; return -4; }
+    if (att && (int64_t)B * P.num_nbr * (ENC_H * 2) * (sp ? 2 : 1) > 0x7fffffffll) { g_enc_error = "attention: batch x neighbours too large for 32-bit scratch offsets"; return -4; }
     if ((int64_t)B * P.obs_dim * 4 > 0xffffffffll) { g_enc_error = "batch x obs_dim too large for 32-bit observation offsets"; return -4; }
     if (B == 0) return 0;
     // launch on the device that owns `obs` (a process may drive several GPUs); the > 64 KB dynamic-LDS attribute is per device
@@ -1652,6 +1811,12 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
                     (int)lds_wide()) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                     (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_split(0)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_embed_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_split(0)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_attn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_split(1)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                     (int)lds_embed()) != hipSuccess) {
                 g_enc_error = "cannot raise the dynamic LDS limit";
@@ -1661,8 +1826,15 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
         }
     }
     const int wmin = wide_min_agents(dev);
-    const bool wide = wmin > 0 && B >= wmin && P.num_nbr > 0 && (P.nbr_encoder == ENC_NBR_MEAN_EMBED || att);
-    if (wide) {
+    const bool wide = !sp && wmin > 0 && B >= wmin && P.num_nbr > 0 && (P.nbr_encoder == ENC_NBR_MEAN_EMBED || att);
+    if (sp) {   // reference precision: the 16-agent bodies on fp16 pairs, one workgroup per CU (two LDS planes)
+        const dim3 grid((B + ENC_TA - 1) / ENC_TA), block(64 * ENC_WAVES);
+        if (att) {
+            hipLaunchKernelGGL(qs_encoder_embed_split_kernel, grid, block, lds_split(0), (hipStream_t)stream, obs, B, P);
+            hipLaunchKernelGGL(qs_encoder_attn_split_kernel, grid, block, lds_split(1), (hipStream_t)stream, obs, B, P, out);
+        } else
+            hipLaunchKernelGGL(qs_encoder_split_kernel, grid, block, lds_split(0), (hipStream_t)stream, obs, B, P, out);
+    } else if (wide) {
         // neighbours per pass: the fewest padded neighbour slots, then the fewest passes (1 -> 1; 2, 4 -> 2; 3, 5, 6, 7, 8 -> 3)
         const dim3 grid((B + ENC_WA - 1) / ENC_WA), block(64 * ENC_WAVES);
         const int wnp = P.num_nbr == 1 ? 1 : (P.num_nbr == 2 || P.num_nbr == 4) ? 2 : 3;

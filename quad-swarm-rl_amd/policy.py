@@ -38,7 +38,7 @@ class EncParams(C.Structure):
     _fields_ = [("self_dim", C.c_int32), ("nbr_dim", C.c_int32), ("num_nbr", C.c_int32), ("obst_dim", C.c_int32), ("obs_dim", C.c_int32),
                 ("nbr_encoder", C.c_int32),
                 ("s1", EncLayer), ("s2", EncLayer), ("n1", EncLayer), ("n2", EncLayer), ("n3", EncLayer), ("o1", EncLayer), ("o2", EncLayer),
-                ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3w", C.c_void_p), ("a3b", C.c_float), ("pad0", C.c_int32),
+                ("v1", EncLayer), ("v2", EncLayer), ("a1e", EncLayer), ("a1m", EncLayer), ("a2", EncLayer), ("a3w", C.c_void_p), ("a3b", C.c_float), ("precision", C.c_int32),
                 ("ebuf", C.c_void_p), ("gbuf", C.c_void_p), ("f", EncLayer),
                 ("mq", EncLayer), ("mk", EncLayer), ("mv", EncLayer), ("mfc", EncLayer), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p),
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("head_out", C.c_void_p), ("head_dim", C.c_int32),
@@ -60,6 +60,8 @@ def lib():
         L.qs_enc_last_error.restype = C.c_char_p
         L.qs_enc_sizeof_params.restype = C.c_size_t
         L.qs_enc_lds_bytes.restype = C.c_size_t
+        L.qs_enc_lds_bytes_split.restype = C.c_size_t
+        L.qs_enc_lds_bytes_split.argtypes = [C.c_int32]
         L.qs_enc_set_wide_min.argtypes = [C.c_int32]
         L.qs_enc_set_wide_min.restype = C.c_int32
         L.qs_rollout_pre.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -331,9 +333,22 @@ def encoder_from_state_dict(sd, num_nbr, nbr_dim=6):
     return module
 
 
-def pack_linear(linear, device, cols=None):
+SPLIT_SCALE = 2048.0          # qs_policy_encoder.hip ENC_SPLIT_SCALE
+FP16_MIN_NORMAL = 2.0 ** -14
+
+
+def split_fp16(x):
+    """float32 array -> (h, l) float16 with x = h + l / 2048 to ~2^-22 relative (the operand format of the reference-precision kernels,
+    qs_policy_encoder.hip split2): h = fp16(x), 0 below the smallest normal; l = fp16((x - h) * 2048)."""
+    x = np.clip(np.asarray(x, dtype=np.float32), -65504.0, 65504.0)
+    h = np.where(np.abs(x) < FP16_MIN_NORMAL, np.float32(0), x).astype(np.float16)
+    l = ((x - h.astype(np.float32)) * np.float32(SPLIT_SCALE)).astype(np.float16)
+    return h, l
+
+
+def pack_linear(linear, device, cols=None, split=False):
     """nn.Linear (or its input columns cols[0]:cols[1]) -> (packed bf16 weights in MFMA A-fragment order, padded fp32 bias, M, K);
-    see include/quadswarm_encoder.h."""
+    split: every fragment as the two fp16 planes of split_fp16, [M/16, K/32, 2, 64, 8].  See include/quadswarm_encoder.h."""
     import torch
     W = linear.weight.detach().float().cpu().numpy()
     if cols is not None:
@@ -349,16 +364,26 @@ def pack_linear(linear, device, cols=None):
     rows = (lane & 15)[None, None, :, None] + 16 * np.arange(M // 16)[:, None, None, None]
     cols = (8 * (lane >> 4))[None, None, :, None] + np.arange(8)[None, None, None, :] + 32 * np.arange(K // 32)[None, :, None, None]
     packed = Wp[rows, cols]                                                     # [M/16, K/32, 64, 8]
-    w = torch.from_numpy(np.ascontiguousarray(packed)).to(device).to(torch.bfloat16).contiguous()
+    if split:
+        w = torch.from_numpy(np.ascontiguousarray(np.stack(split_fp16(packed), axis=2))).to(device).contiguous()
+    else:
+        w = torch.from_numpy(np.ascontiguousarray(packed)).to(device).to(torch.bfloat16).contiguous()
     return w, torch.from_numpy(bp).to(device), M, K
 
 
 class FusedQuadEncoder:
-    """forward(obs[B, D] float32 on the GPU) -> [B, 512] float32 ([B, 256] for the Sim2Real encoder), one kernel launch."""
+    """forward(obs[B, D] float32 on the GPU) -> [B, 512] float32 ([B, 256] for the Sim2Real encoder), one kernel launch.
+    precision "bf16": bf16 operands, fp32 accumulation (features within ~1e-2 of the fp32 module).  precision "fp32": reference precision for a
+    sampler whose learner is fp32 - every operand as a pair of fp16 numbers, three MFMAs per product (qs_enc_params.precision = 1; features
+    within 1e-5 of the fp32 module; QuadMultiEncoder's four neighbour encoders, 16-agent kernels)."""
 
-    def __init__(self, module, device=0):
+    def __init__(self, module, device=0, precision="bf16"):
         import torch
         self._torch = torch
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision: 'bf16' or 'fp32'")
+        self.precision = precision
+        split = precision == "fp32"
         self.device = torch.device("cuda", device)
         if not torch.cuda.is_available():
             raise native.QsError("FusedQuadEncoder needs a GPU: there is no CPU fallback")
@@ -376,12 +401,16 @@ class FusedQuadEncoder:
         self._packed, self._raw = [], []   # what refresh() re-reads: (nn.Linear, cols, packed weights, bias) / (source getter, device tensor)
 
         def layer(linear, cols=None):
-            w, b, M, K = pack_linear(linear, self.device, cols)
+            w, b, M, K = pack_linear(linear, self.device, cols, split)
             self._keep += [w, b]
             self._packed.append((linear, cols, w, b))
             return EncLayer(w.data_ptr(), b.data_ptr(), M, K)
 
         P.nbr_encoder = MODELS.index(getattr(module, "nbr_encoder", "mean_embed"))
+        P.precision = int(split)
+        if split and P.nbr_encoder in (4, 5):
+            raise NotImplementedError("precision='fp32' is built for QuadMultiEncoder (mean_embed, attention, mlp, no_encoder), not for the multi-head encoders")
+        self._split = split
         s2r = P.nbr_encoder == 5   # one-layer embeddings, one head, 256 outputs
         P.s1 = layer(module.self_encoder[0])
         if module.neighbor_encoder is not None:
@@ -433,7 +462,7 @@ class FusedQuadEncoder:
         One attention-score bias lives in the parameter struct (a3b): a graph that was captured before keeps the old value of that one scalar
         until it is recaptured; everything else is picked up by replays."""
         for linear, cols, w, b in self._packed:
-            nw, nb, _, _ = pack_linear(linear, self.device, cols)
+            nw, nb, _, _ = pack_linear(linear, self.device, cols, self._split)
             w.copy_(nw)
             b.copy_(nb)
         for src, dst in self._raw:
@@ -506,10 +535,11 @@ class FusedQuadEncoder:
     __call__ = forward
 
     def _scratch(self, B):
-        """attention only: e_i [B*K, 256] bf16 and W_m e_mean [B, 256] fp32, handed from the first launch to the second"""
+        """attention only: e_i [B*K, 256] bf16 (reference precision: the two fp16 planes, [B*K, 2, 256]) and W_m e_mean [B, 256] fp32, handed
+        from the first launch to the second"""
         if self.attention and B > self._scratch_rows:
             torch = self._torch
-            self._ebuf = torch.empty((B * self.params.num_nbr, HIDDEN), device=self.device, dtype=torch.bfloat16)
+            self._ebuf = torch.empty((B * self.params.num_nbr, HIDDEN * (2 if self._split else 1)), device=self.device, dtype=torch.bfloat16)
             self._gbuf = torch.empty((B, HIDDEN), device=self.device, dtype=torch.float32)
             self.params.ebuf, self.params.gbuf = self._ebuf.data_ptr(), self._gbuf.data_ptr()
             self._scratch_rows = B

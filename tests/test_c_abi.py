@@ -125,7 +125,8 @@ def test_encoder_library_exports_and_layout():
     lib = C.CDLL(policy.ENC_LIB_PATH)
     h = open(os.path.join(REPO, "include", "quadswarm_encoder.h")).read()
     declared = sorted(set(re.findall(r"^(?:int|size_t|const char \*)\s*\*?(qs_enc_\w+)\(", h, flags=re.M)))
-    assert declared == ["qs_enc_benchmark", "qs_enc_forward", "qs_enc_last_error", "qs_enc_lds_bytes", "qs_enc_lds_bytes_of", "qs_enc_sizeof_params"]
+    assert declared == ["qs_enc_benchmark", "qs_enc_forward", "qs_enc_last_error", "qs_enc_lds_bytes", "qs_enc_lds_bytes_of", "qs_enc_lds_bytes_split",
+                        "qs_enc_sizeof_params"]
     for sym in declared:
         assert hasattr(lib, sym), sym
     lib.qs_enc_sizeof_params.restype = C.c_size_t
@@ -140,6 +141,14 @@ def test_encoder_library_exports_and_layout():
         assert 80 * 1024 < lib.qs_enc_lds_bytes_of(model) <= 160 * 1024
     for model in (0, 1, 2, 3):
         assert lib.qs_enc_lds_bytes_of(model) <= 80 * 1024
+    # reference precision (fp16 pairs): two LDS planes, one workgroup per CU
+    lib.qs_enc_lds_bytes_split.restype = C.c_size_t
+    lib.qs_enc_lds_bytes_split.argtypes = [C.c_int32]
+    assert 2 * lib.qs_enc_lds_bytes_of(0) <= lib.qs_enc_lds_bytes_split(0) <= lib.qs_enc_lds_bytes_split(1) <= 160 * 1024
+    P = policy.EncParams()
+    P.precision = 2
+    lib.qs_enc_last_error.restype = C.c_char_p
+    lib.qs_enc_forward.argtypes = [C.c_void_p, C.c_int32, C.POINTER(policy.EncParams), C.c_void_p, C.c_void_p]
     enum = re.search(r"enum \{ QS_ENC_NBR_MEAN_EMBED = 0,(.*?)\};", h, flags=re.S).group(0)
     for i, name in enumerate(("MEAN_EMBED", "ATTENTION", "MLP", "NONE")):
         assert f"QS_ENC_NBR_{name} = {i}" in enum and policy.MODELS[i] == policy.NBR_ENCODERS[i]

@@ -64,3 +64,28 @@ def test_unseeded_factory_draws_from_the_callers_generator():
         assert ka == kb and torch.equal(pa, pb)
     c = policy.encoder_from_cfg(cfg)          # the generator has moved on
     assert not torch.equal(c.self_encoder[0].weight, a.self_encoder[0].weight)
+
+
+def test_reference_precision_operand_format():
+    """precision="fp32" packs every weight as a PAIR of fp16 numbers (include/quadswarm_encoder.h, policy.split_fp16): h + l / 2048 gives the
+    fp32 value back to ~2^-22 relative (2^-26 absolute below 2^-14), h is never a subnormal fp16, and the fragment layout is the bf16 one with two planes per fragment."""
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.uniform(-9, 3, 20000), [0.0, 1.0, -1.0, 65504.0, 1e6, -1e6, 6e-5, 6.2e-5, 1e-7]]).astype(np.float32)
+    h, l = policy.split_fp16(x)
+    assert h.dtype == np.float16 and l.dtype == np.float16 and np.isfinite(h).all() and np.isfinite(l).all()
+    assert ((h == 0) | (np.abs(h.astype(np.float32)) >= 2.0 ** -14)).all()
+    back = h.astype(np.float64) + l.astype(np.float64) / 2048.0
+    want = np.clip(x, -65504.0, 65504.0).astype(np.float64)
+    err = np.abs(back - want)
+    # (below the smallest normal fp16, 2^-14, the value lives in l alone: 11 bits of something that small, <= 2^-26 absolute)
+    assert (err <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -26)).all(), (err / np.maximum(np.abs(want), 1e-30)).max()
+    lin = torch.nn.Linear(40, 24)
+    w16, b, M, K = policy.pack_linear(lin, "cpu")
+    w2, b2, M2, K2 = policy.pack_linear(lin, "cpu", split=True)
+    assert (M, K) == (M2, K2) == (32, 64) and w2.shape == (M // 16, K // 32, 2, 64, 8) and w2.dtype == torch.float16 and torch.equal(b, b2)
+    rebuilt = (w2[:, :, 0].double() + w2[:, :, 1].double() / 2048.0)
+    assert torch.equal(rebuilt.to(torch.bfloat16), w16)                       # same elements in the same fragment slots ...
+    W = np.zeros((M, K)); W[:24, :40] = lin.weight.detach().numpy()
+    lane = np.arange(64)
+    frag = W[(lane & 15)[:, None] + 16 * 1, (8 * (lane >> 4))[:, None] + np.arange(8)[None, :] + 32 * 1]   # tile 1, K-step 1
+    assert np.abs(rebuilt[1, 1].numpy() - frag).max() <= np.abs(frag).max() * 2.0 ** -21   # ... to fp32 accuracy

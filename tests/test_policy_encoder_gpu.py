@@ -226,6 +226,70 @@ def test_fused_multi_head_attention_encoder_matches_torch(shape, batch, sim2real
     assert (got - want16).abs().mean().item() < 5e-4, (got - want16).abs().mean().item()
 
 
+REFERENCE_PRECISION_TOL = 1e-5   # "an fp32-accurate variant ... tested at <= 1e-5 against the fp32 module"
+
+
+@pytest.mark.parametrize("nbr_encoder", ["mean_embed", "attention", "mlp", "no_encoder"])
+@pytest.mark.parametrize("shape", [dict(num_nbr=6, obst_dim=0), dict(num_nbr=2, obst_dim=9, self_dim=19), dict(num_nbr=8, obst_dim=9), dict(num_nbr=5, obst_dim=0)])
+@pytest.mark.parametrize("batch", [1, 77, 8192])
+def test_reference_precision_encoder_matches_the_fp32_module(nbr_encoder, shape, batch):
+    """precision="fp32" (fp16-pair operands, three MFMAs per product; include/quadswarm_encoder.h): the features of the reference's fp32
+    modules to 1e-5 - against the module evaluated in float64 (the value both fp32 evaluations approximate) AND against the fp32 module
+    as torch runs it on the GPU, whose own distance from the float64 value is printed beside ours in the failure message."""
+    import copy
+    import torch
+    from quad_swarm_rl_amd import policy
+    ref = policy.make_reference_encoder(seed=5, nbr_encoder=nbr_encoder, **shape).cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(2.5)
+    fused = policy.FusedQuadEncoder(ref, precision="fp32")
+    g = torch.Generator(device="cuda").manual_seed(batch + 1)
+    D = fused.params.obs_dim
+    obs = (torch.rand((batch, D), device="cuda", generator=g) * 2 - 1) * torch.tensor([3.0] * 3 + [1.0] * (D - 3), device="cuda")
+    with torch.no_grad():
+        want32 = ref(obs)
+        want64 = copy.deepcopy(ref).double()(obs.double())
+    got = fused(obs).clone()
+    again = fused(obs)
+    torch.cuda.synchronize()
+    assert got.shape == (batch, 512) and torch.isfinite(got).all() and torch.equal(got, again)
+    e64, e32, t32 = (got.double() - want64).abs().max().item(), (got - want32).abs().max().item(), (want32.double() - want64).abs().max().item()
+    assert e64 < REFERENCE_PRECISION_TOL and e32 < REFERENCE_PRECISION_TOL, f"fused vs float64 {e64:.2e}, fused vs torch fp32 {e32:.2e}, torch fp32 vs float64 {t32:.2e}"
+    # and the bf16 kernels really are two to three orders of magnitude further away: the mode is not a relabelled bf16 path
+    far = (policy.FusedQuadEncoder(ref)(obs).double() - want64).abs().max().item()
+    assert far > 50 * e64, (far, e64)
+
+
+def test_reference_precision_head_sampling_and_refresh():
+    """the fused head, the Gaussian sampling epilogue and refresh() in reference precision; the multi-head classes say they are not built"""
+    import torch
+    from quad_swarm_rl_amd import native, policy
+    ref = policy.make_reference_encoder(seed=9, num_nbr=6).cuda()
+    fused = policy.FusedQuadEncoder(ref, precision="fp32")
+    head = torch.nn.Linear(512, 4).cuda()
+    fused.set_head(head.weight, head.bias)
+    obs = torch.rand((333, fused.params.obs_dim), device="cuda") * 2 - 1
+    feats = torch.empty((333, 512), device="cuda")
+    with torch.no_grad():
+        want = head(ref(obs))
+    got = fused.forward_head(obs, features=feats).clone()
+    assert (got - want).abs().max().item() < REFERENCE_PRECISION_TOL and (feats - ref(obs)).abs().max().item() < REFERENCE_PRECISION_TOL
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    fused.refresh()
+    with torch.no_grad():
+        want2 = head(ref(obs))
+    assert (fused.forward_head(obs) - want2).abs().max().item() < REFERENCE_PRECISION_TOL and (want2 - want).abs().max().item() > 1e-3
+    with pytest.raises(NotImplementedError):
+        policy.FusedQuadEncoder(policy.make_reference_mha_encoder().cuda(), precision="fp32")
+    mha = policy.FusedQuadEncoder(policy.make_reference_mha_encoder().cuda())
+    mha.params.precision = 1
+    with pytest.raises(native.QsError, match="reference precision"):
+        mha(torch.zeros((4, mha.params.obs_dim), device="cuda"))
+
+
 @pytest.mark.parametrize("sim2real", [False, True])
 @pytest.mark.parametrize("batch", [4112, 16384])
 def test_multi_head_kernels_are_run_to_run_identical_above_one_workgroup_per_cu(batch, sim2real):

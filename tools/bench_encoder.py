@@ -1,6 +1,9 @@
 #!/usr/bin/env python
 """Fused policy encoder (qs_policy_encoder.hip) vs PyTorch on the observations of BASELINE config 2 (8192 agents, obs 54).
-Prints one JSON line: us per forward, TFLOP/s (algorithmic FLOPs of the network) and the fraction of the dense bf16 MFMA peak."""
+Prints one JSON line: us per forward, TFLOP/s (algorithmic FLOPs of the network) and the fraction of the dense bf16 MFMA peak; for
+QuadMultiEncoder also the reference-precision kernels (precision="fp32": fp16-pair operands) with their distance from the module in float64.
+
+    python tools/bench_encoder.py [agents] [attention | mha | sim2real]"""
 import json
 import os
 import sys
@@ -54,7 +57,20 @@ with torch.no_grad():
     obs16 = obs.to(torch.bfloat16)
     t_bf16 = timeit(lambda: ref16(obs16), 100)
 PEAK = 2500.0   # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
+extra = {}
+if not MHA:   # reference precision: three fp16 MFMAs per product (same peak as bf16), against the fp32 module it stands in for
+    import copy
+    fused32 = policy.FusedQuadEncoder(ref, precision="fp32")
+    with torch.no_grad():
+        t32 = fused32.benchmark(obs, out, 300)
+        want64 = copy.deepcopy(ref).double()(obs.double())
+        e_sp = (fused32(obs).double() - want64).abs().max().item()
+        e_bf = (fused(obs).double() - want64).abs().max().item()
+        e_t32 = (ref(obs).double() - want64).abs().max().item()
+    extra = {"reference_precision_us": t32 * 1e6, "reference_precision_speedup_vs_torch_fp32": t_fp32 / t32,
+             "reference_precision_mfma_tflops": 3 * flops / t32 / 1e12, "reference_precision_frac_of_f16_mfma_peak": 3 * flops / t32 / 1e12 / PEAK,
+             "max_abs_error_vs_float64_module": {"reference_precision": e_sp, "bf16": e_bf, "torch_fp32": e_t32}}
 print(json.dumps({"kernel": "qs_encoder_s2r_kernel" if S2R else "qs_encoder_mha_kernel" if MHA else "qs_encoder_embed_kernel + qs_encoder_attn_kernel" if ATT else "qs_encoder_kernel", "agents": B, "obs_dim": D, "algorithmic_gflop": flops / 1e9,
                   "fused_us": t_fused * 1e6, "fused_us_one_python_call_per_pass": t_fused_host * 1e6, "fused_tflops": flops / t_fused / 1e12, "frac_of_bf16_mfma_peak": flops / t_fused / 1e12 / PEAK,
                   "torch_fp32_eager_us": t_fp32 * 1e6, "torch_bf16_eager_us": t_bf16 * 1e6,
-                  "speedup_vs_torch_fp32": t_fp32 / t_fused, "speedup_vs_torch_bf16": t_bf16 / t_fused}))
+                  "speedup_vs_torch_fp32": t_fp32 / t_fused, "speedup_vs_torch_bf16": t_bf16 / t_fused, **extra}))

@@ -19,6 +19,8 @@
 #   gdb:<case>[:var:flags]   the same under rocgdb with precise memory faults: faulting instruction, registers            -> gpurun_out/<tag>_rocgdb_<case>.txt
 #   noise[:shapes]   what the random draws cost at run time: the throughput shapes with the sensor + thrust noise configured off (27 + 4 normal draws per
 #                    drone-step not made) beside the default, same box, interleaved                                      -> gpurun_out/<tag>_noise_share.txt
+#   enc              the policy-encoder tests (tests/test_policy_encoder_gpu.py, test_encoder_fixtures.py) + tools/bench_encoder.py lines (mean_embed, attention:
+#                    bf16 and reference precision)                                                                    -> gpurun_out/<tag>_enc_{pytest,bench}.txt
 #   sweep:<n>        scheduler / switch sweep <n> of tools/sched_sweep.py (objects prebuilt with `SWEEP=<n> python tools/sched_sweep.py build`)  -> gpurun_out/<tag>_sched_sweep.txt
 tag=$1; shift
 mkdir -p gpurun_out
@@ -96,6 +98,18 @@ PY
         us=$(timeout 300 python bench.py --workload ${we%%:*} --envs-per-gpu ${we##*:} --steps 400 --warmup 50 --prewarm 200 --rollout-steps 0 --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train $extra 2>>gpurun_out/${tag}_err.txt | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('%.3f' % (1e3*d['ms_per_step']))")
         echo "$we rep $rep $v: $us" | tee -a $out
       done; done; done ;;
+    enc)
+      ( timeout 1500 python -m pytest tests/test_policy_encoder_gpu.py tests/test_encoder_fixtures.py -m gpu -q -rf --tb=short --maxfail=12 --timeout=600 -p no:cacheprovider 2>&1 | tail -80 ) > gpurun_out/${tag}_enc_pytest.txt
+      tail -5 gpurun_out/${tag}_enc_pytest.txt
+      : > gpurun_out/${tag}_enc_bench.txt
+      for a in "8192" "8192 attention" "4096" "131072"; do timeout 300 python tools/bench_encoder.py $a >> gpurun_out/${tag}_enc_bench.txt 2>> gpurun_out/${tag}_err.txt; done
+      python - <<PYEOF
+import json
+for l in open("gpurun_out/${tag}_enc_bench.txt"):
+    d = json.loads(l)
+    print(d["kernel"], d["agents"], "bf16 %.1f us (%.3f of peak)" % (d["fused_us"], d["frac_of_bf16_mfma_peak"]), "| reference precision %.1f us (%.3f), torch fp32 %.1f us |" % (d.get("reference_precision_us", 0), d.get("reference_precision_frac_of_f16_mfma_peak", 0), d["torch_fp32_eager_us"]), d.get("max_abs_error_vs_float64_module"))
+PYEOF
+      ;;
     sweep:*) SWEEP=${task#sweep:} SWEEP_TAG=$tag python tools/sched_sweep.py run 2 2>&1 | tail -30 ;;
     run:*) sc=${task#run:}; timeout 900 python $sc > gpurun_out/${tag}_$(basename $sc .py).txt 2>&1; tail -25 gpurun_out/${tag}_$(basename $sc .py).txt ;;
     *) echo "unknown task $task" ;;
