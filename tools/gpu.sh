@@ -12,7 +12,7 @@
 #   run:<script.py>  python <script.py>                                       -> gpurun_out/<tag>_<script>.txt
 #   tol              the parity tests in REPORT mode: worst |err| / allowed per case and quantity (tests/tolerances.py) -> gpurun_out/<tag>_tol_report.json
 #   abtree[:wls]     same-box A/B of the step kernels against another tree in build_exp/old (tools/ab_tree.sh)         -> gpurun_out/<tag>_ab_tree.txt
-#   c5[:iters[:batch]]  the in-tree PPO harness on BASELINE config 5 (tools/ppo_c5.py), learning curve                 -> gpurun_out/<tag>_ppo_c5.txt
+#   c5[:iters[:batch[:bf16|fp32]]]  the in-tree PPO harness on BASELINE config 5 (tools/ppo_c5.py), learning curve                 -> gpurun_out/<tag>_ppo_c5.txt
 #   gather           bench.py --workload c4 --force-gather: the exchange at world size 1, every wire                   -> gpurun_out/<tag>_bench_c4_gather_w1.json
 #   diff:<case>[:var:flags]  two code objects of one parity case side by side, bit for bit + against the oracle (tools/flag_diff.py; QS_SPEC_VERIFY=0:
 #                    the flagged object as the compiler delivers it)                                                      -> gpurun_out/<tag>_flag_diff_<case>.txt
@@ -73,8 +73,8 @@ PY
       ( QS_TOL_REPORT=$PWD/gpurun_out/${tag}_tol_report.json timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_vs_reference_f32.py tests/test_fp32_parity_gpu.py -m gpu -q --timeout=900 -p no:cacheprovider 2>&1 | tail -5 ) > gpurun_out/${tag}_tol_pytest.txt; tail -2 gpurun_out/${tag}_tol_pytest.txt ;;
     abtree*) wls=${task#abtree}; wls=${wls#:}; bash tools/ab_tree.sh $tag ${wls//,/ } 2>&1 | tail -20 ;;
     c5*)
-      IFS=: read -r _ iters batch <<< "$task"
-      timeout 900 python tools/ppo_c5.py --iterations ${iters:-24} --batch_size ${batch:-1024} > gpurun_out/${tag}_ppo_c5.txt 2> gpurun_out/${tag}_ppo_c5.err; tail -1 gpurun_out/${tag}_ppo_c5.txt | cut -c1-600 ;;
+      IFS=: read -r _ iters batch prec <<< "$task"
+      timeout 900 python tools/ppo_c5.py --iterations ${iters:-24} --batch_size ${batch:-1024} --sampler_precision ${prec:-fp32} > gpurun_out/${tag}_ppo_c5${prec:+_$prec}.txt 2> gpurun_out/${tag}_ppo_c5.err; tail -1 gpurun_out/${tag}_ppo_c5${prec:+_$prec}.txt | cut -c1-900 ;;
     gather)
       timeout 300 python bench.py --workload c4 --force-gather --cpu-seconds 0 --no-f64 --no-closed-loop --no-variants --no-c5-train > gpurun_out/${tag}_bench_c4_gather_w1.json 2> gpurun_out/${tag}_bench_c4_gather_w1.err
       python -c "import json; d=json.loads(open('gpurun_out/${tag}_bench_c4_gather_w1.json').read().strip().splitlines()[-1]); print({w: (round(v['ms_per_step']*1e3,2), v['verified_against_rccl_gather_after']) for w, v in d['config']['exchange_per_wire'].items()})" ;;

@@ -69,6 +69,9 @@ def make_parser():
                         "graph per rollout (rollout.GraphedRollout over the env's stepper; bf16 encoder) - instead of stepping the torch actor eagerly; the "
                         "behaviour policy's log-probabilities come from the action means the segment records, the values from the float32 critic in "
                         "one batched pass.  Falls back to the eager sampler where the fused kernels do not apply (CPU stand-in envs, float64, widths)")
+    p.add_argument("--sampler_precision", choices=("bf16", "fp32"), default="fp32",
+                   help="operands of the fused sampler's encoder: fp32 = reference precision (fp16 pairs, three MFMAs per product; the behaviour policy IS the "
+                        "learner's float32 actor to ~1e-6, what PPO's ratio assumes), bf16 = the faster kernels (action means ~1e-2 away from the learner's)")
     sf_env.add_quadrotors_env_args(None, p)
     p.set_defaults(quads_num_envs=1024)
     return p
@@ -156,7 +159,7 @@ class Learner:
         self.episodes = 0
         self.terms = None       # [17] means of the per-step reward terms over the last rollout (config.REW_INFO_KEYS order)
         self._rew_info = getattr(getattr(env, "vec", None), "reward_info", None)
-        self.segment, self.sampler_note = None, "eager torch actor"
+        self.segment, self.sampler_note, self.sampler_gap = None, "eager torch actor", None
         if bool(getattr(cfg, "fused_sampler", False)) and self.device.type == "cuda":
             self._make_segment()
 
@@ -165,12 +168,12 @@ class Learner:
         torch, cfg = self.torch, self.cfg
         try:
             from quad_swarm_rl_amd import policy, rollout
-            self.fused = policy.FusedQuadEncoder(self.ac.actor_encoder, device=self.device.index or 0)
+            self.fused = policy.FusedQuadEncoder(self.ac.actor_encoder, device=self.device.index or 0, precision=getattr(cfg, "sampler_precision", "fp32"))
             self.head = rollout.GaussianActionHead(in_features=self.fused.out_dim, device=self.device.index or 0, seed=cfg.seed, sample=True)
             self.head.weight, self.head.bias = self.ac.action_mean.weight, self.ac.action_mean.bias   # set_head copies them; refresh() follows them
             self.head.log_std = self.ac.log_std.detach().clone()
             self.segment = rollout.GraphedRollout(self.env.vec, self.fused, self.head, steps=cfg.rollout)
-            self.sampler_note = f"fused encoder + head + step, one HIP graph of {cfg.rollout} control steps (rollout.GraphedRollout)"
+            self.sampler_note = f"fused encoder ({self.fused.precision} operands) + head + step, one HIP graph of {cfg.rollout} control steps (rollout.GraphedRollout)"
         except Exception as exc:   # noqa: BLE001 - the eager sampler is always there
             self.segment, self.sampler_note = None, f"eager torch actor (fused sampler unavailable: {type(exc).__name__}: {exc})"
 
@@ -192,6 +195,8 @@ class Learner:
             self.obs[:T].copy_(out["obs"]); self.obs[T].copy_(out["last_obs"])
             self.act.copy_(out["actions"]); self.rew.copy_(out["rewards"]); self.done.copy_(out["dones"])
             self.logp.copy_(gaussian_logp(out["means"], self.head.log_std, out["actions"]))
+            # how far the behaviour policy (fused kernels) is from the learner's float32 actor on the same observations: |mean difference|, first step
+            self.sampler_gap = float((self.ac.act_mean(out["obs"][0]) - out["means"][0]).abs().max())
             flat = self.obs.reshape((T + 1) * self.A, self.D)
             vals = self.val.reshape(-1)
             for s0 in range(0, flat.shape[0], 65536):
@@ -365,6 +370,8 @@ def train(cfg, env=None, log=None):
         rec = dict(iteration=it, agent_steps=lr.agent_steps, reward_mean=float(lr.rew.mean()), value_mean=float(lr.val.mean()),
                    action_std=[round(float(x), 4) for x in lr.ac.log_std.detach().exp()], collect_s=round(t1 - t0, 3), update_s=round(t2 - t1, 3),
                    fps=round(per_iter / (t2 - t0), 1), sample_fps=round(per_iter / (t1 - t0), 1), episodes=lr.episodes, **{k: round(v, 6) if isinstance(v, float) else v for k, v in st.items()})
+        if lr.sampler_gap is not None:
+            rec["sampler_action_mean_gap"] = lr.sampler_gap
         if lr.terms is not None:
             tm = lr.terms.tolist()
             rec["terms"] = {k: round(tm[j], 6) for j, k in enumerate(qcfg.REW_INFO_KEYS[:len(tm)])}
@@ -375,7 +382,8 @@ def train(cfg, env=None, log=None):
     summary = dict(c5="ran (in-tree PPO harness: Sample Factory is not installed)", iterations=iters, agent_steps=lr.agent_steps,
                    seconds=round(total, 2), fps=round(lr.agent_steps / total, 1), agents=lr.A, rollout=cfg.rollout, batch_size=cfg.batch_size,
                    first=_brief(recs[0]), last=_brief(recs[-1]), graph_update=bool(recs[-1].get("graph_update")), graph_error=lr._graph_error,
-                   sampler=lr.sampler_note)
+                   sampler=lr.sampler_note, sampler_action_mean_gap_max=max((r.get("sampler_action_mean_gap", 0.0) for r in recs), default=None),
+                   sample_fps_median=sorted(r["sample_fps"] for r in recs)[len(recs) // 2])
     if own:
         env.close()
     return recs, summary
