@@ -754,6 +754,63 @@ __device__ __forceinline__ void stream_rows(const Consts<real> &c, const LdsLayo
     obs_copy_rows<real>(dst_block, s_self, s_rows, S, D, 0, nrows, rowmask, tid);
 }
 
+// The same response in two parts (pair_responses, parallel form).  None of the response's random draws depends on the state - Philox is keyed
+// by (env, step, site, slot, i, j) - and they are nine tenths of its cost (11 Philox blocks, 27 Box-Muller normals): one LANE per Philox
+// block draws them into a table, tbl = [3 attempts][cons, n1, n2][3] | decay[2] | omega words[4]; what has to follow the reference's list order
+// (a later pair reads the velocities an earlier one left) is the arithmetic below, a tenth of the work.
+#define QS_DD_CALLS 11    // Philox blocks behind one pair: 9 normal triples (slot = attempt * 3 + {cons, n1, n2}), the decay pair, the omega words
+#define QS_DD_DRAWS 33
+#define QS_DD_CHUNK 5     // pairs drawn at once by one wave: 55 lanes
+template <typename real>
+__device__ __forceinline__ void collide_drones_draw(const RngKey &key, int call, int i, int j, real *tbl) {
+    uint32_t w[4];
+    rng_words(key, call < 9 ? QS_SITE_DD_N : (call == 9 ? QS_SITE_DD_U : QS_SITE_DD_W), call < 9 ? call : 0, i, j, w);
+    if (call < 9) {   // rng_normal_s<real, 3>
+        real z[4];
+        box_muller4<real>(w, z);
+        const real scale = (call % 3 == 0) ? (real)0.8 : (real)0.15;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tbl[call * 3 + q] = scale * z[q];
+    } else if (call == 9) {   // rng_uniform<real, 2>(0.2, 0.8)
+        tbl[27] = (real)0.2 + ((real)0.8 - (real)0.2) * u01<real>(w[0]);
+        tbl[28] = (real)0.2 + ((real)0.8 - (real)0.2) * u01<real>(w[1]);
+    } else {   // uniform(-1, 1, 3), uniform(10 pi, 20 pi)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) tbl[29 + q] = (real)-1 + (real)2 * u01<real>(w[q]);
+        tbl[32] = (real)(10.0 * QS_PI_D) + (real)(20.0 * QS_PI_D - 10.0 * QS_PI_D) * u01<real>(w[3]);
+    }
+}
+template <typename real>
+__device__ __forceinline__ void collide_drones_apply(const real *tbl, int i, int j, int base, int B, const real *s_pos, real *s_vel, real *s_om) {
+    real p1[3], p2[3], v1[3], v2[3];
+    for (int q = 0; q < 3; ++q) { p1[q] = s_pos[q * B + base + i]; p2[q] = s_pos[q * B + base + j]; v1[q] = s_vel[q * B + base + i];
+        v2[q] = s_vel[q * B + base + j]; }
+    real n[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    real mag = norm3<real>(n), den = (mag == (real)0) ? mag + (real)1e-5 : mag;
+    for (int q = 0; q < 3; ++q) n[q] /= den;
+    real v1n = dot3<real>(v1, n), v2n = dot3<real>(v2, n);
+    real vc[3] = {(v2n - v1n) * n[0], (v2n - v1n) * n[1], (v2n - v1n) * n[2]};
+    real s1[3] = {vc[0], vc[1], vc[2]}, s2[3] = {-vc[0], -vc[1], -vc[2]};
+    for (int t = 0; t < 3; ++t) {
+        real t1[3], t2[3];
+        for (int q = 0; q < 3; ++q) {
+            real a = tbl[t * 9 + q] + tbl[t * 9 + 3 + q], b = -tbl[t * 9 + q] + tbl[t * 9 + 6 + q];
+            s1[q] = vc[q] + a; s2[q] = -vc[q] + b;
+            t1[q] = v1[q] + s1[q]; t2[q] = v2[q] + s2[q];
+        }
+        if (dot3<real>(t1, n) > (real)0 && (real)0 > dot3<real>(t2, n)) break;
+    }
+    real maxv = M<real>::fmax(norm3<real>(v1), norm3<real>(v2));
+    compute_new_vel<real>(maxv, v1, s1, tbl[27]);
+    compute_new_vel<real>(maxv, v2, s2, tbl[28]);
+    const real u[4] = {tbl[29], tbl[30], tbl[31], tbl[32]};
+    real dw[3]; compute_new_omega<real>(u, dw);
+    for (int q = 0; q < 3; ++q) {
+        s_vel[q * B + base + i] = v1[q]; s_vel[q * B + base + j] = v2[q];
+        s_om[q * B + base + i] += dw[q]; s_om[q * B + base + j] -= dw[q];
+    }
+}
+
 // perform_collision_between_drones collisions/quadrotors.py:24-59 on LDS-resident vel/omega (serial per env)
 template <typename real>
 __device__ __forceinline__ void collide_drones_lds(const RngKey &key, int i, int j, int base, int B, const real *s_pos, real *s_vel,

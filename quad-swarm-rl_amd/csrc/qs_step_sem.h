@@ -301,13 +301,64 @@ __device__ __forceinline__ void downwash_phase(const Consts<real> &c, const RngK
 
 // 2) drone-drone responses for the NEW pairs in lexicographic order (collisions/quadrotors.py:24-59); order-dependent and rare: one
 //    lane per env walks the pair list on LDS-resident vel / omega.  s_mask: one uint64 per lane of LDS scratch.
+//    Parallel form (tbl != nullptr: the team kernels; not on a tape, which holds the draws in the serial order): the wave's pairs are
+//    enumerated in that order by scalar code (v_readlane over the lanes that own one), QS_DD_CHUNK at a time; lane 11 p + k draws Philox
+//    block k of pair p into the table (collide_drones_draw), then lane 11 p applies the response - pairs of different environments at the
+//    same time, pairs of one environment one after the other in list order (its r-th pair of the chunk in round r).  Same draws, same
+//    arithmetic, same order as the serial form; measured on the C4 shard 12.8 -> 11.x us per step (the slowest workgroup of a step is the
+//    one with the most collisions: profiles/r06s_exp_rare_paths.txt, r06r_phase_c4.txt).
 template <typename real, typename Sync>
 __device__ __forceinline__ void pair_responses(const RngKey &key, Drone<real> &d, const EnvEvents &ev, uint64_t new_pair, bool active,
     int N, int i, int tid, int base, int B,
-                                               const real *s_pos, real *s_vel, real *s_om, uint64_t *s_mask, int *s_cur_env, Sync sync) {
+                                               const real *s_pos, real *s_vel, real *s_om, uint64_t *s_mask, int *s_cur_env, Sync sync,
+                                               real *tbl = nullptr) {
     if (__builtin_expect(ev.wave_newpair != 0, 0)) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) { s_vel[q * B + tid] = d.vel[q]; s_om[q * B + tid] = d.omega[q]; }
+        if (tbl != nullptr && !QS_ON_TAPE(key)) {
+            const int lane = tid & (QS_WAVE - 1), grp = lane / QS_DD_CALLS, call = lane - grp * QS_DD_CALLS;
+            const uint32_t np_lo = (uint32_t)new_pair, np_hi = (uint32_t)(new_pair >> 32);
+            uint64_t owners = ev.wave_newpair, np = 0;   // lanes that own new pairs, still to be enumerated; rest of the current owner's mask
+            int own = 0;
+            sync();
+            while (owners != 0 || np != 0) {
+                int cnt = 0, last_base = -1, rank = 0, rounds = 0;
+                int ta = 0, tb = 0, tbase = 0, trank = 0;
+                uint32_t tenv = 0, tstep = 0;
+                while (cnt < QS_DD_CHUNK && (owners != 0 || np != 0)) {   // wave-uniform: the next pair in (env, a, b) order
+                    if (np == 0) {
+                        own = __ffsll((long long)owners) - 1;
+                        owners &= owners - 1;
+                        np = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)np_lo, own) |
+                             ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)np_hi, own) << 32);   // (uint32_t): no sign extension of bit 31
+                    }
+                    const int b = __ffsll((long long)np) - 1;
+                    np &= np - 1;
+                    const int obase = __builtin_amdgcn_readlane(base, own);
+                    const uint32_t oenv = (uint32_t)__builtin_amdgcn_readlane((int)key.env, own), ostep = (uint32_t)__builtin_amdgcn_readlane((int)key.step, own);
+                    rank = (obase == last_base) ? rank + 1 : 0;
+                    last_base = obase;
+                    rounds = rank + 1 > rounds ? rank + 1 : rounds;
+                    if (grp == cnt) { ta = own - obase; tb = b; tbase = obase; trank = rank; tenv = oenv; tstep = ostep; }
+                    ++cnt;
+                }
+                const bool mine = grp < cnt;
+                if (mine) {
+                    const RngKey kt = {key.k0, key.k1, tenv, tstep};
+                    collide_drones_draw<real>(kt, call, ta, tb, tbl + grp * QS_DD_DRAWS);
+                }
+                sync();
+                for (int r = 0; r < rounds; ++r) {
+                    if (mine && call == 0 && trank == r) collide_drones_apply<real>(tbl + grp * QS_DD_DRAWS, ta, tb, tbase, B, s_pos, s_vel, s_om);
+                    sync();
+                }
+            }
+            if (ev.newpair_any) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { d.vel[q] = s_vel[q * B + tid]; d.omega[q] = s_om[q * B + tid]; }
+            }
+            return;
+        }
         s_mask[tid] = new_pair;
         sync();
         if (active && ev.newpair_any && i == 0) {

@@ -137,3 +137,21 @@ def test_team_objects_are_schedule_independent(case, monkeypatch):
     """the team objects' scheduler settings against the compiler's defaults (no max-ILP strategy, post-RA scheduler on): same bits"""
     monkeypatch.setenv("QS_TEAM", "1")
     identical_rollout(case, 7, 45, "QS_SPEC_TEAM_FLAGS", "", expect_team=True)
+
+
+RESPONSE_CASES = ["c2_n8_dw", "c4_n32_svs", "e_n17_kall_obst", "c2_n5_kall_short"]
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("case", RESPONSE_CASES)
+def test_parallel_pair_responses_equal_the_serial_form(case, precision, monkeypatch):
+    """Drone-drone collision responses (collisions/quadrotors.py:24-59) are order-dependent - a later pair reads the velocities an earlier one
+    left.  The team kernels draw the random numbers of all new pairs of a wave in parallel (one lane per Philox block) and apply the responses
+    in list order (qs_step_sem.h pair_responses, parallel form); `-DQS_SERIAL_PAIR_RESPONSES` keeps the serial form - one lane per environment
+    walking the list.  Same draws, same arithmetic, same order: floats to a few ulps of one step (two builds of different source fuse different
+    multiply-adds), everything discrete identical.  The crafted events put 2-3 disjoint pairs into every other environment at t = 6 (more than
+    one chunk of 5 pairs per wave at N <= 8) and three mutually colliding drones into the others at t = 14-16 (three pairs that share drones)."""
+    monkeypatch.setenv("QS_TEAM", "1")
+    if precision == "f64" and thp.CASES[case]["num_agents"] > 8:
+        pytest.skip("float64 team layouts of more than 8 drones exceed the 64 KiB of LDS a module-loaded kernel gets")
+    identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", "-DQS_SERIAL_PAIR_RESPONSES", expect_team=True, precision=precision, exact=False)
