@@ -107,6 +107,12 @@ int qs_enc_forward(const float *obs, int32_t B, const qs_enc_params *params, flo
  * value; an argument below -1 only reads. */
 int32_t qs_enc_set_wide_min(int32_t agents);
 
+/* mean_embed on the 32-agent workgroups (2, 4, 5 or 6 neighbours): 1 (default) = the two waves of every SIMD run the layer list half
+ * a layer apart - one in a K loop on the matrix pipe while the other does a tanh epilogue on the VALU (qs_policy_encoder.hip pp_body);
+ * 0 = all eight waves in the same phase (wide_body).  Same features bit for bit.  Environment QS_ENC_PP.  Returns the previous value; a
+ * negative argument only reads. */
+int32_t qs_enc_set_pingpong(int32_t on);
+
 /* Closed-loop glue of a rollout segment (quad-swarm-rl_amd/rollout.py): one launch before the environment step - trajectory copy of
  * the observations, act_out[A, 4] = mean[A, 4] + exp(log_std[4]) * N(0, 1) (log_std NULL: the mean itself; Philox4x32-10 keyed by
  * seed, the device counter and the agent) - and one after it - trajectory copies of rewards / dones, counter += 1.  They replace

@@ -143,6 +143,30 @@ __device__ __forceinline__ float fast_tanh(float x) {   // 1 - 2 / (exp(2x) + 1)
     const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // exp(2x): one multiply, v_exp_f32
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// The same on two values at once.  A wave issues one VALU instruction every ~5 cycles whatever it is (tools/ubench_valu.hip: v_fma_f32 6.6,
+// v_pk_fma_f32 7.0, v_exp_f32 / v_rcp_f32 9-10 ticks per instruction for a wave alone, unchanged with a second wave on the SIMD), so
+// the epilogues are bound by their instruction COUNT: the plain half of the tanh as v_pk_* (one issue per two values), and in
+// tanh2_bias the bias add and the scale of the exponent in one v_pk_fma_f32:  2^(c (a + b)) with c = 2 log2(e) is 2^(a c + bc), bc = b c.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define ENC_TANH_C 2.8853900817779268f
+__device__ __forceinline__ f32x2 tanh2_of_exponent(f32x2 t) {   // t = 2 log2(e) x
+    f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    e = e + (f32x2){1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+    return __builtin_elementwise_fma(r, (f32x2){-2.0f, -2.0f}, (f32x2){1.0f, 1.0f});
+}
+__device__ __forceinline__ f32x2 tanh2(f32x2 x) { return tanh2_of_exponent(x * (f32x2){ENC_TANH_C, ENC_TANH_C}); }
+__device__ __forceinline__ f32x4 tanh4(const f32x4 &x) {
+    const f32x2 lo = tanh2((f32x2){x[0], x[1]}), hi = tanh2((f32x2){x[2], x[3]});
+    return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
+// tanh(a + b) with bc = {b * ENC_TANH_C}: one fused multiply-add instead of an add and a multiply
+__device__ __forceinline__ f32x4 tanh4_bias(const f32x4 &a, const f32x4 &bc) {
+    const f32x2 c = {ENC_TANH_C, ENC_TANH_C};
+    const f32x2 lo = tanh2_of_exponent(__builtin_elementwise_fma((f32x2){a[0], a[1]}, c, (f32x2){bc[0], bc[1]}));
+    const f32x2 hi = tanh2_of_exponent(__builtin_elementwise_fma((f32x2){a[2], a[3]}, c, (f32x2){bc[2], bc[3]}));
+    return (f32x4){lo.x, lo.y, hi.x, hi.y};
+}
 
 // ------------------------------------------------------------------------------------------------
 // Reference precision (qs_enc_params.precision = 1; template parameter SP of the 16-agent kernels).  The reference's modules run in
@@ -1081,6 +1105,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t layer_rsrc(const EncLayer &L) 
     return __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, L.M * L.K * 2, 0x00020000);
 }
 #define ENC_RFRAG(rs, mtile, kst, mt, ks) ENC_WLOAD(__builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (((mtile) + (mt)) * (kst) + (ks)) * 1024, 0)))
+// a ring slot past the layer's K-steps (the 32-wide input layers fill one of the eight): through a resource of zero records - the load
+// returns zero and moves no data (in range it would read the next feature tiles' fragments: 14 KiB per wave and layer of traffic on
+// the CU's 64 B / clock L2 port that nobody multiplies - a third more than the network's weights, ahead of the observation loads)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t layer_rsrc_k(const EncLayer &L, int ks) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)L.w, 0, ks < (L.K >> 5) ? L.M * L.K * 2 : 0, 0x00020000);
+}
+#define ENC_RFRAG_K(L, mtile, kst, mt, ks) ENC_RFRAG(layer_rsrc_k(L, ks), mtile, kst, mt, ks)
 
 __device__ __forceinline__ void ring_fill(WRing &R, const EncLayer &L, int mtile0) {
     const uint32_t voff = (threadIdx.x & 63) * 16;
@@ -1089,8 +1120,7 @@ __device__ __forceinline__ void ring_fill(WRing &R, const EncLayer &L, int mtile
 #pragma unroll
     for (int s = 0; s < ENC_WPD; ++s)
 #pragma unroll
-        // K-steps past a short layer: in-range junk nobody multiplies
-        for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rs, mtile0, kst, mt, s);
+        for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG_K(L, mtile0, kst, mt, s);
 }
 
 // acc (+)= L[features of (wave, mt)] x X[row tiles]; the ring holds L's first ENC_WPD K-steps on entry and Ln's on exit.
@@ -1119,7 +1149,7 @@ __device__ __forceinline__ void gemm_ring(WRing &R, const EncLayer &L, int mtile
 #pragma unroll
         for (int s = 0; s < ENC_WPD; ++s)
 #pragma unroll
-            for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rsn, mtile0n, kn, mt, s);
+            for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG_K(Ln, mtile0n, kn, mt, s);
     } else {
         static_assert(KS % ENC_WPD == 0, "K-steps of a hidden layer: a multiple of the ring depth");
 #pragma unroll
@@ -1145,7 +1175,7 @@ __device__ __forceinline__ void gemm_ring(WRing &R, const EncLayer &L, int mtile
                 if (s + 1 < ENC_WPD) b[nt] = ENC_XFRAG(nt, KS - ENC_WPD + s + 1);
             }
 #pragma unroll
-            for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG(rsn, mtile0n, kn, mt, s);
+            for (int mt = 0; mt < ENC_MT; ++mt) R.a[s][mt] = ENC_RFRAG_K(Ln, mtile0n, kn, mt, s);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -1179,6 +1209,19 @@ __device__ __forceinline__ void layer_ring(WRing &R, const EncLayer &L, int mtil
     add_bias<NT>(acc, b);
 }
 
+// the same without the bias: acc = L X, bc = b * ENC_TANH_C for the tanh4_bias epilogues (mean_embed: wide_body, pp_body)
+struct BiasC { f32x4 v[ENC_MT]; };
+template <int NT, int KS>
+__device__ __forceinline__ void layer_ring_raw(WRing &R, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n, const uint16_t *X,
+    int xstride,
+                                               f32x4 (&acc)[ENC_MT][NT], BiasC &bc) {
+    const Bias b = load_bias(L, mtile0);
+    zero_acc<ENC_MT, NT>(acc);
+    gemm_ring<NT, KS>(R, L, mtile0, Ln, mtile0n, X, xstride, acc);
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) bc.v[mt] = b.v[mt] * ENC_TANH_C;
+}
+
 // epilogues of the wide kernels: one row tile at a time (a scheduling fence after each - interleaving a dozen tanh chains costs
 // more registers than it hides latency, and the weight ring has to stay resident through them)
 template <int NT>
@@ -1188,9 +1231,26 @@ __device__ __forceinline__ void store_tanh_wide(const f32x4 (&acc)[ENC_MT][NT], 
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int mt = 0; mt < ENC_MT; ++mt) {
+            const f32x4 t = tanh4(acc[mt][nt]);
             bf16x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (__bf16)fast_tanh(acc[mt][nt][r]);
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)t[r];
+            *(bf16x4 *)(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4) = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void store_tanh_wide_b(const f32x4 (&acc)[ENC_MT][NT], const BiasC &bc, int mtile0, uint16_t *Y, int ystride, int col0 = 0) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            const f32x4 t = tanh4_bias(acc[mt][nt], bc.v[mt]);
+            bf16x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (__bf16)t[r];
             *(bf16x4 *)(Y + (nt * 16 + (lane & 15)) * ystride + col0 + (mtile0 + mt) * 16 + (lane >> 4) * 4) = v;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1230,28 +1290,11 @@ __device__ __forceinline__ void stage_obs_wide(const float *__restrict__ obs, in
     }
 }
 
-// feed forward on the ring: the wave's 64 output features as two 32-feature halves over the same `cat` rows
-template <int KS>   // K-steps of the feed-forward layer: 16 ([self | neighbourhood]) or 24 (with obstacles)
-__device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, const uint16_t *cat, int a0, int B,
-    float *__restrict__ out, float *red) {
+// linear head on the features of the wide kernels (see feed_forward): red = [8 waves][8 heads][ENC_WA] floats; acc = the wave's tanh'd
+// feed-forward outputs
+__device__ __forceinline__ void wide_head(const EncParams &P, const f32x4 (&acc)[2][ENC_MT][ENC_AT], int a0, int B, float *red) {
     const int wave = wave_id(), lane = threadIdx.x & 63, mf0 = wave * ENC_MTF;
-    const EncLayer none = {nullptr, nullptr, 0, 0};
-    f32x4 acc[2][ENC_MT][ENC_AT];
-    layer_ring<ENC_AT, KS>(R, P.f, mf0, P.f, mf0 + ENC_MT, cat, ENC_CS, acc[0]);
-    layer_ring<ENC_AT, KS>(R, P.f, mf0 + ENC_MT, none, 0, cat, ENC_CS, acc[1]);
-    ENC_STAMP(8);
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int mt = 0; mt < ENC_MT; ++mt)
-#pragma unroll
-            for (int h = 0; h < ENC_AT; ++h) {
-                const int ga = a0 + h * 16 + (lane & 15);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[hf][mt][h][r] = fast_tanh(acc[hf][mt][h][r]);
-                if (out && ga < B) *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + hf * ENC_MT + mt) * 16 + (lane >> 4) * 4) = acc[hf][mt][h];
-            }
-    if (P.head_dim > 0) {   // linear head on the features (see feed_forward): red = [8 waves][8 heads][ENC_WA] floats
+    {
         for (int hd = 0; hd < P.head_dim; ++hd) {
             float sp[ENC_AT];
 #pragma unroll
@@ -1284,6 +1327,42 @@ __device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, 
     }
 }
 
+// feed forward on the ring: the wave's 64 output features as two 32-feature halves over the same `cat` rows
+template <int KS>   // K-steps of the feed-forward layer: 16 ([self | neighbourhood]) or 24 (with obstacles)
+__device__ __forceinline__ void feed_forward_wide(WRing &R, const EncParams &P, const uint16_t *cat, int a0, int B,
+    float *__restrict__ out, float *red) {
+    const int wave = wave_id(), lane = threadIdx.x & 63, mf0 = wave * ENC_MTF;
+    const EncLayer none = {nullptr, nullptr, 0, 0};
+    f32x4 acc[2][ENC_MT][ENC_AT];
+    BiasC bc[2];
+    layer_ring_raw<ENC_AT, KS>(R, P.f, mf0, P.f, mf0 + ENC_MT, cat, ENC_CS, acc[0], bc[0]);
+    layer_ring_raw<ENC_AT, KS>(R, P.f, mf0 + ENC_MT, none, 0, cat, ENC_CS, acc[1], bc[1]);
+    ENC_STAMP(8);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int h = 0; h < ENC_AT; ++h) {
+                const int ga = a0 + h * 16 + (lane & 15);
+                acc[hf][mt][h] = tanh4_bias(acc[hf][mt][h], bc[hf].v[mt]);
+                if (out && ga < B) *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + hf * ENC_MT + mt) * 16 + (lane >> 4) * 4) = acc[hf][mt][h];
+            }
+    if (P.head_dim > 0) wide_head(P, acc, a0, B, red);
+}
+
+// mean += tanh(acc + b) of the row tiles of neighbours t0.. (a neighbour slot past the count: masked out)
+template <int NT>
+__device__ __forceinline__ void tanh_into_mean(const f32x4 (&acc)[ENC_MT][NT], const BiasC &bc, int t0, int num_nbr, f32x4 (&mean)[ENC_MT][ENC_AT]) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float keep = t0 + nt / ENC_AT < num_nbr ? 1.0f : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) mean[mt][nt % ENC_AT] += keep * tanh4_bias(acc[mt][nt], bc.v[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // mean_embed, wide: per-neighbour MLP in passes of WNP neighbours (WNP * ENC_AT row tiles, tile = neighbour * ENC_AT + agent half).
 // WNP is a template parameter picked per neighbour count at launch (one pass body, no run-time tile counts); a last pass that
 // runs past the neighbour count works on zero rows and is masked out of the mean.
@@ -1294,23 +1373,16 @@ __device__ __forceinline__ void mean_pass_wide(WRing &R, const EncParams &P, int
     constexpr int NT = WNP * ENC_AT;
     const int wave = wave_id(), mt0 = wave * ENC_MT;
     f32x4 acc[ENC_MT][NT];
-    layer_ring<NT, 1>(R, P.n1, mt0, P.n2, mt0, x_nbr + t0 * ENC_WA * ENC_XS, ENC_XS, acc);
+    BiasC bc;
+    layer_ring_raw<NT, 1>(R, P.n1, mt0, P.n2, mt0, x_nbr + t0 * ENC_WA * ENC_XS, ENC_XS, acc, bc);
     ENC_STAMP(4);
     if (t0) __syncthreads();   // the previous pass's second layer is done reading buf_a
-    store_tanh_wide<NT>(acc, mt0, buf_a, ENC_YS);
+    store_tanh_wide_b<NT>(acc, bc, mt0, buf_a, ENC_YS);
     __syncthreads();
     ENC_STAMP(5);
-    layer_ring<NT, 8>(R, P.n2, mt0, after, mt_after, buf_a, ENC_YS, acc);
+    layer_ring_raw<NT, 8>(R, P.n2, mt0, after, mt_after, buf_a, ENC_YS, acc, bc);
     ENC_STAMP(6);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const float keep = t0 + nt / ENC_AT < P.num_nbr ? 1.0f : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < ENC_MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mean[mt][nt % ENC_AT][r] += keep * fast_tanh(acc[mt][nt][r]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    tanh_into_mean<NT>(acc, bc, t0, P.num_nbr, mean);
 }
 
 template <int WNP>
@@ -1335,19 +1407,20 @@ __device__ __forceinline__ void wide_body(const float *__restrict__ obs, int B, 
     ENC_STAMP(1);
     {
         f32x4 acc[ENC_MT][ENC_AT];
-        layer_ring<ENC_AT, 1>(R, P.s1, mt0, P.s2, mt0, x_self, ENC_XS, acc);
-        store_tanh_wide<ENC_AT>(acc, mt0, buf_b, ENC_YS);
+        BiasC bc;
+        layer_ring_raw<ENC_AT, 1>(R, P.s1, mt0, P.s2, mt0, x_self, ENC_XS, acc, bc);
+        store_tanh_wide_b<ENC_AT>(acc, bc, mt0, buf_b, ENC_YS);
         __syncthreads();
-        layer_ring<ENC_AT, 8>(R, P.s2, mt0, obst ? P.o1 : P.n1, mt0, buf_b, ENC_YS, acc);
-        store_tanh_wide<ENC_AT>(acc, mt0, cat, ENC_CS, 0);                                    // self encoder -> cat[:, 0:256]
+        layer_ring_raw<ENC_AT, 8>(R, P.s2, mt0, obst ? P.o1 : P.n1, mt0, buf_b, ENC_YS, acc, bc);
+        store_tanh_wide_b<ENC_AT>(acc, bc, mt0, cat, ENC_CS, 0);                              // self encoder -> cat[:, 0:256]
         ENC_STAMP(2);
         if (obst) {
-            layer_ring<ENC_AT, 1>(R, P.o1, mt0, P.o2, mt0, x_obst, ENC_XS, acc);
+            layer_ring_raw<ENC_AT, 1>(R, P.o1, mt0, P.o2, mt0, x_obst, ENC_XS, acc, bc);
             __syncthreads();   // the self encoder's second layer is done reading buf_b
-            store_tanh_wide<ENC_AT>(acc, mt0, buf_b, ENC_YS);
+            store_tanh_wide_b<ENC_AT>(acc, bc, mt0, buf_b, ENC_YS);
             __syncthreads();
-            layer_ring<ENC_AT, 8>(R, P.o2, mt0, P.n1, mt0, buf_b, ENC_YS, acc);
-            store_tanh_wide<ENC_AT>(acc, mt0, cat, ENC_CS, col_obst);                         // obstacle encoder -> cat[:, 512:768]
+            layer_ring_raw<ENC_AT, 8>(R, P.o2, mt0, P.n1, mt0, buf_b, ENC_YS, acc, bc);
+            store_tanh_wide_b<ENC_AT>(acc, bc, mt0, cat, ENC_CS, col_obst);                   // obstacle encoder -> cat[:, 512:768]
         }
     }
     ENC_STAMP(3);
@@ -1383,6 +1456,149 @@ __device__ __forceinline__ void wide_body(const float *__restrict__ obs, int B, 
         wide_body<n>(obs, B, P, out);                                                                                                               \
     }
 ENC_WIDE_KERNEL(1) ENC_WIDE_KERNEL(2) ENC_WIDE_KERNEL(3)
+
+// ------------------------------------------------------------------------------------------------
+// mean_embed, 32 agents per workgroup, the two waves of every SIMD half a layer apart ("ping-pong").
+//
+// In wide_body all eight waves run the same phase at the same time: the two waves of a SIMD queue for its matrix pipe through every
+// K loop and for its VALU through every tanh epilogue, and each of the two units idles through the other's phase.  Here the work is cut
+// into JOBS - one layer on one group of row tiles: G (K loop: MFMA + LDS fragment reads + weight stream) then T (bias, tanh, bf16, LDS
+// store) - and waves 4-7 (the second wave of SIMD 0-3) run the same job list ONE SLOT behind waves 0-3: while one wave of a SIMD is in a
+// G the other is in a T, matrix pipe beside VALU (MI355X_MICROARCH.md, two waves per SIMD).  One s_barrier per slot keeps the two halves
+// in that pairing.  A job that reads what job j wrote has to be at least two jobs behind j (the late half's T(j) ends one slot after
+// the early half's); the list is ordered for that, with one empty job in front of the feed-forward layer:
+//     n1(A) s1 n2(A) n1(B) s2 n2(B) [o1 - o2] - f(lo) f(hi)          A / B: the first / second WNP neighbours, 2 * WNP row tiles each
+// LDS buffers as in wide_body; the single hidden buffer of the neighbour MLP is rewritten by T(n1(B)) two slots after the last G(n2(A))
+// has read it.  Same MFMA order per output, same epilogues: the features are those of wide_body bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define ENC_SLOT() __syncthreads()   // end of a slot: LDS writes of this wave's T visible, every wave of both halves has arrived
+template <int WNP, bool OBST>
+__device__ __forceinline__ void pp_body(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *x_self = (uint16_t *)smem;                              // [WA][XS]
+    uint16_t *x_nbr = x_self + ENC_WA * ENC_XS;                       // [WSLOTS*WA][XS]
+    uint16_t *x_obst = x_nbr + ENC_WSLOTS * ENC_WA * ENC_XS;          // [WA][XS]
+    uint16_t *buf_a = x_obst + ENC_WA * ENC_XS;                       // [3*WA][YS]   hidden layer of the neighbour MLP (one group at a time)
+    uint16_t *buf_b = buf_a + 3 * ENC_WA * ENC_YS;                    // [WA][YS]     hidden layer of the self / obstacle MLPs
+    uint16_t *cat = buf_b + ENC_WA * ENC_YS;                          // [WA][CS]: self | neighbourhood | obstacles
+    constexpr int NT = WNP * ENC_AT, KSF = OBST ? 24 : 16;
+    const int wave = wave_id(), lane = threadIdx.x & 63, a0 = blockIdx.x * ENC_WA, mt0 = wave * ENC_MT, mf0 = wave * ENC_MTF, NB = P.num_nbr;
+    const bool late = wave >= ENC_WAVES / 2;
+    const EncLayer none = {nullptr, nullptr, 0, 0};
+
+    ENC_STAMP(0);
+    WRing R;
+    ring_fill(R, P.n1, mt0);   // in flight while the observations are staged
+    traj_copy(P, a0, ENC_WA, B);
+    stage_obs_wide(obs, B, P, a0, x_self, x_nbr, x_obst);
+    __syncthreads();
+    ENC_STAMP(1);
+    if (late) ENC_SLOT();
+    f32x4 accn[ENC_MT][NT], accs[ENC_MT][ENC_AT], mean[ENC_MT][ENC_AT];
+    BiasC bcn, bcs;
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+        for (int h = 0; h < ENC_AT; ++h) mean[mt][h] = (f32x4){0, 0, 0, 0};
+    // n1(A)
+    layer_ring_raw<NT, 1>(R, P.n1, mt0, P.s1, mt0, x_nbr, ENC_XS, accn, bcn);
+    ENC_SLOT();
+    store_tanh_wide_b<NT>(accn, bcn, mt0, buf_a, ENC_YS);
+    ENC_SLOT();
+    // s1
+    layer_ring_raw<ENC_AT, 1>(R, P.s1, mt0, P.n2, mt0, x_self, ENC_XS, accs, bcs);
+    ENC_SLOT();
+    store_tanh_wide_b<ENC_AT>(accs, bcs, mt0, buf_b, ENC_YS);
+    ENC_SLOT();
+    ENC_STAMP(2);
+    // n2(A)
+    layer_ring_raw<NT, 8>(R, P.n2, mt0, P.n1, mt0, buf_a, ENC_YS, accn, bcn);
+    ENC_SLOT();
+    tanh_into_mean<NT>(accn, bcn, 0, NB, mean);
+    ENC_SLOT();
+    ENC_STAMP(3);
+    // n1(B)
+    layer_ring_raw<NT, 1>(R, P.n1, mt0, P.s2, mt0, x_nbr + WNP * ENC_WA * ENC_XS, ENC_XS, accn, bcn);
+    ENC_SLOT();
+    store_tanh_wide_b<NT>(accn, bcn, mt0, buf_a, ENC_YS);
+    ENC_SLOT();
+    ENC_STAMP(4);
+    // s2
+    layer_ring_raw<ENC_AT, 8>(R, P.s2, mt0, P.n2, mt0, buf_b, ENC_YS, accs, bcs);
+    ENC_SLOT();
+    store_tanh_wide_b<ENC_AT>(accs, bcs, mt0, cat, ENC_CS, 0);                                       // self encoder -> cat[:, 0:256]
+    ENC_SLOT();
+    ENC_STAMP(5);
+    // n2(B)
+    layer_ring_raw<NT, 8>(R, P.n2, mt0, OBST ? P.o1 : P.f, OBST ? mt0 : mf0, buf_a, ENC_YS, accn, bcn);
+    ENC_SLOT();
+    tanh_into_mean<NT>(accn, bcn, WNP, NB, mean);
+    {
+        const float inv = 1.0f / (float)NB;   // torch.mean(neighbor_embeds, dim=1) (:41-42)
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int h = 0; h < ENC_AT; ++h) {
+                bf16x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (__bf16)(mean[mt][h][r] * inv);
+                *(bf16x4 *)(cat + (h * 16 + (lane & 15)) * ENC_CS + ENC_H + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+            }
+    }
+    ENC_SLOT();
+    ENC_STAMP(6);
+    if constexpr (OBST) {
+        // o1 (buf_b: the last G(s2) read it two slots ago)
+        layer_ring_raw<ENC_AT, 1>(R, P.o1, mt0, P.o2, mt0, x_obst, ENC_XS, accs, bcs);
+        ENC_SLOT();
+        store_tanh_wide_b<ENC_AT>(accs, bcs, mt0, buf_b, ENC_YS);
+        ENC_SLOT();
+        ENC_SLOT(); ENC_SLOT();   // (empty job)
+        // o2
+        layer_ring_raw<ENC_AT, 8>(R, P.o2, mt0, P.f, mf0, buf_b, ENC_YS, accs, bcs);
+        ENC_SLOT();
+        store_tanh_wide_b<ENC_AT>(accs, bcs, mt0, cat, ENC_CS, 2 * ENC_H);                           // obstacle encoder -> cat[:, 512:768]
+        ENC_SLOT();
+    }
+    ENC_SLOT(); ENC_SLOT();   // (empty job: the feed-forward layer reads what the late half's T of the job before wrote)
+    ENC_STAMP(7);
+    // f: the wave's 64 output features as two 32-feature halves over the same `cat` rows
+    f32x4 acc[2][ENC_MT][ENC_AT];
+    BiasC bcf[2];
+    layer_ring_raw<ENC_AT, KSF>(R, P.f, mf0, P.f, mf0 + ENC_MT, cat, ENC_CS, acc[0], bcf[0]);
+    ENC_SLOT();
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        if (hf == 1) {
+            ENC_SLOT();
+            layer_ring_raw<ENC_AT, KSF>(R, P.f, mf0 + ENC_MT, none, 0, cat, ENC_CS, acc[1], bcf[1]);
+            ENC_SLOT();
+            ENC_STAMP(8);
+        }
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int h = 0; h < ENC_AT; ++h) {
+                const int ga = a0 + h * 16 + (lane & 15);
+                acc[hf][mt][h] = tanh4_bias(acc[hf][mt][h], bcf[hf].v[mt]);
+                if (out && ga < B) *(f32x4 *)(out + (size_t)ga * (2 * ENC_H) + (mf0 + hf * ENC_MT + mt) * 16 + (lane >> 4) * 4) = acc[hf][mt][h];
+            }
+    }
+    ENC_SLOT();
+    if (!late) ENC_SLOT();
+    if (P.head_dim > 0) wide_head(P, acc, a0, B, (float *)buf_a);
+    ENC_STAMP(9);
+}
+#define ENC_PP_KERNEL(n)                                                                                                                           \
+    extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_pp##n##_kernel(const float *__restrict__ obs, int B, EncParams P,  \
+                                                                                               float *__restrict__ out) {                         \
+        pp_body<n, false>(obs, B, P, out);                                                                                                          \
+    }                                                                                                                                               \
+    extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_pp##n##o_kernel(const float *__restrict__ obs, int B, EncParams P, \
+                                                                                                float *__restrict__ out) {                         \
+        pp_body<n, true>(obs, B, P, out);                                                                                                           \
+    }
+ENC_PP_KERNEL(1) ENC_PP_KERNEL(2) ENC_PP_KERNEL(3)
 
 // ------------------------------------------------------------------------------------------------
 // attention, wide.  Launch 1: e_i -> ebuf, g = W_m e_mean -> gbuf (see qs_encoder_embed_kernel).
@@ -1731,6 +1947,9 @@ static int wide_min_agents(int dev) {
         n = 256; } cus[dev] = n; }
     return ENC_TA * cus[dev] + 1;
 }
+// mean_embed on 32-agent workgroups: the ping-pong schedule (pp_body) or, QS_ENC_PP=0 / qs_enc_set_pingpong(0), the lock-step one (wide_body)
+static int g_pp = [] { const char *e = getenv("QS_ENC_PP"); return e ? atoi(e) : 1; }();
+int32_t qs_enc_set_pingpong(int32_t on) { const int prev = g_pp; if (on >= 0) g_pp = on != 0; return prev; }
 // -1: the default rule; < -1: read only
 int32_t qs_enc_set_wide_min(int32_t agents) { const int prev = g_wide_min; if (agents >= -1) g_wide_min = agents; return prev; }
 static size_t lds_embed(void) { return sizeof(uint16_t) * (ENC_MAX_NBR * ENC_TA * ENC_XS + ENC_NH * ENC_TA * ENC_YS + ENC_TA * ENC_YS); }
@@ -1811,6 +2030,12 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
                     (int)lds_wide()) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_wide3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                     (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_pp1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_pp2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_pp3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_pp1o_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_pp2o_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_pp3o_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wide()) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                     (int)lds_split(0)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_embed_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1850,6 +2075,13 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
                 hipLaunchKernelGGL(qs_encoder_embed_wide3_kernel, grid, block, lds_embed_wide(), st, obs, B, P);
                 hipLaunchKernelGGL(qs_encoder_attn_wide3_kernel, grid, block, lds_attn_wide(), st, obs, B, P, out);
             }
+        } else if (g_pp && (P.num_nbr == 2 || (P.num_nbr >= 4 && P.num_nbr <= 6))) {
+            // two groups of ceil(K / 2) neighbours, the two waves of a SIMD half a layer apart (pp_body)
+            const int half = (P.num_nbr + 1) / 2;
+            const bool ob = P.obst_dim > 0;
+            if (half == 1) hipLaunchKernelGGL(ob ? qs_encoder_pp1o_kernel : qs_encoder_pp1_kernel, grid, block, lds_wide(), st, obs, B, P, out);
+            else if (half == 2) hipLaunchKernelGGL(ob ? qs_encoder_pp2o_kernel : qs_encoder_pp2_kernel, grid, block, lds_wide(), st, obs, B, P, out);
+            else hipLaunchKernelGGL(ob ? qs_encoder_pp3o_kernel : qs_encoder_pp3_kernel, grid, block, lds_wide(), st, obs, B, P, out);
         } else if (wnp == 1)
             hipLaunchKernelGGL(qs_encoder_wide1_kernel, grid, block, lds_wide(), st, obs, B, P, out);
         else if (wnp == 2)

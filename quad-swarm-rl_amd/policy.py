@@ -64,6 +64,8 @@ def lib():
         L.qs_enc_lds_bytes_split.argtypes = [C.c_int32]
         L.qs_enc_set_wide_min.argtypes = [C.c_int32]
         L.qs_enc_set_wide_min.restype = C.c_int32
+        L.qs_enc_set_pingpong.argtypes = [C.c_int32]
+        L.qs_enc_set_pingpong.restype = C.c_int32
         L.qs_rollout_pre.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p, C.c_void_p]
         L.qs_rollout_post.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.qs_enc_forward.argtypes = [C.c_void_p, C.c_int32, C.POINTER(EncParams), C.c_void_p, C.c_void_p]

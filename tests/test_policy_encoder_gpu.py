@@ -106,6 +106,52 @@ def test_wide_workgroup_kernels_match_torch_and_the_narrow_kernels(shape, batch,
     assert (wide - narrow).abs().max().item() < (2e-2 if attention else 8e-3), (wide - narrow).abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [dict(num_nbr=6, obst_dim=0), dict(num_nbr=6, obst_dim=9), dict(num_nbr=2, obst_dim=9, self_dim=19), dict(num_nbr=2, obst_dim=0),
+                                   dict(num_nbr=4, obst_dim=0), dict(num_nbr=5, obst_dim=9)])
+@pytest.mark.parametrize("batch", [1, 33, 4111, 8192])
+@pytest.mark.parametrize("head", [0, 4])
+def test_pingpong_schedule_equals_the_lockstep_schedule_bit_for_bit(shape, batch, head):
+    """mean_embed on the 32-agent workgroups with 2, 4, 5 or 6 neighbours runs the two waves of every SIMD half a layer apart (pp_body: one in a
+    K loop, the other in a tanh epilogue; qs_enc_set_pingpong).  It is a schedule, not arithmetic: the same MFMAs in the same order per
+    output as wide_body - features (and a fused head's outputs) identical bit for bit, run to run as well."""
+    import torch
+    from quad_swarm_rl_amd import policy
+    ref = policy.make_reference_encoder(seed=29, **shape).cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(2.0)
+    fused = policy.FusedQuadEncoder(ref)
+    g = torch.Generator(device="cuda").manual_seed(batch + 5)
+    D = fused.params.obs_dim
+    obs = (torch.rand((batch, D), device="cuda", generator=g) * 2 - 1) * torch.tensor([3.0] * 3 + [1.0] * (D - 3), device="cuda")
+    if head:
+        fused.set_head(torch.randn((head, 512), device="cuda", generator=g) * 0.05, torch.randn((head,), device="cuda", generator=g))
+
+    def run():
+        feats = torch.empty((batch, 512), device="cuda")
+        if not head:
+            return fused(obs, out=feats), None
+        return feats, fused.forward_head(obs, features=feats).clone()
+
+    prev = policy.lib().qs_enc_set_wide_min(1)
+    prev_pp = policy.lib().qs_enc_set_pingpong(1)
+    try:
+        pp, pp_head = run()
+        for _ in range(3):
+            again, again_head = run()
+            assert torch.equal(again, pp) and (not head or torch.equal(again_head, pp_head))
+        policy.lib().qs_enc_set_pingpong(0)
+        lock, lock_head = run()
+    finally:
+        policy.lib().qs_enc_set_wide_min(prev)
+        policy.lib().qs_enc_set_pingpong(prev_pp)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pp).all()
+    assert torch.equal(pp, lock), (pp - lock).abs().max().item()
+    if head:
+        assert torch.equal(pp_head, lock_head)
+
+
 @pytest.mark.parametrize("shape", [dict(num_nbr=6, obst_dim=0), dict(num_nbr=2, obst_dim=9, self_dim=19), dict(num_nbr=8, obst_dim=0),
                                    dict(num_nbr=1, obst_dim=0), dict(num_nbr=5, obst_dim=9)])
 @pytest.mark.parametrize("batch", [1, 16, 77, 8192])

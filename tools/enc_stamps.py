@@ -19,6 +19,8 @@ torch.cuda.synchronize()
 st = (C.c_ulonglong * 16)()
 policy.lib().qs_enc_stamps(st)
 names = ["start", "obs staged", "self enc", "obst enc", "n1 gemm (last pass)", "n1 stored+barrier", "n2 gemm", "nbr done", "ff gemm", "end"]
+if os.environ.get("QS_ENC_PP", "1") != "0":   # pp_body: wave 0 (the early half)
+    names = ["start", "obs staged", "n1(A) s1", "n2(A)", "n1(B)", "s2", "n2(B)", "[o1 - o2] -", "f(lo) + G f(hi)", "end"]
 us = fused.benchmark(obs, out, 200) * 1e6
 print(f"kernel {us:.1f} us per forward; stamps span {st[9] - st[0]} ticks -> {us * 1e3 / max(st[9] - st[0], 1):.2f} ns per tick (if workgroup 0 spans the kernel)")
 t0 = st[0]
