@@ -1257,36 +1257,46 @@ __device__ __forceinline__ void store_tanh_wide_b(const f32x4 (&acc)[ENC_MT][NT]
     }
 }
 
-// observation rows of the workgroup's ENC_WA agents -> bf16 staging rows (self [WA][XS] | neighbours [(k*WA + a)][XS] | obstacles [WA][XS])
+// observation rows of the workgroup's ENC_WA agents -> bf16 staging rows (self [WA][XS] | neighbours [(k*WA + a)][XS] | obstacles [WA][XS]; the
+// three are contiguous).  One lane = one 8-column chunk of one staging row: its eight observation elements through the buffer resource
+// (a column past the row's width, a neighbour slot past the count, an agent past the batch: out of range, reads as zero - the padding
+// needs no separate clearing), four v_cvt_pk_bf16_f32, one ds_write_b128.  Chunk-major order over rows padded to 6 waves: the chunk
+// index is wave-uniform, and a chunk past every input width is written as zeros without loads.  No division, no lane-divergent branch,
+// every LDS element written once (no barrier inside): ~40 instructions per lane and iteration where the element-wise version spent
+// ~50 per ELEMENT on index arithmetic under exec masks - in a kernel that issues one instruction per ~5 ticks per wave.
 __device__ __forceinline__ void stage_obs_wide(const float *__restrict__ obs, int B, const EncParams &P, int a0, uint16_t *x_self,
     uint16_t *x_nbr, uint16_t *x_obst) {
+    (void)x_nbr; (void)x_obst;
+    constexpr int ROWS = (2 + ENC_WSLOTS) * ENC_WA, ROWS_P = (ROWS + 63) / 64 * 64, ITERS = (4 * ROWS_P + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);
+    static_assert(ENC_WA == 32 && ENC_XS % 8 == 0, "row decoding by shifts; 16-byte aligned chunks");
     const int tid = threadIdx.x, D = P.obs_dim, NB = P.num_nbr;
-    uint32_t *z = (uint32_t *)x_self;   // the three are contiguous: clear the padding first
-    for (int idx = tid; idx < (2 + ENC_WSLOTS) * ENC_WA * ENC_XS / 2; idx += 64 * ENC_WAVES) z[idx] = 0;
-    constexpr int PER = (ENC_WA * (32 + 32 * ENC_MAX_NBR + 32) + 64 * ENC_WAVES - 1) / (64 * ENC_WAVES);
-    const int total = ENC_WA * D;
-    const size_t first = (size_t)a0 * D;
     const __amdgpu_buffer_rsrc_t ors = obs_rsrc(obs, B, D);
-    const uint32_t mD = div_magic(D), mN = div_magic(P.nbr_dim > 0 ? P.nbr_dim : 1);
-    float v[PER];
+    const int maxdim = max(P.self_dim, max(P.nbr_dim, P.obst_dim));
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
+    for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * 64 * ENC_WAVES;
-        v[it] = obs_at(ors, idx < total, (uint32_t)first + idx);   // rows past the batch: beyond the resource
-    }
-    __syncthreads();
+        const int ch = __builtin_amdgcn_readfirstlane(idx / ROWS_P), row = idx - ch * ROWS_P, col0 = ch * 8;   // ROWS_P: a multiple of 64
+        if (ch >= 4) break;
+        const bool is_self = row < ENC_WA, is_obst = row >= (1 + ENC_WSLOTS) * ENC_WA;
+        const int r = row - ENC_WA, nb = r >> 5;
+        const int a = is_self ? row : (is_obst ? row - (1 + ENC_WSLOTS) * ENC_WA : (r & (ENC_WA - 1)));
+        const int dim = is_self ? P.self_dim : (is_obst ? P.obst_dim : (nb < NB ? P.nbr_dim : 0));
+        const int cbase = is_self ? 0 : (is_obst ? P.self_dim + P.nbr_dim * NB : P.self_dim + nb * P.nbr_dim);
+        const int ga = a0 + a;
+        const uint32_t first = (uint32_t)ga * (uint32_t)D + (uint32_t)(cbase + col0);
+        const int left = (ga < B && row < ROWS) ? dim - col0 : 0;   // valid elements of this chunk
+        bf16x8 h;
+        if (col0 < maxdim) {
+            float v[8];
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        const int idx = tid + it * 64 * ENC_WAVES;
-        if (idx < total) {
-            const int a = div_by(idx, mD), cidx = idx - a * D;
-            const uint16_t h = __builtin_bit_cast(uint16_t, (__bf16)v[it]);
-            if (cidx < P.self_dim) x_self[a * ENC_XS + cidx] = h;
-            else if (cidx < P.self_dim + P.nbr_dim * NB) {
-                const int q = cidx - P.self_dim, nb = div_by(q, mN), j = q - nb * P.nbr_dim;
-                x_nbr[(nb * ENC_WA + a) * ENC_XS + j] = h;
-            } else x_obst[a * ENC_XS + (cidx - P.self_dim - P.nbr_dim * NB)] = h;
+            for (int u = 0; u < 8; ++u) v[u] = obs_at(ors, u < left, first + u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = (__bf16)v[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) h[u] = (__bf16)0.0f;
         }
+        if (row < ROWS) *(bf16x8 *)(x_self + row * ENC_XS + col0) = h;
     }
 }
 
