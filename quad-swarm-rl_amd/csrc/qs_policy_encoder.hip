@@ -1222,6 +1222,51 @@ __device__ __forceinline__ void layer_ring_raw(WRing &R, const EncLayer &L, int 
     for (int mt = 0; mt < ENC_MT; ++mt) bc.v[mt] = b.v[mt] * ENC_TANH_C;
 }
 
+// A 512-wide layer (16 K-steps) on TWO rings: R holds its K-steps 0-7 and R2 its K-steps 8-15 on entry, the next layer's (or feature
+// half's) on exit.  The feed-forward layer's 512 KB are half of the network's weights and four times its MFMA time on the CU's 64 B / clock
+// port; with its first feature half resident when the layer starts (R through the ring as always, R2 filled while the neighbour MLP - which
+// leaves the port three quarters idle - still runs), only the second half streams under the first half's K loop and epilogue.
+template <int NT>
+__device__ __forceinline__ void gemm_ring2(WRing &R, WRing &R2, const EncLayer &Ln, int mtile0n, const uint16_t *X, int xstride,
+                                           f32x4 (&acc)[ENC_MT][NT]) {
+    const int lane = threadIdx.x & 63, kn = Ln.K >> 5;
+    const uint16_t *xrow = X + (lane & 15) * xstride + 8 * (lane >> 4);
+    const uint32_t voff = lane * 16;
+    bf16x8 b[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) b[nt] = ENC_XFRAG(nt, 0);
+#pragma unroll
+    for (int s = 0; s < 2 * ENC_WPD; ++s) {
+        WRing &Q = s < ENC_WPD ? R : R2;
+        const int q = s & (ENC_WPD - 1);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            mfma_tile<ENC_MT, NT>(Q.a[q], b[nt], acc, nt);
+            if (s + 1 < 2 * ENC_WPD) b[nt] = ENC_XFRAG(nt, s + 1);
+        }
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) Q.a[q][mt] = ENC_RFRAG_K(Ln, mtile0n, kn, mt, s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void ring2_fill(WRing &R2, const EncLayer &L, int mtile0) {   // K-steps 8-15 of L
+    const uint32_t voff = (threadIdx.x & 63) * 16;
+    const int kst = L.K >> 5;
+#pragma unroll
+    for (int s = 0; s < ENC_WPD; ++s)
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) R2.a[s][mt] = ENC_RFRAG_K(L, mtile0, kst, mt, ENC_WPD + s);
+}
+template <int NT>
+__device__ __forceinline__ void layer_ring2_raw(WRing &R, WRing &R2, const EncLayer &L, int mtile0, const EncLayer &Ln, int mtile0n,
+                                                const uint16_t *X, int xstride, f32x4 (&acc)[ENC_MT][NT], BiasC &bc) {
+    const Bias b = load_bias(L, mtile0);
+    zero_acc<ENC_MT, NT>(acc);
+    gemm_ring2<NT>(R, R2, Ln, mtile0n, X, xstride, acc);
+#pragma unroll
+    for (int mt = 0; mt < ENC_MT; ++mt) bc.v[mt] = b.v[mt] * ENC_TANH_C;
+}
+
 // epilogues of the wide kernels: one row tile at a time (a scheduling fence after each - interleaving a dozen tanh chains costs
 // more registers than it hides latency, and the weight ring has to stay resident through them)
 template <int NT>
@@ -1540,6 +1585,8 @@ __device__ __forceinline__ void pp_body(const float *__restrict__ obs, int B, co
     ENC_SLOT();
     ENC_STAMP(5);
     // n2(B)
+    WRing R2;
+    if constexpr (!OBST) ring2_fill(R2, P.f, mf0);   // the feed-forward layer's K-steps 8-15 (gemm_ring2): in flight from here on
     layer_ring_raw<NT, 8>(R, P.n2, mt0, OBST ? P.o1 : P.f, OBST ? mt0 : mf0, buf_a, ENC_YS, accn, bcn);
     ENC_SLOT();
     tanh_into_mean<NT>(accn, bcn, WNP, NB, mean);
@@ -1575,13 +1622,15 @@ __device__ __forceinline__ void pp_body(const float *__restrict__ obs, int B, co
     // f: the wave's 64 output features as two 32-feature halves over the same `cat` rows
     f32x4 acc[2][ENC_MT][ENC_AT];
     BiasC bcf[2];
-    layer_ring_raw<ENC_AT, KSF>(R, P.f, mf0, P.f, mf0 + ENC_MT, cat, ENC_CS, acc[0], bcf[0]);
+    if constexpr (OBST) layer_ring_raw<ENC_AT, KSF>(R, P.f, mf0, P.f, mf0 + ENC_MT, cat, ENC_CS, acc[0], bcf[0]);
+    else layer_ring2_raw<ENC_AT>(R, R2, P.f, mf0, P.f, mf0 + ENC_MT, cat, ENC_CS, acc[0], bcf[0]);
     ENC_SLOT();
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
         if (hf == 1) {
             ENC_SLOT();
-            layer_ring_raw<ENC_AT, KSF>(R, P.f, mf0 + ENC_MT, none, 0, cat, ENC_CS, acc[1], bcf[1]);
+            if constexpr (OBST) layer_ring_raw<ENC_AT, KSF>(R, P.f, mf0 + ENC_MT, none, 0, cat, ENC_CS, acc[1], bcf[1]);
+            else layer_ring2_raw<ENC_AT>(R, R2, P.f, mf0 + ENC_MT, none, 0, cat, ENC_CS, acc[1], bcf[1]);
             ENC_SLOT();
             ENC_STAMP(8);
         }
