@@ -566,6 +566,59 @@ template <typename real> struct NbrSel {
     int bi[8];                 // K <= 8: indices of the (up to 8) nearest in order
     uint64_t taken;            // 8 < K < N-1: drones already emitted (arg-min rounds over the LDS metric column)
 };
+// fp32, K <= 8: the sorted top-(K + 1) list as ONE 32-bit integer key per entry - the metric's order-preserving bit pattern with its low
+// IB bits replaced by the drone index - so that the insertion is one v_med3_i32 per slot (new[k] = med3(cand, old[k-1], old[k]) of a
+// sorted list) instead of a compare and four selects.  The truncation is monotone, so two entries with DIFFERENT truncated metrics are
+// in the exact order; wherever the exact (metric, index) order could differ from the key order - inside the first K, or across the
+// K / K+1 boundary - two neighbouring entries of the sorted first K + 1 share a truncated metric, which is what the return value
+// reports (false = within 2^IB ulps of a tie: the caller takes the exact path; ~1e-4 of the drones).  IB = bits of a drone index.
+__device__ __forceinline__ int qs_med3_i32(int a, int b, int c) {
+    int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+template <typename real>
+__device__ __forceinline__ bool nbr_select_keys(const Consts<real> &c, int N, int i, int base, int B, const real *s_pos, const real *s_vel,
+                                                const real mypos[3], const real myvel[3], int bi[8]) {
+    const int K = c.num_neighbors;
+    const int IB = N <= 8 ? 3 : (N <= 16 ? 4 : (N <= 32 ? 5 : 6)), IM = (1 << IB) - 1;
+#ifdef QS_NBR_TRUNC_BITS   // (tests: a wider truncation than the index needs - the exact path is taken often, inside the same waves)
+    const int TM = (1 << QS_NBR_TRUNC_BITS) - 1;
+#else
+    const int TM = IM;
+#endif
+    int key[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) key[k] = 0x7fffffff;
+    for (int j0 = 0; j0 < N; j0 += 4) {
+        real rp[4][3], rv[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = (j0 + u < N) ? j0 + u : N - 1;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            const int b = __float_as_int((float)nbr_metric<real>(rp[u], rv[u]));
+            int cand = ((b ^ ((b >> 31) & 0x7fffffff)) & ~TM) | (j & IM);   // signed order = float order; -inf-wards truncation
+            cand = (j < N && j != i) ? cand : ((0x7fffffff & ~TM) | (j & IM));
+            int below = key[0];
+            key[0] = cand < key[0] ? cand : key[0];
+#pragma unroll
+            for (int k = 1; k < 9; ++k)   // (K is a literal in the specialised objects: K + 1 slots)
+                if (k <= K) { const int nk = qs_med3_i32(cand, below, key[k]); below = key[k]; key[k] = nk; }
+        }
+    }
+    uint32_t closest = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t x = (uint32_t)(key[k] ^ key[k + 1]);
+        closest = (k < K && x < closest) ? x : closest;
+        bi[k] = key[k] & IM;
+    }
+    return closest > (uint32_t)TM;
+}
+
 template <typename real>
 __device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, int base, int B, int tid, const real *s_pos,
     const real *s_vel,
@@ -573,6 +626,11 @@ __device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, 
     const int K = c.num_neighbors;
     S.taken = 1ull << i;
     if (K <= 0 || K == N - 1) return;
+#ifndef QS_EXACT_NBR_SELECT   // (-DQS_EXACT_NBR_SELECT: every drone on the exact path below; tests/test_object_identity_gpu.py)
+    if constexpr (sizeof(real) == 4) {
+        if (K <= 8 && nbr_select_keys<real>(c, N, i, base, B, s_pos, s_vel, mypos, myvel, S.bi)) return;
+    }
+#endif
     if (N <= 8) {   // all candidates at once, rank-by-counting (independent compares), then the inverse permutation: only the 8 indices
         real mj[8];  // stay live (the emit re-reads the chosen drones from LDS: registers decide the occupancy of this kernel)
         int rank[8];

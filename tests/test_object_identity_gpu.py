@@ -155,3 +155,19 @@ def test_parallel_pair_responses_equal_the_serial_form(case, precision, monkeypa
     if precision == "f64" and thp.CASES[case]["num_agents"] > 8:
         pytest.skip("float64 team layouts of more than 8 drones exceed the 64 KiB of LDS a module-loaded kernel gets")
     identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", "-DQS_SERIAL_PAIR_RESPONSES", expect_team=True, precision=precision, exact=False)
+
+
+SELECT_CASES = ["c4_n32_svs", "e_n33_k8", "x_n40_obst", "c2_n8_dw", "c3_n8_obst", "e_n64_k6"]
+
+
+@pytest.mark.parametrize("flag", ["-DQS_EXACT_NBR_SELECT", "-DQS_NBR_TRUNC_BITS=16"])
+@pytest.mark.parametrize("case", SELECT_CASES)
+def test_key_selection_of_neighbours_equals_the_exact_selection(case, flag, monkeypatch):
+    """The float32 single-wave kernels keep the K + 1 nearest as one integer key each - the metric's ordered bit pattern with the drone index
+    in its low bits, one v_med3_i32 per slot and candidate (qs_kernels.h nbr_select_keys) - and take the exact (metric, index) insertion only
+    where two neighbouring entries share a truncated metric.  `-DQS_EXACT_NBR_SELECT` sends every drone down the exact path;
+    `-DQS_NBR_TRUNC_BITS=16` truncates 16 bits instead of 3-6, so that the key order is wrong often and only the tie report keeps the result
+    right (the exact path runs for some lanes of most waves).  All three must choose the same neighbours in the same order: observation rows to
+    a few ulps of one step (builds of different source fuse different multiply-adds), everything discrete identical."""
+    monkeypatch.setenv("QS_TEAM", "0")
+    identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", flag, expect_team=False, precision="f32", exact=False)
