@@ -205,6 +205,22 @@ template <typename real> __device__ __forceinline__ real nbr_metric(const real r
     const real rd = M<real>::fmax(norm3<real>(rp), (real)0.01);
     return rd + (rp[0] * rv[0] + rp[1] * rv[1] + rp[2] * rv[2]) * M<real>::rcp(rd);
 }
+// fp32: the multiply-add chain written out (the one the compiler forms from the expression above), so that the two-partners-at-once form
+// below (v_pk_mul / v_pk_fma_f32: both halves round like the scalar instruction) gives the same bits as this one
+template <> __device__ __forceinline__ float nbr_metric<float>(const float rp[3], const float rv[3]) {
+    const float d2 = __builtin_fmaf(rp[2], rp[2], __builtin_fmaf(rp[1], rp[1], rp[0] * rp[0]));
+    const float dot = __builtin_fmaf(rp[2], rv[2], __builtin_fmaf(rp[1], rv[1], rp[0] * rv[0]));
+    const float rd = fmaxf(__builtin_amdgcn_sqrtf(d2), 0.01f);
+    return __builtin_fmaf(dot, __builtin_amdgcn_rcpf(rd), rd);
+}
+typedef float qs_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ qs_f32x2 nbr_metric_x2(const qs_f32x2 rp[3], const qs_f32x2 rv[3]) {
+    const qs_f32x2 d2 = __builtin_elementwise_fma(rp[2], rp[2], __builtin_elementwise_fma(rp[1], rp[1], rp[0] * rp[0]));
+    const qs_f32x2 dot = __builtin_elementwise_fma(rp[2], rv[2], __builtin_elementwise_fma(rp[1], rv[1], rp[0] * rv[0]));
+    const qs_f32x2 rd = {fmaxf(__builtin_amdgcn_sqrtf(d2.x), 0.01f), fmaxf(__builtin_amdgcn_sqrtf(d2.y), 0.01f)};
+    const qs_f32x2 rc = {__builtin_amdgcn_rcpf(rd.x), __builtin_amdgcn_rcpf(rd.y)};
+    return __builtin_elementwise_fma(dot, rc, rd);
+}
 // (metric, index) with the order "smaller metric first, lower index first" = position in the stable argsort
 template <typename real> struct NbrKey;
 template <> struct NbrKey<float> {
@@ -589,17 +605,24 @@ __device__ __forceinline__ bool nbr_select_keys(const Consts<real> &c, int N, in
 #pragma unroll
     for (int k = 0; k < 9; ++k) key[k] = 0x7fffffff;
     for (int j0 = 0; j0 < N; j0 += 4) {
-        real rp[4][3], rv[4][3];
+        float m4[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = (j0 + u < N) ? j0 + u : N - 1;
+        for (int h = 0; h < 2; ++h) {   // two partners per packed instruction (neighbouring LDS words = an aligned register pair)
+            const int ja = (j0 + 2 * h < N) ? j0 + 2 * h : N - 1, jb = (j0 + 2 * h + 1 < N) ? j0 + 2 * h + 1 : N - 1;
+            qs_f32x2 rp[3], rv[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { rp[u][a] = s_pos[a * B + base + j] - mypos[a]; rv[u][a] = s_vel[a * B + base + j] - myvel[a]; }
+            for (int a = 0; a < 3; ++a) {
+                const qs_f32x2 pj = {(float)s_pos[a * B + base + ja], (float)s_pos[a * B + base + jb]};
+                const qs_f32x2 vj = {(float)s_vel[a * B + base + ja], (float)s_vel[a * B + base + jb]};
+                rp[a] = pj - (float)mypos[a]; rv[a] = vj - (float)myvel[a];
+            }
+            const qs_f32x2 m = nbr_metric_x2(rp, rv);
+            m4[2 * h] = m.x; m4[2 * h + 1] = m.y;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + u;
-            const int b = __float_as_int((float)nbr_metric<real>(rp[u], rv[u]));
+            const int b = __float_as_int(m4[u]);
             int cand = ((b ^ ((b >> 31) & 0x7fffffff)) & ~TM) | (j & IM);   // signed order = float order; -inf-wards truncation
             cand = (j < N && j != i) ? cand : ((0x7fffffff & ~TM) | (j & IM));
             int below = key[0];
@@ -628,7 +651,8 @@ __device__ __forceinline__ void nbr_select(const Consts<real> &c, int N, int i, 
     if (K <= 0 || K == N - 1) return;
 #ifndef QS_EXACT_NBR_SELECT   // (-DQS_EXACT_NBR_SELECT: every drone on the exact path below; tests/test_object_identity_gpu.py)
     if constexpr (sizeof(real) == 4) {
-        if (K <= 8 && nbr_select_keys<real>(c, N, i, base, B, s_pos, s_vel, mypos, myvel, S.bi)) return;
+        // (N <= 8: rank-by-counting below stays - measured at 8 x 131072, profiles/r06s2_ab_keys_packed_scan.txt: 97.8 us against 99.2 with keys)
+        if (K <= 8 && N > 8 && nbr_select_keys<real>(c, N, i, base, B, s_pos, s_vel, mypos, myvel, S.bi)) return;
     }
 #endif
     if (N <= 8) {   // all candidates at once, rank-by-counting (independent compares), then the inverse permutation: only the 8 indices

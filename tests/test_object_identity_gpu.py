@@ -157,7 +157,7 @@ def test_parallel_pair_responses_equal_the_serial_form(case, precision, monkeypa
     identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", "-DQS_SERIAL_PAIR_RESPONSES", expect_team=True, precision=precision, exact=False)
 
 
-SELECT_CASES = ["c4_n32_svs", "e_n33_k8", "x_n40_obst", "c2_n8_dw", "c3_n8_obst", "e_n64_k6"]
+SELECT_CASES = ["c4_n32_svs", "e_n33_k8", "x_n40_obst", "e_n64_k6", "c4_n12_svs_short", "x_svs_odd"]   # 32 / 33 / 40 / 64 / 12 / 9 drones: 5, 6, 6, 6, 4, 4 index bits
 
 
 @pytest.mark.parametrize("flag", ["-DQS_EXACT_NBR_SELECT", "-DQS_NBR_TRUNC_BITS=16"])
