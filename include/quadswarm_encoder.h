@@ -19,8 +19,9 @@
  * accumulation, ~2^-22 relative per product; features within 1e-5 of the fp32 module (tests/test_policy_encoder_gpu.py).  Weights are then
  * packed as two 1 KiB planes per fragment:
  *   w[(((mt * (K/32) + ks) * 2 + plane) * 64 + lane) * 8 + j] = (plane ? l : h)(W[mt*16 + (lane & 15)][ks*32 + 8*(lane >> 4) + j]),
- * `ebuf` rows are the two planes [2][256], and the 16-agent kernels run with one workgroup per CU (two LDS planes).  Built for
- * QuadMultiEncoder's four neighbour encoders; the two multi-head classes return -4.
+ * `ebuf` rows are the two planes [2][256], and the 16-agent kernels run with one workgroup per CU (two LDS planes).  Built for every
+ * encoder class: QuadMultiEncoder's four neighbour encoders and the two multi-head classes (embeddings, q / k / v, output projection and
+ * feed-forward layer on fp16 pairs; scores, softmax, residual and LayerNorm in fp32; the value projection runs once per query token).
  */
 #ifndef QUADSWARM_ENCODER_H
 #define QUADSWARM_ENCODER_H

@@ -737,44 +737,43 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MT][NT]) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0, 0, 0, 0};
 }
 // 16-row MLP like mlp2_one_tile, but the fp32 result also stays in registers (the attention block's residual)
+template <bool SP = false>
 __device__ __forceinline__ void mlp2_keep(const EncLayer &L1, const EncLayer &L2, int mt0, const uint16_t *X, int xstride, uint16_t *hid,
     uint16_t *Y,
                                           f32x4 (&keep)[ENC_MT]) {
     const int lane = threadIdx.x & 63;
     f32x4 acc[ENC_MT][1];
     init_bias<ENC_MT, 1>(L1, mt0, acc);
-    gemm_tiles<ENC_MT, 1>(L1, mt0, X, xstride, acc);
-    store_tanh<ENC_MT, 1>(acc, mt0, hid, ENC_YS);
+    gemm_tiles<ENC_MT, 1, SP>(L1, mt0, X, xstride, acc);
+    store_tanh<ENC_MT, 1, SP>(acc, mt0, hid, ENC_YS);
     __syncthreads();
     init_bias<ENC_MT, 1>(L2, mt0, acc);
-    gemm_tiles<ENC_MT, 1>(L2, mt0, hid, ENC_YS, acc);
+    gemm_tiles<ENC_MT, 1, SP>(L2, mt0, hid, ENC_YS, acc);
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) {
-        bf16x4 v;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { keep[mt][r] = fast_tanh(acc[mt][0][r]); v[r] = (__bf16)keep[mt][r]; }
-        *(bf16x4 *)(Y + (lane & 15) * ENC_YS + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        for (int r = 0; r < 4; ++r) keep[mt][r] = fast_tanh(acc[mt][0][r]);
+        put4<SP>(Y + (lane & 15) * ENC_YS + (mt0 + mt) * 16 + (lane >> 4) * 4, keep[mt]);
     }
 }
 
 // one-layer embedding of 16 rows: Y[:, col..] = tanh(L X); KEEP: the fp32 result also stays in registers (the attention block's residual)
-template <bool KEEP>
+template <bool KEEP, bool SP = false>
 __device__ __forceinline__ void mlp1_keep(const EncLayer &L1, int mt0, const uint16_t *X, int xstride, uint16_t *Y, int ystride,
     f32x4 (&keep)[ENC_MT]) {
     const int lane = threadIdx.x & 63;
     f32x4 acc[ENC_MT][1];
     init_bias<ENC_MT, 1>(L1, mt0, acc);
-    gemm_tiles<ENC_MT, 1>(L1, mt0, X, xstride, acc);
+    gemm_tiles<ENC_MT, 1, SP>(L1, mt0, X, xstride, acc);
 #pragma unroll
     for (int mt = 0; mt < ENC_MT; ++mt) {
-        bf16x4 v;
+        f32x4 t;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float t = fast_tanh(acc[mt][0][r]);
-            if constexpr (KEEP) keep[mt][r] = t;
-            v[r] = (__bf16)t;
+            t[r] = fast_tanh(acc[mt][0][r]);
+            if constexpr (KEEP) keep[mt][r] = t[r];
         }
-        *(bf16x4 *)(Y + (lane & 15) * ystride + (mt0 + mt) * 16 + (lane >> 4) * 4) = v;
+        put4<SP>(Y + (lane & 15) * ystride + (mt0 + mt) * 16 + (lane >> 4) * 4, t);
     }
 }
 
@@ -814,9 +813,9 @@ __device__ __forceinline__ void mha_body(const float *__restrict__ obs, int B, c
     } else {
         mlp2_one_tile(P.s1, P.s2, mt0, x_self, ENC_XS, hid, cat, ENC_CS, 0);
         __syncthreads();
-        mlp2_keep(P.n1, P.n2, mt0, x_nbr, ENC_XW, hid, tok, resid[0]);
+        mlp2_keep<>(P.n1, P.n2, mt0, x_nbr, ENC_XW, hid, tok, resid[0]);
         __syncthreads();
-        mlp2_keep(P.o1, P.o2, mt0, x_obst, ENC_XS, hid, tok + ENC_TA * ENC_YS, resid[1]);
+        mlp2_keep<>(P.o1, P.o2, mt0, x_obst, ENC_XS, hid, tok + ENC_TA * ENC_YS, resid[1]);
     }
     __syncthreads();
 
@@ -936,6 +935,167 @@ extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_k
 extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_s2r_kernel(const float *__restrict__ obs, int B, EncParams P,
     float *__restrict__ out) {
     mha_body<true>(obs, B, P, out);
+}
+
+// The same block in reference precision (fp16 pairs, see split2).  Two LDS planes leave room for ONE token's concatenated heads, so the
+// value projection, the weighted sum and the output projection run per query token (the value GEMM twice); the inputs and the MLPs'
+// hidden layer share their space with that buffer (dead before it is written), the reduction scratch sits behind it in the h plane.
+#define ENC_MHS_TOK 0
+#define ENC_MHS_CAT (2 * ENC_TA * ENC_YS)
+#define ENC_MHS_OBUF (ENC_MHS_CAT + ENC_TA * ENC_CS)
+#define ENC_MHS_RED (ENC_MHS_OBUF + ENC_TA * ENC_OS)
+static_assert(ENC_MHS_RED + 2 * (4 * 2 * 4 * 16 + ENC_WAVES * 2 * 2 * 16) <= ENC_SPLANE, "the multi-head layout fits one plane");
+static_assert(2 * ENC_TA * ENC_XS + ENC_TA * ENC_XW + ENC_TA * ENC_YS <= ENC_TA * ENC_OS, "inputs + hidden layer fit under the heads buffer");
+template <bool S2R>
+__device__ __forceinline__ void mha_body_split(const float *__restrict__ obs, int B, const EncParams &P, float *__restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint16_t *tok = (uint16_t *)smem + ENC_MHS_TOK;                   // [2][16][YS]  tokens: neighbour embedding, obstacle embedding
+    uint16_t *cat = (uint16_t *)smem + ENC_MHS_CAT;                   // [16][CS]: self | token 0 | token 1
+    uint16_t *obuf = (uint16_t *)smem + ENC_MHS_OBUF;                 // [16][OS]  attention output of ONE query token, heads concatenated
+    uint16_t *x_self = obuf;                                          // [16][XS]   (the inputs and `hid` are dead when obuf is written)
+    uint16_t *x_obst = x_self + ENC_TA * ENC_XS;                      // [16][XS]
+    uint16_t *x_nbr = x_obst + ENC_TA * ENC_XS;                       // [16][XW]
+    uint16_t *hid = x_nbr + ENC_TA * ENC_XW;                          // [16][YS]
+    float *red_s = (float *)((uint16_t *)smem + ENC_MHS_RED);         // [4 heads][2 waves][4 (i,j)][16]  partial scores
+    float *red_ln = red_s + 4 * 2 * 4 * 16;                           // [8 waves][2 tokens][2 (sum, sum of squares)][16]
+    const int tid = threadIdx.x, wave = wave_id(), lane = tid & 63, a0 = blockIdx.x * ENC_TA;
+    const int NB = P.num_nbr, D = P.obs_dim, mt0 = wave * ENC_MT, nbw = P.nbr_dim * NB;
+    traj_copy(P, a0, ENC_TA, B);
+    for (int idx = tid; idx < ENC_TA * 128; idx += 64 * ENC_WAVES) {
+        const int a = idx >> 7, c = idx & 127, ga = a0 + a;
+        int col = -1;
+        uint16_t *dst;
+        if (c < 32) { dst = x_self + a * ENC_XS + c; if (c < P.self_dim) col = c; }
+        else if (c < 64) { dst = x_obst + a * ENC_XS + (c - 32); if (c - 32 < P.obst_dim) col = P.self_dim + nbw + (c - 32); }
+        else { dst = x_nbr + a * ENC_XW + (c - 64); if (c - 64 < nbw) col = P.self_dim + (c - 64); }
+        put1<true>(dst, obs_at(obs_rsrc(obs, B, D), ga < B && col >= 0, (uint32_t)ga * (uint32_t)D + col));
+    }
+    __syncthreads();
+    f32x4 resid[2][ENC_MT];
+    if constexpr (S2R) {
+        mlp1_keep<false, true>(P.s1, mt0, x_self, ENC_XS, cat, ENC_CS, resid[0]);
+        mlp1_keep<true, true>(P.n1, mt0, x_nbr, ENC_XW, tok, ENC_YS, resid[0]);
+        mlp1_keep<true, true>(P.o1, mt0, x_obst, ENC_XS, tok + ENC_TA * ENC_YS, ENC_YS, resid[1]);
+    } else {
+        mlp2_one_tile<true>(P.s1, P.s2, mt0, x_self, ENC_XS, hid, cat, ENC_CS, 0);
+        __syncthreads();
+        mlp2_keep<true>(P.n1, P.n2, mt0, x_nbr, ENC_XW, hid, tok, resid[0]);
+        __syncthreads();
+        mlp2_keep<true>(P.o1, P.o2, mt0, x_obst, ENC_XS, hid, tok + ENC_TA * ENC_YS, resid[1]);
+    }
+    __syncthreads();
+    constexpr int QT = 2, QC = S2R ? 1 : 4;   // (two feature tiles per chunk: the fp16-pair GEMM holds two weight rings and two accumulator sets)
+    float sc[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll 1
+    for (int c = 0; c < QC; ++c) {
+        f32x4 q[QT][2], k[QT][2];
+        zero_acc<QT, 2>(q);
+        gemm_tiles<QT, 2, true>(P.mq, (wave * QC + c) * QT, tok, ENC_YS, q);
+        zero_acc<QT, 2>(k);
+        gemm_tiles<QT, 2, true>(P.mk, (wave * QC + c) * QT, tok, ENC_YS, k);
+#pragma unroll
+        for (int mt = 0; mt < QT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sc[i][j] += q[mt][i][r] * k[mt][j][r];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float t = lane_groups_sum(sc[i][j]);
+            if (lane < 16) red_s[(wave * 4 + i * 2 + j) * 16 + lane] = t;
+        }
+    __syncthreads();   // (also: every wave is done with the inputs and `hid`, obuf may be written)
+    float pr[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float t[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float acc_s = 0.0f;
+            if constexpr (S2R) {
+#pragma unroll
+                for (int w = 0; w < ENC_WAVES; ++w) acc_s += red_s[(w * 4 + i * 2 + j) * 16 + (lane & 15)];
+            } else
+                acc_s = red_s[((wave & ~1) * 4 + i * 2 + j) * 16 + (lane & 15)] + red_s[((wave | 1) * 4 + i * 2 + j) * 16 + (lane & 15)];
+            t[j] = acc_s * (1.0f / 16.0f);
+        }
+        const float m = fmaxf(t[0], t[1]), e0 = __expf(t[0] - m), e1 = __expf(t[1] - m), rd = 1.0f / (e0 + e1);
+        pr[i][0] = e0 * rd;
+        pr[i][1] = e1 * rd;
+    }
+    f32x4 y[ENC_MT][2];
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {   // per query token: o_i = sum_j p_ij v_j -> obuf, then fc + residual -> y[.][i]
+        const float p0 = i == 0 ? pr[0][0] : pr[1][0], p1 = i == 0 ? pr[0][1] : pr[1][1];
+#pragma unroll 1
+        for (int c = 0; c < QC; ++c) {
+            f32x4 v[QT][2];
+            zero_acc<QT, 2>(v);
+            gemm_tiles<QT, 2, true>(P.mv, (wave * QC + c) * QT, tok, ENC_YS, v);
+#pragma unroll
+            for (int mt = 0; mt < QT; ++mt) {
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = p0 * v[mt][0][r] + p1 * v[mt][1][r];
+                put4<true>(obuf + (lane & 15) * ENC_OS + ((wave * QC + c) * QT + mt) * 16 + (lane >> 4) * 4, o);
+            }
+        }
+        __syncthreads();
+        f32x4 yi[ENC_MT][1];
+        zero_acc<ENC_MT, 1>(yi);
+        gemm_tiles<ENC_MT, 1, true>(P.mfc, mt0, obuf, ENC_OS, yi);
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float t = yi[mt][0][r] + (i == 0 ? resid[0][mt][r] : resid[1][mt][r]);
+                if (i == 0) y[mt][0][r] = t; else y[mt][1][r] = t;
+                s1 += t;
+                s2 += t * t;
+            }
+        s1 = lane_groups_sum(s1);
+        s2 = lane_groups_sum(s2);
+        if (lane < 16) {
+            red_ln[((wave * 2 + i) * 2 + 0) * 16 + lane] = s1;
+            red_ln[((wave * 2 + i) * 2 + 1) * 16 + lane] = s2;
+        }
+        __syncthreads();   // every wave has read this token's obuf; the sums are visible
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int w = 0; w < ENC_WAVES; ++w) {
+            s1 += red_ln[((w * 2 + i) * 2 + 0) * 16 + (lane & 15)];
+            s2 += red_ln[((w * 2 + i) * 2 + 1) * 16 + (lane & 15)];
+        }
+        const float mean = s1 * (1.0f / ENC_H), var = fmaxf(s2 * (1.0f / ENC_H) - mean * mean, 0.0f), rstd = 1.0f / __builtin_sqrtf(var + 1e-6f);
+#pragma unroll
+        for (int mt = 0; mt < ENC_MT; ++mt) {
+            const int f0 = (mt0 + mt) * 16 + (lane >> 4) * 4;
+            const f32x4 g = *(const f32x4 *)(P.ln_w + f0), bb = *(const f32x4 *)(P.ln_b + f0);
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (y[mt][i][r] - mean) * rstd * g[r] + bb[r];
+            put4<true>(cat + (lane & 15) * ENC_CS + ENC_H * (1 + i) + f0, o);
+        }
+    }
+    __syncthreads();
+    feed_forward<S2R ? ENC_MTF / 2 : ENC_MTF, true>(P, cat, a0, B, out, (float *)hid);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_mha_split_kernel(const float *__restrict__ obs, int B, EncParams P,
+    float *__restrict__ out) {
+    mha_body_split<false>(obs, B, P, out);
+}
+extern "C" __global__ void __launch_bounds__(64 * ENC_WAVES, 2) qs_encoder_s2r_split_kernel(const float *__restrict__ obs, int B, EncParams P,
+    float *__restrict__ out) {
+    mha_body_split<true>(obs, B, P, out);
 }
 
 
@@ -2036,7 +2196,6 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
     const bool att = P.nbr_encoder == ENC_NBR_ATTENTION && P.num_nbr > 0, s2r = P.nbr_encoder == ENC_MODEL_S2R,
         mha = P.nbr_encoder == ENC_MODEL_MHA || s2r, sp = P.precision == 1;
     if (P.precision != 0 && P.precision != 1) { g_enc_error = "precision: 0 (bf16) or 1 (reference precision, fp16 pairs)"; return -1; }
-    if (sp && mha) { g_enc_error = "reference precision is built for QuadMultiEncoder (mean_embed, attention, mlp, no_encoder), not for the multi-head encoders"; return -4; }
     if (P.num_nbr > ENC_MAX_NBR || P.self_dim > 32 || P.obst_dim > 32 || P.nbr_dim > 32 || P.nbr_encoder < 0
         || P.nbr_encoder > ENC_MODEL_S2R ||
         (att && P.self_dim + P.nbr_dim > 32) || ((P.nbr_encoder == ENC_NBR_MLP || mha) && P.nbr_dim * P.num_nbr > 64) ||
@@ -2101,6 +2260,10 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
                     (int)lds_split(0)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_attn_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                     (int)lds_split(1)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_mha_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_split(0)) != hipSuccess ||
+                hipFuncSetAttribute((const void *)qs_encoder_s2r_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                    (int)lds_split(0)) != hipSuccess ||
                 hipFuncSetAttribute((const void *)qs_encoder_embed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                     (int)lds_embed()) != hipSuccess) {
                 g_enc_error = "cannot raise the dynamic LDS limit";
@@ -2113,7 +2276,9 @@ int qs_enc_forward(const float *obs, int32_t B, const EncParams *params, float *
     const bool wide = !sp && wmin > 0 && B >= wmin && P.num_nbr > 0 && (P.nbr_encoder == ENC_NBR_MEAN_EMBED || att);
     if (sp) {   // reference precision: the 16-agent bodies on fp16 pairs, one workgroup per CU (two LDS planes)
         const dim3 grid((B + ENC_TA - 1) / ENC_TA), block(64 * ENC_WAVES);
-        if (att) {
+        if (s2r) hipLaunchKernelGGL(qs_encoder_s2r_split_kernel, grid, block, lds_split(0), (hipStream_t)stream, obs, B, P, out);
+        else if (mha) hipLaunchKernelGGL(qs_encoder_mha_split_kernel, grid, block, lds_split(0), (hipStream_t)stream, obs, B, P, out);
+        else if (att) {
             hipLaunchKernelGGL(qs_encoder_embed_split_kernel, grid, block, lds_split(0), (hipStream_t)stream, obs, B, P);
             hipLaunchKernelGGL(qs_encoder_attn_split_kernel, grid, block, lds_split(1), (hipStream_t)stream, obs, B, P, out);
         } else

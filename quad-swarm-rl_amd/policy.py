@@ -410,8 +410,6 @@ class FusedQuadEncoder:
 
         P.nbr_encoder = MODELS.index(getattr(module, "nbr_encoder", "mean_embed"))
         P.precision = int(split)
-        if split and P.nbr_encoder in (4, 5):
-            raise NotImplementedError("precision='fp32' is built for QuadMultiEncoder (mean_embed, attention, mlp, no_encoder), not for the multi-head encoders")
         self._split = split
         s2r = P.nbr_encoder == 5   # one-layer embeddings, one head, 256 outputs
         P.s1 = layer(module.self_encoder[0])

@@ -308,7 +308,7 @@ def test_reference_precision_encoder_matches_the_fp32_module(nbr_encoder, shape,
 
 
 def test_reference_precision_head_sampling_and_refresh():
-    """the fused head, the Gaussian sampling epilogue and refresh() in reference precision; the multi-head classes say they are not built"""
+    """the fused head, the Gaussian sampling epilogue and refresh() in reference precision; an unknown precision code is refused"""
     import torch
     from quad_swarm_rl_amd import native, policy
     ref = policy.make_reference_encoder(seed=9, num_nbr=6).cuda()
@@ -328,12 +328,46 @@ def test_reference_precision_head_sampling_and_refresh():
     with torch.no_grad():
         want2 = head(ref(obs))
     assert (fused.forward_head(obs) - want2).abs().max().item() < REFERENCE_PRECISION_TOL and (want2 - want).abs().max().item() > 1e-3
-    with pytest.raises(NotImplementedError):
-        policy.FusedQuadEncoder(policy.make_reference_mha_encoder().cuda(), precision="fp32")
-    mha = policy.FusedQuadEncoder(policy.make_reference_mha_encoder().cuda())
-    mha.params.precision = 1
-    with pytest.raises(native.QsError, match="reference precision"):
-        mha(torch.zeros((4, mha.params.obs_dim), device="cuda"))
+    bad = policy.FusedQuadEncoder(policy.make_reference_mha_encoder().cuda())
+    bad.params.precision = 2
+    with pytest.raises(native.QsError, match="precision"):
+        bad(torch.zeros((4, bad.params.obs_dim), device="cuda"))
+
+
+@pytest.mark.parametrize("shape", [dict(num_nbr=2), dict(num_nbr=6), dict(num_nbr=8, self_dim=18), dict(num_nbr=1, obst_dim=25)])
+@pytest.mark.parametrize("batch", [1, 77, 8192])
+@pytest.mark.parametrize("sim2real", [False, True])
+def test_reference_precision_multi_head_encoder_matches_the_fp32_module(shape, batch, sim2real):
+    """precision="fp32" for QuadMultiHeadAttentionEncoder and its Sim2Real subclass (quad_multi_model.py:124-248, attention_layer.py:12-97):
+    embeddings, q / k / v projections, the heads' output projection and the feed-forward layer on fp16 pairs; scores, softmax, residual and
+    LayerNorm in fp32.  Same bar as the neighbour encoders: 1e-5 from the module in float64 and from torch's fp32 forward."""
+    import copy
+    import torch
+    from quad_swarm_rl_amd import policy
+    ref = (policy.make_reference_sim2real_encoder if sim2real else policy.make_reference_mha_encoder)(seed=11, **shape).cuda()
+    with torch.no_grad():
+        for p in ref.parameters():
+            p.mul_(2.0)
+        a = ref.attention_layer
+        a.w_qs.weight.mul_(1.5)   # scores of a few units: the 2-way softmax weights spread over 0.04 .. 0.96
+        a.layer_norm.weight.uniform_(0.5, 1.5)
+        a.layer_norm.bias.uniform_(-0.3, 0.3)
+    fused = policy.FusedQuadEncoder(ref, precision="fp32")
+    assert fused.params.nbr_encoder == (5 if sim2real else 4) and fused.params.precision == 1
+    g = torch.Generator(device="cuda").manual_seed(batch + 2000)
+    D = fused.params.obs_dim
+    obs = (torch.rand((batch, D), device="cuda", generator=g) * 2 - 1) * torch.tensor([3.0] * 3 + [1.0] * (D - 3), device="cuda")
+    with torch.no_grad():
+        want32 = ref(obs)
+        want64 = copy.deepcopy(ref).double()(obs.double())
+    got = fused(obs).clone()
+    again = fused(obs)
+    torch.cuda.synchronize()
+    assert got.shape == (batch, 256 if sim2real else 512) and torch.isfinite(got).all() and torch.equal(got, again)
+    e64, e32, t32 = (got.double() - want64).abs().max().item(), (got - want32).abs().max().item(), (want32.double() - want64).abs().max().item()
+    assert e64 < REFERENCE_PRECISION_TOL and e32 < REFERENCE_PRECISION_TOL, f"fused vs float64 {e64:.2e}, fused vs torch fp32 {e32:.2e}, torch fp32 vs float64 {t32:.2e}"
+    far = (policy.FusedQuadEncoder(ref)(obs).double() - want64).abs().max().item()
+    assert far > 50 * e64, (far, e64)
 
 
 @pytest.mark.parametrize("sim2real", [False, True])

@@ -58,7 +58,7 @@ with torch.no_grad():
     t_bf16 = timeit(lambda: ref16(obs16), 100)
 PEAK = 2500.0   # TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md)
 extra = {}
-if not MHA:   # reference precision: three fp16 MFMAs per product (same peak as bf16), against the fp32 module it stands in for
+if True:   # reference precision: three fp16 MFMAs per product (same peak as bf16), against the fp32 module it stands in for
     import copy
     fused32 = policy.FusedQuadEncoder(ref, precision="fp32")
     with torch.no_grad():
