@@ -591,19 +591,50 @@ template <typename real> struct NbrSel {
 __device__ __forceinline__ int qs_med3_i32(int a, int b, int c) {
     int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
 }
+// the key list of one drone: K + 1 sorted entries (9 slots for K <= 8), the index / truncation masks
+struct NbrKeys {
+    int key[9];
+    int IM, TM;
+    __device__ __forceinline__ void init(int N) {
+        const int IB = N <= 8 ? 3 : (N <= 16 ? 4 : (N <= 32 ? 5 : 6));
+        IM = (1 << IB) - 1;
+#ifdef QS_NBR_TRUNC_BITS   // (tests: a wider truncation than the index needs - the exact path is taken often, inside the same waves)
+        TM = (1 << QS_NBR_TRUNC_BITS) - 1;
+#else
+        TM = IM;
+#endif
+#pragma unroll
+        for (int k = 0; k < 9; ++k) key[k] = 0x7fffffff;
+    }
+    // candidate j with metric m (valid: a partner, i.e. j < N and j != i)
+    __device__ __forceinline__ void insert(float m, int j, bool valid, int K) {
+        const int b = __float_as_int(m);
+        int cand = ((b ^ ((b >> 31) & 0x7fffffff)) & ~TM) | (j & IM);   // signed order = float order; -inf-wards truncation
+        cand = valid ? cand : ((0x7fffffff & ~TM) | (j & IM));
+        int below = key[0];
+        key[0] = cand < key[0] ? cand : key[0];
+#pragma unroll
+        for (int k = 1; k < 9; ++k)   // (K is a literal in the specialised objects: K + 1 slots)
+            if (k <= K) { const int nk = qs_med3_i32(cand, below, key[k]); below = key[k]; key[k] = nk; }
+    }
+    // indices of the K nearest in order; false: two neighbouring entries of the first K + 1 share a truncated metric
+    __device__ __forceinline__ bool finish(int K, int bi[8]) const {
+        uint32_t closest = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t x = (uint32_t)(key[k] ^ key[k + 1]);
+            closest = (k < K && x < closest) ? x : closest;
+            bi[k] = key[k] & IM;
+        }
+        return closest > (uint32_t)TM;
+    }
+};
 template <typename real>
 __device__ __forceinline__ bool nbr_select_keys(const Consts<real> &c, int N, int i, int base, int B, const real *s_pos, const real *s_vel,
                                                 const real mypos[3], const real myvel[3], int bi[8]) {
     const int K = c.num_neighbors;
-    const int IB = N <= 8 ? 3 : (N <= 16 ? 4 : (N <= 32 ? 5 : 6)), IM = (1 << IB) - 1;
-#ifdef QS_NBR_TRUNC_BITS   // (tests: a wider truncation than the index needs - the exact path is taken often, inside the same waves)
-    const int TM = (1 << QS_NBR_TRUNC_BITS) - 1;
-#else
-    const int TM = IM;
-#endif
-    int key[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) key[k] = 0x7fffffff;
+    NbrKeys L;
+    L.init(N);
     for (int j0 = 0; j0 < N; j0 += 4) {
         float m4[4];
 #pragma unroll
@@ -620,26 +651,9 @@ __device__ __forceinline__ bool nbr_select_keys(const Consts<real> &c, int N, in
             m4[2 * h] = m.x; m4[2 * h + 1] = m.y;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            const int b = __float_as_int(m4[u]);
-            int cand = ((b ^ ((b >> 31) & 0x7fffffff)) & ~TM) | (j & IM);   // signed order = float order; -inf-wards truncation
-            cand = (j < N && j != i) ? cand : ((0x7fffffff & ~TM) | (j & IM));
-            int below = key[0];
-            key[0] = cand < key[0] ? cand : key[0];
-#pragma unroll
-            for (int k = 1; k < 9; ++k)   // (K is a literal in the specialised objects: K + 1 slots)
-                if (k <= K) { const int nk = qs_med3_i32(cand, below, key[k]); below = key[k]; key[k] = nk; }
-        }
+        for (int u = 0; u < 4; ++u) L.insert(m4[u], j0 + u, (j0 + u < N) & (j0 + u != i), K);
     }
-    uint32_t closest = 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t x = (uint32_t)(key[k] ^ key[k + 1]);
-        closest = (k < K && x < closest) ? x : closest;
-        bi[k] = key[k] & IM;
-    }
-    return closest > (uint32_t)TM;
+    return L.finish(K, bi);
 }
 
 template <typename real>
