@@ -102,7 +102,7 @@ PY
       ( timeout 1500 python -m pytest tests/test_policy_encoder_gpu.py tests/test_encoder_fixtures.py -m gpu -q -rf --tb=short --maxfail=12 --timeout=600 -p no:cacheprovider 2>&1 | tail -80 ) > gpurun_out/${tag}_enc_pytest.txt
       tail -5 gpurun_out/${tag}_enc_pytest.txt
       : > gpurun_out/${tag}_enc_bench.txt
-      for a in "8192" "8192 attention" "4096" "131072"; do timeout 300 python tools/bench_encoder.py $a >> gpurun_out/${tag}_enc_bench.txt 2>> gpurun_out/${tag}_err.txt; done
+      for a in "8192" "8192 attention" "4096" "131072" "8192 mha" "8192 sim2real"; do timeout 300 python tools/bench_encoder.py $a >> gpurun_out/${tag}_enc_bench.txt 2>> gpurun_out/${tag}_err.txt; done
       python - <<PYEOF
 import json
 for l in open("gpurun_out/${tag}_enc_bench.txt"):
