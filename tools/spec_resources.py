@@ -26,8 +26,8 @@ def resources(wl="c2", team=-1, extra="", precision="f32", out=None, envs=None, 
     fm = "-ffast-math -fno-slp-vectorize" if precision == "f32" else ""
     if team > 0:   # the team objects' scheduler flags (kSpecFlagsTeam / kSpecFlagsTeam8 in quadswarm_hip.hip)
         fm += " -mllvm -amdgpu-sched-strategy=max-ilp" + (" -mllvm -enable-post-misched=0" if team == 8 else "")
-    elif team == 0 and os.environ.get("QS_SPEC_SINGLE_FLAGS"):   # (the single-wave objects' default is no scheduler flag: kSpecFlagsSingleF32)
-        fm += " " + os.environ["QS_SPEC_SINGLE_FLAGS"]
+    elif team == 0 and precision == "f32":   # the single-wave fp32 objects' default: the RP trackers (kSpecFlagsSingleF32 in quadswarm_hip.hip)
+        fm += " " + os.environ.get("QS_SPEC_SINGLE_FLAGS", "-mllvm -amdgpu-use-amdgpu-trackers")
     subprocess.check_call(f"/opt/rocm/bin/hipcc --genco --offload-arch=gfx950 -O3 -std=c++17 {fm} {extra} -S -DQS_SPEC_FILE='\"{hdr}\"' "
                           f"{native.CSRC}/qs_spec_kernels.hip -o {out} 2>/dev/null", shell=True)
     text = open(out).read()
