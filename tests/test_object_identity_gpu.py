@@ -171,3 +171,29 @@ def test_key_selection_of_neighbours_equals_the_exact_selection(case, flag, monk
     a few ulps of one step (builds of different source fuse different multiply-adds), everything discrete identical."""
     monkeypatch.setenv("QS_TEAM", "0")
     identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", flag, expect_team=False, precision="f32", exact=False)
+
+
+REDO_CASES = ["c4_n32_svs", "c4_n12_svs_short", "x_svs_odd", "s_static_diff", "s_dynamic_formations"]   # 32 / 12 / 9 / 10 / 9 drones, K = 6
+
+
+@pytest.mark.parametrize("case", REDO_CASES)
+def test_redoing_only_the_changed_rows_of_the_metric_matrix_equals_redoing_the_environment(case, monkeypatch):
+    """Team kernels, more than 8 drones (pair-once): when an interaction changes a velocity behind the pair scan, the default build re-evaluates
+    only the metrics of pairs with a CHANGED drone (rows / columns of the matrix in LDS, one more workgroup barrier) and ranks from the matrix
+    again; `-DQS_REDO_ROWS=0` re-evaluates every metric of the environment (qs_step_team.inc).  Same neighbours, same order, same rows: the
+    crafted events put collisions, wall / ceiling hits and downwash into the environments at t = 6, 14-16, 22."""
+    monkeypatch.setenv("QS_TEAM", "1")
+    identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", "-DQS_REDO_ROWS=0", expect_team=True, precision="f32", exact=False)
+
+
+STASH_CASES = ["c2_n8_dw", "c3_n8_obst", "c4_n32_svs", "e_n17_kall_obst", "c2_n5_kall_short", "x_svs_odd"]
+
+
+@pytest.mark.parametrize("case", STASH_CASES)
+def test_sensor_noise_drawn_ahead_equals_sensor_noise_drawn_on_demand(case, monkeypatch):
+    """A step whose interactions changed something observes twice (quadrotor_multi.py:598-599): fresh sensor noise, new self observation.  The
+    team kernels' default build lets wave 2 draw that noise while it waits for barrier 1 and parks the 12 values in the row's neighbour columns;
+    wave 0 - the critical path - only reads them.  `-DQS_SN_STASH=0`: wave 0 draws them itself when they are needed.  Philox is keyed by (env,
+    step, site, pass, drone): the same values either way, every array identical."""
+    monkeypatch.setenv("QS_TEAM", "1")
+    identical_rollout(case, 7, 45, "QS_SPEC_EXTRA_FLAGS", "-DQS_SN_STASH=0", expect_team=True, precision="f32", exact=False)
